@@ -1,0 +1,130 @@
+/*
+ * powdr_gpu.h — C ABI of libpowdr_gpu (MI355X / gfx950 build).
+ *
+ * Boundary B1: this header declares, byte for byte, the three
+ * entry points powdr's Rust host binds in
+ *     /root/reference/openvm/src/cuda_abi.rs:8-64      (extern "C" block)
+ * and the #[repr(C)] structs of
+ *     cuda_abi.rs:66-95 (OriginalAir, Subst, DerivedExprSpec)
+ *     cuda_abi.rs:137-169 (OpCode, DevInteraction, ExprSpan)
+ * which the reference implements in CUDA at
+ *     openvm/cuda/src/apc_tracegen.cu:106-146, apc_apply_bus.cu:119-169.
+ * The library must be named `powdr_gpu` (reference openvm/build.rs:16).
+ *
+ * All pointers are DEVICE pointers owned by the caller; the callee never frees
+ * them. Return value: 0 = success, otherwise a hipError_t cast to int (the
+ * reference returns `(int)cudaGetLastError()`; Rust maps it through
+ * `CudaError::from_result`).
+ *
+ * Field elements (`Fp` in the reference, `BabyBear` on the Rust side) are
+ * 32-bit words in Montgomery form, R = 2^32, p = 0x78000001 (assumption A1 of
+ * SURVEY.md). PUSH_CONST operands and histogram indices are canonical.
+ */
+#ifndef POWDR_GPU_H
+#define POWDR_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint32_t PowdrFp; /* BabyBear, Montgomery form */
+
+/* cuda_abi.rs:66-73 / apc_tracegen.cu:10-15 — 24 bytes, pointer at offset 8 */
+typedef struct {
+    int32_t width;          /* number of columns */
+    int32_t height;         /* number of rows (Ha) */
+    const PowdrFp* buffer;  /* column-major base: col*height + row (device) */
+    int32_t row_block_size; /* stride (in rows) between consecutive APC calls */
+} OriginalAir;
+
+/* cuda_abi.rs:75-86 / apc_tracegen.cu:17-22 — 16 bytes */
+typedef struct {
+    int32_t air_index; /* index into d_original_airs */
+    int32_t col;       /* source column within this AIR */
+    int32_t row;       /* base row offset within the row-block */
+    int32_t apc_col;   /* destination APC column */
+} Subst;
+
+/* cuda_abi.rs:162-169 / expr_eval.cuh:91-95 — 8 bytes */
+typedef struct {
+    uint32_t off; /* offset (u32 words) into the bytecode buffer */
+    uint32_t len; /* length (u32 words) of the expression */
+} ExprSpan;
+
+/* cuda_abi.rs:88-95 / apc_tracegen.cu:24-29 — 16 bytes */
+typedef struct {
+    uint64_t col_base; /* apc_col_index * H */
+    ExprSpan span;
+} DerivedExprSpec;
+
+/* cuda_abi.rs:149-160 / apc_apply_bus.cu:11-17 — 12 bytes */
+typedef struct {
+    uint32_t bus_id;
+    uint32_t num_args;
+    uint32_t args_index_off; /* into ExprSpan[]: [mult, arg0, arg1, ...] */
+} DevInteraction;
+
+/* cuda_abi.rs:137-147 / expr_eval.cuh:12-20 */
+enum PowdrOpCode {
+    POWDR_OP_PUSH_APC = 0,   /* followed by element offset col*H */
+    POWDR_OP_PUSH_CONST = 1, /* followed by canonical u32 < p */
+    POWDR_OP_ADD = 2,
+    POWDR_OP_SUB = 3,
+    POWDR_OP_MUL = 4,
+    POWDR_OP_NEG = 5,
+    POWDR_OP_INV_OR_ZERO = 6
+};
+#define POWDR_EXPR_STACK_CAPACITY 16 /* expr_eval.cuh:22 */
+#define POWDR_BITWISE_NUM_BITS 8     /* apc_apply_bus.cu:20 */
+
+/* cuda_abi.rs:12-19 ⇄ apc_tracegen.cu:126-146.
+ * out[apc_col*H + r] = r < num_apc_calls
+ *        ? air.buffer[col*air.height + row + r*air.row_block_size] : 0
+ * for every Subst and every r < output_height. output_height must be a power
+ * of two (0 allowed); otherwise hipErrorInvalidValue is returned (the
+ * reference aborts through assert). */
+int _apc_tracegen(PowdrFp* d_output, size_t output_height,
+                  const OriginalAir* d_original_airs, const Subst* d_subs,
+                  size_t n_subs, int num_apc_calls);
+
+/* cuda_abi.rs:24-31 ⇄ apc_tracegen.cu:106-124. Sequential over derived
+ * columns per row; rows >= num_apc_calls are zero-filled; n_cols == 0 → 0. */
+int _apc_apply_derived_expr(PowdrFp* d_output, size_t output_height,
+                            int num_apc_calls, const DerivedExprSpec* d_specs,
+                            size_t n_cols, const uint32_t* d_bytecode);
+
+/* cuda_abi.rs:36-63 ⇄ apc_apply_bus.cu:119-169. num_apc_calls <= 0 → 0. */
+int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
+                   const uint32_t* d_bytecode, size_t bytecode_len,
+                   const DevInteraction* d_interactions, size_t n_interactions,
+                   const ExprSpan* d_arg_spans, size_t n_arg_spans,
+                   uint32_t var_range_bus_id, uint32_t* d_var_hist,
+                   size_t var_num_bins, uint32_t tuple2_bus_id,
+                   uint32_t* d_tuple2_hist, uint32_t tuple2_sz0,
+                   uint32_t tuple2_sz1, uint32_t bitwise_bus_id,
+                   uint32_t* d_bitwise_hist);
+
+/* ---- extensions (not part of the reference ABI) ------------------------- */
+
+/* All launches of this library go to this stream (default: the null stream,
+ * like the reference, cuda/mod.rs:374-378). Pass a hipStream_t as void*. */
+void powdr_gpu_set_stream(void* hip_stream);
+void* powdr_gpu_get_stream(void);
+
+/* Per-kernel timing with HIP events recorded on the launch stream.
+ * enable=1 starts collecting (and clears); powdr_gpu_timing_report writes
+ * "name count total_ms\n" lines into buf (NUL terminated) and returns the
+ * number of bytes needed. It synchronises the stream. */
+void powdr_gpu_timing_enable(int enable);
+size_t powdr_gpu_timing_report(char* buf, size_t cap);
+
+/* Library/ABI self-description for load checks. */
+const char* powdr_gpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POWDR_GPU_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of libpowdr_gpu.so — the same symbols and struct layouts the
+reference's Rust FFI declares in /root/reference/openvm/src/cuda_abi.rs:8-169.
+
+Fails loudly (ImportError) if the shared library has not been built; there is no
+fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_LIBPATH = Path(__file__).resolve().parent / "lib" / "libpowdr_gpu.so"
+
+
+class OriginalAir(C.Structure):  # cuda_abi.rs:66-73 — 24 bytes
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("buffer", C.c_void_p), ("row_block_size", C.c_int32)]
+
+
+class Subst(C.Structure):  # cuda_abi.rs:75-86 — 16 bytes
+    _fields_ = [("air_index", C.c_int32), ("col", C.c_int32), ("row", C.c_int32), ("apc_col", C.c_int32)]
+
+
+class ExprSpan(C.Structure):  # cuda_abi.rs:162-169 — 8 bytes
+    _fields_ = [("off", C.c_uint32), ("len", C.c_uint32)]
+
+
+class DerivedExprSpec(C.Structure):  # cuda_abi.rs:88-95 — 16 bytes
+    _fields_ = [("col_base", C.c_uint64), ("span", ExprSpan)]
+
+
+class DevInteraction(C.Structure):  # cuda_abi.rs:149-160 — 12 bytes
+    _fields_ = [("bus_id", C.c_uint32), ("num_args", C.c_uint32), ("args_index_off", C.c_uint32)]
+
+
+assert C.sizeof(OriginalAir) == 24 and OriginalAir.buffer.offset == 8
+assert C.sizeof(Subst) == 16 and C.sizeof(ExprSpan) == 8
+assert C.sizeof(DerivedExprSpec) == 16 and C.sizeof(DevInteraction) == 12
+
+# every symbol include/powdr_gpu.h declares
+ABI_SYMBOLS = [
+    "_apc_tracegen", "_apc_apply_derived_expr", "_apc_apply_bus",
+    "powdr_gpu_set_stream", "powdr_gpu_get_stream", "powdr_gpu_timing_enable",
+    "powdr_gpu_timing_report", "powdr_gpu_version",
+]
+
+
+def _load():
+    if not _LIBPATH.exists():
+        raise ImportError(
+            f"{_LIBPATH} is missing: build it with `python -m powdr_amd.build` "
+            "(the product has no CPU fallback)")
+    lib = C.CDLL(str(_LIBPATH))
+    vp, sz, i32, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
+    lib._apc_tracegen.argtypes = [vp, sz, vp, vp, sz, i32]
+    lib._apc_tracegen.restype = i32
+    lib._apc_apply_derived_expr.argtypes = [vp, sz, i32, vp, sz, vp]
+    lib._apc_apply_derived_expr.restype = i32
+    lib._apc_apply_bus.argtypes = [vp, i32, vp, sz, vp, sz, vp, sz, u32, vp, sz, u32, vp, u32, u32, u32, vp]
+    lib._apc_apply_bus.restype = i32
+    lib.powdr_gpu_set_stream.argtypes = [vp]
+    lib.powdr_gpu_get_stream.restype = vp
+    lib.powdr_gpu_timing_enable.argtypes = [i32]
+    lib.powdr_gpu_timing_report.argtypes = [C.c_char_p, sz]
+    lib.powdr_gpu_timing_report.restype = sz
+    lib.powdr_gpu_version.restype = C.c_char_p
+    return lib
+
+
+lib = _load()
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise HipError(f"{what} failed with hipError {rc}")
+
+
+def timing_report() -> dict:
+    """{kernel name: (launch count, total ms)} since the last powdr_gpu_timing_enable(1)."""
+    n = lib.powdr_gpu_timing_report(None, 0)
+    buf = C.create_string_buffer(n + 16)
+    lib.powdr_gpu_timing_report(buf, n + 16)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.rsplit(" ", 2)
+        out[name] = (int(cnt), float(ms))
+    return out

@@ -1,0 +1,384 @@
+// _apc_tracegen for gfx950: the APC-trace gather, redesigned around the memory
+// system of MI355X instead of the reference's one-thread-per-row loop
+// (/root/reference/openvm/cuda/src/apc_tracegen.cu:35-66).
+//
+// Semantics (identical to the reference, apc_tracegen.cu:43-64):
+//   for every Subst s and every r < H:
+//     out[s.apc_col*H + r] = r < num_calls
+//         ? air[s.air_index].buffer[s.col*air.height + s.row + r*air.row_block_size]
+//         : 0
+// Duplicate apc_col targets resolve like the reference's sequential loop: the
+// substitution with the highest index wins.
+//
+// Why a redesign: in the reference a wave's 64 lanes (= 64 consecutive APC
+// calls) read one source cell each at a stride of row_block_size*4 bytes
+// (1 272 B for the keccak BaseAlu block), i.e. one 128-B line per 4 useful
+// bytes, and every thread re-reads the 16-B Subst + 24-B OriginalAir records
+// for each cell. Here the substitutions are regrouped by SOURCE COLUMN
+// (air, col). All cells of one source column that feed APC calls
+// r0..r0+R are the contiguous range  col*height + [r0*b, (r0+R)*b)  of the
+// column-major dummy trace, so a workgroup streams that range with 16-byte
+// coalesced loads into an LDS tile (row pitch padded to an odd number of words
+// -> conflict-free transposed reads) and then writes each substituted APC
+// column as full 128/256-byte coalesced segments. Sparse source columns are cut
+// into row chunks so that unused stretches of a block are never fetched.
+//
+// The regrouping ("plan") is computed on the host from a D2H copy of the
+// Subst/OriginalAir tables (a few hundred KB at most) and memoised by content
+// hash: the same APC is replayed for every segment.
+#include "babybear.hpp"
+#include "common.hpp"
+#include "../../include/powdr_gpu.h"
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// One unit of work: rows [j0, j0+J) of the row block of source column (air, col),
+// for a tile of R consecutive APC calls.
+struct GatherJob {
+    int32_t air;        // index into d_original_airs
+    int32_t col;        // source column
+    int32_t b;          // row_block_size of the air
+    int32_t j0;         // first block row covered
+    int32_t J;          // number of block rows covered
+    int32_t pitch;      // LDS row pitch in words (odd)
+    uint32_t magicJ;    // ceil(2^32 / J) for e / J
+    uint32_t sub_begin; // into plan subs
+    uint32_t sub_count;
+};
+
+struct PlanSub {
+    int32_t j;        // block row (absolute, s.row)
+    int32_t apc_col;
+};
+
+struct RClass {
+    int R;              // calls per tile
+    uint32_t job_begin; // into jobs array
+    uint32_t job_count;
+    size_t lds_bytes;   // max over jobs
+};
+
+struct Plan {
+    GatherJob* d_jobs = nullptr;
+    PlanSub* d_subs = nullptr;
+    std::vector<RClass> classes;
+    size_t n_jobs = 0, n_subs = 0;
+};
+
+constexpr int kBlock = 256;
+constexpr int kMaxTileWords = 12 * 1024;  // 48 KB LDS tile -> 3 workgroups / CU
+constexpr int kMaxR = 1024;
+constexpr int kMinR = 32;
+constexpr int kMaxChunkJ = kMaxTileWords / kMinR - 1;  // 383
+
+__device__ __forceinline__ uint32_t fast_div(uint32_t e, uint32_t magic, uint32_t J) {
+    // exact for e < 2^16, J < 2^16 (e*J < 2^32); J == 1 handled by magic == 0
+    return magic ? __umulhi(e, magic) : e;
+    (void)J;
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void apc_gather_tile_kernel(
+    uint32_t* __restrict__ out, size_t H, const OriginalAir* __restrict__ airs,
+    const GatherJob* __restrict__ jobs, const PlanSub* __restrict__ subs, int num_calls) {
+    extern __shared__ uint32_t tile[];
+    const GatherJob job = jobs[blockIdx.y];
+    const size_t r0 = (size_t)blockIdx.x * R;
+    const int tid = threadIdx.x;
+
+    // number of calls of this tile that carry data
+    int valid = 0;
+    if (r0 < (size_t)num_calls) {
+        size_t v = (size_t)num_calls - r0;
+        valid = v < (size_t)R ? (int)v : R;
+    }
+
+    if (valid > 0) {
+        const OriginalAir air = airs[job.air];
+        const uint32_t* __restrict__ src =
+            air.buffer + (size_t)job.col * (size_t)(uint32_t)air.height;
+        const int J = job.J, b = job.b, pitch = job.pitch;
+        if (J == b) {
+            // whole block rows: the tile is one contiguous range of the column
+            const uint32_t* base = src + r0 * (size_t)b;
+            const uint32_t n = (uint32_t)valid * (uint32_t)b;
+            if ((((uintptr_t)base) & 15u) == 0) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4* base4 = reinterpret_cast<const u32x4*>(base);
+                const uint32_t n4 = n >> 2;
+                for (uint32_t q = tid; q < n4; q += kBlock) {
+                    u32x4 v = __builtin_nontemporal_load(base4 + q);
+                    uint32_t e = q << 2;
+                    uint32_t i = fast_div(e, job.magicJ, J);
+                    uint32_t j = e - i * (uint32_t)J;
+                    uint32_t vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        tile[i * pitch + j] = vals[k];
+                        if (++j == (uint32_t)J) { j = 0; ++i; }
+                    }
+                }
+                for (uint32_t e = (n4 << 2) + tid; e < n; e += kBlock) {
+                    uint32_t i = fast_div(e, job.magicJ, J);
+                    uint32_t j = e - i * (uint32_t)J;
+                    tile[i * pitch + j] = base[e];
+                }
+            } else {
+                for (uint32_t e = tid; e < n; e += kBlock) {
+                    uint32_t i = fast_div(e, job.magicJ, J);
+                    uint32_t j = e - i * (uint32_t)J;
+                    tile[i * pitch + j] = __builtin_nontemporal_load(base + e);
+                }
+            }
+        } else {
+            // a chunk of each block: `valid` segments of J words, b words apart
+            const uint32_t* base = src + r0 * (size_t)b + job.j0;
+            const uint32_t n = (uint32_t)valid * (uint32_t)J;
+            for (uint32_t e = tid; e < n; e += kBlock) {
+                uint32_t i = fast_div(e, job.magicJ, J);
+                uint32_t j = e - i * (uint32_t)J;
+                tile[i * pitch + j] = __builtin_nontemporal_load(base + (size_t)i * b + j);
+            }
+        }
+    }
+    __syncthreads();
+
+    // Transposed write-out: lanes run over calls, (sub-)waves over substitutions.
+    const size_t rows_left = H - r0;  // H may be smaller than the tile
+    const int rows = rows_left < (size_t)R ? (int)rows_left : R;
+    constexpr int kLanes = R < 64 ? R : 64;       // lanes per substitution per pass
+    constexpr int kSubsPerPass = kBlock / kLanes; // substitutions handled at once
+    const int lane_i = tid % kLanes;
+    const int slot = tid / kLanes;
+    const PlanSub* __restrict__ js = subs + job.sub_begin;
+    for (uint32_t s = slot; s < job.sub_count; s += kSubsPerPass) {
+        const PlanSub ps = js[s];
+        uint32_t* __restrict__ dst = out + (size_t)ps.apc_col * H + r0;
+        const int j = ps.j - job.j0;
+#pragma unroll
+        for (int i = lane_i; i < R; i += kLanes) {
+            if (i < rows) {
+                uint32_t v = (i < valid) ? tile[i * job.pitch + j] : 0u;
+                __builtin_nontemporal_store(v, dst + i);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host: plan construction + cache
+// ---------------------------------------------------------------------------------------------
+
+uint64_t fnv1a(const void* p, size_t n, uint64_t h) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+struct PlanKey {
+    uint64_t hash;
+    size_t n_subs;
+    bool operator==(const PlanKey& o) const { return hash == o.hash && n_subs == o.n_subs; }
+};
+struct PlanKeyHash { size_t operator()(const PlanKey& k) const { return (size_t)k.hash; } };
+
+std::mutex g_plan_mu;
+std::unordered_map<PlanKey, Plan, PlanKeyHash> g_plans;
+
+int pick_R(int J) {
+    int pitch = J | 1;
+    int R = kMaxR;
+    while (R > kMinR && (size_t)R * pitch > (size_t)kMaxTileWords) R >>= 1;
+    return R;
+}
+
+int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bsize, Plan& plan) {
+    const size_t n = subs_in.size();
+    // 1. resolve duplicate destinations like the sequential reference loop: last wins
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    std::vector<char> keep(n, 1);
+    {
+        std::unordered_map<int32_t, uint32_t> last;
+        last.reserve(n * 2);
+        for (size_t i = 0; i < n; ++i) {
+            auto it = last.find(subs_in[i].apc_col);
+            if (it != last.end()) keep[it->second] = 0;
+            last[subs_in[i].apc_col] = (uint32_t)i;
+        }
+    }
+    // 2. sort by (air, col, row)
+    std::vector<uint32_t> idx;
+    idx.reserve(n);
+    for (size_t i = 0; i < n; ++i) if (keep[i]) idx.push_back((uint32_t)i);
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t c) {
+        const Subst& x = subs_in[a]; const Subst& y = subs_in[c];
+        if (x.air_index != y.air_index) return x.air_index < y.air_index;
+        if (x.col != y.col) return x.col < y.col;
+        if (x.row != y.row) return x.row < y.row;
+        return a < c;
+    });
+    // 3. cut every (air, col) group into jobs
+    std::vector<GatherJob> jobs;
+    std::vector<PlanSub> psubs;
+    psubs.reserve(idx.size());
+    std::vector<int> jobR;
+    size_t g = 0;
+    while (g < idx.size()) {
+        size_t ge = g;
+        const Subst& s0 = subs_in[idx[g]];
+        while (ge < idx.size() && subs_in[idx[ge]].air_index == s0.air_index &&
+               subs_in[idx[ge]].col == s0.col) ++ge;
+        const int b = bsize[s0.air_index];
+        // candidate A: one job covering whole blocks (contiguous stream, no edge waste)
+        // candidate B: chunks around the used rows. Cost model in bytes per call.
+        std::vector<std::pair<size_t, size_t>> chunks;  // [begin,end) into idx
+        {
+            size_t c = g;
+            while (c < ge) {
+                size_t ce = c + 1;
+                int jstart = subs_in[idx[c]].row;
+                while (ce < ge && subs_in[idx[ce]].row - jstart < kMaxChunkJ &&
+                       // do not bridge gaps that cost more than a fresh segment (128 B edge)
+                       subs_in[idx[ce]].row - subs_in[idx[ce - 1]].row <= 48)
+                    ++ce;
+                chunks.push_back({c, ce});
+                c = ce;
+            }
+        }
+        size_t cost_chunks = 0;
+        for (auto& ch : chunks) {
+            int J = subs_in[idx[ch.second - 1]].row - subs_in[idx[ch.first]].row + 1;
+            cost_chunks += (size_t)J * 4 + 128;
+        }
+        const int max_row = subs_in[idx[ge - 1]].row;
+        const bool whole_ok = b >= 1 && b <= kMaxChunkJ && max_row < b;
+        const size_t cost_whole = (size_t)b * 4;
+        auto emit = [&](size_t cb, size_t ce, int j0, int J) {
+            GatherJob job;
+            job.air = s0.air_index; job.col = s0.col; job.b = b; job.j0 = j0; job.J = J;
+            job.pitch = J | 1;
+            job.magicJ = J == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)J - 1) / (uint64_t)J);
+            job.sub_begin = (uint32_t)psubs.size();
+            job.sub_count = (uint32_t)(ce - cb);
+            for (size_t k = cb; k < ce; ++k)
+                psubs.push_back({subs_in[idx[k]].row, subs_in[idx[k]].apc_col});
+            jobs.push_back(job);
+            jobR.push_back(pick_R(J));
+        };
+        if (whole_ok && cost_whole <= cost_chunks) {
+            emit(g, ge, 0, b);
+        } else {
+            for (auto& ch : chunks) {
+                int j0 = subs_in[idx[ch.first]].row;
+                int J = subs_in[idx[ch.second - 1]].row - j0 + 1;
+                emit(ch.first, ch.second, j0, J);
+            }
+        }
+        g = ge;
+    }
+    // 4. order jobs by tile class R
+    std::vector<uint32_t> jorder(jobs.size());
+    for (size_t i = 0; i < jobs.size(); ++i) jorder[i] = (uint32_t)i;
+    std::stable_sort(jorder.begin(), jorder.end(), [&](uint32_t a, uint32_t c) { return jobR[a] < jobR[c]; });
+    std::vector<GatherJob> sorted(jobs.size());
+    plan.classes.clear();
+    for (size_t i = 0; i < jorder.size(); ++i) {
+        sorted[i] = jobs[jorder[i]];
+        int R = jobR[jorder[i]];
+        size_t lds = (size_t)R * sorted[i].pitch * 4;
+        if (plan.classes.empty() || plan.classes.back().R != R)
+            plan.classes.push_back({R, (uint32_t)i, 0, 0});
+        plan.classes.back().job_count++;
+        plan.classes.back().lds_bytes = std::max(plan.classes.back().lds_bytes, lds);
+    }
+    plan.n_jobs = sorted.size();
+    plan.n_subs = psubs.size();
+    if (plan.n_jobs) {
+        PW_HIP_TRY(hipMalloc(&plan.d_jobs, sorted.size() * sizeof(GatherJob)));
+        PW_HIP_TRY(hipMalloc(&plan.d_subs, psubs.size() * sizeof(PlanSub)));
+        PW_HIP_TRY(hipMemcpy(plan.d_jobs, sorted.data(), sorted.size() * sizeof(GatherJob), hipMemcpyHostToDevice));
+        PW_HIP_TRY(hipMemcpy(plan.d_subs, psubs.data(), psubs.size() * sizeof(PlanSub), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+template <int R>
+void launch_class(const RClass& c, uint32_t* out, size_t H, const OriginalAir* airs,
+                  const Plan& plan, int num_calls) {
+    unsigned tiles = pw::div_up(H, R);
+    // gridDim.y is limited to 65535 jobs per launch
+    for (uint32_t j = 0; j < c.job_count; j += 65535u) {
+        uint32_t cnt = std::min<uint32_t>(65535u, c.job_count - j);
+        dim3 grid(tiles, cnt, 1);
+        hipLaunchKernelGGL(apc_gather_tile_kernel<R>, grid, dim3(kBlock), c.lds_bytes, pw::stream(),
+                           out, H, airs, plan.d_jobs + c.job_begin + j, plan.d_subs, num_calls);
+    }
+}
+
+}  // namespace
+
+extern "C" int _apc_tracegen(PowdrFp* d_output, size_t output_height,
+                             const OriginalAir* d_original_airs, const Subst* d_subs,
+                             size_t n_subs, int num_apc_calls) {
+    const size_t H = output_height;
+    if ((H & (H - 1)) != 0) return (int)hipErrorInvalidValue;  // reference: assert, apc_tracegen.cu:134
+    if (H == 0 || n_subs == 0) return (int)hipGetLastError();
+    if (num_apc_calls < 0) num_apc_calls = 0;
+    if ((size_t)num_apc_calls > H) num_apc_calls = (int)H;  // rows r >= H do not exist
+
+    // D2H the (small) tables, hash, look the plan up.
+    std::vector<Subst> subs(n_subs);
+    PW_HIP_TRY(hipMemcpyAsync(subs.data(), d_subs, n_subs * sizeof(Subst), hipMemcpyDeviceToHost, pw::stream()));
+    PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
+    int max_air = -1;
+    for (auto& s : subs) {
+        if (s.air_index < 0 || s.col < 0 || s.row < 0 || s.apc_col < 0) return (int)hipErrorInvalidValue;
+        max_air = std::max(max_air, s.air_index);
+    }
+    std::vector<OriginalAir> airs((size_t)max_air + 1);
+    PW_HIP_TRY(hipMemcpyAsync(airs.data(), d_original_airs, airs.size() * sizeof(OriginalAir), hipMemcpyDeviceToHost, pw::stream()));
+    PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
+    std::vector<int32_t> bsize(airs.size());
+    for (size_t i = 0; i < airs.size(); ++i) {
+        bsize[i] = airs[i].row_block_size;
+        if (bsize[i] < 0) return (int)hipErrorInvalidValue;
+    }
+    uint64_t h = fnv1a(subs.data(), n_subs * sizeof(Subst), 1469598103934665603ull);
+    h = fnv1a(bsize.data(), bsize.size() * sizeof(int32_t), h);
+    PlanKey key{h, n_subs};
+
+    Plan* plan = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        auto it = g_plans.find(key);
+        if (it == g_plans.end()) {
+            Plan p;
+            int rc = build_plan(subs, bsize, p);
+            if (rc) return rc;
+            it = g_plans.emplace(key, std::move(p)).first;
+        }
+        plan = &it->second;
+    }
+
+    pw::ScopedKernelTimer t("apc_gather_tile_kernel");
+    uint32_t* out = d_output;
+    for (const RClass& c : plan->classes) {
+        switch (c.R) {
+            case 32: launch_class<32>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
+            case 64: launch_class<64>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
+            case 128: launch_class<128>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
+            case 256: launch_class<256>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
+            case 512: launch_class<512>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
+            case 1024: launch_class<1024>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
+            default: return (int)hipErrorInvalidValue;
+        }
+    }
+    return (int)hipGetLastError();
+}

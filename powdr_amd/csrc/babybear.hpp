@@ -1,0 +1,100 @@
+// BabyBear field arithmetic for gfx950 device code and for the host-side
+// transcript. p = 2^31 - 2^27 + 1 (pinned by
+// /root/reference/number/src/baby_bear.rs:46-55). Elements live in memory in
+// Montgomery form with R = 2^32, the representation of the reference's device
+// type `Fp` (used at openvm/cuda/src/expr_eval.cuh:36-89) and of
+// p3_baby_bear::BabyBear behind `BabyBearField`
+// (number/src/plonky3_macros.rs:42) — assumption A1 of SURVEY.md.
+//
+// All values are kept fully reduced in [0, p). The Montgomery product is the
+// additive form: t = a*b; m = lo32(t) * (-p^-1); (t + m*p) >> 32 < 2p, one
+// conditional subtract. On CDNA4 this is two v_mad_u64_u32 + one v_mul_lo_u32.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PW_HD __host__ __device__ __forceinline__
+#else
+#define PW_HD inline
+#endif
+
+namespace bb {
+
+constexpr uint32_t P = 0x78000001u;
+constexpr uint32_t NEG_PINV = 0x77ffffffu;  // -p^-1 mod 2^32
+constexpr uint32_t R_MOD_P = 0x0ffffffeu;   // 2^32 mod p  == monty(1)
+constexpr uint32_t R2_MOD_P = 1172168163u;  // 2^64 mod p
+
+PW_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// x in [0, 2p) -> [0, p)
+PW_HD uint32_t reduce_2p(uint32_t x) { return umin(x, x - P); }
+
+PW_HD uint32_t add(uint32_t a, uint32_t b) { return reduce_2p(a + b); }
+PW_HD uint32_t sub(uint32_t a, uint32_t b) {
+    uint32_t d = a - b;
+    return umin(d, d + P);
+}
+PW_HD uint32_t neg(uint32_t a) { return a == 0 ? 0u : P - a; }
+
+// Montgomery reduction of t < p * 2^32: returns t * 2^-32 mod p.
+PW_HD uint32_t monty_reduce(uint64_t t) {
+    uint32_t m = (uint32_t)t * NEG_PINV;
+    uint64_t u = t + (uint64_t)m * P;
+    return reduce_2p((uint32_t)(u >> 32));
+}
+PW_HD uint32_t mul(uint32_t a, uint32_t b) { return monty_reduce((uint64_t)a * b); }
+PW_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
+
+// canonical u32 (< p) <-> Montgomery
+PW_HD uint32_t to_monty(uint32_t canonical) { return mul(canonical, R2_MOD_P); }
+PW_HD uint32_t from_monty(uint32_t x) { return monty_reduce((uint64_t)x); }
+
+PW_HD uint32_t double_(uint32_t a) { return add(a, a); }
+PW_HD uint32_t halve(uint32_t a) {
+    // a/2 mod p: if odd add p (p odd) then shift. a + p < 2^32.
+    uint32_t t = (a & 1u) ? a + P : a;
+    return t >> 1;
+}
+
+PW_HD uint32_t pow_u32(uint32_t a, uint32_t e) {
+    uint32_t r = R_MOD_P;
+    while (e) {
+        if (e & 1u) r = mul(r, a);
+        a = sqr(a);
+        e >>= 1;
+    }
+    return r;
+}
+
+// a^(p-2); p-2 = 0b1110111111111111111111111111111 (31 bits).
+// Chain: x^7 -> x^(2^3-1); then p-2 = (2^4-1)<<27 - ... handled generically:
+// p-2 = 0x77ffffff = 7 * 2^28 + (2^27 - 1).
+PW_HD uint32_t inv(uint32_t a) {
+    uint32_t x2 = sqr(a);
+    uint32_t x3 = mul(x2, a);          // a^3      (2 bits)
+    uint32_t x6 = sqr(x3);
+    uint32_t x7 = mul(x6, a);          // a^7      (3 bits)
+    // a^(2^27-1): build by doubling chain of all-ones exponents
+    uint32_t o3 = x7;                  // 2^3-1
+    uint32_t o6 = o3;
+    for (int i = 0; i < 3; ++i) o6 = sqr(o6);
+    o6 = mul(o6, o3);                  // 2^6-1
+    uint32_t o12 = o6;
+    for (int i = 0; i < 6; ++i) o12 = sqr(o12);
+    o12 = mul(o12, o6);                // 2^12-1
+    uint32_t o24 = o12;
+    for (int i = 0; i < 12; ++i) o24 = sqr(o24);
+    o24 = mul(o24, o12);               // 2^24-1
+    uint32_t o27 = o24;
+    for (int i = 0; i < 3; ++i) o27 = sqr(o27);
+    o27 = mul(o27, o3);                // 2^27-1
+    // result = a^(7*2^28) * a^(2^27-1): (a^7)^(2^28)
+    uint32_t hi = x7;
+    for (int i = 0; i < 28; ++i) hi = sqr(hi);
+    return mul(hi, o27);
+}
+PW_HD uint32_t inv_or_zero(uint32_t a) { return a == 0 ? 0u : inv(a); }
+
+}  // namespace bb

@@ -1,0 +1,93 @@
+// libpowdr_gpu runtime plumbing: launch stream + per-kernel event timing.
+#include "common.hpp"
+#include "../../include/powdr_gpu.h"
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+namespace pw {
+
+static hipStream_t g_stream = nullptr;  // null stream, like the reference (cuda/mod.rs:374-378)
+static bool g_timing = false;
+static std::mutex g_mu;
+struct TimedLaunch {
+    const char* name;
+    hipEvent_t e0, e1;
+};
+static std::vector<TimedLaunch> g_launches;
+
+hipStream_t stream() { return g_stream; }
+void set_stream(hipStream_t s) { g_stream = s; }
+bool timing_enabled() { return g_timing; }
+
+void timing_begin(const char*, hipEvent_t* e0) {
+    (void)hipEventCreate(e0);
+    (void)hipEventRecord(*e0, g_stream);
+}
+void timing_end(const char* name, hipEvent_t e0) {
+    hipEvent_t e1;
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e1, g_stream);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_launches.push_back({name, e0, e1});
+}
+
+static void clear_launches() {
+    for (auto& l : g_launches) {
+        (void)hipEventDestroy(l.e0);
+        (void)hipEventDestroy(l.e1);
+    }
+    g_launches.clear();
+}
+
+}  // namespace pw
+
+extern "C" {
+
+void powdr_gpu_set_stream(void* s) { pw::set_stream((hipStream_t)s); }
+void* powdr_gpu_get_stream(void) { return (void*)pw::stream(); }
+
+void powdr_gpu_timing_enable(int enable) {
+    std::lock_guard<std::mutex> lk(pw::g_mu);
+    pw::clear_launches();
+    pw::g_timing = enable != 0;
+}
+
+size_t powdr_gpu_timing_report(char* buf, size_t cap) {
+    (void)hipStreamSynchronize(pw::g_stream);
+    std::lock_guard<std::mutex> lk(pw::g_mu);
+    std::map<std::string, std::pair<int, double>> agg;
+    std::vector<std::string> order;
+    for (auto& l : pw::g_launches) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, l.e0, l.e1);
+        auto it = agg.find(l.name);
+        if (it == agg.end()) {
+            order.push_back(l.name);
+            agg[l.name] = {1, (double)ms};
+        } else {
+            it->second.first += 1;
+            it->second.second += ms;
+        }
+    }
+    std::string out;
+    char line[256];
+    for (auto& n : order) {
+        snprintf(line, sizeof line, "%s %d %.6f\n", n.c_str(), agg[n].first, agg[n].second);
+        out += line;
+    }
+    if (buf && cap) {
+        size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return out.size() + 1;
+}
+
+const char* powdr_gpu_version(void) { return "powdr_gpu-mi355x 0.1 (gfx950; Fp=BabyBear Montgomery R=2^32)"; }
+
+}  // extern "C"

@@ -1,0 +1,376 @@
+"""Synthetic APC workloads in the reference's own wire format.
+
+No guest program can be built without a Rust/RISC-V toolchain, so benchmarks and
+parity tests run on seeded synthetic autoprecompiles whose SHAPES are pinned by
+the reference's tests:
+
+  C1  sha256-shaped      W = 1 204, H = 2^16,  377 constraints,   954 bus interactions
+  C2  guest-keccak APC   W = 2 022, H = 2^20,  187 constraints, 1 734 bus interactions
+      (openvm-riscv/src/lib.rs:1377-1458), gathered from 5 original AIRs
+      (w, b) = (36,318) BaseAlu, (53,116) Shift, (41,241) LoadStore, (26,1), (18,1)
+  C3  guest-ecrecover    W = 3 731, H = 2^22, 3 114 constraints, 2 314 bus interactions
+
+The generator emits the JSON document `serde_json` would produce for
+`Apc<BabyBear, Instr, _, _>` (autoprecompiles/src/lib.rs:185-195), so the product
+host loader (csrc/host) and the oracle loader both parse exactly what they would
+parse for a real exported APC. Everything is deterministic in `seed`.
+
+Column kinds steer both the dummy-trace filler (so that lookups are in range)
+and the constraint generator (so that every constraint vanishes on valid rows
+and on the all-zero padding rows, as `is_valid`-guarded APC constraints do).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+P = 0x78000001
+
+# opcode of the first instruction class member per original AIR (OpenVM RV32IM numbering)
+AIR_OPCODES = {
+    "BaseAlu": [0x200, 0x202, 0x203, 0x204],
+    "Shift": [0x205, 0x206],
+    "LoadStore": [0x210, 0x213],
+    "BranchEqual": [0x220],
+    "JalLui": [0x230],
+    "LessThan": [0x208],
+    "Mul": [0x250],
+    "DivRem": [0x254],
+}
+
+BUS_EXEC, BUS_MEMORY, BUS_PC, BUS_VAR_RANGE, BUS_BITWISE, BUS_TUPLE = 0, 1, 2, 3, 6, 7
+TUPLE_SIZES = (256, 2048)  # openvm-bus-interaction-handler/src/lib.rs:44
+VAR_RANGE_MAX_BITS = 17  # bins = 2^(17+1)
+
+
+@dataclass
+class Shape:
+    name: str
+    width: int
+    log_height: int
+    n_constraints: int
+    n_interactions: int
+    airs: list  # [(air name, width, instructions per call)]
+    n_quotient: int = 4
+    config_id: int = 0
+
+
+SHAPES = {
+    "C1": Shape("sha256-shaped", 1204, 16, 377, 954,
+                [("BaseAlu", 36, 160), ("Shift", 53, 60), ("LoadStore", 41, 96), ("LessThan", 37, 12)], config_id=1),
+    "C2": Shape("guest-keccak", 2022, 20, 187, 1734,
+                [("BaseAlu", 36, 318), ("Shift", 53, 116), ("LoadStore", 41, 241), ("BranchEqual", 26, 1), ("JalLui", 18, 1)], config_id=2),
+    "C3": Shape("guest-ecrecover", 3731, 22, 3114, 2314,
+                [("BaseAlu", 36, 420), ("Shift", 53, 64), ("LoadStore", 41, 310), ("Mul", 31, 96), ("LessThan", 37, 40), ("BranchEqual", 26, 1)], config_id=3),
+    # small shapes for tests
+    "T0": Shape("tiny", 24, 6, 9, 20, [("BaseAlu", 36, 3), ("Shift", 53, 2), ("JalLui", 18, 1)], n_quotient=2, config_id=100),
+    "T1": Shape("small", 160, 10, 40, 120, [("BaseAlu", 36, 20), ("Shift", 53, 7), ("LoadStore", 41, 12), ("BranchEqual", 26, 1)], n_quotient=3, config_id=101),
+}
+
+
+@dataclass
+class SynthApc:
+    doc: dict  # the JSON document (wire format)
+    shape: Shape
+    poly_ids: list  # ascending; column index = position
+    kinds: dict  # poly_id -> (kind, bound)   kind in valid|derived|bit|tri|byte|range|field
+    instr_air: list  # per instruction: AIR name ('' if the instruction has no substitutions)
+    airs: list  # [(name, width, effective row_block_size)] in order of first appearance
+    source_of: dict  # poly_id -> (air name, block row, column) for substituted columns
+    n_nodes_bus: int = 0
+    n_nodes_constraints: int = 0
+
+
+def _ref(pid):
+    return f"c{pid}_0@{pid}"
+
+
+def _count(e):
+    if isinstance(e, list):
+        return 1 + sum(_count(x) for x in e if not (isinstance(x, str) and x in "+-*"))
+    return 1
+
+
+def generate(shape: Shape | str, seed: int = 0, verbosity: float = 1.0, density_note: str = "uniform") -> SynthApc:
+    if isinstance(shape, str):
+        shape = SHAPES[shape]
+    rng = np.random.Generator(np.random.PCG64(0x504F574452 ^ shape.config_id ^ (seed << 20)))
+    W = shape.width
+    # sparse, ascending poly ids (the reference orders columns by id, powdr.rs:44-57)
+    poly_ids = sorted(rng.choice(4 * W, size=W, replace=False).tolist())
+
+    # ---- column kinds -------------------------------------------------------------------
+    nq = shape.n_quotient
+    order = rng.permutation(W).tolist()
+    kinds: dict[int, tuple] = {}
+    valid_pid = poly_ids[order[0]]
+    kinds[valid_pid] = ("valid", 2)
+    derived_pids = [poly_ids[i] for i in order[1 : 1 + nq]]
+    for pid in derived_pids:
+        kinds[pid] = ("derived", P)
+    rest = [poly_ids[i] for i in order[1 + nq :]]
+    n = len(rest)
+    cuts = np.cumsum([int(n * f) for f in (0.08, 0.02, 0.35, 0.25)]).tolist()
+    for i, pid in enumerate(rest):
+        if i < cuts[0]:
+            kinds[pid] = ("bit", 2)
+        elif i < cuts[1]:
+            kinds[pid] = ("tri", 3)
+        elif i < cuts[2]:
+            kinds[pid] = ("byte", 256)
+        elif i < cuts[3]:
+            bits = int(rng.choice([11, 12, 13, 14, 17]))
+            kinds[pid] = ("range", 1 << bits)
+        else:
+            kinds[pid] = ("field", P)
+    by_kind: dict[str, list] = {}
+    for pid, (k, bnd) in kinds.items():
+        by_kind.setdefault(k, []).append(pid)
+    for v in by_kind.values():
+        v.sort()
+
+    def pick(kind):
+        lst = by_kind[kind]
+        return lst[int(rng.integers(len(lst)))]
+
+    def pad(e, nodes_target):
+        """Inflate an expression the way un-optimised machines look (0 + x, x * 1)."""
+        while _count(e) < nodes_target:
+            r = rng.random()
+            if r < 0.4:
+                e = [0, "+", e]
+            elif r < 0.7:
+                e = [e, "*", 1]
+            elif r < 0.85:
+                e = [e, "-", 0]
+            else:
+                e = ["-", ["-", e]]
+        return e
+
+    # ---- derived columns ----------------------------------------------------------------
+    derived_json = [[_ref(valid_pid), {"Constant": 1}]]
+    derived_defs = {}
+    non_derived = [p for p in rest]
+    for k, pid in enumerate(derived_pids):
+        a, b, c = (non_derived[int(i)] for i in rng.integers(len(non_derived), size=3))
+        if k % 2 == 0:
+            e1 = [[_ref(a), "*", _ref(b)], "+", _ref(c)]  # degree 2 numerator
+            e2 = [_ref(pick("field")), "+", int(rng.integers(1, 1000))]
+        else:
+            e1 = [_ref(a), "+", [int(rng.integers(1, 1 << 20)), "*", _ref(b)]]
+            e2 = 1  # plain expression column
+            if k >= 1 and rng.random() < 0.5:
+                e1 = [e1, "+", _ref(derived_pids[k - 1])]  # later derived columns may read earlier ones
+        derived_json.append([_ref(pid), {"QuotientOrZero": [e1, e2]}])
+        derived_defs[pid] = (e1, e2)
+
+    # ---- substitutions: every non-derived column <- one cell of one original instruction -----
+    cells_per_air = [(name, w, b) for name, w, b in shape.airs]
+    total_cells = sum(w * b for _, w, b in cells_per_air)
+    n_sub = len(non_derived)
+    assert n_sub <= total_cells, "more APC columns than source cells"
+    flat = rng.choice(total_cells, size=n_sub, replace=False)
+    flat.sort()
+    # instructions: b_k per AIR, shuffled program order
+    instr_list = []
+    for name, w, b in cells_per_air:
+        for j in range(b):
+            instr_list.append((name, j))
+    perm = rng.permutation(len(instr_list)).tolist()
+    instr_list = [instr_list[i] for i in perm]
+    cell_owner = {}  # (air, j) -> [(col, pid)]
+    base = 0
+    bounds = []
+    for name, w, b in cells_per_air:
+        bounds.append((base, base + w * b, name, w))
+        base += w * b
+    sub_cols = rng.permutation(non_derived).tolist()
+    for cell, pid in zip(flat.tolist(), sub_cols):
+        for lo, hi, name, w in bounds:
+            if lo <= cell < hi:
+                j, col = divmod(cell - lo, w)
+                cell_owner.setdefault((name, j), []).append((col, pid))
+                break
+    instructions, subs_json, instr_air = [], [], []
+    eff_rows: dict[str, int] = {}
+    air_order: list[str] = []
+    source_of = {}
+    for name, j in instr_list:
+        ops = AIR_OPCODES[name]
+        opcode = ops[int(rng.integers(len(ops)))]
+        instructions.append([opcode] + [int(x) for x in rng.integers(0, 128, size=7)])
+        owned = sorted(cell_owner.get((name, j), []))
+        subs_json.append([{"original_poly_index": c, "apc_poly_id": p} for c, p in owned])
+        if owned:
+            if name not in air_order:
+                air_order.append(name)
+            row = eff_rows.get(name, 0)
+            eff_rows[name] = row + 1
+            instr_air.append(name)
+            for c, p in owned:
+                source_of[p] = (name, row, c)
+        else:
+            instr_air.append("")
+    widths = {name: w for name, w, _ in cells_per_air}
+    airs = [(name, widths[name], eff_rows[name]) for name in air_order]
+
+    # ---- bus interactions ------------------------------------------------------------------
+    n_int = shape.n_interactions
+    n_exec = 2
+    remaining = n_int - n_exec
+    n_mem = int(remaining * 0.30)
+    n_var = int(remaining * 0.45)
+    n_bit = remaining - n_mem - n_var
+    n_tuple = max(1, n_var // 20)
+    n_var -= n_tuple
+    plan = ["exec"] * n_exec + ["mem"] * n_mem + ["var"] * n_var + ["tuple"] * n_tuple + ["bitwise"] * n_bit
+    plan = [plan[i] for i in rng.permutation(len(plan)).tolist()]
+    mean_nodes = 6.0 * verbosity
+
+    def mult_expr():
+        r = rng.random()
+        if r < 0.75:
+            return _ref(valid_pid)
+        if r < 0.92:
+            return [_ref(valid_pid), "*", _ref(pick("bit"))]
+        return [_ref(valid_pid), "*", int(rng.integers(2, 4))]
+
+    def nodes():
+        return max(1, int(rng.exponential(mean_nodes)))
+
+    buses = []
+    for kind in plan:
+        if kind == "exec":
+            buses.append({"id": BUS_EXEC, "mult": ["-", _ref(valid_pid)] if len(buses) % 2 else _ref(valid_pid),
+                          "args": [pad(_ref(pick("field")), nodes()), pad(_ref(pick("field")), nodes())]})
+        elif kind == "mem":
+            args = [int(rng.integers(1, 3)), pad(_ref(pick("field")), nodes())]
+            args += [_ref(pick("byte")) for _ in range(4)] + [pad(_ref(pick("field")), nodes())]
+            buses.append({"id": BUS_MEMORY, "mult": mult_expr() if rng.random() < 0.5 else ["-", mult_expr()], "args": args})
+        elif kind == "var":
+            if rng.random() < 0.7:
+                pid = pick("range")
+                bits = kinds[pid][1].bit_length() - 1
+                val = _ref(pid)
+            else:
+                val = [_ref(pick("byte")), "+", [256, "*", _ref(pick("byte"))]]
+                bits = int(rng.choice([16, 17]))
+            buses.append({"id": BUS_VAR_RANGE, "mult": mult_expr(), "args": [pad(val, nodes()), bits]})
+        elif kind == "tuple":
+            r11 = [p for p in by_kind["range"] if kinds[p][1] <= TUPLE_SIZES[1]]
+            v1 = _ref(r11[int(rng.integers(len(r11)))]) if r11 else _ref(pick("byte"))
+            buses.append({"id": BUS_TUPLE, "mult": mult_expr(), "args": [pad(_ref(pick("byte")), nodes()), v1]})
+        else:
+            sel = int(rng.integers(0, 2))
+            x, y = _ref(pick("byte")), _ref(pick("byte"))
+            if rng.random() < 0.3:
+                x = [[255, "-", _ref(pick("byte"))], "*", 1]
+            buses.append({"id": BUS_BITWISE, "mult": mult_expr(),
+                          "args": [pad(x, nodes()), pad(y, nodes()), _ref(pick("byte")), sel]})
+
+    # ---- constraints (vanish on valid rows and on all-zero rows) ---------------------------
+    cons = [[_ref(valid_pid), "*", [_ref(valid_pid), "-", 1]]]
+
+    def lin():
+        a, b = pick("field"), pick("byte")
+        return [[_ref(a), "+", [int(rng.integers(1, P)), "*", _ref(b)]], "+", int(rng.integers(0, P))]
+
+    while len(cons) < shape.n_constraints:
+        r = rng.random()
+        if r < 0.35:
+            b = _ref(pick("bit"))
+            c = [b, "*", [b, "-", 1]]
+            if rng.random() < 0.5:
+                c = [c, "*", lin()]
+        elif r < 0.45:
+            t = _ref(pick("tri"))
+            c = [t, "*", [[t, "-", 1], "*", [t, "-", 2]]]
+        else:
+            pid = derived_pids[int(rng.integers(len(derived_pids)))] if derived_pids else None
+            if pid is None:
+                continue
+            e1, e2 = derived_defs[pid]
+            body = [[_ref(pid), "*", e2], "-", e1]  # d*e2 - e1, degree <= 2
+            c = [_ref(valid_pid), "*", body]
+        cons.append(pad(c, int(_count(c) * (1 + rng.random() * verbosity))))
+
+    doc = {
+        "block": {"blocks": [{"start_pc": 0x200000, "instructions": instructions}]},
+        "machine": {"constraints": cons, "bus_interactions": buses, "derived_columns": derived_json},
+        "subs": subs_json,
+        "optimistic_constraints": {"fetches_by_step": {}, "constraints_to_check_by_step": {}},
+        "bus_map": {"bus_ids": {"0": "ExecutionBridge", "1": "Memory", "2": "PcLookup",
+                                "3": {"Other": "VariableRangeChecker"}, "6": {"Other": "BitwiseLookup"},
+                                "7": {"Other": {"TupleRangeChecker": list(TUPLE_SIZES)}}}},
+    }
+    # every column must be referenced by a constraint or a bus interaction to exist
+    # (main_columns = unique references); reference the stragglers through memory sends.
+    referenced = set()
+
+    def walk(e):
+        if isinstance(e, str):
+            if "@" in e:
+                referenced.add(int(e[e.rfind("@") + 1 :]))
+        elif isinstance(e, list):
+            for x in e:
+                walk(x)
+
+    for c in cons:
+        walk(c)
+    for b in buses:
+        walk(b["mult"])
+        for a in b["args"]:
+            walk(a)
+    missing = [p for p in poly_ids if p not in referenced]
+    # fold the missing columns into the args of memory interactions (8 at a time)
+    mem_idx = [i for i, b in enumerate(buses) if b["id"] == BUS_MEMORY]
+    k = 0
+    while missing:
+        chunk, missing = missing[:8], missing[8:]
+        e = _ref(chunk[0])
+        for p in chunk[1:]:
+            e = [e, "+", _ref(p)]
+        b = buses[mem_idx[k % len(mem_idx)]]
+        b["args"].append(e)
+        k += 1
+
+    s = SynthApc(doc, shape, poly_ids, kinds, instr_air, airs, source_of)
+    s.n_nodes_bus = sum(_count(b["mult"]) + sum(_count(a) for a in b["args"]) for b in buses)
+    s.n_nodes_constraints = sum(_count(c) for c in cons)
+    return s
+
+
+def next_pow2_or_zero(n: int) -> int:
+    """openvm_circuit::utils::next_power_of_two_or_zero."""
+    return 0 if n == 0 else 1 << (n - 1).bit_length()
+
+
+def dummy_trace_dims(s: SynthApc, num_calls: int, pow2: bool = True):
+    """[(air name, width, height, row_block_size)]; height like the original chips' traces:
+    next_pow2(rows) (cuda/mod.rs:244-245 takes `common_main` of the dummy chip)."""
+    out = []
+    for name, w, b in s.airs:
+        rows = b * num_calls
+        h = next_pow2_or_zero(rows) if pow2 else (rows + 3) // 4 * 4
+        out.append((name, w, max(h, 4), b))
+    return out
+
+
+def fill_dummy_traces_numpy(s: SynthApc, num_calls: int, seed: int = 0, pow2: bool = True):
+    """Canonical column-major dummy traces (numpy uint32), cells that feed bounded column
+    kinds drawn below their bound. Returns list of arrays in `s.airs` order."""
+    rng = np.random.Generator(np.random.PCG64(seed + 977))
+    dims = dummy_trace_dims(s, num_calls, pow2)
+    bufs = []
+    for name, w, h, b in dims:
+        bufs.append(rng.integers(0, P, size=w * h, dtype=np.uint32))
+    idx = {name: i for i, (name, _, _, _) in enumerate(dims)}
+    for pid, (name, row, col) in s.source_of.items():
+        kind, bound = s.kinds[pid]
+        if bound >= P:
+            continue
+        _, w, h, b = dims[idx[name]]
+        view = bufs[idx[name]][col * h + row : col * h + row + b * num_calls : b]
+        view[:] = rng.integers(0, bound, size=len(view), dtype=np.uint32)
+    return bufs, dims

@@ -1,0 +1,268 @@
+"""Parity of the HIP trace-generation kernels against the CPU oracle, through the C ABI.
+
+Bit-exact: BabyBear cells compared in canonical form, histograms as u32 counters.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import apc_model as om
+from powdr_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from powdr_amd import abi, tracegen  # raises if libpowdr_gpu.so is missing
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch, abi, tracegen
+
+
+def to_dev(torch, a_canonical):
+    return torch.from_numpy(om.to_monty(a_canonical).view(np.int32)).cuda()
+
+
+def from_dev(t):
+    return om.from_monty(t.cpu().numpy().view(np.uint32))
+
+
+def hist_np(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def run_gpu(gpu, W, H, num_calls, bufs, dims, air_names, rbs, subs, derived, bus, prefill=None):
+    torch, abi, tg = gpu
+    out = tg.DeviceMatrix.zeros(H, W)
+    if prefill is not None:
+        out.buf.copy_(torch.from_numpy(prefill.view(np.int32)))
+    name_to = {n: i for i, (n, _, _, _) in enumerate(dims)}
+    airs = []
+    keep = []
+    for n, b in zip(air_names, rbs):
+        _, w, h, _ = dims[name_to[n]]
+        t = to_dev(torch, bufs[name_to[n]])
+        keep.append(t)
+        airs.append((t, w, h, b))
+    keep.append(tg.apc_tracegen(out, airs, subs, num_calls))
+    if derived is not None:
+        keep.append(tg.apc_apply_derived_expr(out, num_calls, *derived))
+    per = tg.Periphery.fresh()
+    if bus is not None:
+        inter, spans, bc = bus
+        keep.append(tg.apc_apply_bus(out, num_calls, bc, inter, spans, per))
+    torch.cuda.synchronize()
+    return out, per
+
+
+@pytest.mark.parametrize("shape,num_calls,seed", [("T0", 1, 0), ("T0", 5, 1), ("T0", 64, 2), ("T1", 37, 3),
+                                                   ("T1", 1000, 4), ("T1", 4096, 5), ("C1", 300, 6)])
+def test_synthetic_apc_parity(gpu, shape, num_calls, seed):
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+
+    s = synth.generate(shape, seed=seed)
+    apc, idx, want, hist, (bufs, dims, gt, order) = run_oracle_gpu_convention(s, num_calls, seed=seed)
+    W, H = want.shape
+    derived = om.compile_derived(apc, idx, H)
+    inter, spans, bc = om.compile_bus(apc, idx, H)
+    out, per = run_gpu(gpu, W, H, num_calls, bufs, dims, gt.air_names, gt.row_block_size, gt.subs, derived, (inter, spans, bc))
+    got = from_dev(out.buf).reshape(W, H)
+    assert (got == want).all()
+    assert (hist_np(per.var_hist) == hist["var"]).all()
+    assert (hist_np(per.tuple_hist) == hist["tuple"]).all()
+    assert (hist_np(per.bitwise_hist) == hist["bitwise"]).all()
+    assert hist["var"].sum() > 0
+
+
+def _scaled(bc, pos, H):
+    bc = bc.copy()
+    bc[pos] = (bc[pos].astype(np.uint64) * H).astype(np.uint32)
+    return bc
+
+
+@pytest.mark.parametrize("name,num_calls", [("single_div_nondet", 77), ("keccak_apc_pre_opt", 96)])
+def test_reference_fixture_apc_parity(gpu, name, num_calls):
+    """The reference's own APC fixtures (autoprecompiles/tests/*.json.gz, compiled to flat
+    tables by tests/golden/make_golden.py): full pre-optimisation keccak block = 27 521
+    substitutions from 5 AIRs and 13 262 bus interactions."""
+    z = np.load(GOLDEN / f"{name}.apc.npz")
+    W = len(z["poly_ids"])
+    H = synth.next_pow2_or_zero(num_calls)
+    rng = np.random.default_rng(42)
+    bound = z["col_bound"]
+    rbs, widths, subs = z["row_block_size"], z["air_widths"], z["subs"]
+    bufs, dims = [], []
+    for k, (w, b) in enumerate(zip(widths, rbs)):
+        h = max(synth.next_pow2_or_zero(int(b) * num_calls), 4)
+        bufs.append(rng.integers(0, 256, size=int(w) * h, dtype=np.uint32))
+        dims.append((str(z["air_names"][k]), int(w), h, int(b)))
+    # cells feeding tighter-bounded columns
+    for a, col, row, apc_col in subs:
+        if bound[apc_col] < 256:
+            _, w, h, b = dims[a]
+            v = bufs[a][col * h + row : col * h + row + b * num_calls : b]
+            v[:] = rng.integers(0, bound[apc_col], size=len(v), dtype=np.uint32)
+    want = om.c_apc_tracegen(H, W, bufs, [d[2] for d in dims], rbs, subs, num_calls)
+    bc = _scaled(z["bus_bc"], z["bus_apc_pos"], H)
+    hist = dict(var=np.zeros(1 << 18, np.uint32), tuple=np.zeros(256 * 2048, np.uint32), bitwise=np.zeros(2 * 65536, np.uint32))
+    om.c_apc_apply_bus(want, num_calls, bc, z["bus_inter"], z["bus_spans"], 3, hist["var"], 7, hist["tuple"], 256, 2048, 6, hist["bitwise"])
+    names = [d[0] for d in dims]
+    out, per = run_gpu(gpu, W, H, num_calls, bufs, dims, names, rbs.tolist(), subs, None, (z["bus_inter"], z["bus_spans"], bc))
+    assert (from_dev(out.buf) == want).all()
+    assert (hist_np(per.var_hist) == hist["var"]).all()
+    assert (hist_np(per.tuple_hist) == hist["tuple"]).all()
+    assert (hist_np(per.bitwise_hist) == hist["bitwise"]).all()
+    assert hist["var"].sum() > 0 and hist["bitwise"].sum() > 0
+
+
+def test_gather_edge_cases(gpu):
+    torch, abi, tg = gpu
+    rng = np.random.default_rng(7)
+    # (a) H = 0 and n_subs = 0 succeed and touch nothing
+    out = tg.DeviceMatrix.zeros(0, 4)
+    src = to_dev(torch, rng.integers(0, om.P, size=64, dtype=np.uint32))
+    tg.apc_tracegen(out, [(src, 4, 16, 1)], np.zeros((0, 4), np.int32), 0)
+    # (b) non-power-of-two height is rejected (reference: assert, apc_tracegen.cu:134)
+    out = tg.DeviceMatrix.zeros(24, 2)
+    with pytest.raises(abi.HipError):
+        tg.apc_tracegen(out, [(src, 4, 16, 1)], np.array([[0, 0, 0, 0]], np.int32), 3)
+    # (c) duplicate destination: the later substitution wins, like the sequential reference loop;
+    #     padding rows are zeroed even if the caller did not clear the buffer; untouched columns stay
+    H, W, calls = 16, 3, 11
+    a0 = rng.integers(0, om.P, size=5 * 64, dtype=np.uint32)  # width 5, height 64, block 4
+    subs = np.array([[0, 1, 2, 0], [0, 3, 0, 0], [0, 4, 3, 2]], np.int32)
+    prefill = om.to_monty(rng.integers(0, om.P, size=H * W, dtype=np.uint32))
+    want = om.from_monty(prefill.copy())
+    om.c_apc_tracegen(H, W, [a0], [64], [4], subs, calls, out=want)
+    out = tg.DeviceMatrix.zeros(H, W)
+    out.buf.copy_(torch.from_numpy(prefill.view(np.int32)))
+    tg.apc_tracegen(out, [(to_dev(torch, a0), 5, 64, 4)], subs, calls)
+    torch.cuda.synchronize()
+    assert (from_dev(out.buf) == want).all()
+
+
+@pytest.mark.parametrize("b,n_sub_rows,calls", [(1, 1, 1000), (2, 2, 513), (7, 3, 300), (64, 64, 200),
+                                                  (383, 50, 130), (600, 40, 70), (1500, 9, 33), (318, 318, 257)])
+def test_gather_block_shapes(gpu, b, n_sub_rows, calls):
+    """Row-block sizes around every planner decision: tiny blocks (big R), blocks that fit one
+    LDS tile, blocks larger than a tile (row chunks), dense and sparse substitutions."""
+    torch, abi, tg = gpu
+    rng = np.random.default_rng(b * 1000 + calls)
+    w = 6
+    H = synth.next_pow2_or_zero(calls)
+    h = synth.next_pow2_or_zero(b * calls)
+    h = max(h, 4)
+    src = rng.integers(0, om.P, size=w * h, dtype=np.uint32)
+    rows = np.sort(rng.choice(b, size=min(n_sub_rows, b), replace=False))
+    recs = []
+    apc_col = 0
+    for col in (0, 2, 5):
+        for r in rows:
+            if rng.random() < 0.8:
+                recs.append((0, col, int(r), apc_col))
+                apc_col += 1
+    recs = np.array(recs, np.int32)
+    recs = recs[rng.permutation(len(recs))]
+    W = apc_col
+    want = om.c_apc_tracegen(H, W, [src], [h], [b], recs, calls)
+    out = tg.DeviceMatrix.zeros(H, W)
+    tg.apc_tracegen(out, [(to_dev(torch, src), w, h, b)], recs, calls)
+    torch.cuda.synchronize()
+    assert (from_dev(out.buf) == want).all()
+
+
+def test_derived_and_bus_edge_cases(gpu):
+    torch, abi, tg = gpu
+    H, W, calls = 8, 4, 6
+    rng = np.random.default_rng(3)
+    trace = rng.integers(0, om.P, size=H * W, dtype=np.uint32)
+    trace[0:H] = [0, 1, 2, 3, 300, 255, 0, 0]        # column 0: x
+    trace[H : 2 * H] = [0, 7, 255, 256, 1, 2, 0, 0]   # column 1: y
+    out = tg.DeviceMatrix.zeros(H, W)
+    out.buf.copy_(to_dev(torch, trace))
+    # n_cols == 0 returns immediately (apc_tracegen.cu:114); num_calls <= 0 for the bus too
+    tg.apc_apply_derived_expr(out, calls, np.zeros(0, np.uint64), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(1, np.uint32))
+    per = tg.Periphery.fresh()
+    inter = np.array([[6, 4, 0], [3, 2, 5], [7, 2, 8], [9, 1, 11]], np.uint32)  # bitwise, var, tuple, unknown bus
+    PA, PC = om.OP_PUSH_APC, om.OP_PUSH_CONST
+    bc, spans = [], []
+
+    def span(words):
+        spans.append((len(bc), len(words)))
+        bc.extend(words)
+
+    span([PC, 3])              # mult 3
+    span([PA, 0 * H])          # x
+    span([PA, 1 * H])          # y
+    span([PC, 0])              # x^y (never read)
+    span([PC, 1])              # selector xor
+    span([PC, 2])              # var: mult 2
+    span([PA, 0 * H])          # value = x
+    span([PC, 9])              # bits
+    span([PC, 1])              # tuple: mult
+    span([PA, 1 * H])          # v0 = y
+    span([PA, 0 * H])          # v1 = x
+    span([PC, 1])              # unknown bus: mult
+    span([PA, 3 * H])
+    tg.apc_apply_bus(out, 0, bc, inter, spans, per)
+    torch.cuda.synchronize()
+    assert int(per.var_hist.sum()) == 0
+    tg.apc_apply_bus(out, calls, bc, inter, spans, per)
+    torch.cuda.synchronize()
+    want = dict(var=np.zeros(1 << 18, np.uint32), tuple=np.zeros(256 * 2048, np.uint32), bitwise=np.zeros(2 * 65536, np.uint32))
+    om.c_apc_apply_bus(trace, calls, np.array(bc, np.uint32), inter, np.array(spans, np.uint32), 3, want["var"], 7, want["tuple"], 256, 2048, 6, want["bitwise"])
+    assert (hist_np(per.var_hist) == want["var"]).all()
+    assert (hist_np(per.tuple_hist) == want["tuple"]).all()
+    assert (hist_np(per.bitwise_hist) == want["bitwise"]).all()
+    # x = 300 is not a byte: dropped; multiplicity 3 applied as +3
+    assert want["bitwise"][65536 + 1 * 256 + 7] == 3 and want["bitwise"].sum() == 3 * 4
+    # derived: later columns read earlier ones of the same row; rows >= calls are zeroed
+    col_base = np.array([2 * H, 3 * H], np.uint64)
+    dbc = [PA, 1 * H, om.OP_INV_OR_ZERO, PA, 0 * H, om.OP_MUL,   # col2 = x / y or 0
+           PA, 2 * H, PA, 2 * H, om.OP_MUL, om.OP_NEG]            # col3 = -(col2^2)
+    offs, lens = np.array([0, 6], np.uint32), np.array([6, 6], np.uint32)
+    want_t = trace.copy()
+    om.c_apc_apply_derived(want_t, H, calls, col_base, offs, lens, np.array(dbc, np.uint32))
+    tg.apc_apply_derived_expr(out, calls, col_base, offs, lens, np.array(dbc, np.uint32))
+    torch.cuda.synchronize()
+    assert (from_dev(out.buf) == want_t).all()
+    assert (want_t[2 * H + calls : 3 * H] == 0).all() and want_t[2 * H] == 0  # y = 0 -> 0
+
+
+def test_large_gather_property(gpu):
+    """C2-shaped gather at 2^15 calls (sources ~5 GB): every output cell equals the source cell
+    the substitution names, checked on device with an independent torch gather; padding is zero."""
+    torch, abi, tg = gpu
+    s = synth.generate("C2", seed=0)
+    apc = om.load_apc(s.doc)
+    idx = apc.poly_id_to_index()
+    gt = om.build_gpu_tables(apc, idx)
+    calls = (1 << 15) - 123
+    H = 1 << 15
+    W = len(idx)
+    dims = {n: (w, b) for n, w, b in s.airs}
+    g = torch.Generator(device="cuda").manual_seed(1)
+    airs = []
+    for n, b in zip(gt.air_names, gt.row_block_size):
+        w, b2 = dims[n]
+        assert b2 == b
+        h = max(synth.next_pow2_or_zero(b * calls), 4)
+        airs.append((torch.randint(0, om.P, (w * h,), dtype=torch.int32, device="cuda", generator=g), w, h, b))
+    out = tg.DeviceMatrix(torch.full((H * W,), 0x55, dtype=torch.int32, device="cuda"), H, W)
+    keep = tg.apc_tracegen(out, airs, gt.subs, calls)
+    torch.cuda.synchronize()
+    r = torch.arange(calls, device="cuda", dtype=torch.int64)
+    m = out.buf.view(W, H)
+    sel = np.random.default_rng(0).choice(len(gt.subs), size=300, replace=False)
+    for a, col, row, apc_col in gt.subs[sel]:
+        t, w, h, b = airs[a]
+        want = t[col * h + row + r * b]
+        assert torch.equal(m[apc_col, :calls], want)
+        assert int(m[apc_col, calls:].abs().sum()) == 0
+    # columns without a substitution (derived ones) are untouched
+    untouched = sorted(set(range(W)) - set(gt.subs[:, 3].tolist()))
+    assert untouched and all(int((m[c] != 0x55).sum()) == 0 for c in untouched)
