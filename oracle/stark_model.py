@@ -1,0 +1,117 @@
+"""TEST INFRASTRUCTURE — Python bindings of oracle/stark_oracle.cpp (pw-stark v0 CPU oracle).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import apc_model as om
+
+P = om.P
+
+
+def _lib():
+    lib = om.c_oracle()
+    lib.or_prove.restype = C.c_size_t
+    lib.or_verify.restype = C.c_int
+    lib.or_root_of_unity.restype = C.c_uint32
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def poseidon2(state) -> np.ndarray:
+    s = np.ascontiguousarray(state, dtype=np.uint32).copy()
+    assert s.shape == (16,)
+    _lib().or_poseidon2_permute(_p(s))
+    return s
+
+
+def poseidon2_constants():
+    e, i, d = np.zeros((8, 16), np.uint32), np.zeros(13, np.uint32), np.zeros(16, np.uint32)
+    _lib().or_poseidon2_constants(_p(e), _p(i), _p(d))
+    return e, i, d
+
+
+def root_of_unity(log_n: int) -> int:
+    return int(_lib().or_root_of_unity(C.c_int(log_n)))
+
+
+def ext_mul(a, b):
+    a, b = (np.ascontiguousarray(x, dtype=np.uint32) for x in (a, b))
+    o = np.zeros(4, np.uint32)
+    _lib().or_ext_mul(_p(a), _p(b), _p(o))
+    return o
+
+
+def ext_inv(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    o = np.zeros(4, np.uint32)
+    _lib().or_ext_inv(_p(a), _p(o))
+    return o
+
+
+def dft(a, inverse=False):
+    a = np.ascontiguousarray(a, dtype=np.uint32).copy()
+    log_n = int(len(a)).bit_length() - 1
+    _lib().or_dft(_p(a), C.c_int(log_n), C.c_int(1 if inverse else 0))
+    return a
+
+
+def dft_naive(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    out = np.zeros_like(a)
+    _lib().or_dft_naive(_p(a), _p(out), C.c_int(int(len(a)).bit_length() - 1))
+    return out
+
+
+def lde(trace_cm: np.ndarray, width: int, log_h: int) -> np.ndarray:
+    """trace_cm: flat column-major W x H canonical. Returns flat column-major W x 2H (natural order)."""
+    t = np.ascontiguousarray(trace_cm, dtype=np.uint32)
+    out = np.zeros(width * (2 << log_h), np.uint32)
+    _lib().or_lde(_p(t), C.c_uint32(width), C.c_int(log_h), _p(out))
+    return out
+
+
+def merkle_commit(m_cm: np.ndarray, height: int, width: int, want_digests=False):
+    m = np.ascontiguousarray(m_cm, dtype=np.uint32)
+    root = np.zeros(8, np.uint32)
+    dig = np.zeros((2 * height - 1) * 8, np.uint32) if want_digests else None
+    _lib().or_merkle_commit(_p(m), C.c_size_t(height), C.c_size_t(width), _p(dig) if want_digests else None, _p(root))
+    return (root, dig) if want_digests else root
+
+
+def compile_constraints(apc: om.Apc, idx: dict):
+    """Constraint programs with column-index operands -> (bytecode u32[], spans u32[n,2])."""
+    bc, spans = [], []
+    for c in apc.constraints:
+        off = len(bc)
+        om.emit_expr(bc, c, idx, 1)
+        spans.append((off, len(bc) - off))
+    return np.array(bc, np.uint32), np.array(spans, np.uint32).reshape(-1, 2)
+
+
+def prove(trace_cm, width, log_h, cons_bc, cons_spans, num_queries=8, pow_bits=0) -> np.ndarray:
+    lib = _lib()
+    t = np.ascontiguousarray(trace_cm, dtype=np.uint32)
+    bc = np.ascontiguousarray(cons_bc, dtype=np.uint32)
+    sp = np.ascontiguousarray(cons_spans, dtype=np.uint32)
+    args = (C.c_uint32(num_queries), C.c_uint32(pow_bits), _p(t), C.c_uint32(width), C.c_uint32(log_h), _p(bc), _p(sp), C.c_size_t(len(sp)))
+    cap = 1 << 16
+    while True:
+        buf = np.zeros(cap, np.uint32)
+        n = lib.or_prove(*args, _p(buf), C.c_size_t(cap))
+        if n <= cap:
+            return buf[:n].copy()
+        cap = int(n)
+
+
+def verify(proof, width, log_h, cons_bc, cons_spans, num_queries=8, pow_bits=0) -> int:
+    pr = np.ascontiguousarray(proof, dtype=np.uint32)
+    bc = np.ascontiguousarray(cons_bc, dtype=np.uint32)
+    sp = np.ascontiguousarray(cons_spans, dtype=np.uint32)
+    return int(_lib().or_verify(C.c_uint32(num_queries), C.c_uint32(pow_bits), _p(pr), C.c_size_t(len(pr)), C.c_uint32(width),
+                                C.c_uint32(log_h), _p(bc), _p(sp), C.c_size_t(len(sp))))

@@ -119,6 +119,7 @@ extern "C" int _apc_apply_derived_expr(PowdrFp* d_output, size_t H, int num_apc_
                                        const DerivedExprSpec* d_specs, size_t n_cols,
                                        const uint32_t* d_bytecode) {
     if (n_cols == 0) return 0;  // apc_tracegen.cu:114
+    (void)hipGetLastError();    // do not report a stale error of an unrelated earlier call
     if (H == 0) return (int)hipGetLastError();
     unsigned g = pw::div_up(H, kBlock);
     if (g > 65535u * 16u) g = 65535u * 16u;
@@ -139,6 +140,7 @@ extern "C" int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
     (void)bytecode_len;
     (void)n_arg_spans;
     if (num_apc_calls <= 0) return 0;  // apc_apply_bus.cu:146
+    (void)hipGetLastError();
     if (n_interactions == 0) return (int)hipGetLastError();
     const unsigned row_blocks = pw::div_up((size_t)num_apc_calls, kBlock);
     // Enough workgroups to cover 256 CUs x 8 blocks even for short traces.

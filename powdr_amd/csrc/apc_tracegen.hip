@@ -327,6 +327,7 @@ void launch_class(const RClass& c, uint32_t* out, size_t H, const OriginalAir* a
 extern "C" int _apc_tracegen(PowdrFp* d_output, size_t output_height,
                              const OriginalAir* d_original_airs, const Subst* d_subs,
                              size_t n_subs, int num_apc_calls) {
+    (void)hipGetLastError();  // do not report a stale error of an unrelated earlier call
     const size_t H = output_height;
     if ((H & (H - 1)) != 0) return (int)hipErrorInvalidValue;  // reference: assert, apc_tracegen.cu:134
     if (H == 0 || n_subs == 0) return (int)hipGetLastError();

@@ -111,7 +111,7 @@ def generate(shape: Shape | str, seed: int = 0, verbosity: float = 1.0, density_
         kinds[pid] = ("derived", P)
     rest = [poly_ids[i] for i in order[1 + nq :]]
     n = len(rest)
-    cuts = np.cumsum([int(n * f) for f in (0.08, 0.02, 0.35, 0.25)]).tolist()
+    cuts = np.cumsum([max(2, int(n * f)) for f in (0.08, 0.02, 0.35, 0.25)]).tolist()
     for i, pid in enumerate(rest):
         if i < cuts[0]:
             kinds[pid] = ("bit", 2)

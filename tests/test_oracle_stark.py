@@ -1,0 +1,130 @@
+"""CPU tests of the pw-stark v0 oracle: internal consistency of every stage and the
+accept/reject behaviour of prove -> verify (the only kind of check the reference's own
+tests make on this path: openvm-riscv/src/lib.rs:337-341 `verify_app_proof`)."""
+import numpy as np
+import pytest
+
+from oracle import apc_model as om
+from oracle import stark_model as sm
+from powdr_amd import synth
+
+P = om.P
+
+
+def test_field_constants():
+    g = 0x1A427A41  # 31^15: generator of the order-2^27 subgroup
+    assert pow(31, 15, P) == g
+    assert pow(g, 1 << 27, P) == 1 and pow(g, 1 << 26, P) != 1
+    assert sm.root_of_unity(27) == g and sm.root_of_unity(1) == P - 1
+    # 11 is a quadratic non-residue, so X^4 - 11 is irreducible over BabyBear (p = 1 mod 4)
+    assert pow(11, (P - 1) // 2, P) == P - 1
+
+
+def test_ext_field():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        a = rng.integers(0, P, 4, dtype=np.uint32)
+        b = rng.integers(0, P, 4, dtype=np.uint32)
+        assert (sm.ext_mul(a, b) == sm.ext_mul(b, a)).all()
+        assert (sm.ext_mul(a, sm.ext_inv(a)) == [1, 0, 0, 0]).all()
+    x = np.array([0, 1, 0, 0], np.uint32)
+    x2 = sm.ext_mul(x, x)
+    assert (sm.ext_mul(x2, x2) == [11, 0, 0, 0]).all()
+
+
+def test_dft_matches_naive_and_inverts():
+    rng = np.random.default_rng(1)
+    for log_n in (1, 2, 5, 8):
+        a = rng.integers(0, P, 1 << log_n, dtype=np.uint32)
+        f = sm.dft(a)
+        assert (f == sm.dft_naive(a)).all()
+        assert (sm.dft(f, inverse=True) == a).all()
+
+
+def test_lde_is_low_degree_extension():
+    rng = np.random.default_rng(2)
+    log_h, W = 5, 3
+    H = 1 << log_h
+    t = rng.integers(0, P, W * H, dtype=np.uint32)
+    l = sm.lde(t, W, log_h).reshape(W, 2 * H)
+    w = sm.root_of_unity(log_h + 1)
+    for c in range(W):
+        coef = sm.dft(t[c * H : (c + 1) * H], inverse=True)
+        for j in (0, 1, 7, 2 * H - 1):
+            x = 31 * pow(w, j, P) % P
+            want = sum(int(coef[i]) * pow(x, i, P) for i in range(H)) % P
+            assert int(l[c, j]) == want
+
+
+def test_poseidon2_is_a_permutation_with_fixed_constants():
+    e, i, d = sm.poseidon2_constants()
+    assert e.shape == (8, 16) and (e < P).all() and (i < P).all()
+    assert d[1] == 1 and d[0] == P - 2 and (2 * int(d[3])) % P == 1  # [-2, 1, 2, 1/2, ...]
+    z = sm.poseidon2(np.zeros(16, np.uint32))
+    o = sm.poseidon2(np.arange(16, dtype=np.uint32))
+    assert len(set(z.tolist())) > 8 and (z != o).any()
+    # regression pin of this repo's own constant table (NOT a reference KAT: constants are unpinned)
+    assert z[:4].tolist() == sm.poseidon2(np.zeros(16, np.uint32))[:4].tolist()
+
+
+def test_merkle_commit_structure():
+    rng = np.random.default_rng(3)
+    H, W = 16, 11
+    m = rng.integers(0, P, W * H, dtype=np.uint32)
+    root, dig = sm.merkle_commit(m, H, W, want_digests=True)
+    dig = dig.reshape(-1, 8)
+    assert (dig[-1] == root).all()
+    # parent = first 8 words of permute(left || right)
+    st = np.concatenate([dig[0], dig[1]])
+    assert (sm.poseidon2(st)[:8] == dig[H]).all()
+    # leaf = overwrite-mode sponge over the row, rate 8
+    row = m.reshape(W, H)[:, 0]
+    s = np.zeros(16, np.uint32)
+    s[:8] = row[:8]
+    s = sm.poseidon2(s)
+    s[:3] = row[8:11]
+    s = sm.poseidon2(s)
+    assert (s[:8] == dig[0]).all()
+
+
+def synthetic_trace(shape, num_calls, seed):
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+
+    s = synth.generate(shape, seed=seed)
+    apc, idx, trace, hist, _ = run_oracle_gpu_convention(s, num_calls, seed=seed)
+    return s, apc, idx, trace
+
+
+@pytest.mark.parametrize("shape,calls", [("T0", 7), ("T0", 64), ("T1", 100)])
+def test_prove_verify_accepts_and_rejects(shape, calls):
+    s, apc, idx, trace = synthetic_trace(shape, calls, seed=4)
+    W, H = trace.shape
+    log_h = H.bit_length() - 1
+    bc, spans = sm.compile_constraints(apc, idx)
+    flat = np.ascontiguousarray(trace).reshape(-1)
+    proof = sm.prove(flat, W, log_h, bc, spans, num_queries=6)
+    assert sm.verify(proof, W, log_h, bc, spans, num_queries=6) == 0
+    # deterministic
+    assert (sm.prove(flat, W, log_h, bc, spans, num_queries=6) == proof).all()
+    # any flipped word is rejected
+    rng = np.random.default_rng(5)
+    for pos in rng.choice(len(proof), size=12, replace=False):
+        bad = proof.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        assert sm.verify(bad, W, log_h, bc, spans, num_queries=6) != 0
+    # a trace that violates a constraint does not yield an accepting proof
+    bad_trace = flat.copy()
+    valid_col = idx[[p for p, k in s.kinds.items() if k[0] == "valid"][0]]
+    bad_trace[valid_col * H] = 2  # is_valid * (is_valid - 1) != 0
+    bad_proof = sm.prove(bad_trace, W, log_h, bc, spans, num_queries=6)
+    assert sm.verify(bad_proof, W, log_h, bc, spans, num_queries=6) != 0
+
+
+def test_proof_of_work():
+    s, apc, idx, trace = synthetic_trace("T0", 5, seed=6)
+    W, H = trace.shape
+    bc, spans = sm.compile_constraints(apc, idx)
+    flat = np.ascontiguousarray(trace).reshape(-1)
+    proof = sm.prove(flat, W, 3, bc, spans, num_queries=3, pow_bits=8)
+    assert sm.verify(proof, W, 3, bc, spans, num_queries=3, pow_bits=8) == 0
+    assert sm.verify(proof, W, 3, bc, spans, num_queries=3, pow_bits=0) != 0
