@@ -1,0 +1,72 @@
+/*
+ * powdr_prover.h — C ABI of the MI355X STARK prover ("pw-stark v0") in libpowdr_gpu.
+ *
+ * Boundary B2. The reference reaches its prover through the Rust
+ * trait seam `StarkEngine::prove(pk, ProvingContext{per_trace: [(air_id,
+ * AirProvingContext{cached_mains, common_main, public_values})]})`:
+ *   call sites  /root/reference/openvm/src/trace_generation.rs:97-139 (callback(seg_idx, vm, pk, ctx)),
+ *               /root/reference/openvm-riscv/src/lib.rs:327-341 (sdk.app_prover(exe).prove + verify_app_proof)
+ *   engines     /root/reference/openvm/src/lib.rs:69-95 (BabyBearPoseidon2CpuEngine / ...GpuEngine)
+ *   the AIR     /root/reference/openvm/src/powdr_extension/chip.rs:94-130 (PowdrAir::eval: current-row
+ *               constraints `assert_zero(expr)`, no public values, no cached/preprocessed trace)
+ * The trait's method list lives in the un-vendored `openvm-stark-backend` crate, so this
+ * header is the plain-C surface a third engine `E` (beside the CPU and CUDA engines) would
+ * call from its `prove`: one AIR = one prover object built from the AIR's constraint
+ * programs (what keygen extracts from `PowdrAir::eval` through the symbolic builder), and
+ * `pw_prover_prove` consumes the AirProvingContext's `common_main` as a column-major
+ * device matrix — exactly what `PowdrChipGpu::generate_proving_ctx` returns
+ * (/root/reference/openvm/src/powdr_extension/trace_generator/cuda/mod.rs:404-421).
+ *
+ * All `d_` pointers are device pointers owned by the caller. Field words are BabyBear in
+ * Montgomery form on the device; proof words are canonical u32 (little endian).
+ * Return value 0 = success, otherwise a hipError_t (or -1 for malformed arguments).
+ */
+#ifndef POWDR_PROVER_H
+#define POWDR_PROVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PwProver PwProver;
+
+typedef struct {
+    uint32_t num_queries; /* FRI queries (blow-up is fixed at 2: constraint degree <= 3) */
+    uint32_t pow_bits;    /* proof-of-work bits before the query phase, 0 = none */
+} PwStarkConfig;
+
+/* Constraint programs: post-fix bytecode with the trace-generation opcodes
+ * (PUSH_APC=0 with a COLUMN INDEX operand, PUSH_CONST=1, ADD=2, SUB=3, MUL=4, NEG=5),
+ * spans = {off, len} pairs in u32 words. Host pointers; copied. */
+PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, const uint32_t* cons_bytecode,
+                           size_t bytecode_len, const uint32_t* cons_spans, size_t n_constraints);
+void pw_prover_destroy(PwProver* p);
+
+/* Prove one trace (column-major, width x 2^log_height, Montgomery words, device).
+ * *proof_words points at host memory owned by the prover, valid until the next call. */
+int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t log_height, const uint32_t** proof_words,
+                    size_t* n_words);
+
+/* Bytes of device memory the prover currently holds. */
+size_t pw_prover_device_bytes(const PwProver* p);
+
+/* ---- single stages, exposed for parity tests and per-stage measurement ---- */
+
+/* d_coeffs (width x H) receives H-scaled coefficients in bit-reversed order; d_lde (width x 2H)
+ * receives natural-order evaluations on the coset 31 * <g_{n+1}>. */
+int pw_lde_batch(const uint32_t* d_trace, uint32_t width, uint32_t log_height, uint32_t* d_coeffs, uint32_t* d_lde);
+
+/* Poseidon2 Merkle tree of a column-major matrix; d_digests gets (2*height - 1) * 8 words,
+ * leaves first, root last. */
+int pw_merkle_commit(const uint32_t* d_matrix, size_t height, uint32_t width, uint32_t* d_digests);
+
+/* Host-side Poseidon2 permutation used by the transcript (canonical words in/out). */
+void pw_poseidon2_permute_host(uint32_t* state16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POWDR_PROVER_H */

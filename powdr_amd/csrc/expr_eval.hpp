@@ -31,10 +31,13 @@ constexpr int kStackCap = POWDR_EXPR_STACK_CAPACITY;
 
 // `stk` points at this thread's column: slot k lives at stk[k * stride].
 // Returns the value in Montgomery form.
-template <int STRIDE>
+// COLUMN_OPERANDS = false: PUSH_APC operand is an element offset (reference encoding);
+//                   true:  operand is a column index, cell = trace[operand * col_stride + r]
+//                          (used by the quotient kernel, whose matrices exceed 2^32 elements).
+template <int STRIDE, bool COLUMN_OPERANDS = false>
 __device__ __forceinline__ uint32_t eval_expr(const uint32_t* __restrict__ bc, uint32_t len,
                                               const uint32_t* __restrict__ trace, size_t r,
-                                              uint32_t* __restrict__ stk) {
+                                              uint32_t* __restrict__ stk, size_t col_stride = 1) {
     uint32_t top = 0;  // cached top of stack (valid when sp > 0)
     int sp = 0;        // number of live entries, including `top`
     for (uint32_t ip = 0; ip < len;) {
@@ -43,7 +46,10 @@ __device__ __forceinline__ uint32_t eval_expr(const uint32_t* __restrict__ bc, u
             const uint32_t operand = bc[ip++];
             if (sp > 0 && sp < kStackCap) stk[(sp - 1) * STRIDE] = top;
             sp = sp < kStackCap ? sp + 1 : sp;
-            top = (op == POWDR_OP_PUSH_APC) ? trace[(size_t)operand + r] : bb::to_monty(operand);
+            if (op == POWDR_OP_PUSH_APC)
+                top = COLUMN_OPERANDS ? trace[(size_t)operand * col_stride + r] : trace[(size_t)operand + r];
+            else
+                top = bb::to_monty(operand);
         } else if (op <= POWDR_OP_MUL) {
             // binary: a = second from top, b = top
             sp = sp > 1 ? sp - 1 : sp;

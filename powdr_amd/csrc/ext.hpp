@@ -1,0 +1,86 @@
+// Degree-4 extension E = F[X]/(X^4 - 11) of BabyBear on Montgomery words, for
+// device kernels and the host transcript. Challenges (alpha, zeta, gamma, beta)
+// and everything derived from them live in E; trace data stays in F.
+#pragma once
+#include "babybear.hpp"
+
+namespace bb {
+
+struct Ext {
+    uint32_t c[4];
+};
+
+// 11 in Montgomery form: 11 * 2^32 mod p
+PW_HD uint32_t w11() { return 939524073u; }  // 0x37ffffe9
+
+PW_HD Ext ext_zero() { return {{0u, 0u, 0u, 0u}}; }
+PW_HD Ext ext_one() { return {{R_MOD_P, 0u, 0u, 0u}}; }
+PW_HD Ext ext_from_base(uint32_t a) { return {{a, 0u, 0u, 0u}}; }
+PW_HD Ext ext_add(const Ext& a, const Ext& b) {
+    return {{add(a.c[0], b.c[0]), add(a.c[1], b.c[1]), add(a.c[2], b.c[2]), add(a.c[3], b.c[3])}};
+}
+PW_HD Ext ext_sub(const Ext& a, const Ext& b) {
+    return {{sub(a.c[0], b.c[0]), sub(a.c[1], b.c[1]), sub(a.c[2], b.c[2]), sub(a.c[3], b.c[3])}};
+}
+PW_HD Ext ext_neg(const Ext& a) { return {{neg(a.c[0]), neg(a.c[1]), neg(a.c[2]), neg(a.c[3])}}; }
+PW_HD Ext ext_scale(const Ext& a, uint32_t k) {
+    return {{mul(a.c[0], k), mul(a.c[1], k), mul(a.c[2], k), mul(a.c[3], k)}};
+}
+PW_HD bool ext_eq(const Ext& a, const Ext& b) {
+    return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2] && a.c[3] == b.c[3];
+}
+
+// 64-bit accumulation of Montgomery products: each a*b < p^2 < 2^62, so up to 4 products
+// fit in 64 bits only after a pre-reduction; we reduce each partial dot product through
+// monty_reduce of a sum of at most 2 raw products plus an 11-scaled reduced term.
+PW_HD Ext ext_mul(const Ext& a, const Ext& b) {
+    const uint32_t W = w11();
+    // high part first (to be multiplied by 11)
+    uint32_t h0 = add(add(mul(a.c[1], b.c[3]), mul(a.c[2], b.c[2])), mul(a.c[3], b.c[1]));
+    uint32_t h1 = add(mul(a.c[2], b.c[3]), mul(a.c[3], b.c[2]));
+    uint32_t h2 = mul(a.c[3], b.c[3]);
+    Ext r;
+    r.c[0] = add(mul(a.c[0], b.c[0]), mul(W, h0));
+    r.c[1] = add(add(mul(a.c[0], b.c[1]), mul(a.c[1], b.c[0])), mul(W, h1));
+    r.c[2] = add(add(add(mul(a.c[0], b.c[2]), mul(a.c[1], b.c[1])), mul(a.c[2], b.c[0])), mul(W, h2));
+    r.c[3] = add(add(mul(a.c[0], b.c[3]), mul(a.c[1], b.c[2])), add(mul(a.c[2], b.c[1]), mul(a.c[3], b.c[0])));
+    return r;
+}
+PW_HD Ext ext_sqr(const Ext& a) { return ext_mul(a, a); }
+
+// Inverse via the norm to the quadratic subfield K = F[Y]/(Y^2 - 11), Y = X^2:
+// a = A0 + A1 X with A0 = (a0, a2), A1 = (a1, a3) in K; a^-1 = (A0 - A1 X) / (A0^2 - Y A1^2).
+PW_HD Ext ext_inv(const Ext& a) {
+    const uint32_t W = w11();
+    // A0^2 = (a0^2 + 11 a2^2, 2 a0 a2), A1^2 = (a1^2 + 11 a3^2, 2 a1 a3)
+    uint32_t s0 = add(sqr(a.c[0]), mul(W, sqr(a.c[2])));
+    uint32_t s1 = double_(mul(a.c[0], a.c[2]));
+    uint32_t t0 = add(sqr(a.c[1]), mul(W, sqr(a.c[3])));
+    uint32_t t1 = double_(mul(a.c[1], a.c[3]));
+    // D = A0^2 - Y*A1^2,  Y*(t0 + t1 Y) = 11 t1 + t0 Y
+    uint32_t d0 = sub(s0, mul(W, t1));
+    uint32_t d1 = sub(s1, t0);
+    // D^-1 = (d0 - d1 Y) / (d0^2 - 11 d1^2)
+    uint32_t n = sub(sqr(d0), mul(W, sqr(d1)));
+    uint32_t ni = inv(n);
+    uint32_t e0 = mul(d0, ni);
+    uint32_t e1 = neg(mul(d1, ni));
+    // R0 = A0 * E, R1 = -A1 * E  (K multiplication)
+    uint32_t r00 = add(mul(a.c[0], e0), mul(W, mul(a.c[2], e1)));
+    uint32_t r01 = add(mul(a.c[0], e1), mul(a.c[2], e0));
+    uint32_t r10 = neg(add(mul(a.c[1], e0), mul(W, mul(a.c[3], e1))));
+    uint32_t r11 = neg(add(mul(a.c[1], e1), mul(a.c[3], e0)));
+    return {{r00, r10, r01, r11}};
+}
+
+PW_HD Ext ext_pow(Ext a, uint64_t e) {
+    Ext r = ext_one();
+    while (e) {
+        if (e & 1) r = ext_mul(r, a);
+        a = ext_sqr(a);
+        e >>= 1;
+    }
+    return r;
+}
+
+}  // namespace bb

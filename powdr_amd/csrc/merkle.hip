@@ -1,0 +1,174 @@
+// Poseidon2 Merkle commitment kernels for gfx950.
+//
+//   leaf j   = overwrite-mode sponge (rate 8, width 16) over row j of a column-major
+//              matrix; one lane per row, so every column access of a wave is one
+//              contiguous 256-byte segment and the sponge state lives in 16 VGPRs.
+//   node     = first 8 words of Poseidon2(left || right); one lane per parent,
+//              children are 64 contiguous bytes.
+// This stage is integer-VALU bound (~670 Montgomery products + ~1 500 modular additions
+// per permutation, 253 permutations per 2 022-column row), not HBM bound and not MFMA
+// work — see DESIGN.md §kernels.
+#include "prover_internal.hpp"
+
+namespace pw {
+
+namespace {
+
+constexpr int kBlock = 256;
+__constant__ p2::Params c_params;
+p2::Params g_host_params;
+bool g_params_ready = false;
+bool g_params_uploaded = false;
+
+__global__ __launch_bounds__(kBlock) void leaf_hash_kernel(const uint32_t* __restrict__ m, size_t height,
+                                                            uint32_t width, size_t col_stride,
+                                                            uint32_t* __restrict__ digests) {
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= height) return;
+    uint32_t st[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0u;
+    const uint32_t* col = m + j;
+    uint32_t c0 = 0;
+    for (; c0 + 8 <= width; c0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st[k] = col[(size_t)(c0 + k) * col_stride];
+        p2::permute(st, c_params);
+    }
+    if (c0 < width) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (c0 + k < width) st[k] = col[(size_t)(c0 + k) * col_stride];
+        p2::permute(st, c_params);
+    }
+    uint4* out = reinterpret_cast<uint4*>(digests + j * 8);
+    out[0] = make_uint4(st[0], st[1], st[2], st[3]);
+    out[1] = make_uint4(st[4], st[5], st[6], st[7]);
+}
+
+__global__ __launch_bounds__(kBlock) void ext_pair_leaf_kernel(const bb::Ext* __restrict__ v, size_t half,
+                                                                uint32_t* __restrict__ digests) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= half) return;
+    uint32_t st[16];
+    const bb::Ext a = v[i], b = v[i + half];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { st[k] = a.c[k]; st[4 + k] = b.c[k]; st[8 + k] = 0u; st[12 + k] = 0u; }
+    p2::permute(st, c_params);
+    uint4* out = reinterpret_cast<uint4*>(digests + i * 8);
+    out[0] = make_uint4(st[0], st[1], st[2], st[3]);
+    out[1] = make_uint4(st[4], st[5], st[6], st[7]);
+}
+
+__global__ __launch_bounds__(kBlock) void compress_kernel(const uint32_t* __restrict__ children, size_t n_parents,
+                                                           uint32_t* __restrict__ parents) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_parents) return;
+    const uint4* in = reinterpret_cast<const uint4*>(children + i * 16);
+    uint4 a = in[0], b = in[1], c = in[2], d = in[3];
+    uint32_t st[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    p2::permute(st, c_params);
+    uint4* out = reinterpret_cast<uint4*>(parents + i * 8);
+    out[0] = make_uint4(st[0], st[1], st[2], st[3]);
+    out[1] = make_uint4(st[4], st[5], st[6], st[7]);
+}
+
+// Proof-of-work: thread t tries witness base + t; the transcript absorbs the pending words plus
+// the witness (overwrite mode), permutes, and samples the LAST rate word (out.pop_back()).
+__global__ __launch_bounds__(kBlock) void pow_kernel(const uint32_t* __restrict__ state16, const uint32_t* __restrict__ pending,
+                                                      uint32_t in_len, uint32_t bits, uint32_t base, uint32_t* best) {
+    const uint32_t w = base + blockIdx.x * kBlock + threadIdx.x;
+    if (w >= bb::P) return;
+    uint32_t st[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = state16[i];
+    // absorb pending words then the witness
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if ((uint32_t)i < in_len) st[i] = pending[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if ((uint32_t)i == in_len) st[i] = bb::to_monty(w);
+    p2::permute(st, c_params);
+    uint32_t sample;
+    if (in_len == 7) {
+        // the witness filled the rate: duplexing happened inside observe(); sample() pops out[7]
+        sample = st[7];
+    } else {
+        sample = st[7];
+    }
+    if ((bb::from_monty(sample) & ((1u << bits) - 1u)) == 0u) atomicMin(best, w);
+}
+
+int build_levels(uint32_t* digests, size_t n_leaves) {
+    size_t off = 0;
+    for (size_t n = n_leaves; n > 1; n >>= 1) {
+        size_t parents = n >> 1;
+        ScopedKernelTimer t("compress_kernel");
+        hipLaunchKernelGGL(compress_kernel, dim3(div_up(parents, kBlock)), dim3(kBlock), 0, stream(), digests + off,
+                           parents, digests + off + n * 8);
+        off += n * 8;
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+const p2::Params& poseidon2_params_host() {
+    if (!g_params_ready) {
+        p2::generate_params(g_host_params);
+        g_params_ready = true;
+    }
+    return g_host_params;
+}
+
+int poseidon2_upload_params() {
+    if (g_params_uploaded) return 0;
+    const p2::Params& p = poseidon2_params_host();
+    PW_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_params), &p, sizeof(p2::Params)));
+    g_params_uploaded = true;
+    return 0;
+}
+
+int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests) {
+    int rc = poseidon2_upload_params();
+    if (rc) return rc;
+    {
+        ScopedKernelTimer t("leaf_hash_kernel");
+        hipLaunchKernelGGL(leaf_hash_kernel, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width,
+                           col_stride, digests);
+    }
+    return build_levels(digests, height);
+}
+
+int merkle_commit_ext_pairs(const bb::Ext* v, size_t half, uint32_t* digests) {
+    int rc = poseidon2_upload_params();
+    if (rc) return rc;
+    {
+        ScopedKernelTimer t("ext_pair_leaf_kernel");
+        hipLaunchKernelGGL(ext_pair_leaf_kernel, dim3(div_up(half, kBlock)), dim3(kBlock), 0, stream(), v, half, digests);
+    }
+    return build_levels(digests, half);
+}
+
+int pow_grind(const uint32_t* d_state16, const uint32_t* d_pending, uint32_t in_len, uint32_t bits, uint32_t* witness_out) {
+    int rc = poseidon2_upload_params();
+    if (rc) return rc;
+    uint32_t* d_best;
+    PW_HIP_TRY(hipMalloc(&d_best, 4));
+    const uint32_t batch = 1u << 20;
+    uint32_t best = 0xffffffffu;
+    for (uint64_t base = 0; base < bb::P; base += batch) {
+        PW_HIP_TRY(hipMemcpyAsync(d_best, &best, 4, hipMemcpyHostToDevice, stream()));
+        hipLaunchKernelGGL(pow_kernel, dim3(batch / kBlock), dim3(kBlock), 0, stream(), d_state16, d_pending, in_len, bits,
+                           (uint32_t)base, d_best);
+        PW_HIP_TRY(hipMemcpyAsync(&best, d_best, 4, hipMemcpyDeviceToHost, stream()));
+        PW_HIP_TRY(hipStreamSynchronize(stream()));
+        if (best != 0xffffffffu) break;
+    }
+    (void)hipFree(d_best);
+    *witness_out = best;
+    return best == 0xffffffffu ? (int)hipErrorUnknown : 0;
+}
+
+}  // namespace pw

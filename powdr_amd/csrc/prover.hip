@@ -1,0 +1,362 @@
+// pw-stark v0 prover: host orchestration of the HIP stages, Fiat-Shamir transcript, proof
+// assembly. Protocol definition: oracle/stark_oracle.cpp (header comment) and DESIGN.md;
+// the byte string produced here must equal the oracle's for the same trace.
+//
+// Data stays in HBM from the caller's trace to the last FRI layer; the host only sees
+// 32-byte roots, the W+8 opened values and the query answers (a few hundred KB), which is
+// what it needs to run the transcript.
+#include "prover_internal.hpp"
+#include "../../include/powdr_prover.h"
+
+#include <cstring>
+#include <vector>
+
+namespace pw {
+
+namespace {
+
+constexpr uint32_t kMagic = 0x31535750u;  // "PWS1"
+
+// ---- duplex-sponge challenger on Montgomery words (spec: oracle/stark_oracle.cpp Challenger) ----
+struct Challenger {
+    uint32_t st[16];
+    std::vector<uint32_t> in, out;
+    Challenger() { memset(st, 0, sizeof st); }
+    void duplex() {
+        for (size_t i = 0; i < in.size(); ++i) st[i] = in[i];
+        in.clear();
+        p2::permute(st, poseidon2_params_host());
+        out.assign(st, st + 8);
+    }
+    void observe(uint32_t m) { out.clear(); in.push_back(m); if (in.size() == 8) duplex(); }
+    void observe_canonical(uint32_t c) { observe(bb::to_monty(c)); }
+    void observe_words(const uint32_t* w, size_t n) { for (size_t i = 0; i < n; ++i) observe(w[i]); }
+    void observe_ext(const bb::Ext& e) { observe_words(e.c, 4); }
+    uint32_t sample() { if (!in.empty() || out.empty()) duplex(); uint32_t v = out.back(); out.pop_back(); return v; }
+    bb::Ext sample_ext() { bb::Ext e; for (int i = 0; i < 4; ++i) e.c[i] = sample(); return e; }
+    uint32_t sample_bits(int b) { return bb::from_monty(sample()) & ((1u << b) - 1u); }
+};
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) return (int)e;
+        bytes = need;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+__global__ void gather_records_kernel(const uint32_t* __restrict__ arena, const uint64_t* __restrict__ offsets,
+                                      uint32_t words_per_record, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * words_per_record) return;
+    const uint32_t r = i / words_per_record, w = i - r * words_per_record;
+    out[i] = arena[offsets[r] + w];
+}
+
+}  // namespace
+
+}  // namespace pw
+
+struct PwProver {
+    PwStarkConfig cfg;
+    uint32_t width;
+    std::vector<uint32_t> h_spans;
+    uint32_t n_constraints;
+    uint32_t* d_bytecode = nullptr;
+    uint32_t* d_spans = nullptr;
+    // device buffers, grown on demand
+    pw::DeviceBuf coef, lde, digests, q, qcoef, qlde, ext_arena, misc;
+    std::vector<uint32_t> proof;
+};
+
+using namespace pw;
+
+extern "C" PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, const uint32_t* bc, size_t bc_len,
+                                      const uint32_t* spans, size_t n_constraints) {
+    if (!cfg || !width) return nullptr;
+    PwProver* p = new PwProver();
+    p->cfg = *cfg;
+    p->width = width;
+    p->n_constraints = (uint32_t)n_constraints;
+    p->h_spans.assign(spans, spans + 2 * n_constraints);
+    size_t bl = bc_len ? bc_len : 1, sl = n_constraints ? 2 * n_constraints : 1;
+    if (hipMalloc(&p->d_bytecode, bl * 4) != hipSuccess || hipMalloc(&p->d_spans, sl * 4) != hipSuccess) {
+        delete p;
+        return nullptr;
+    }
+    if (bc_len) (void)hipMemcpy(p->d_bytecode, bc, bc_len * 4, hipMemcpyHostToDevice);
+    if (n_constraints) (void)hipMemcpy(p->d_spans, spans, 2 * n_constraints * 4, hipMemcpyHostToDevice);
+    return p;
+}
+
+extern "C" void pw_prover_destroy(PwProver* p) {
+    if (!p) return;
+    for (DeviceBuf* b : {&p->coef, &p->lde, &p->digests, &p->q, &p->qcoef, &p->qlde, &p->ext_arena, &p->misc}) b->release();
+    if (p->d_bytecode) (void)hipFree(p->d_bytecode);
+    if (p->d_spans) (void)hipFree(p->d_spans);
+    delete p;
+}
+
+extern "C" size_t pw_prover_device_bytes(const PwProver* p) {
+    return p->coef.bytes + p->lde.bytes + p->digests.bytes + p->q.bytes + p->qcoef.bytes + p->qlde.bytes +
+           p->ext_arena.bytes + p->misc.bytes;
+}
+
+#define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t log_h, const uint32_t** proof_words,
+                               size_t* n_words) {
+    if (!p || !d_trace || log_h < 1 || log_h > 26) return -1;
+    (void)hipGetLastError();
+    const uint32_t W = p->width, nc = p->n_constraints;
+    const size_t H = (size_t)1 << log_h, N = 2 * H;
+    const int logN = (int)log_h + 1;
+    const uint32_t K = W + 8;
+    hipStream_t st = stream();
+    TRY(poseidon2_upload_params());
+
+    // ---- buffers --------------------------------------------------------------------------
+    // digest arena: trace tree | quotient tree | FRI trees
+    const size_t tree_words = merkle_words(N);
+    size_t fri_words = 0;
+    for (uint32_t l = 0; l < log_h; ++l) fri_words += merkle_words((N >> l) / 2);
+    TRY(p->coef.ensure((size_t)W * H * 4));
+    TRY(p->lde.ensure((size_t)W * N * 4));
+    TRY(p->digests.ensure((2 * tree_words + fri_words) * 4));
+    TRY(p->q.ensure(4 * N * 4));
+    TRY(p->qcoef.ensure(8 * H * 4));
+    TRY(p->qlde.ensure(8 * N * 4));
+    // ext arena: FRI layer vectors v_0 (N) .. v_log_h (2): 2N ext; weights (H)
+    TRY(p->ext_arena.ensure((2 * N + H + 16) * sizeof(bb::Ext)));
+    const uint32_t n_chunks = div_up(H, 8192);
+    const size_t misc_ext = (size_t)K * n_chunks + K + K + nc + 64;
+    const uint32_t nq = p->cfg.num_queries;
+    const size_t path_records = (size_t)nq * (2 * (size_t)logN + (size_t)log_h * logN) + 16;
+    size_t misc_bytes = misc_ext * sizeof(bb::Ext) + (size_t)nq * 4 + (size_t)nq * (W + 8) * 4 + path_records * (8 + 32) +
+                        (size_t)nq * log_h * (8 + 16) + 4096;
+    TRY(p->misc.ensure(misc_bytes));
+
+    uint32_t* d_coef = p->coef.as<uint32_t>();
+    uint32_t* d_lde = p->lde.as<uint32_t>();
+    uint32_t* d_dig = p->digests.as<uint32_t>();
+    uint32_t* d_tdig = d_dig;
+    uint32_t* d_qdig = d_dig + tree_words;
+    uint32_t* d_fdig = d_dig + 2 * tree_words;
+    uint32_t* d_q = p->q.as<uint32_t>();
+    uint32_t* d_qcoef = p->qcoef.as<uint32_t>();
+    uint32_t* d_qlde = p->qlde.as<uint32_t>();
+    bb::Ext* d_v = p->ext_arena.as<bb::Ext>();          // FRI layers, consecutive
+    bb::Ext* d_weights = d_v + 2 * N;
+    bb::Ext* d_scratch = p->misc.as<bb::Ext>();          // K * n_chunks
+    bb::Ext* d_opened = d_scratch + (size_t)K * n_chunks; // K
+    bb::Ext* d_gpow = d_opened + K;                        // K
+    bb::Ext* d_apow = d_gpow + K;                          // nc
+    uint8_t* d_tail = reinterpret_cast<uint8_t*>(d_apow + nc + 8);
+
+    std::vector<uint32_t>& pf = p->proof;
+    pf.clear();
+    auto put = [&](uint32_t canonical) { pf.push_back(canonical); };
+    auto put_monty = [&](const uint32_t* w, size_t n) { for (size_t i = 0; i < n; ++i) pf.push_back(bb::from_monty(w[i])); };
+
+    Challenger ch;
+    for (uint32_t x : {kMagic % bb::P, log_h, W, nc, p->cfg.num_queries, p->cfg.pow_bits}) ch.observe_canonical(x);
+    for (uint32_t x : {kMagic, log_h, W, nc, p->cfg.num_queries, p->cfg.pow_bits}) put(x);
+
+    // ---- 1. trace: coefficients, LDE, commitment ---------------------------------------------
+    TRY(intt_dif(d_trace, d_coef, H, H, W, (int)log_h));
+    TRY(coset_lde_from_coeffs(d_coef, d_lde, H, N, W, (int)log_h));
+    TRY(merkle_commit_matrix(d_lde, N, W, N, d_tdig));
+    uint32_t root[8];
+    PW_HIP_TRY(hipMemcpyAsync(root, d_tdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
+    PW_HIP_TRY(hipStreamSynchronize(st));
+    put_monty(root, 8);
+    ch.observe_words(root, 8);
+
+    // ---- 2. quotient ---------------------------------------------------------------------------
+    const bb::Ext alpha = ch.sample_ext();
+    {
+        std::vector<bb::Ext> apow(nc ? nc : 1);
+        bb::Ext a = bb::ext_one();
+        for (size_t j = nc; j-- > 0;) { apow[j] = a; a = bb::ext_mul(a, alpha); }
+        if (nc) PW_HIP_TRY(hipMemcpyAsync(d_apow, apow.data(), nc * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
+        PW_HIP_TRY(hipStreamSynchronize(st));  // apow is a stack-local vector
+    }
+    const uint32_t s_m = bb::to_monty(field::kCosetShift);
+    uint32_t sH = s_m;
+    for (uint32_t i = 0; i < log_h; ++i) sH = bb::sqr(sH);
+    const uint32_t one = bb::R_MOD_P;
+    const uint32_t zinv_even = bb::inv(bb::sub(sH, one));
+    const uint32_t zinv_odd = bb::inv(bb::sub(bb::neg(sH), one));
+    ConstraintProgram prog{p->d_bytecode, p->d_spans, nc};
+    TRY(quotient_eval(d_lde, N, prog, d_apow, zinv_even, zinv_odd, d_q));
+    TRY(intt_dif(d_q, d_q, N, N, 4, logN));
+    TRY(quotient_split(d_q, H, (int)log_h, d_qcoef));
+    TRY(coset_lde_from_coeffs(d_qcoef, d_qlde, H, N, 8, (int)log_h));
+    TRY(merkle_commit_matrix(d_qlde, N, 8, N, d_qdig));
+    PW_HIP_TRY(hipMemcpyAsync(root, d_qdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
+    PW_HIP_TRY(hipStreamSynchronize(st));
+    put_monty(root, 8);
+    ch.observe_words(root, 8);
+
+    // ---- 3. openings at zeta -------------------------------------------------------------------
+    const bb::Ext zeta = ch.sample_ext();
+    TRY(zeta_weights(zeta, (int)log_h, d_weights));
+    TRY(ext_dot_columns(d_coef, H, W, H, d_weights, d_opened, d_scratch));
+    TRY(ext_dot_columns(d_qcoef, H, 8, H, d_weights, d_opened + W, d_scratch));
+    std::vector<bb::Ext> opened(K);
+    PW_HIP_TRY(hipMemcpyAsync(opened.data(), d_opened, K * sizeof(bb::Ext), hipMemcpyDeviceToHost, st));
+    PW_HIP_TRY(hipStreamSynchronize(st));
+    for (auto& e : opened) { put_monty(e.c, 4); ch.observe_ext(e); }
+
+    // ---- 4. reduced-opening vector -------------------------------------------------------------
+    const bb::Ext gamma = ch.sample_ext();
+    bb::Ext opened_sum = bb::ext_zero();
+    {
+        std::vector<bb::Ext> gpow(K);
+        bb::Ext g = bb::ext_one();
+        for (uint32_t k = 0; k < K; ++k) { gpow[k] = g; g = bb::ext_mul(g, gamma); }
+        for (uint32_t k = 0; k < K; ++k) opened_sum = bb::ext_add(opened_sum, bb::ext_mul(gpow[k], opened[k]));
+        PW_HIP_TRY(hipMemcpyAsync(d_gpow, gpow.data(), K * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
+        PW_HIP_TRY(hipStreamSynchronize(st));
+    }
+    TRY(deep_quotient(d_lde, W, d_qlde, 8, N, logN, d_gpow, opened_sum, zeta, d_v));
+
+    // ---- 5. FRI commit phase --------------------------------------------------------------------
+    std::vector<size_t> layer_off(log_h + 1), tree_off(log_h);  // offsets in Ext / in words
+    {
+        size_t o = 0, t = 0;
+        for (uint32_t l = 0; l <= log_h; ++l) { layer_off[l] = o; o += N >> l; }
+        for (uint32_t l = 0; l < log_h; ++l) { tree_off[l] = t; t += merkle_words((N >> l) / 2); }
+    }
+    uint32_t shift = s_m;
+    for (uint32_t l = 0; l < log_h; ++l) {
+        const size_t half = (N >> l) / 2;
+        bb::Ext* v = d_v + layer_off[l];
+        uint32_t* dg = d_fdig + tree_off[l];
+        TRY(merkle_commit_ext_pairs(v, half, dg));
+        PW_HIP_TRY(hipMemcpyAsync(root, dg + merkle_words(half) - 8, 32, hipMemcpyDeviceToHost, st));
+        PW_HIP_TRY(hipStreamSynchronize(st));
+        put_monty(root, 8);
+        ch.observe_words(root, 8);
+        const bb::Ext beta = ch.sample_ext();
+        TRY(fri_fold(v, half, logN - (int)l, shift, beta, d_v + layer_off[l + 1]));
+        shift = bb::sqr(shift);
+    }
+    bb::Ext final_poly;
+    PW_HIP_TRY(hipMemcpyAsync(&final_poly, d_v + layer_off[log_h], sizeof(bb::Ext), hipMemcpyDeviceToHost, st));
+    PW_HIP_TRY(hipStreamSynchronize(st));
+    put_monty(final_poly.c, 4);
+    ch.observe_ext(final_poly);
+
+    // ---- 6. proof of work ------------------------------------------------------------------------
+    uint32_t witness = 0;
+    if (p->cfg.pow_bits) {
+        uint32_t* d_state = reinterpret_cast<uint32_t*>(d_tail);
+        uint32_t pending[8] = {0};
+        for (size_t i = 0; i < ch.in.size(); ++i) pending[i] = ch.in[i];
+        PW_HIP_TRY(hipMemcpyAsync(d_state, ch.st, 64, hipMemcpyHostToDevice, st));
+        PW_HIP_TRY(hipMemcpyAsync(d_state + 16, pending, 32, hipMemcpyHostToDevice, st));
+        TRY(pow_grind(d_state, d_state + 16, (uint32_t)ch.in.size(), p->cfg.pow_bits, &witness));
+    }
+    put(witness);
+    ch.observe_canonical(witness);
+    if (p->cfg.pow_bits) (void)ch.sample_bits((int)p->cfg.pow_bits);
+
+    // ---- 7. queries --------------------------------------------------------------------------------
+    if (nq) {
+        std::vector<uint32_t> idx(nq);
+        for (auto& i : idx) i = ch.sample_bits(logN);
+        // layout of the tail buffer
+        uint32_t* d_idx = reinterpret_cast<uint32_t*>(d_tail);
+        uint32_t* d_trows = d_idx + nq;
+        uint32_t* d_qrows = d_trows + (size_t)nq * W;
+        uint64_t* d_offs = reinterpret_cast<uint64_t*>(d_qrows + (size_t)nq * 8 + ((nq * (W + 9)) & 1));
+        // digest records (8 words) then FRI sibling records (4 words)
+        std::vector<uint64_t> dig_offs, ext_offs;
+        const size_t paths_per_query = 2 * (size_t)logN;
+        for (uint32_t qi = 0; qi < nq; ++qi) {
+            const size_t i = idx[qi];
+            for (int tree = 0; tree < 2; ++tree) {
+                const size_t base = tree ? tree_words : 0;
+                for (int l = 0; l < logN; ++l)
+                    dig_offs.push_back(base + merkle_level_offset(N, l) + (((i >> l) ^ 1) * 8));
+            }
+            for (uint32_t l = 0; l < log_h; ++l) {
+                const size_t Nl = N >> l, half = Nl / 2, pp = i & (Nl - 1);
+                ext_offs.push_back((layer_off[l] + (pp ^ half)) * 4);
+                const size_t leaf = pp & (half - 1);
+                for (int lv = 0; lv < logN - 1 - (int)l; ++lv)
+                    dig_offs.push_back(2 * tree_words + tree_off[l] + merkle_level_offset(half, lv) + (((leaf >> lv) ^ 1) * 8));
+            }
+        }
+        (void)paths_per_query;
+        const size_t n_dig = dig_offs.size(), n_ext = ext_offs.size();
+        uint64_t* d_dig_offs = d_offs;
+        uint64_t* d_ext_offs = d_offs + n_dig;
+        uint32_t* d_dig_out = reinterpret_cast<uint32_t*>(d_ext_offs + n_ext);
+        uint32_t* d_ext_out = d_dig_out + n_dig * 8;
+        PW_HIP_TRY(hipMemcpyAsync(d_idx, idx.data(), nq * 4, hipMemcpyHostToDevice, st));
+        PW_HIP_TRY(hipMemcpyAsync(d_dig_offs, dig_offs.data(), n_dig * 8, hipMemcpyHostToDevice, st));
+        if (n_ext) PW_HIP_TRY(hipMemcpyAsync(d_ext_offs, ext_offs.data(), n_ext * 8, hipMemcpyHostToDevice, st));
+        TRY(gather_rows(d_lde, N, W, d_idx, nq, d_trows));
+        TRY(gather_rows(d_qlde, N, 8, d_idx, nq, d_qrows));
+        hipLaunchKernelGGL(gather_records_kernel, dim3(div_up(n_dig * 8, 256)), dim3(256), 0, st, d_dig, d_dig_offs, 8u,
+                           (uint32_t)n_dig, d_dig_out);
+        if (n_ext)
+            hipLaunchKernelGGL(gather_records_kernel, dim3(div_up(n_ext * 4, 256)), dim3(256), 0, st,
+                               reinterpret_cast<const uint32_t*>(d_v), d_ext_offs, 4u, (uint32_t)n_ext, d_ext_out);
+        std::vector<uint32_t> trows((size_t)nq * W), qrows((size_t)nq * 8), dig(n_dig * 8), ext(n_ext * 4 + 1);
+        PW_HIP_TRY(hipMemcpyAsync(trows.data(), d_trows, trows.size() * 4, hipMemcpyDeviceToHost, st));
+        PW_HIP_TRY(hipMemcpyAsync(qrows.data(), d_qrows, qrows.size() * 4, hipMemcpyDeviceToHost, st));
+        PW_HIP_TRY(hipMemcpyAsync(dig.data(), d_dig_out, n_dig * 32, hipMemcpyDeviceToHost, st));
+        if (n_ext) PW_HIP_TRY(hipMemcpyAsync(ext.data(), d_ext_out, n_ext * 16, hipMemcpyDeviceToHost, st));
+        PW_HIP_TRY(hipStreamSynchronize(st));
+        size_t dpos = 0, epos = 0;
+        for (uint32_t qi = 0; qi < nq; ++qi) {
+            put(idx[qi]);
+            put_monty(&trows[(size_t)qi * W], W);
+            put_monty(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
+            put_monty(&qrows[(size_t)qi * 8], 8);
+            put_monty(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
+            for (uint32_t l = 0; l < log_h; ++l) {
+                put_monty(&ext[epos * 4], 4); epos += 1;
+                const size_t depth = (size_t)logN - 1 - l;
+                put_monty(&dig[dpos * 8], depth * 8); dpos += depth;
+            }
+        }
+    }
+    *proof_words = pf.data();
+    *n_words = pf.size();
+    return (int)hipGetLastError();
+}
+
+// ---- single stages -----------------------------------------------------------------------------------
+
+extern "C" int pw_lde_batch(const uint32_t* d_trace, uint32_t width, uint32_t log_h, uint32_t* d_coeffs, uint32_t* d_lde) {
+    (void)hipGetLastError();
+    const size_t H = (size_t)1 << log_h;
+    TRY(intt_dif(d_trace, d_coeffs, H, H, width, (int)log_h));
+    TRY(coset_lde_from_coeffs(d_coeffs, d_lde, H, 2 * H, width, (int)log_h));
+    return (int)hipGetLastError();
+}
+
+extern "C" int pw_merkle_commit(const uint32_t* d_matrix, size_t height, uint32_t width, uint32_t* d_digests) {
+    (void)hipGetLastError();
+    if (!height || (height & (height - 1))) return -1;
+    return merkle_commit_matrix(d_matrix, height, width, height, d_digests);
+}
+
+extern "C" void pw_poseidon2_permute_host(uint32_t* s) {
+    uint32_t m[16];
+    for (int i = 0; i < 16; ++i) m[i] = bb::to_monty(s[i] % bb::P);
+    p2::permute(m, poseidon2_params_host());
+    for (int i = 0; i < 16; ++i) s[i] = bb::from_monty(m[i]);
+}

@@ -1,0 +1,73 @@
+// Internal interfaces between the prover's translation units (not part of the C ABI).
+#pragma once
+#include "babybear.hpp"
+#include "ext.hpp"
+#include "poseidon2.hpp"
+#include "common.hpp"
+
+#include <stddef.h>
+#include <stdint.h>
+
+namespace pw {
+
+namespace field {
+constexpr uint32_t kTwoAdicGen = 0x1a427a41u;  // canonical; 31^15, order 2^27
+constexpr uint32_t kCosetShift = 31u;          // canonical
+// Montgomery-form primitive 2^n-th root of unity
+inline uint32_t root_of_unity(int n) {
+    uint32_t g = bb::to_monty(kTwoAdicGen);
+    for (int i = n; i < 27; ++i) g = bb::sqr(g);
+    return g;
+}
+}  // namespace field
+
+// ---- ntt.hip ---------------------------------------------------------------------------
+int intt_dif(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n);
+int coset_lde_from_coeffs(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n);
+const uint32_t* shift_table(int n);  // s^k / 2^n (Montgomery), k < 2^n, device
+
+// ---- merkle.hip ------------------------------------------------------------------------
+// Digest tree layout: level 0 = leaves (n_leaves x 8 words), then n_leaves/2, ... , 1;
+// all levels concatenated: total (2*n_leaves - 1) * 8 words. root = last 8 words.
+const p2::Params& poseidon2_params_host();
+int poseidon2_upload_params();
+int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests);
+// leaves = hash of the 8 words (v[i], v[i + half]) of an Ext vector of length 2*half
+int merkle_commit_ext_pairs(const bb::Ext* v, size_t half, uint32_t* digests);
+inline size_t merkle_words(size_t n_leaves) { return (2 * n_leaves - 1) * 8; }
+inline size_t merkle_level_offset(size_t n_leaves, int level) {  // in words
+    size_t off = 0, n = n_leaves;
+    for (int l = 0; l < level; ++l) { off += n * 8; n >>= 1; }
+    return off;
+}
+
+// ---- stark_kernels.hip -----------------------------------------------------------------
+struct ConstraintProgram {
+    const uint32_t* d_bytecode;  // PUSH_COL operands = column index
+    const uint32_t* d_spans;     // {off, len} pairs
+    uint32_t n_constraints;
+};
+// q[k*N + j] (k < 4) = coordinate k of  sum_c alpha_pow[c] * C_c(lde row j) * zinv[j & 1]
+int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, const bb::Ext* d_alpha_pows,
+                  uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q);
+// chunk coefficients from the unscaled DIF-iNTT of q over N = 2H points:
+// out[(4*ch + k)*H + q'] = cbr[k*N + 2q' + ch] * s^-(bitrev(q') + ch*H) / 2   (H-scaled bit-reversed coefficients)
+int quotient_split(const uint32_t* cbr, size_t H, int log_h, uint32_t* out);
+// weights[q] = z^(bitrev_n(q)) / 2^n  (Ext), for coefficient vectors as intt_dif leaves them
+int zeta_weights(bb::Ext z, int log_h, bb::Ext* weights);
+// out[c] = sum_q cols[c*stride + q] * weights[q]
+int ext_dot_columns(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t len, const bb::Ext* weights, bb::Ext* out,
+                    bb::Ext* scratch);
+// v[j] = (sum_k gpow[k] * M_k[j] - opened_sum) / (x_j - zeta), x_j = s * g^j, over two matrices
+int deep_quotient(const uint32_t* lde_a, uint32_t wa, const uint32_t* lde_b, uint32_t wb, size_t N, int logN,
+                  const bb::Ext* d_gpow, bb::Ext opened_sum, bb::Ext zeta, bb::Ext* v);
+// out[i] = (a+b)/2 + beta (a-b)/(2 x_i), a = v[i], b = v[i+half], x_i = shift * w^i
+int fri_fold(const bb::Ext* v, size_t half, int log_size, uint32_t shift, bb::Ext beta, bb::Ext* out);
+// gather row `idx` of a column-major matrix into out[0..width)
+int gather_rows(const uint32_t* m, size_t height, uint32_t width, const uint32_t* d_indices, uint32_t n_idx, uint32_t* out);
+// proof-of-work search: smallest witness w (checked in blocks) such that the transcript state,
+// after observing w, samples a value with `bits` low zero bits. state = 16 words sponge state,
+// in_len = number of pending absorbed words (they are in pending[]).
+int pow_grind(const uint32_t* state16, const uint32_t* pending, uint32_t in_len, uint32_t bits, uint32_t* witness_out);
+
+}  // namespace pw

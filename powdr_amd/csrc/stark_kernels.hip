@@ -1,0 +1,232 @@
+// pw-stark v0 device kernels other than NTT and Merkle hashing: constraint/quotient
+// evaluation on the extended domain, quotient chunking, openings at zeta, the DEEP
+// (reduced-opening) vector, FRI folding, row gathers for query answers.
+// Every kernel maps one lane to one row of a column-major matrix, so a wave reads
+// 256 contiguous bytes per column; per-column coefficients (alpha^i, gamma^k) and
+// constraint bytecode are wave-uniform and arrive through scalar loads.
+#include "prover_internal.hpp"
+#include "expr_eval.hpp"
+
+namespace pw {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ bb::Ext load_ext_uniform(const bb::Ext* p) { return *p; }
+
+// ---- quotient ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void quotient_kernel(const uint32_t* __restrict__ lde, size_t N,
+                                                           const uint32_t* __restrict__ bytecode,
+                                                           const uint32_t* __restrict__ spans, uint32_t n_constraints,
+                                                           const bb::Ext* __restrict__ alpha_pows, uint32_t zinv_even,
+                                                           uint32_t zinv_odd, uint32_t* __restrict__ q) {
+    __shared__ uint32_t stack_lds[kStackCap * kBlock];
+    uint32_t* stk = stack_lds + threadIdx.x;
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= N) return;
+    bb::Ext acc = bb::ext_zero();
+    for (uint32_t c = 0; c < n_constraints; ++c) {
+        const uint32_t off = spans[2 * c], len = spans[2 * c + 1];
+        const uint32_t v = eval_expr<kBlock, true>(bytecode + off, len, lde, j, stk, N);
+        const bb::Ext a = alpha_pows[c];
+        acc.c[0] = bb::add(acc.c[0], bb::mul(a.c[0], v));
+        acc.c[1] = bb::add(acc.c[1], bb::mul(a.c[1], v));
+        acc.c[2] = bb::add(acc.c[2], bb::mul(a.c[2], v));
+        acc.c[3] = bb::add(acc.c[3], bb::mul(a.c[3], v));
+    }
+    const uint32_t zi = (j & 1) ? zinv_odd : zinv_even;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[(size_t)k * N + j] = bb::mul(acc.c[k], zi);
+}
+
+// out[(4*ch + k)*H + q'] = cbr[k*N + 2q' + ch] * s^-(bitrev(q') + ch*H) / 2
+__global__ __launch_bounds__(kBlock) void quotient_split_kernel(const uint32_t* __restrict__ cbr, size_t H, int log_h,
+                                                                 uint32_t sinv, uint32_t half_m, uint32_t* __restrict__ out) {
+    const size_t qp = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (qp >= H) return;
+    const uint32_t kk = log_h ? (__brev((uint32_t)qp) >> (32 - log_h)) : 0u;
+    const uint32_t f_lo = bb::mul(bb::pow_u32(sinv, kk), half_m);
+    const uint32_t f_hi = bb::mul(f_lo, bb::pow_u32(sinv, (uint32_t)H));
+    const size_t N = 2 * H;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint2 pr = *reinterpret_cast<const uint2*>(cbr + (size_t)k * N + 2 * qp);
+        out[(size_t)k * H + qp] = bb::mul(pr.x, f_lo);
+        out[(size_t)(4 + k) * H + qp] = bb::mul(pr.y, f_hi);
+    }
+}
+
+// ---- openings ----------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void zeta_weights_kernel(bb::Ext z, int log_h, uint32_t ninv, bb::Ext* __restrict__ w) {
+    const size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q >= ((size_t)1 << log_h)) return;
+    const uint32_t k = log_h ? (__brev((uint32_t)q) >> (32 - log_h)) : 0u;
+    w[q] = bb::ext_scale(bb::ext_pow(z, k), ninv);
+}
+
+constexpr int kDotRowsPerBlock = 8192;
+__global__ __launch_bounds__(kBlock) void ext_dot_partial_kernel(const uint32_t* __restrict__ cols, size_t stride, size_t len,
+                                                                  const bb::Ext* __restrict__ weights,
+                                                                  bb::Ext* __restrict__ partial, uint32_t n_chunks) {
+    __shared__ uint32_t red[4][kBlock / 64];
+    const uint32_t* col = cols + (size_t)blockIdx.y * stride;
+    const size_t q0 = (size_t)blockIdx.x * kDotRowsPerBlock;
+    const size_t q1 = q0 + kDotRowsPerBlock < len ? q0 + kDotRowsPerBlock : len;
+    uint64_t acc[4] = {0, 0, 0, 0};  // sums of reduced products: < 32 * p < 2^36
+    for (size_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
+        const uint32_t v = col[q];
+        const bb::Ext w = weights[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += bb::mul(w.c[k], v);
+    }
+    uint32_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = (uint32_t)(acc[k] % bb::P);
+    // wave reduction
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) r[k] = bb::add(r[k], __shfl_down(r[k], off, 64));
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[k][wave] = r[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bb::Ext o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t s = red[k][0];
+            for (int w = 1; w < kBlock / 64; ++w) s = bb::add(s, red[k][w]);
+            o.c[k] = s;
+        }
+        partial[(size_t)blockIdx.y * n_chunks + blockIdx.x] = o;
+    }
+}
+__global__ void ext_dot_final_kernel(const bb::Ext* __restrict__ partial, uint32_t n_cols, uint32_t n_chunks, bb::Ext* __restrict__ out) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cols) return;
+    bb::Ext acc = bb::ext_zero();
+    for (uint32_t i = 0; i < n_chunks; ++i) acc = bb::ext_add(acc, partial[(size_t)c * n_chunks + i]);
+    out[c] = acc;
+}
+
+// ---- DEEP / reduced opening ----------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void deep_kernel(const uint32_t* __restrict__ ma, uint32_t wa,
+                                                       const uint32_t* __restrict__ mb, uint32_t wb, size_t N,
+                                                       const bb::Ext* __restrict__ gpow, bb::Ext opened_sum, bb::Ext zeta,
+                                                       uint32_t shift, uint32_t wN, bb::Ext* __restrict__ v) {
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= N) return;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const uint32_t* pa = ma + j;
+#pragma unroll 4
+    for (uint32_t k = 0; k < wa; ++k) {
+        const uint32_t x = pa[(size_t)k * N];
+        const bb::Ext g = gpow[k];
+        a0 = bb::add(a0, bb::mul(g.c[0], x));
+        a1 = bb::add(a1, bb::mul(g.c[1], x));
+        a2 = bb::add(a2, bb::mul(g.c[2], x));
+        a3 = bb::add(a3, bb::mul(g.c[3], x));
+    }
+    const uint32_t* pb = mb + j;
+    for (uint32_t k = 0; k < wb; ++k) {
+        const uint32_t x = pb[(size_t)k * N];
+        const bb::Ext g = gpow[wa + k];
+        a0 = bb::add(a0, bb::mul(g.c[0], x));
+        a1 = bb::add(a1, bb::mul(g.c[1], x));
+        a2 = bb::add(a2, bb::mul(g.c[2], x));
+        a3 = bb::add(a3, bb::mul(g.c[3], x));
+    }
+    const bb::Ext acc = {{a0, a1, a2, a3}};
+    const uint32_t xj = bb::mul(shift, bb::pow_u32(wN, (uint32_t)j));
+    const bb::Ext den = bb::ext_sub(bb::ext_from_base(xj), zeta);
+    v[j] = bb::ext_mul(bb::ext_sub(acc, opened_sum), bb::ext_inv(den));
+}
+
+// ---- FRI fold ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void fri_fold_kernel(const bb::Ext* __restrict__ v, size_t half, uint32_t shift_inv_half,
+                                                           uint32_t w_inv, uint32_t inv2, bb::Ext beta, bb::Ext* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= half) return;
+    const bb::Ext a = v[i], b = v[i + half];
+    // 1 / (2 x_i) = (1 / (2 shift)) * w^-i
+    const uint32_t xinv = bb::mul(shift_inv_half, bb::pow_u32(w_inv, (uint32_t)i));
+    const bb::Ext s = bb::ext_scale(bb::ext_add(a, b), inv2);
+    const bb::Ext d = bb::ext_scale(bb::ext_sub(a, b), xinv);
+    out[i] = bb::ext_add(s, bb::ext_mul(beta, d));
+}
+
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const uint32_t* __restrict__ m, size_t height, uint32_t width,
+                                                              const uint32_t* __restrict__ idx, uint32_t* __restrict__ out) {
+    const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= width) return;
+    out[(size_t)blockIdx.y * width + c] = m[(size_t)c * height + idx[blockIdx.y]];
+}
+
+}  // namespace
+
+int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, const bb::Ext* d_alpha_pows,
+                  uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q) {
+    ScopedKernelTimer t("quotient_kernel");
+    hipLaunchKernelGGL(quotient_kernel, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, N, prog.d_bytecode,
+                       prog.d_spans, prog.n_constraints, d_alpha_pows, zinv_even, zinv_odd, q);
+    return (int)hipGetLastError();
+}
+
+int quotient_split(const uint32_t* cbr, size_t H, int log_h, uint32_t* out) {
+    const uint32_t sinv = bb::inv(bb::to_monty(field::kCosetShift));
+    const uint32_t half_m = bb::inv(bb::to_monty(2));
+    ScopedKernelTimer t("quotient_split_kernel");
+    hipLaunchKernelGGL(quotient_split_kernel, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), cbr, H, log_h, sinv, half_m, out);
+    return (int)hipGetLastError();
+}
+
+int zeta_weights(bb::Ext z, int log_h, bb::Ext* weights) {
+    const uint32_t ninv = bb::inv(bb::to_monty((uint32_t)(((uint64_t)1 << log_h) % bb::P)));
+    ScopedKernelTimer t("zeta_weights_kernel");
+    hipLaunchKernelGGL(zeta_weights_kernel, dim3(div_up((size_t)1 << log_h, kBlock)), dim3(kBlock), 0, stream(), z, log_h, ninv, weights);
+    return (int)hipGetLastError();
+}
+
+int ext_dot_columns(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t len, const bb::Ext* weights, bb::Ext* out,
+                    bb::Ext* scratch) {
+    const uint32_t n_chunks = div_up(len, kDotRowsPerBlock);
+    for (uint32_t c0 = 0; c0 < n_cols; c0 += 65535u) {
+        uint32_t cc = n_cols - c0 < 65535u ? n_cols - c0 : 65535u;
+        ScopedKernelTimer t("ext_dot_partial_kernel");
+        hipLaunchKernelGGL(ext_dot_partial_kernel, dim3(n_chunks, cc), dim3(kBlock), 0, stream(), cols + (size_t)c0 * stride,
+                           stride, len, weights, scratch + (size_t)c0 * n_chunks, n_chunks);
+    }
+    hipLaunchKernelGGL(ext_dot_final_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, stream(), scratch, n_cols, n_chunks, out);
+    return (int)hipGetLastError();
+}
+
+int deep_quotient(const uint32_t* lde_a, uint32_t wa, const uint32_t* lde_b, uint32_t wb, size_t N, int logN,
+                  const bb::Ext* d_gpow, bb::Ext opened_sum, bb::Ext zeta, bb::Ext* v) {
+    ScopedKernelTimer t("deep_kernel");
+    hipLaunchKernelGGL(deep_kernel, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde_a, wa, lde_b, wb, N, d_gpow,
+                       opened_sum, zeta, bb::to_monty(field::kCosetShift), field::root_of_unity(logN), v);
+    return (int)hipGetLastError();
+}
+
+int fri_fold(const bb::Ext* v, size_t half, int log_size, uint32_t shift, bb::Ext beta, bb::Ext* out) {
+    const uint32_t inv2 = bb::inv(bb::to_monty(2));
+    const uint32_t shift_inv_half = bb::mul(bb::inv(shift), inv2);
+    const uint32_t w_inv = bb::inv(field::root_of_unity(log_size));
+    ScopedKernelTimer t("fri_fold_kernel");
+    hipLaunchKernelGGL(fri_fold_kernel, dim3(div_up(half, kBlock)), dim3(kBlock), 0, stream(), v, half, shift_inv_half, w_inv, inv2, beta, out);
+    return (int)hipGetLastError();
+}
+
+int gather_rows(const uint32_t* m, size_t height, uint32_t width, const uint32_t* d_indices, uint32_t n_idx, uint32_t* out) {
+    if (!n_idx || !width) return 0;
+    ScopedKernelTimer t("gather_rows_kernel");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(div_up(width, kBlock), n_idx), dim3(kBlock), 0, stream(), m, height, width, d_indices, out);
+    return (int)hipGetLastError();
+}
+
+}  // namespace pw

@@ -1,0 +1,73 @@
+"""ctypes binding of the pw-stark v0 prover entry points (include/powdr_prover.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+lib = abi.lib
+
+
+class PwStarkConfig(C.Structure):
+    _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
+
+
+PROVER_SYMBOLS = ["pw_prover_create", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+                  "pw_lde_batch", "pw_merkle_commit", "pw_poseidon2_permute_host"]
+
+lib.pw_prover_create.restype = C.c_void_p
+lib.pw_prover_create.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+lib.pw_prover_destroy.argtypes = [C.c_void_p]
+lib.pw_prover_prove.restype = C.c_int
+lib.pw_prover_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]
+lib.pw_prover_device_bytes.restype = C.c_size_t
+lib.pw_prover_device_bytes.argtypes = [C.c_void_p]
+lib.pw_lde_batch.restype = C.c_int
+lib.pw_lde_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+lib.pw_merkle_commit.restype = C.c_int
+lib.pw_merkle_commit.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+lib.pw_poseidon2_permute_host.argtypes = [C.c_void_p]
+
+
+def poseidon2_host(state) -> np.ndarray:
+    s = np.ascontiguousarray(state, dtype=np.uint32).copy()
+    lib.pw_poseidon2_permute_host(s.ctypes.data_as(C.c_void_p))
+    return s
+
+
+class Prover:
+    """One AIR = one prover (constraint programs fixed at construction)."""
+
+    def __init__(self, width: int, cons_bytecode, cons_spans, num_queries: int = 100, pow_bits: int = 0):
+        bc = np.ascontiguousarray(cons_bytecode, dtype=np.uint32)
+        sp = np.ascontiguousarray(cons_spans, dtype=np.uint32).reshape(-1, 2)
+        cfg = PwStarkConfig(num_queries, pow_bits)
+        self.width = width
+        self._h = lib.pw_prover_create(C.byref(cfg), width, bc.ctypes.data_as(C.c_void_p), len(bc),
+                                       sp.ctypes.data_as(C.c_void_p), len(sp))
+        if not self._h:
+            raise RuntimeError("pw_prover_create failed")
+
+    def prove(self, d_trace_ptr: int, log_height: int, copy: bool = True) -> np.ndarray:
+        words = C.POINTER(C.c_uint32)()
+        n = C.c_size_t()
+        rc = lib.pw_prover_prove(self._h, d_trace_ptr, log_height, C.byref(words), C.byref(n))
+        abi.check(rc, "pw_prover_prove")
+        a = np.ctypeslib.as_array(words, shape=(n.value,))
+        return a.copy() if copy else a
+
+    def device_bytes(self) -> int:
+        return int(lib.pw_prover_device_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            lib.pw_prover_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
