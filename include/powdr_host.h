@@ -1,0 +1,95 @@
+/*
+ * powdr_host.h — host-side mirror (C++ behind a C ABI) of the reference's GPU
+ * trace-generation host path, for this repository's MI355X kernels.
+ *
+ * What it mirrors (paths under /root/reference):
+ *   the APC data model and its serde wire format
+ *       autoprecompiles/src/lib.rs:177-195 (Apc, Substitution),
+ *       autoprecompiles/src/symbolic_machine.rs:115-133,201-209 (SymbolicMachine, main_columns),
+ *       expression/src/lib.rs:209-246 + autoprecompiles/src/expression.rs:51-80 (expression / reference serde),
+ *       constraint-solver/src/constraint_system.rs:97-137 (DerivedVariable, ComputationMethod)
+ *   the bytecode compilers  openvm/src/powdr_extension/trace_generator/cuda/mod.rs:49-177
+ *       (emit_expr, compile_derived_to_gpu, compile_bus_to_gpu)
+ *   `PowdrTraceGeneratorGpu::try_generate_witness`  cuda/mod.rs:201-401
+ *       (OriginalAir/Subst table construction :272-328, the three kernel calls :334-398)
+ * The reference's Rust toolchain is absent here, so the host side is C++; a Rust caller
+ * would bind these entry points exactly like cuda_abi.rs binds the kernels.
+ */
+#ifndef POWDR_HOST_H
+#define POWDR_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "powdr_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PowdrApc PowdrApc;
+
+/* Parse the JSON document serde_json produces for `Apc` (keys: block, machine{constraints,
+ * bus_interactions, derived_columns}, subs, ...). Returns NULL and fills `err` on failure. */
+PowdrApc* powdr_apc_from_json(const char* json, size_t len, char* err, size_t err_cap);
+void powdr_apc_free(PowdrApc* apc);
+
+/* machine.main_columns().count(): unique references of constraints + bus interactions */
+uint32_t powdr_apc_width(const PowdrApc* apc);
+/* ascending poly ids; column index = position (autoprecompiles/src/powdr.rs:44-57) */
+const uint64_t* powdr_apc_poly_ids(const PowdrApc* apc);
+uint32_t powdr_apc_num_constraints(const PowdrApc* apc);
+uint32_t powdr_apc_num_bus_interactions(const PowdrApc* apc);
+uint32_t powdr_apc_num_derived_columns(const PowdrApc* apc);
+uint32_t powdr_apc_num_instructions(const PowdrApc* apc);
+uint32_t powdr_apc_instruction_opcode(const PowdrApc* apc, uint32_t i);
+uint32_t powdr_apc_instruction_num_subs(const PowdrApc* apc, uint32_t i);
+
+/* compile_bus_to_gpu (cuda/mod.rs:143-177) for a trace of `apc_height` rows. Call with NULL
+ * outputs to obtain the sizes. Returns the number of bytecode words. */
+size_t powdr_apc_compile_bus(const PowdrApc* apc, size_t apc_height, DevInteraction* interactions,
+                             ExprSpan* arg_spans, size_t* n_arg_spans, uint32_t* bytecode);
+/* compile_derived_to_gpu (cuda/mod.rs:100-141). Returns the number of bytecode words. */
+size_t powdr_apc_compile_derived(const PowdrApc* apc, size_t apc_height, DerivedExprSpec* specs, uint32_t* bytecode);
+/* Constraint programs for pw_prover_create: PUSH operands are column indices. `spans` gets
+ * n_constraints {off,len} pairs. Returns the number of bytecode words. */
+size_t powdr_apc_compile_constraints(const PowdrApc* apc, ExprSpan* spans, uint32_t* bytecode);
+/* Subst/row_block_size tables (cuda/mod.rs:272-328). instr_air[i] = id of the original AIR of
+ * instruction i (what `original_airs.opcode_to_air` yields), any value for instructions
+ * without substitutions. AIRs are numbered by first appearance: air_ids_out[k] = caller id of
+ * table entry k, row_block_out[k] = instructions per call. Returns the number of Subst
+ * records; *n_airs gets the number of table entries. NULL outputs = size query. */
+size_t powdr_apc_build_substitutions(const PowdrApc* apc, const int32_t* instr_air, Subst* subs,
+                                     int32_t* air_ids_out, int32_t* row_block_out, size_t* n_airs);
+
+/* A column-major device matrix (DeviceMatrix<BabyBear>) */
+typedef struct {
+    const PowdrFp* buffer;
+    int32_t width;
+    int32_t height;
+} PowdrDeviceMatrix;
+
+/* The shared periphery chips' device histograms + bus ids (cuda/mod.rs:357-372) */
+typedef struct {
+    uint32_t var_range_bus_id;
+    uint32_t* d_var_hist;
+    size_t var_num_bins;
+    uint32_t tuple2_bus_id;
+    uint32_t* d_tuple2_hist;
+    uint32_t tuple2_sz0, tuple2_sz1;
+    uint32_t bitwise_bus_id;
+    uint32_t* d_bitwise_hist;
+} PowdrPeriphery;
+
+/* try_generate_witness (cuda/mod.rs:201-401): d_output must hold
+ * width * next_power_of_two_or_zero(num_apc_calls) words; it is zero-filled here
+ * (cuda/mod.rs:266-269), gathered into, derived columns applied, bus interactions replayed
+ * into the periphery histograms. dummy_by_air[id] = dummy trace of the AIR with caller id
+ * `id` (ids as used in instr_air). Runs on the library stream; tables are cached per height. */
+int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, const PowdrDeviceMatrix* dummy_by_air,
+                                   size_t n_dummy, size_t num_apc_calls, PowdrFp* d_output,
+                                   const PowdrPeriphery* periphery);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POWDR_HOST_H */

@@ -1,0 +1,527 @@
+// Host side of GPU APC trace generation (see include/powdr_host.h for what it mirrors).
+#include "../../../include/powdr_host.h"
+#include "../common.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+constexpr uint32_t kP = 0x78000001u;
+
+// ---------------------------------------------------------------------------------- JSON
+struct JVal;
+using JPtr = std::unique_ptr<JVal>;
+struct JVal {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    bool b = false;
+    bool neg = false;
+    uint64_t u = 0;  // magnitude of an integer number
+    std::string s;
+    std::vector<JPtr> arr;
+    std::vector<std::pair<std::string, JPtr>> obj;
+    const JVal* get(const char* key) const {
+        for (auto& kv : obj) if (kv.first == key) return kv.second.get();
+        return nullptr;
+    }
+};
+
+struct JParser {
+    const char* p;
+    const char* end;
+    [[noreturn]] void fail(const char* what) const {
+        throw std::runtime_error(std::string("JSON: ") + what + " at byte " + std::to_string((size_t)(p - begin)));
+    }
+    const char* begin;
+    JParser(const char* s, size_t n) : p(s), end(s + n), begin(s) {}
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+    JPtr parse() {
+        // iterative-friendly recursive descent; nesting depth of the fixtures is a few hundred at most
+        ws();
+        if (p >= end) fail("unexpected end");
+        JPtr v(new JVal());
+        char c = *p;
+        if (c == '{') {
+            v->kind = JVal::Obj;
+            ++p; ws();
+            if (p < end && *p == '}') { ++p; return v; }
+            for (;;) {
+                ws();
+                if (p >= end || *p != '"') fail("expected key");
+                std::string k = str();
+                ws();
+                if (p >= end || *p != ':') fail("expected ':'");
+                ++p;
+                v->obj.emplace_back(std::move(k), parse());
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == '}') { ++p; break; }
+                fail("expected ',' or '}'");
+            }
+        } else if (c == '[') {
+            v->kind = JVal::Arr;
+            ++p; ws();
+            if (p < end && *p == ']') { ++p; return v; }
+            for (;;) {
+                v->arr.push_back(parse());
+                ws();
+                if (p < end && *p == ',') { ++p; continue; }
+                if (p < end && *p == ']') { ++p; break; }
+                fail("expected ',' or ']'");
+            }
+        } else if (c == '"') {
+            v->kind = JVal::Str;
+            v->s = str();
+        } else if (c == '-' || (c >= '0' && c <= '9')) {
+            v->kind = JVal::Num;
+            if (c == '-') { v->neg = true; ++p; }
+            if (p >= end || *p < '0' || *p > '9') fail("bad number");
+            while (p < end && *p >= '0' && *p <= '9') { v->u = v->u * 10 + (uint64_t)(*p - '0'); ++p; }
+            if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) fail("non-integer number");
+        } else if (!strncmp(p, "true", 4)) { v->kind = JVal::Bool; v->b = true; p += 4; }
+        else if (!strncmp(p, "false", 5)) { v->kind = JVal::Bool; p += 5; }
+        else if (!strncmp(p, "null", 4)) { p += 4; }
+        else fail("unexpected character");
+        return v;
+    }
+    std::string str() {
+        ++p;  // opening quote
+        std::string out;
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                ++p;
+                if (p >= end) fail("bad escape");
+                switch (*p) {
+                    case 'n': out += '\n'; break;
+                    case 't': out += '\t'; break;
+                    case 'r': out += '\r'; break;
+                    case 'b': out += '\b'; break;
+                    case 'f': out += '\f'; break;
+                    case 'u': {
+                        if (end - p < 5) fail("bad \\u escape");
+                        unsigned cp = (unsigned)strtoul(std::string(p + 1, p + 5).c_str(), nullptr, 16);
+                        if (cp < 0x80) out += (char)cp;
+                        else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+                        else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+                        p += 4;
+                        break;
+                    }
+                    default: out += *p;
+                }
+                ++p;
+            } else out += *p++;
+        }
+        if (p >= end) fail("unterminated string");
+        ++p;
+        return out;
+    }
+};
+
+// ---------------------------------------------------------------------------------- model
+enum NodeKind : uint8_t { N_NUM, N_REF, N_ADD, N_SUB, N_MUL, N_NEG };
+struct Node { NodeKind kind; uint32_t a, b; };  // NUM: a = canonical value; REF: a = index into refs; NEG: a = child
+struct BusInteraction { uint32_t id; uint32_t mult; std::vector<uint32_t> args; };
+struct Derived { uint64_t poly_id; bool is_const; uint32_t constant; uint32_t e1, e2; };
+struct Sub { uint32_t original_poly_index; uint64_t apc_poly_id; };
+
+}  // namespace
+
+struct PowdrApc {
+    std::vector<Node> nodes;
+    std::vector<uint64_t> ref_ids;                     // poly id per REF slot
+    std::vector<uint32_t> constraints;                 // root node per constraint
+    std::vector<BusInteraction> buses;
+    std::vector<Derived> derived;
+    std::vector<std::vector<uint32_t>> instructions;   // [opcode, a..g]
+    std::vector<std::vector<Sub>> subs;
+    std::vector<uint64_t> poly_ids;                    // ascending
+    std::unordered_map<uint64_t, uint32_t> id_to_index;
+
+    // device-side caches for generate_witness_gpu, keyed by trace height
+    struct Compiled {
+        uint32_t* d_dbc = nullptr; DerivedExprSpec* d_specs = nullptr; size_t n_specs = 0;
+        uint32_t* d_bbc = nullptr; size_t bbc_len = 0; DevInteraction* d_inter = nullptr; size_t n_inter = 0;
+        ExprSpan* d_spans = nullptr; size_t n_spans = 0;
+    };
+    std::map<size_t, Compiled> compiled;
+    // substitution tables keyed by the instr_air assignment hash
+    struct SubTables { std::vector<Subst> subs; std::vector<int32_t> air_ids, row_block; Subst* d_subs = nullptr; OriginalAir* d_airs = nullptr; };
+    std::map<uint64_t, SubTables> sub_tables;
+
+    ~PowdrApc() {
+        for (auto& kv : compiled) {
+            auto& c = kv.second;
+            for (void* q : {(void*)c.d_dbc, (void*)c.d_specs, (void*)c.d_bbc, (void*)c.d_inter, (void*)c.d_spans}) if (q) (void)hipFree(q);
+        }
+        for (auto& kv : sub_tables) { if (kv.second.d_subs) (void)hipFree(kv.second.d_subs); if (kv.second.d_airs) (void)hipFree(kv.second.d_airs); }
+    }
+};
+
+namespace {
+
+uint64_t parse_ref(const std::string& s) {
+    size_t pos = s.rfind('@');
+    if (pos == std::string::npos) throw std::runtime_error("Invalid format for AlgebraicReference: " + s);
+    char* e = nullptr;
+    unsigned long long id = strtoull(s.c_str() + pos + 1, &e, 10);
+    if (!e || *e != 0 || pos + 1 == s.size()) throw std::runtime_error("Invalid ID in AlgebraicReference: " + s.substr(pos + 1));
+    return (uint64_t)id;
+}
+
+uint32_t field_of(const JVal& v) {
+    uint64_t m = v.u % kP;
+    return (uint32_t)(v.neg && m ? kP - m : m);
+}
+
+// expression/src/lib.rs:209-246: [l, op, r] | [op, e] | number | "name@id".
+// Explicit work stack: the fixtures contain left-leaning sums thousands of terms deep.
+uint32_t build_expr(PowdrApc& apc, const JVal& root) {
+    struct Frame { const JVal* v; uint32_t slot; int state; uint32_t lhs; };
+    auto leaf = [&](const JVal& v, uint32_t& out) -> bool {
+        if (v.kind == JVal::Num) { apc.nodes.push_back({N_NUM, field_of(v), 0}); out = (uint32_t)apc.nodes.size() - 1; return true; }
+        if (v.kind == JVal::Str) {
+            apc.ref_ids.push_back(parse_ref(v.s));
+            apc.nodes.push_back({N_REF, (uint32_t)apc.ref_ids.size() - 1, 0});
+            out = (uint32_t)apc.nodes.size() - 1;
+            return true;
+        }
+        return false;
+    };
+    uint32_t result = 0;
+    if (leaf(root, result)) return result;
+    std::vector<Frame> st;
+    st.push_back({&root, 0, 0, 0});
+    uint32_t ret = 0;
+    while (!st.empty()) {
+        Frame& f = st.back();
+        const JVal& v = *f.v;
+        if (v.kind != JVal::Arr || (v.arr.size() != 3 && v.arr.size() != 2)) throw std::runtime_error("cannot parse expression");
+        const bool unary = v.arr.size() == 2;
+        const JVal& first = unary ? *v.arr[1] : *v.arr[0];
+        if (f.state == 0) {
+            f.state = 1;
+            uint32_t id;
+            if (leaf(first, id)) { ret = id; } else { st.push_back({&first, 0, 0, 0}); continue; }
+        }
+        if (f.state == 1) {
+            f.lhs = ret;
+            if (unary) {
+                if (v.arr[0]->kind != JVal::Str || v.arr[0]->s != "-") throw std::runtime_error("unknown unary operator");
+                apc.nodes.push_back({N_NEG, f.lhs, 0});
+                ret = (uint32_t)apc.nodes.size() - 1;
+                st.pop_back();
+                continue;
+            }
+            f.state = 2;
+            uint32_t id;
+            const JVal& second = *v.arr[2];
+            if (leaf(second, id)) { ret = id; } else { st.push_back({&second, 0, 0, 0}); continue; }
+        }
+        // state 2: both operands ready (ret = rhs)
+        {
+            const JVal& op = *v.arr[1];
+            if (op.kind != JVal::Str || op.s.size() != 1) throw std::runtime_error("bad binary operator");
+            NodeKind k = op.s[0] == '+' ? N_ADD : op.s[0] == '-' ? N_SUB : op.s[0] == '*' ? N_MUL : N_NUM;
+            if (k == N_NUM) throw std::runtime_error("unknown binary operator " + op.s);
+            apc.nodes.push_back({k, f.lhs, ret});
+            ret = (uint32_t)apc.nodes.size() - 1;
+            st.pop_back();
+        }
+    }
+    return ret;
+}
+
+// emit_expr, cuda/mod.rs:49-81 (post-order walk with an explicit stack)
+void emit_expr(const PowdrApc& apc, uint32_t root, size_t apc_height, std::vector<uint32_t>& bc) {
+    std::vector<std::pair<uint32_t, bool>> st;
+    st.push_back({root, false});
+    while (!st.empty()) {
+        auto [n, done] = st.back();
+        st.pop_back();
+        const Node& nd = apc.nodes[n];
+        switch (nd.kind) {
+            case N_NUM: bc.push_back(POWDR_OP_PUSH_CONST); bc.push_back(nd.a); break;
+            case N_REF: {
+                uint32_t idx = apc.id_to_index.at(apc.ref_ids[nd.a]);
+                bc.push_back(POWDR_OP_PUSH_APC);
+                bc.push_back((uint32_t)((uint64_t)idx * apc_height));  // `as u32`, cuda/mod.rs:62
+                break;
+            }
+            case N_NEG:
+                if (done) bc.push_back(POWDR_OP_NEG);
+                else { st.push_back({n, true}); st.push_back({nd.a, false}); }
+                break;
+            default:
+                if (done) bc.push_back(nd.kind == N_ADD ? POWDR_OP_ADD : nd.kind == N_SUB ? POWDR_OP_SUB : POWDR_OP_MUL);
+                else { st.push_back({n, true}); st.push_back({nd.b, false}); st.push_back({nd.a, false}); }
+        }
+    }
+}
+
+void collect_refs(const PowdrApc& apc, uint32_t root, std::vector<uint64_t>& out) {
+    std::vector<uint32_t> st{root};
+    while (!st.empty()) {
+        uint32_t n = st.back(); st.pop_back();
+        const Node& nd = apc.nodes[n];
+        if (nd.kind == N_REF) out.push_back(apc.ref_ids[nd.a]);
+        else if (nd.kind == N_NEG) st.push_back(nd.a);
+        else if (nd.kind != N_NUM) { st.push_back(nd.a); st.push_back(nd.b); }
+    }
+}
+
+uint64_t next_pow2_or_zero(uint64_t n) { if (!n) return 0; uint64_t p = 1; while (p < n) p <<= 1; return p; }
+
+template <class T> int upload(T*& d, const std::vector<T>& h) {
+    size_t bytes = (h.size() ? h.size() : 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)&d, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (!h.empty()) { e = hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice); if (e != hipSuccess) return (int)e; }
+    return 0;
+}
+
+struct BusTables { std::vector<DevInteraction> inter; std::vector<ExprSpan> spans; std::vector<uint32_t> bc; };
+BusTables compile_bus(const PowdrApc& apc, size_t h) {
+    BusTables t;
+    for (auto& b : apc.buses) {
+        uint32_t off_idx = (uint32_t)t.spans.size();
+        auto span = [&](uint32_t e) { uint32_t off = (uint32_t)t.bc.size(); emit_expr(apc, e, h, t.bc); t.spans.push_back({off, (uint32_t)t.bc.size() - off}); };
+        span(b.mult);
+        for (uint32_t a : b.args) span(a);
+        t.inter.push_back({b.id, (uint32_t)b.args.size(), off_idx});
+    }
+    return t;
+}
+struct DerivedTables { std::vector<DerivedExprSpec> specs; std::vector<uint32_t> bc; };
+DerivedTables compile_derived(const PowdrApc& apc, size_t h) {
+    DerivedTables t;
+    for (auto& d : apc.derived) {
+        uint32_t off = (uint32_t)t.bc.size();
+        if (d.is_const) { t.bc.push_back(POWDR_OP_PUSH_CONST); t.bc.push_back(d.constant); }
+        else {
+            emit_expr(apc, d.e2, h, t.bc); t.bc.push_back(POWDR_OP_INV_OR_ZERO);
+            emit_expr(apc, d.e1, h, t.bc); t.bc.push_back(POWDR_OP_MUL);
+        }
+        DerivedExprSpec s;
+        s.col_base = (uint64_t)apc.id_to_index.at(d.poly_id) * h;
+        s.span = {off, (uint32_t)t.bc.size() - off};
+        t.specs.push_back(s);
+    }
+    return t;
+}
+
+uint64_t fnv(const void* p, size_t n) { uint64_t h = 1469598103934665603ull; auto c = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; } return h; }
+
+}  // namespace
+
+extern "C" {
+
+PowdrApc* powdr_apc_from_json(const char* json, size_t len, char* err, size_t err_cap) {
+    std::unique_ptr<PowdrApc> apc(new PowdrApc());
+    try {
+        JParser jp(json, len);
+        JPtr root = jp.parse();
+        const JVal* block = root->get("block");
+        const JVal* machine = root->get("machine");
+        const JVal* subs = root->get("subs");
+        if (!block || !machine || !subs) throw std::runtime_error("missing block/machine/subs");
+        const JVal* blocks = block->get("blocks");
+        if (!blocks) throw std::runtime_error("missing block.blocks");
+        for (auto& b : blocks->arr) {
+            const JVal* ins = b->get("instructions");
+            if (!ins) throw std::runtime_error("missing instructions");
+            for (auto& i : ins->arr) {
+                std::vector<uint32_t> v;
+                for (auto& x : i->arr) v.push_back((uint32_t)x->u);
+                apc->instructions.push_back(std::move(v));
+            }
+        }
+        for (auto& row : subs->arr) {
+            std::vector<Sub> r;
+            for (auto& s : row->arr) {
+                const JVal* o = s->get("original_poly_index");
+                const JVal* a = s->get("apc_poly_id");
+                if (!o || !a) throw std::runtime_error("bad substitution");
+                r.push_back({(uint32_t)o->u, a->u});
+            }
+            apc->subs.push_back(std::move(r));
+        }
+        if (apc->subs.size() != apc->instructions.size()) throw std::runtime_error("subs / instructions length mismatch (zip_eq)");
+        const JVal* cons = machine->get("constraints");
+        const JVal* buses = machine->get("bus_interactions");
+        const JVal* derived = machine->get("derived_columns");
+        if (!cons || !buses || !derived) throw std::runtime_error("missing machine fields");
+        for (auto& c : cons->arr) apc->constraints.push_back(build_expr(*apc, *c));
+        for (auto& b : buses->arr) {
+            BusInteraction bi;
+            const JVal* id = b->get("id"); const JVal* m = b->get("mult"); const JVal* args = b->get("args");
+            if (!id || !m || !args) throw std::runtime_error("bad bus interaction");
+            bi.id = (uint32_t)id->u;
+            bi.mult = build_expr(*apc, *m);
+            for (auto& a : args->arr) bi.args.push_back(build_expr(*apc, *a));
+            apc->buses.push_back(std::move(bi));
+        }
+        for (auto& d : derived->arr) {
+            if (d->kind != JVal::Arr || d->arr.size() != 2) throw std::runtime_error("bad derived column");
+            Derived dv{};
+            dv.poly_id = parse_ref(d->arr[0]->s);
+            const JVal& method = *d->arr[1];
+            if (const JVal* c = method.get("Constant")) { dv.is_const = true; dv.constant = field_of(*c); }
+            else if (const JVal* q = method.get("QuotientOrZero")) {
+                if (q->arr.size() != 2) throw std::runtime_error("bad QuotientOrZero");
+                dv.e1 = build_expr(*apc, *q->arr[0]);
+                dv.e2 = build_expr(*apc, *q->arr[1]);
+            } else throw std::runtime_error("unknown ComputationMethod");
+            apc->derived.push_back(dv);
+        }
+        // main_columns: unique references in constraints and bus interactions, ascending id
+        std::vector<uint64_t> ids;
+        for (uint32_t c : apc->constraints) collect_refs(*apc, c, ids);
+        for (auto& b : apc->buses) { collect_refs(*apc, b.mult, ids); for (uint32_t a : b.args) collect_refs(*apc, a, ids); }
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        apc->poly_ids = ids;
+        for (size_t i = 0; i < ids.size(); ++i) apc->id_to_index[ids[i]] = (uint32_t)i;
+        // every substitution / derived target must be a main column (the reference indexes the BTreeMap)
+        for (auto& row : apc->subs) for (auto& s : row) if (!apc->id_to_index.count(s.apc_poly_id)) throw std::runtime_error("substitution targets an unknown column");
+        for (auto& d : apc->derived) if (!apc->id_to_index.count(d.poly_id)) throw std::runtime_error("derived column is not a main column");
+    } catch (const std::exception& e) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+        return nullptr;
+    }
+    return apc.release();
+}
+
+void powdr_apc_free(PowdrApc* apc) { delete apc; }
+uint32_t powdr_apc_width(const PowdrApc* a) { return (uint32_t)a->poly_ids.size(); }
+const uint64_t* powdr_apc_poly_ids(const PowdrApc* a) { return a->poly_ids.data(); }
+uint32_t powdr_apc_num_constraints(const PowdrApc* a) { return (uint32_t)a->constraints.size(); }
+uint32_t powdr_apc_num_bus_interactions(const PowdrApc* a) { return (uint32_t)a->buses.size(); }
+uint32_t powdr_apc_num_derived_columns(const PowdrApc* a) { return (uint32_t)a->derived.size(); }
+uint32_t powdr_apc_num_instructions(const PowdrApc* a) { return (uint32_t)a->instructions.size(); }
+uint32_t powdr_apc_instruction_opcode(const PowdrApc* a, uint32_t i) { return a->instructions[i].empty() ? 0 : a->instructions[i][0]; }
+uint32_t powdr_apc_instruction_num_subs(const PowdrApc* a, uint32_t i) { return (uint32_t)a->subs[i].size(); }
+
+size_t powdr_apc_compile_bus(const PowdrApc* apc, size_t h, DevInteraction* inter, ExprSpan* spans, size_t* n_spans, uint32_t* bc) {
+    BusTables t = compile_bus(*apc, h);
+    if (n_spans) *n_spans = t.spans.size();
+    if (inter) memcpy(inter, t.inter.data(), t.inter.size() * sizeof(DevInteraction));
+    if (spans) memcpy(spans, t.spans.data(), t.spans.size() * sizeof(ExprSpan));
+    if (bc) memcpy(bc, t.bc.data(), t.bc.size() * 4);
+    return t.bc.size();
+}
+
+size_t powdr_apc_compile_derived(const PowdrApc* apc, size_t h, DerivedExprSpec* specs, uint32_t* bc) {
+    DerivedTables t = compile_derived(*apc, h);
+    if (specs) memcpy(specs, t.specs.data(), t.specs.size() * sizeof(DerivedExprSpec));
+    if (bc) memcpy(bc, t.bc.data(), t.bc.size() * 4);
+    return t.bc.size();
+}
+
+size_t powdr_apc_compile_constraints(const PowdrApc* apc, ExprSpan* spans, uint32_t* bc) {
+    std::vector<uint32_t> out;
+    size_t k = 0;
+    for (uint32_t c : apc->constraints) {
+        uint32_t off = (uint32_t)out.size();
+        emit_expr(*apc, c, 1, out);
+        if (spans) spans[k] = {off, (uint32_t)out.size() - off};
+        ++k;
+    }
+    if (bc) memcpy(bc, out.data(), out.size() * 4);
+    return out.size();
+}
+
+size_t powdr_apc_build_substitutions(const PowdrApc* apc, const int32_t* instr_air, Subst* subs, int32_t* air_ids_out,
+                                     int32_t* row_block_out, size_t* n_airs) {
+    // group instructions (with substitutions) by AIR, in order of first appearance
+    std::vector<int32_t> order;
+    std::unordered_map<int32_t, size_t> slot;
+    std::vector<std::vector<uint32_t>> rows;  // instruction indices per AIR slot
+    for (size_t i = 0; i < apc->instructions.size(); ++i) {
+        if (apc->subs[i].empty()) continue;
+        int32_t a = instr_air[i];
+        auto it = slot.find(a);
+        if (it == slot.end()) { it = slot.emplace(a, order.size()).first; order.push_back(a); rows.emplace_back(); }
+        rows[it->second].push_back((uint32_t)i);
+    }
+    size_t n = 0;
+    for (size_t k = 0; k < order.size(); ++k) {
+        for (size_t row = 0; row < rows[k].size(); ++row)
+            for (auto& s : apc->subs[rows[k][row]]) {
+                if (subs) subs[n] = {(int32_t)k, (int32_t)s.original_poly_index, (int32_t)row, (int32_t)apc->id_to_index.at(s.apc_poly_id)};
+                ++n;
+            }
+        if (air_ids_out) air_ids_out[k] = order[k];
+        if (row_block_out) row_block_out[k] = (int32_t)rows[k].size();
+    }
+    if (n_airs) *n_airs = order.size();
+    return n;
+}
+
+int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, const PowdrDeviceMatrix* dummy, size_t n_dummy,
+                                   size_t num_calls, PowdrFp* d_output, const PowdrPeriphery* per) {
+    const size_t width = apc->poly_ids.size();
+    const size_t height = (size_t)next_pow2_or_zero(num_calls);
+    if (height == 0) return 0;  // the APC was not called: DeviceMatrix::dummy()
+    hipStream_t st = pw::stream();
+    // cuda/mod.rs:266-269: zero-initialised so that unassigned columns stay zero
+    PW_HIP_TRY(hipMemsetAsync(d_output, 0, width * height * sizeof(PowdrFp), st));
+
+    // ---- OriginalAir / Subst tables (cuda/mod.rs:272-332) ----
+    uint64_t key = fnv(instr_air, apc->instructions.size() * sizeof(int32_t));
+    auto it = apc->sub_tables.find(key);
+    if (it == apc->sub_tables.end()) {
+        PowdrApc::SubTables t;
+        size_t n_airs = 0;
+        size_t n = powdr_apc_build_substitutions(apc, instr_air, nullptr, nullptr, nullptr, &n_airs);
+        t.subs.resize(n); t.air_ids.resize(n_airs); t.row_block.resize(n_airs);
+        powdr_apc_build_substitutions(apc, instr_air, t.subs.data(), t.air_ids.data(), t.row_block.data(), &n_airs);
+        int rc = upload(t.d_subs, t.subs);
+        if (rc) return rc;
+        PW_HIP_TRY(hipMalloc((void**)&t.d_airs, (n_airs ? n_airs : 1) * sizeof(OriginalAir)));
+        it = apc->sub_tables.emplace(key, std::move(t)).first;
+    }
+    PowdrApc::SubTables& stb = it->second;
+    std::vector<OriginalAir> airs(stb.air_ids.size());
+    for (size_t k = 0; k < airs.size(); ++k) {
+        int32_t id = stb.air_ids[k];
+        if (id < 0 || (size_t)id >= n_dummy) return -1;
+        airs[k].width = dummy[id].width; airs[k].height = dummy[id].height; airs[k].buffer = dummy[id].buffer;
+        airs[k].row_block_size = stb.row_block[k];
+    }
+    if (!airs.empty()) PW_HIP_TRY(hipMemcpyAsync(stb.d_airs, airs.data(), airs.size() * sizeof(OriginalAir), hipMemcpyHostToDevice, st));
+    PW_HIP_TRY(hipStreamSynchronize(st));  // `airs` is a local
+    int rc = _apc_tracegen(d_output, height, stb.d_airs, stb.d_subs, stb.subs.size(), (int)num_calls);
+    if (rc) return rc;
+
+    // ---- derived columns + bus interactions, compiled once per height ----
+    auto ct = apc->compiled.find(height);
+    if (ct == apc->compiled.end()) {
+        PowdrApc::Compiled c;
+        DerivedTables d = compile_derived(*apc, height);
+        BusTables b = compile_bus(*apc, height);
+        c.n_specs = d.specs.size(); c.bbc_len = b.bc.size(); c.n_inter = b.inter.size(); c.n_spans = b.spans.size();
+        if ((rc = upload(c.d_specs, d.specs)) || (rc = upload(c.d_dbc, d.bc)) || (rc = upload(c.d_bbc, b.bc)) ||
+            (rc = upload(c.d_inter, b.inter)) || (rc = upload(c.d_spans, b.spans))) return rc;
+        ct = apc->compiled.emplace(height, c).first;
+    }
+    const PowdrApc::Compiled& c = ct->second;
+    rc = _apc_apply_derived_expr(d_output, height, (int)num_calls, c.d_specs, c.n_specs, c.d_dbc);
+    if (rc) return rc;
+    if (per) {
+        rc = _apc_apply_bus(d_output, (int)num_calls, c.d_bbc, c.bbc_len, c.d_inter, c.n_inter, c.d_spans, c.n_spans,
+                            per->var_range_bus_id, per->d_var_hist, per->var_num_bins, per->tuple2_bus_id, per->d_tuple2_hist,
+                            per->tuple2_sz0, per->tuple2_sz1, per->bitwise_bus_id, per->d_bitwise_hist);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

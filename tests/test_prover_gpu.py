@@ -124,6 +124,7 @@ def test_large_proof_verifies(gpu):
     pr = prover.Prover(W, bc, spans, num_queries=30, pow_bits=0)
     proof = pr.prove(out.ptr(), log_h)
     assert sm.verify(proof, W, log_h, bc, spans, num_queries=30) == 0
-    out.buf[3 * H + 17] += 1  # break one cell
+    valid_col = idx[[q for q, k in s.kinds.items() if k[0] == "valid"][0]]
+    out.buf[valid_col * H + 17] = 2 * 0x0FFFFFFE % P  # is_valid = 2 (Montgomery) breaks is_valid*(is_valid-1)
     bad = pr.prove(out.ptr(), log_h)
     assert sm.verify(bad, W, log_h, bc, spans, num_queries=30) != 0
