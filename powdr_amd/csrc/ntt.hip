@@ -1,19 +1,28 @@
-// Radix-2 NTT / low-degree extension over BabyBear for gfx950, LDS-staged.
+// Radix-2 NTT / low-degree extension over BabyBear for gfx950: LDS-staged stage groups with
+// register-resident radix-16 rounds.
 //
-// Column-major matrices of 2^n-row columns; every column is an independent
-// transform (blockIdx.y = column). A transform is cut into "stage groups": one
-// kernel launch runs k consecutive butterfly stages on tiles of 2^(k+c) elements
-// held in LDS, so the data crosses HBM once per group instead of once per stage.
-// A tile gathers the 2^k elements whose indices differ in the group's k active bits,
-// times 2^c neighbouring columns-of-the-4-step-matrix (c low index bits) so that
-// every global access is a >= 64-byte contiguous segment.
+// Column-major matrices of 2^n-row columns; every column is an independent transform
+// (blockIdx.y = column). A transform of n stages is cut into "stage groups": one launch runs k
+// consecutive butterfly stages on a tile of 2^(k+c) elements, so the data crosses HBM once per
+// group, not once per stage. A tile gathers the 2^k elements whose indices differ in the
+// group's k active bits, times 2^c neighbouring elements (c low index bits) so that every global
+// access of a strided group is a 64-byte contiguous segment.
+//
+// Inside a group a thread owns 16 (or 32) elements in VGPRs and runs up to 4 stages on them
+// without touching LDS ("round", a radix-16 butterfly network); rounds exchange data through a
+// padded LDS tile (one extra word per 32: conflict-free for every round's access pattern). The
+// first round of a group loads straight from HBM into registers and the last round stores
+// straight from registers to HBM. Twiddles: the factor of a butterfly splits into a per-thread
+// base (one table lookup per round, squared from stage to stage) times a constant 16th/8th/4th
+// root of unity, so no per-butterfly table traffic exists.
 //
 //   inverse  = DIF (Gentleman-Sande), natural-order input -> bit-reversed output
 //   forward  = DIT (Cooley-Tukey),    bit-reversed input  -> natural-order output
-// so iNTT followed by the coset NTT needs no bit-reversal pass. Zero-padding the
-// coefficient vector from H to 2H in bit-reversed order is a duplication
-// (padded[2q] = c[q], padded[2q+1] = 0, and the first DIT stage maps (a, 0) to
-// (a, a)), which the expand kernel fuses with the coset scaling s^k / H.
+// so iNTT followed by the coset NTT needs no bit-reversal pass. Zero-padding the coefficient
+// vector from H to 2H in bit-reversed order is a duplication (padded[2q] = c[q], padded[2q+1] = 0,
+// and the first DIT stage maps (a, 0) to (a, a)); the first DIT group of the LDE reads the
+// H-sized coefficient array directly, applies the coset scaling s^k/H and duplicates in
+// registers (EXPAND), so the 2H-sized vector is written exactly once per group.
 //
 // LDE definition (natural order, as oracle/stark_oracle.cpp `lde_column`):
 //   L[j] = T(s * g_{n+1}^j),  j < 2H,  s = 31.
@@ -30,95 +39,249 @@ namespace pw {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kTileLog = 13;        // 8192 elements = 32 KB of LDS per workgroup
-constexpr int kStridedC = 4;        // 16 neighbouring elements = 64-byte segments
-constexpr int kStridedK = kTileLog - kStridedC;
+constexpr int kStridedC = 4;  // 16 neighbouring elements = 64-byte segments
+
+__constant__ uint32_t c_roots16[2][8];  // [0]: w16^r forward, [1]: inverse (Montgomery), r < 8
 
 __global__ void fill_powers_kernel(uint32_t* out, uint32_t base, uint32_t scale, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = bb::mul(bb::pow_u32(base, (uint32_t)i), scale);
 }
+__global__ void bitrev_copy_kernel(const uint32_t* in, uint32_t* out, int n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((size_t)1 << n)) return;
+    uint32_t k = n ? (__brev((uint32_t)i) >> (32 - n)) : 0u;
+    out[i] = in[k];
+}
 
-// One stage group. DIF: active bits [n-s0-k, n-s0), stage order high bit -> low bit.
-//                  DIT: active bits [s0, s0+k),     stage order low bit -> high bit.
-// `lowbits` = number of index bits below the active bits; c = min(lowbits, cmax) of them
-// ride along in the tile.
-template <bool DIF>
-__global__ __launch_bounds__(kBlock) void ntt_group_kernel(
-    const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t in_stride, size_t out_stride,
-    int n, int s0, int k, int c, const uint32_t* __restrict__ tw /* w^j, j < 2^(n-1) */) {
-    extern __shared__ uint32_t tile[];
-    const int lowbits = DIF ? n - s0 - k : s0;
-    const int E = 1 << (k + c);
-    const uint32_t cmask = (1u << c) - 1u;
-    // decompose the tile id into (hi, lo_hi)
-    const int lo_hi_bits = lowbits - c;
-    const size_t tile_id = blockIdx.x;
-    const size_t lo_hi = tile_id & (((size_t)1 << lo_hi_bits) - 1);
-    const size_t hi = tile_id >> lo_hi_bits;
-    const size_t base = (hi << (lowbits + k)) | (lo_hi << c);
-    const uint32_t* src = in + (size_t)blockIdx.y * in_stride;
-    uint32_t* dst = out + (size_t)blockIdx.y * out_stride;
+struct GroupParams {
+    int n;        // log2 of the transform size
+    int s0;       // first stage of the group
+    int k;        // stages in the group
+    int c;        // passive low bits carried in the tile
+    int lowbits;  // index bits below the active bits (DIF: n-s0-k, DIT: s0)
+    int B;        // k + c: in-tile index bits
+    int n_rounds;
+    int rb[4];    // window start (tile bit) per round, in execution order
+    int logr[4];  // window width per round
+    unsigned long long n_tiles;  // tiles per column = 2^(n-B)
+};
 
-    for (int e = threadIdx.x; e < E; e += kBlock) {
-        size_t t = (size_t)(e >> c), lo = (size_t)(e & cmask);
-        tile[e] = src[base | (t << lowbits) | lo];
+__device__ __forceinline__ uint32_t lds_phys(uint32_t l) { return l + (l >> 5); }
+
+struct IndexMap {
+    int B, c, lowbits, k;
+    uint32_t cmask;
+    size_t tile0;
+    size_t n_tiles;
+    // global index of local element l; valid = tile exists
+    __device__ __forceinline__ size_t global(uint32_t l, bool& valid) const {
+        const uint32_t i = l & ((1u << B) - 1u);
+        const size_t tile = tile0 + (l >> B);
+        valid = tile < n_tiles;
+        const int lo_hi_bits = lowbits - c;
+        const size_t lo_hi = tile & (((size_t)1 << lo_hi_bits) - 1);
+        const size_t hi = tile >> lo_hi_bits;
+        return (hi << (lowbits + k)) | ((size_t)(i >> c) << lowbits) | (lo_hi << c) | (size_t)(i & cmask);
     }
-    __syncthreads();
-    const size_t lo_base = lo_hi << c;
-    for (int j = 0; j < k; ++j) {
-        const int pos = DIF ? (k - 1 - j) : j;  // active bit handled by this stage
-        const int s = s0 + j;                   // global stage number
-        for (int b = threadIdx.x; b < (E >> 1); b += kBlock) {
-            const uint32_t lo = (uint32_t)b & cmask;
-            const uint32_t tt = (uint32_t)b >> c;
-            const uint32_t t0 = ((tt >> pos) << (pos + 1)) | (tt & ((1u << pos) - 1u));
-            const uint32_t t1 = t0 | (1u << pos);
-            const uint32_t i0 = (t0 << c) | lo, i1 = (t1 << c) | lo;
-            // p mod d with d = distance of this stage
-            const size_t pm = ((size_t)(t0 & ((1u << pos) - 1u)) << lowbits) | lo_base | lo;
-            const size_t ex = DIF ? (pm << s) : (pm << (n - s - 1));
-            const uint32_t w = tw[ex];
-            uint32_t a = tile[i0], bq = tile[i1];
-            if (DIF) {
-                tile[i0] = bb::add(a, bq);
-                tile[i1] = bb::mul(bb::sub(a, bq), w);
-            } else {
-                bq = bb::mul(bq, w);
-                tile[i0] = bb::add(a, bq);
-                tile[i1] = bb::sub(a, bq);
+    // global index bits below tile bit `rb` for the slot whose local index (with the window zeroed) is l
+    __device__ __forceinline__ size_t glow(uint32_t l, int rb) const {
+        const uint32_t i = l & ((1u << rb) - 1u);
+        const size_t tile = tile0 + (l >> B);
+        if (tile >= n_tiles) return 0;  // padding slot of a short transform: any in-range twiddle
+        const int lo_hi_bits = lowbits - c;
+        const size_t lo_hi = tile & (((size_t)1 << lo_hi_bits) - 1);
+        return ((size_t)(i >> c) << lowbits) | (lo_hi << c) | (size_t)(i & cmask);
+    }
+};
+
+// One round: LOGR stages on the window [rb, rb+LOGR) of the tile index. x holds EPT elements:
+// x[m * R + rho], R = 2^LOGR, slot sigma = tid + 256 m.
+template <bool DIF, int LOGR, int EPT>
+__device__ __forceinline__ void round_butterflies(uint32_t* x, const IndexMap& im, const GroupParams& gp, int rb,
+                                                  const uint32_t* __restrict__ tw, int tid) {
+    constexpr int R = 1 << LOGR;
+    constexpr int SLOTS = EPT / R;
+    const uint32_t* roots = c_roots16[DIF ? 1 : 0];
+#pragma unroll
+    for (int m = 0; m < SLOTS; ++m) {
+        const uint32_t sigma = (uint32_t)tid + 256u * m;
+        const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
+        const size_t g = im.glow(l0, rb);
+        // base[q] = w^(g << shift_q)
+        uint32_t base[LOGR];
+        if (DIF) {
+            // s_q = s0 + k - 1 - (rb + q - c); smallest shift at q = LOGR-1; base[q-1] = base[q]^2
+            const int s_top = gp.s0 + gp.k - 1 - (rb + (LOGR - 1) - gp.c);
+            base[LOGR - 1] = tw[g << s_top];
+#pragma unroll
+            for (int q = LOGR - 2; q >= 0; --q) base[q] = bb::sqr(base[q + 1]);
+        } else {
+            // shift_q = n - 1 - (s0 + rb + q - c); smallest at q = LOGR-1; base[q-1] = base[q]^2
+            const int sh_top = gp.n - 1 - (gp.s0 + rb + (LOGR - 1) - gp.c);
+            base[LOGR - 1] = tw[g << sh_top];
+#pragma unroll
+            for (int q = LOGR - 2; q >= 0; --q) base[q] = bb::sqr(base[q + 1]);
+        }
+        uint32_t* v = x + m * R;
+#pragma unroll
+        for (int qi = 0; qi < LOGR; ++qi) {
+            const int q = DIF ? (LOGR - 1 - qi) : qi;
+            // twiddles of this stage: base[q] * w_{2^(q+1)}^r, r < 2^q;  w_{2^(q+1)}^r = w16^(r << (3 - q))
+            uint32_t t[1 << (LOGR - 1)];
+#pragma unroll
+            for (int r = 0; r < (1 << q); ++r) t[r] = r == 0 ? base[q] : bb::mul(base[q], roots[r << (3 - q)]);
+#pragma unroll
+            for (int u = 0; u < R / 2; ++u) {
+                const int lowp = u & ((1 << q) - 1);
+                const int i0 = ((u >> q) << (q + 1)) | lowp;
+                const int i1 = i0 | (1 << q);
+                const uint32_t a = v[i0], b = v[i1];
+                if (DIF) {
+                    v[i0] = bb::add(a, b);
+                    v[i1] = bb::mul(bb::sub(a, b), t[lowp]);
+                } else {
+                    const uint32_t bt = bb::mul(b, t[lowp]);
+                    v[i0] = bb::add(a, bt);
+                    v[i1] = bb::sub(a, bt);
+                }
             }
         }
-        __syncthreads();
-    }
-    for (int e = threadIdx.x; e < E; e += kBlock) {
-        size_t t = (size_t)(e >> c), lo = (size_t)(e & cmask);
-        dst[base | (t << lowbits) | lo] = tile[e];
     }
 }
 
-// out[2q] = out[2q+1] = in[q] * scale[bitrev_n(q)]   (zero-pad + first DIT stage + coset scaling)
-__global__ __launch_bounds__(kBlock) void expand_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                        size_t in_stride, size_t out_stride, int n,
-                                                        const uint32_t* __restrict__ scale) {
-    size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (q >= ((size_t)1 << n)) return;
-    uint32_t k = n ? (__brev((uint32_t)q) >> (32 - n)) : 0u;
-    uint32_t v = bb::mul(in[(size_t)blockIdx.y * in_stride + q], scale[k]);
-    uint2* o = reinterpret_cast<uint2*>(out + (size_t)blockIdx.y * out_stride + 2 * q);
-    *o = make_uint2(v, v);
+template <int LOGR, int EPT, class F>
+__device__ __forceinline__ void for_each_element(int rb, int tid, F&& f) {
+    constexpr int R = 1 << LOGR;
+    constexpr int SLOTS = EPT / R;
+#pragma unroll
+    for (int m = 0; m < SLOTS; ++m) {
+        const uint32_t sigma = (uint32_t)tid + 256u * m;
+        const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
+#pragma unroll
+        for (int rho = 0; rho < R; ++rho) f(m * R + rho, l0 | ((uint32_t)rho << rb));
+    }
+}
+
+// EXPAND: `src` is the H-sized bit-reversed coefficient array (n = log2(2H)); element g of the
+// 2H-sized vector is src[g >> 1] * scale_br[g >> 1].
+template <bool DIF, int LOGR, int EPT, bool EXPAND>
+__device__ __forceinline__ void run_round(uint32_t* x, uint32_t* tile, const IndexMap& im, const GroupParams& gp, int round,
+                                          const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                          const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid) {
+    const int rb = gp.rb[round];
+    const bool first = round == 0, last = round == gp.n_rounds - 1;
+    constexpr int R = 1 << LOGR;
+    if (first) {
+        if (!EXPAND && rb == 0 && gp.c == 0 && LOGR >= 2) {
+            // the thread's R elements are contiguous in memory: 16-byte loads
+            constexpr int SLOTS = EPT / R;
+#pragma unroll
+            for (int m = 0; m < SLOTS; ++m) {
+                const uint32_t l0 = ((uint32_t)tid + 256u * m) << LOGR;
+                bool valid;
+                const size_t g = im.global(l0, valid);
+                const uint4* p = reinterpret_cast<const uint4*>(src + g);
+#pragma unroll
+                for (int v4 = 0; v4 < R / 4; ++v4) {
+                    uint4 d = valid ? p[v4] : make_uint4(0, 0, 0, 0);
+                    x[m * R + 4 * v4 + 0] = d.x; x[m * R + 4 * v4 + 1] = d.y;
+                    x[m * R + 4 * v4 + 2] = d.z; x[m * R + 4 * v4 + 3] = d.w;
+                }
+            }
+        } else {
+            for_each_element<LOGR, EPT>(rb, tid, [&](int reg, uint32_t l) {
+                bool valid;
+                const size_t g = im.global(l, valid);
+                uint32_t v = 0u;
+                if (valid) v = EXPAND ? bb::mul(src[g >> 1], scale_br[g >> 1]) : src[g];
+                x[reg] = v;
+            });
+        }
+    } else {
+        for_each_element<LOGR, EPT>(rb, tid, [&](int reg, uint32_t l) { x[reg] = tile[lds_phys(l)]; });
+        // a middle round overwrites the tile it has just read: every wave must have finished reading
+        if (!last) __syncthreads();
+    }
+    round_butterflies<DIF, LOGR, EPT>(x, im, gp, rb, tw, tid);
+    if (last) {
+        if (rb == 0 && gp.c == 0 && LOGR >= 2) {
+            constexpr int SLOTS = EPT / R;
+#pragma unroll
+            for (int m = 0; m < SLOTS; ++m) {
+                const uint32_t l0 = ((uint32_t)tid + 256u * m) << LOGR;
+                bool valid;
+                const size_t g = im.global(l0, valid);
+                if (valid) {
+                    uint4* p = reinterpret_cast<uint4*>(dst + g);
+#pragma unroll
+                    for (int v4 = 0; v4 < R / 4; ++v4)
+                        p[v4] = make_uint4(x[m * R + 4 * v4], x[m * R + 4 * v4 + 1], x[m * R + 4 * v4 + 2], x[m * R + 4 * v4 + 3]);
+                }
+            }
+        } else {
+            for_each_element<LOGR, EPT>(rb, tid, [&](int reg, uint32_t l) {
+                bool valid;
+                const size_t g = im.global(l, valid);
+                if (valid) dst[g] = x[reg];
+            });
+        }
+    } else {
+        for_each_element<LOGR, EPT>(rb, tid, [&](int reg, uint32_t l) { tile[lds_phys(l)] = x[reg]; });
+    }
+}
+
+template <bool DIF, int LOGT, bool EXPAND>
+__global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                           size_t in_stride, size_t out_stride, GroupParams gp,
+                                                           const uint32_t* __restrict__ tw,
+                                                           const uint32_t* __restrict__ scale_br) {
+    constexpr int EPT = (1 << LOGT) / kBlock;
+    __shared__ uint32_t tile[(1 << LOGT) + ((1 << LOGT) >> 5)];
+    uint32_t x[EPT];
+    const int tid = threadIdx.x;
+    IndexMap im;
+    im.B = gp.B; im.c = gp.c; im.lowbits = gp.lowbits; im.k = gp.k;
+    im.cmask = (1u << gp.c) - 1u;
+    im.tile0 = (size_t)blockIdx.x << (LOGT - gp.B);
+    im.n_tiles = (size_t)gp.n_tiles;
+    const uint32_t* src = in + (size_t)blockIdx.y * in_stride;
+    uint32_t* dst = out + (size_t)blockIdx.y * out_stride;
+    for (int r = 0; r < gp.n_rounds; ++r) {
+        switch (gp.logr[r]) {
+            case 1: run_round<DIF, 1, EPT, EXPAND>(x, tile, im, gp, r, src, dst, tw, scale_br, tid); break;
+            case 2: run_round<DIF, 2, EPT, EXPAND>(x, tile, im, gp, r, src, dst, tw, scale_br, tid); break;
+            case 3: run_round<DIF, 3, EPT, EXPAND>(x, tile, im, gp, r, src, dst, tw, scale_br, tid); break;
+            default: run_round<DIF, 4, EPT, EXPAND>(x, tile, im, gp, r, src, dst, tw, scale_br, tid); break;
+        }
+        if (r + 1 < gp.n_rounds) __syncthreads();  // the next round reads what this round wrote
+    }
 }
 
 struct Tables {
-    uint32_t* tw_fwd = nullptr;  // g_n^j, j < 2^(n-1)
-    uint32_t* tw_inv = nullptr;  // g_n^-j
-    uint32_t* shift = nullptr;   // s^k / 2^n, k < 2^n
+    uint32_t* tw_fwd = nullptr;    // g_n^j, j < 2^(n-1)
+    uint32_t* tw_inv = nullptr;    // g_n^-j
+    uint32_t* shift = nullptr;     // s^k / 2^n, k < 2^n
+    uint32_t* shift_br = nullptr;  // shift[bitrev_n(q)]
 };
 std::mutex g_mu;
 std::map<int, Tables> g_tables;
+bool g_roots_uploaded = false;
+
+int upload_roots() {
+    if (g_roots_uploaded) return 0;
+    uint32_t h[2][8];
+    const uint32_t w16 = field::root_of_unity(4), w16i = bb::inv(w16);
+    uint32_t a = bb::R_MOD_P, b = bb::R_MOD_P;
+    for (int r = 0; r < 8; ++r) { h[0][r] = a; h[1][r] = b; a = bb::mul(a, w16); b = bb::mul(b, w16i); }
+    PW_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_roots16), h, sizeof h));
+    g_roots_uploaded = true;
+    return 0;
+}
 
 const Tables* tables(int n) {
     std::lock_guard<std::mutex> lk(g_mu);
+    if (upload_roots()) return nullptr;
     auto it = g_tables.find(n);
     if (it != g_tables.end()) return &it->second;
     Tables t;
@@ -126,6 +289,7 @@ const Tables* tables(int n) {
     if (hipMalloc(&t.tw_fwd, half * 4) != hipSuccess) return nullptr;
     if (hipMalloc(&t.tw_inv, half * 4) != hipSuccess) return nullptr;
     if (hipMalloc(&t.shift, full * 4) != hipSuccess) return nullptr;
+    if (hipMalloc(&t.shift_br, full * 4) != hipSuccess) return nullptr;
     uint32_t w = field::root_of_unity(n);
     uint32_t one = bb::R_MOD_P;
     hipLaunchKernelGGL(fill_powers_kernel, dim3(div_up(half, 256)), dim3(256), 0, stream(), t.tw_fwd, w, one, half);
@@ -133,71 +297,109 @@ const Tables* tables(int n) {
     uint32_t ninv = bb::inv(bb::to_monty((uint32_t)(((uint64_t)1 << n) % bb::P)));
     hipLaunchKernelGGL(fill_powers_kernel, dim3(div_up(full, 256)), dim3(256), 0, stream(), t.shift,
                        bb::to_monty(field::kCosetShift), ninv, full);
+    hipLaunchKernelGGL(bitrev_copy_kernel, dim3(div_up(full, 256)), dim3(256), 0, stream(), t.shift, t.shift_br, n);
     return &g_tables.emplace(n, t).first->second;
 }
 
-struct Group { int s0, k, c; };
-
-// Split stages [first, n) into groups. Contiguous groups (no low bits, or fewer than
-// kStridedC of them) may take up to kTileLog - c stages, strided groups kStridedK.
-std::vector<Group> plan_groups(bool dif, int n, int first) {
-    std::vector<Group> g;
+// Split stages [first, n) into groups of at most `LOGT - c` stages and each group into rounds.
+std::vector<GroupParams> plan_groups(bool dif, int n, int first, int& logt_out) {
+    std::vector<GroupParams> out;
+    const int total = n - first;
+    // tile size: 2^13 when it saves a pass or the transform is large, else 2^12
+    int logt = 12;
+    {
+        auto passes = [&](int lt) {
+            int s = first, p = 0;
+            while (s < n) {
+                int rem = n - s, k = rem < lt ? rem : lt;
+                for (; k >= 1; --k) { int lb = dif ? n - s - k : s; int c = lb < kStridedC ? lb : kStridedC; if (k + c <= lt) break; }
+                s += k; ++p;
+            }
+            return p;
+        };
+        if (total > 0 && passes(13) < passes(12)) logt = 13;
+    }
+    logt_out = logt;
     int s = first;
     while (s < n) {
-        int remaining = n - s;
-        // low bits available if this group takes `k` stages
-        auto lowbits = [&](int k) { return dif ? n - s - k : s; };
-        int k = remaining < kTileLog ? remaining : kTileLog;
-        for (; k >= 1; --k) {
-            int lb = lowbits(k);
-            int c = lb < kStridedC ? lb : kStridedC;
-            if (k + c <= kTileLog) break;
+        int rem = n - s, k = rem < logt ? rem : logt;
+        int c = 0;
+        for (; k >= 1; --k) { int lb = dif ? n - s - k : s; c = lb < kStridedC ? lb : kStridedC; if (k + c <= logt) break; }
+        GroupParams g{};
+        g.n = n; g.s0 = s; g.k = k; g.c = c; g.lowbits = dif ? n - s - k : s; g.B = k + c;
+        g.n_tiles = 1ull << (n - g.B);
+        // rounds: ceil(k/4) windows of nearly equal width
+        int nr = (k + 3) / 4;
+        g.n_rounds = nr;
+        int widths[4];
+        for (int r = 0; r < nr; ++r) widths[r] = k / nr + (r < k % nr ? 1 : 0);
+        if (dif) {  // from the top active bit downwards
+            int top = c + k;
+            for (int r = 0; r < nr; ++r) { top -= widths[r]; g.rb[r] = top; g.logr[r] = widths[r]; }
+        } else {    // from the lowest active bit upwards
+            int bot = c;
+            for (int r = 0; r < nr; ++r) { g.rb[r] = bot; g.logr[r] = widths[r]; bot += widths[r]; }
         }
-        // balance: avoid a tiny trailing group (e.g. 9 + 1): cap k so that the rest is not < 3
-        int rest = remaining - k;
-        if (rest > 0 && rest < 3 && k > 4) k -= (3 - rest);
-        int lb = lowbits(k);
-        int c = lb < kStridedC ? lb : kStridedC;
-        g.push_back({s, k, c});
+        out.push_back(g);
         s += k;
     }
-    return g;
+    return out;
 }
 
 template <bool DIF>
 void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n,
-                int first_stage, const uint32_t* tw, const char* name) {
-    auto groups = plan_groups(DIF, n, first_stage);
+                int first_stage, const uint32_t* tw, const uint32_t* expand_scale_br, const char* name) {
+    int logt = 12;
+    auto groups = plan_groups(DIF, n, first_stage, logt);
     const uint32_t* src = in;
     size_t src_stride = in_stride;
+    bool expand = expand_scale_br != nullptr;
     for (auto& g : groups) {
-        size_t tiles = ((size_t)1 << n) >> (g.k + g.c);
+        const size_t tiles = (size_t)1 << (n - g.B);
+        const size_t per_wg = (size_t)1 << (logt - g.B);
+        const unsigned wgs = (unsigned)((tiles + per_wg - 1) / per_wg);
         for (uint32_t c0 = 0; c0 < cols; c0 += 65535u) {
             uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;
             ScopedKernelTimer t(name);
-            hipLaunchKernelGGL(ntt_group_kernel<DIF>, dim3((unsigned)tiles, cc), dim3(kBlock), (size_t)4 << (g.k + g.c),
-                               stream(), src + (size_t)c0 * src_stride, out + (size_t)c0 * out_stride, src_stride,
-                               out_stride, n, g.s0, g.k, g.c, tw);
+            const uint32_t* s_ = src + (size_t)c0 * src_stride;
+            uint32_t* d_ = out + (size_t)c0 * out_stride;
+            dim3 grid(wgs, cc), block(kBlock);
+#define PW_LAUNCH_NTT(LT, EX) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, EX>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br)
+            if (logt == 13) { if (expand) PW_LAUNCH_NTT(13, true); else PW_LAUNCH_NTT(13, false); }
+            else            { if (expand) PW_LAUNCH_NTT(12, true); else PW_LAUNCH_NTT(12, false); }
+#undef PW_LAUNCH_NTT
         }
         src = out;
         src_stride = out_stride;
+        expand = false;
+        expand_scale_br = nullptr;
     }
     if (groups.empty() && in != out) {
-        // n == first_stage: nothing to do but copy
         for (uint32_t c = 0; c < cols; ++c)
             (void)hipMemcpyAsync(out + (size_t)c * out_stride, in + (size_t)c * in_stride, (size_t)4 << n,
                                  hipMemcpyDeviceToDevice, stream());
     }
 }
 
+// out[2q] = out[2q+1] = in[q] * scale_br[q]  (only used when the forward transform has no DIT stage
+// left after the duplication, i.e. H = 1)
+__global__ void expand_small_kernel(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_stride, size_t h,
+                                    const uint32_t* scale_br) {
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= h) return;
+    uint32_t v = bb::mul(in[(size_t)blockIdx.y * in_stride + q], scale_br[q]);
+    out[(size_t)blockIdx.y * out_stride + 2 * q] = v;
+    out[(size_t)blockIdx.y * out_stride + 2 * q + 1] = v;
+}
+
 }  // namespace
 
 // Unscaled inverse NTT: natural-order evaluations on <g_n> -> bit-reversed coefficient order,
-// out[q] = n * coefficient[bitrev(q)].
+// out[q] = 2^n * coefficient[bitrev(q)].
 int intt_dif(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n) {
     const Tables* t = tables(n);
     if (!t) return (int)hipErrorOutOfMemory;
-    run_groups<true>(in, out, in_stride, out_stride, cols, n, 0, t->tw_inv, "ntt_group_kernel<dif>");
+    run_groups<true>(in, out, in_stride, out_stride, cols, n, 0, t->tw_inv, nullptr, "ntt_group_kernel<dif>");
     return (int)hipGetLastError();
 }
 
@@ -207,13 +409,14 @@ int coset_lde_from_coeffs(const uint32_t* coeffs, uint32_t* out, size_t in_strid
     const Tables* tn = tables(n);
     const Tables* t1 = tables(n + 1);
     if (!tn || !t1) return (int)hipErrorOutOfMemory;
-    for (uint32_t c0 = 0; c0 < cols; c0 += 65535u) {
-        uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;
-        ScopedKernelTimer t("expand_kernel");
-        hipLaunchKernelGGL(expand_kernel, dim3(div_up((size_t)1 << n, kBlock), cc), dim3(kBlock), 0, stream(),
-                           coeffs + (size_t)c0 * in_stride, out + (size_t)c0 * out_stride, in_stride, out_stride, n, tn->shift);
+    if (n == 0) {
+        ScopedKernelTimer t("expand_small_kernel");
+        hipLaunchKernelGGL(expand_small_kernel, dim3(1, cols), dim3(64), 0, stream(), coeffs, out, in_stride, out_stride,
+                           (size_t)1, tn->shift_br);
+        return (int)hipGetLastError();
     }
-    run_groups<false>(out, out, out_stride, out_stride, cols, n + 1, 1, t1->tw_fwd, "ntt_group_kernel<dit>");
+    // stage 0 of the size-2^(n+1) DIT is the duplication done by the EXPAND load of the first group
+    run_groups<false>(coeffs, out, in_stride, out_stride, cols, n + 1, 1, t1->tw_fwd, tn->shift_br, "ntt_group_kernel<dit>");
     return (int)hipGetLastError();
 }
 
