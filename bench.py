@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--pow-bits", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log-height", type=int, default=11)
+    ap.add_argument("--cpu-log-height", type=int, default=14)
     ap.add_argument("--exact-source-heights", action="store_true",
                     help="allocate dummy traces with b*calls rows instead of next_pow2 (less HBM)")
     return ap.parse_args()
@@ -154,8 +154,7 @@ def main():
     log_h = args.log_height or shape.log_height
     wl = build_workload(args.shape, log_h, args.exact_source_heights, seed=rank)
     pr = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits)
-    roots = torch.zeros(8, dtype=torch.int32, device="cuda")
-    gathered = torch.zeros(8 * world, dtype=torch.int32, device="cuda") if world > 1 else None
+    from powdr_amd import sharding
 
     def step():
         for t in (wl["per"].var_hist, wl["per"].tuple_hist, wl["per"].bitwise_hist):
@@ -163,10 +162,8 @@ def main():
         wl["apc"].generate_witness_gpu(wl["instr_air"], wl["dummy"], wl["calls"], wl["out"].data_ptr(), wl["per"])
         proof = pr.prove(wl["out"].data_ptr(), log_h, copy=False)
         if world > 1:
-            import torch.distributed as dist
-
-            roots.copy_(torch.from_numpy(proof[6:14].astype(np.int64).astype(np.int32)))
-            dist.all_gather_into_tensor(gathered, roots)  # the final commitment merge (32 B per segment)
+            # the final commitment merge: all-gather of the per-segment trace roots (32 B per segment)
+            sharding.merge_commitments([rank], proof[6:14].reshape(1, 8), world)
         return proof
 
     def barrier():

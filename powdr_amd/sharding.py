@@ -1,0 +1,68 @@
+"""Multi-GPU sharding of the proving path: independent segments / AIR proofs across ranks.
+
+The reference proves segments strictly sequentially on one device
+(/root/reference/openvm/src/trace_generation.rs:111-141); once metered execution has fixed the
+segment boundaries (:107-109) the per-segment proofs are independent, so the MI355X design shards
+them one process per GPU with NO data-path collective. The only exchange is the final
+"commitment merge": every rank contributes the 8-word trace commitment of each proof it made and
+all ranks receive the full, segment-ordered list (RCCL all-gather over xGMI on GPUs: 32 bytes
+per proof; gloo in the CPU tests). `torch.distributed` is plumbing here.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def assign_units(cells_per_unit, world_size: int):
+    """Largest-first greedy balance of proof units (segments or AIRs) by cell count.
+    Returns a list of unit-index lists, one per rank; deterministic."""
+    loads = [0] * world_size
+    out = [[] for _ in range(world_size)]
+    for u in sorted(range(len(cells_per_unit)), key=lambda i: (-cells_per_unit[i], i)):
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        out[r].append(u)
+        loads[r] += cells_per_unit[u]
+    for lst in out:
+        lst.sort()
+    return out
+
+
+def merge_commitments(local_units, local_roots, n_units: int, group=None) -> np.ndarray:
+    """All-gather the per-proof commitments. local_units: indices this rank proved;
+    local_roots: uint32 [len(local_units), 8]. Returns uint32 [n_units, 8] on every rank,
+    rows of units nobody proved are zero."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    roots = np.zeros((n_units, 8), dtype=np.uint32)
+    mine = np.asarray(local_roots, dtype=np.uint32).reshape(-1, 8)
+    for u, r in zip(local_units, mine):
+        roots[u] = r
+    if world == 1:
+        return roots
+    backend = dist.get_backend(group)
+    device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    # every rank owns disjoint rows, so a sum-free gather of full tables + OR-merge is exact
+    t = torch.from_numpy(roots.view(np.int32).reshape(-1).copy()).to(device)
+    gathered = torch.empty(world * t.numel(), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(gathered, t, group=group)
+    g = gathered.cpu().numpy().view(np.uint32).reshape(world, n_units, 8)
+    return np.bitwise_or.reduce(g, axis=0)
+
+
+def commitment_digest(roots: np.ndarray) -> np.ndarray:
+    """One 8-word digest over the ordered list of commitments (binary Poseidon2 tree, the host
+    transcript permutation of libpowdr_gpu; canonical words)."""
+    from . import prover
+
+    level = [np.asarray(r, dtype=np.uint32) for r in roots]
+    if not level:
+        return np.zeros(8, np.uint32)
+    while len(level) > 1:
+        nxt = []
+        for i in range(0, len(level), 2):
+            right = level[i + 1] if i + 1 < len(level) else np.zeros(8, np.uint32)
+            nxt.append(prover.poseidon2_host(np.concatenate([level[i], right]))[:8])
+        level = nxt
+    return level[0]
