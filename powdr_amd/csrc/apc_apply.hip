@@ -25,6 +25,11 @@
 #include "expr_eval.hpp"
 #include "../../include/powdr_gpu.h"
 
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -66,15 +71,29 @@ __device__ __forceinline__ uint32_t bitwise_index(uint32_t x, uint32_t y, uint32
     return selector * (1u << (2 * POWDR_BITWISE_NUM_BITS)) + (x << POWDR_BITWISE_NUM_BITS) + y;
 }
 
+// Binned mode (long traces). The device-wide atomic rate (27 G/s on MI355X, any scope, see
+// profiles/r01_microbench_atomics.txt) would bound this stage at ~1 atomic per lookup, and hot bins
+// (bytes that are mostly 0, constant range widths) serialise far below that. Instead the
+// evaluation kernel writes one packed item (bin | multiplicity << 20) per (periphery interaction,
+// row) into a dense buffer — coalesced, no atomics — and a second kernel counts the items of
+// one 32 K-bin partition of one table in an LDS histogram (LDS atomics), touching global
+// memory with one atomicAdd per non-empty bin per workgroup.
+constexpr uint32_t kItemNone = 0xffffffffu;
+constexpr uint32_t kItemBinBits = 20;
+constexpr uint32_t kItemMaxMult = 1u << (32 - kItemBinBits);
+
+template <bool BINNED>
 __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
     const uint32_t* __restrict__ trace, int num_calls, const uint32_t* __restrict__ bytecode,
     const DevInteraction* __restrict__ interactions, uint32_t n_interactions,
-    const ExprSpan* __restrict__ spans, BusParams p, uint32_t per_chunk) {
+    const ExprSpan* __restrict__ spans, BusParams p, uint32_t per_chunk,
+    const int32_t* __restrict__ slot_of, uint32_t* __restrict__ items, size_t item_stride) {
     __shared__ uint32_t stack_lds[pw::kStackCap * kBlock];
     uint32_t* stk = stack_lds + threadIdx.x;
-    const int r_i = blockIdx.x * kBlock + threadIdx.x;
-    if (r_i >= num_calls) return;
-    const size_t r = (size_t)r_i;
+    const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = r < (size_t)num_calls;
+    if (!BINNED && !live) return;
+    if (BINNED && r >= item_stride) return;
     const uint32_t i0 = blockIdx.y * per_chunk;
     const uint32_t i1 = min(n_interactions, i0 + per_chunk);
 
@@ -86,31 +105,93 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
         else if (intr.bus_id == p.bitwise_bus) kind = 2;
         else continue;  // execution bridge / memory / pc lookup: no periphery side effect
 
-        const ExprSpan* sp = spans + intr.args_index_off;
-        const ExprSpan ms = sp[0];
-        const uint32_t m = bb::from_monty(pw::eval_expr<kBlock>(bytecode + ms.off, ms.len, trace, r, stk));
-        if (m == 0u) continue;
-
-        const ExprSpan s0 = sp[1], s1 = sp[2];
-        const uint32_t a0 = bb::from_monty(pw::eval_expr<kBlock>(bytecode + s0.off, s0.len, trace, r, stk));
-        const uint32_t a1 = bb::from_monty(pw::eval_expr<kBlock>(bytecode + s1.off, s1.len, trace, r, stk));
-        if (kind == 0) {
-            // [value, max_bits] -> bin (1 << max_bits) + value - 1   (apc_apply_bus.cu:74)
-            // (shift counts >= 32 give 0, as PTX shl.b32 does for the reference build)
-            const uint32_t idx = (a1 < 32u ? (1u << a1) : 0u) + a0 - 1u;
-            if (idx < p.var_bins) atomicAdd(p.var_hist + idx, m);
-        } else if (kind == 1) {
-            // [v0, v1] -> bin v0 * sz1 + v1                         (apc_apply_bus.cu:89)
-            const uint32_t idx = a0 * p.tuple_sz1 + a1;
-            if (idx < p.tuple_sz0 * p.tuple_sz1) atomicAdd(p.tuple_hist + idx, m);
-        } else {
-            // [x, y, x_xor_y, selector]; arg 2 is never read (apc_apply_bus.cu:94-99)
-            const ExprSpan s3 = sp[4];
-            const uint32_t sel = bb::from_monty(pw::eval_expr<kBlock>(bytecode + s3.off, s3.len, trace, r, stk));
-            if (sel <= 1u && a0 < 256u && a1 < 256u)
-                atomicAdd(p.bitwise_hist + bitwise_index(a0, a1, sel), m);
+        uint32_t bin = kItemNone, m = 0u;
+        uint32_t* table = kind == 0 ? p.var_hist : kind == 1 ? p.tuple_hist : p.bitwise_hist;
+        if (live) {
+            const ExprSpan* sp = spans + intr.args_index_off;
+            const ExprSpan ms = sp[0];
+            m = bb::from_monty(pw::eval_expr<kBlock>(bytecode + ms.off, ms.len, trace, r, stk));
+            if (m != 0u) {
+                const ExprSpan s0 = sp[1], s1 = sp[2];
+                const uint32_t a0 = bb::from_monty(pw::eval_expr<kBlock>(bytecode + s0.off, s0.len, trace, r, stk));
+                const uint32_t a1 = bb::from_monty(pw::eval_expr<kBlock>(bytecode + s1.off, s1.len, trace, r, stk));
+                if (kind == 0) {
+                    // [value, max_bits] -> bin (1 << max_bits) + value - 1   (apc_apply_bus.cu:74)
+                    // (shift counts >= 32 give 0, as PTX shl.b32 does for the reference build)
+                    const uint32_t idx = (a1 < 32u ? (1u << a1) : 0u) + a0 - 1u;
+                    if (idx < p.var_bins) bin = idx;
+                } else if (kind == 1) {
+                    // [v0, v1] -> bin v0 * sz1 + v1                         (apc_apply_bus.cu:89)
+                    const uint32_t idx = a0 * p.tuple_sz1 + a1;
+                    if (idx < p.tuple_sz0 * p.tuple_sz1) bin = idx;
+                } else {
+                    // [x, y, x_xor_y, selector]; arg 2 is never read (apc_apply_bus.cu:94-99)
+                    const ExprSpan s3 = sp[4];
+                    const uint32_t sel = bb::from_monty(pw::eval_expr<kBlock>(bytecode + s3.off, s3.len, trace, r, stk));
+                    if (sel <= 1u && a0 < 256u && a1 < 256u) bin = bitwise_index(a0, a1, sel);
+                }
+            }
+        }
+        if (BINNED) {
+            uint32_t item = kItemNone;
+            if (bin != kItemNone) {
+                if (m < kItemMaxMult && bin < (1u << kItemBinBits)) item = bin | (m << kItemBinBits);
+                else atomicAdd(table + bin, m);  // does not fit the packed item: rare, direct
+            }
+            items[(size_t)slot_of[i] * item_stride + r] = item;
+        } else if (bin != kItemNone) {
+            atomicAdd(table + bin, m);
         }
     }
+}
+
+constexpr uint32_t kPartBins = 32768;  // 128 KB of LDS counters
+constexpr int kHistBlock = 1024;
+
+__global__ __launch_bounds__(kHistBlock) void bus_histogram_kernel(
+    const uint32_t* __restrict__ items, size_t item_stride, const uint32_t* __restrict__ slots, uint32_t n_slots,
+    uint32_t* __restrict__ hist, uint32_t bins, uint32_t rows_per_chunk) {
+    __shared__ uint32_t lh[kPartBins];
+    const uint32_t bin0 = blockIdx.x * kPartBins;
+    for (uint32_t b = threadIdx.x; b < kPartBins; b += kHistBlock) lh[b] = 0u;
+    __syncthreads();
+    const size_t r0 = (size_t)blockIdx.y * rows_per_chunk;
+    const size_t r1 = r0 + rows_per_chunk < item_stride ? r0 + rows_per_chunk : item_stride;
+    for (uint32_t s = 0; s < n_slots; ++s) {
+        const uint4* it = reinterpret_cast<const uint4*>(items + (size_t)slots[s] * item_stride);
+        for (size_t q = (r0 >> 2) + threadIdx.x; q < (r1 >> 2); q += kHistBlock) {
+            const uint4 v = it[q];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t b = (w[k] & ((1u << kItemBinBits) - 1u)) - bin0;
+                if (w[k] != kItemNone && b < kPartBins) atomicAdd(&lh[b], w[k] >> kItemBinBits);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < kPartBins; b += kHistBlock) {
+        const uint32_t c = lh[b];
+        if (c && bin0 + b < bins) atomicAdd(hist + bin0 + b, c);
+    }
+}
+
+// host-side classification of the interaction list, cached by content
+struct BusPlan {
+    int32_t* d_slot_of = nullptr;        // per interaction: item slot or -1
+    uint32_t* d_slots[3] = {nullptr, nullptr, nullptr};  // slot ids per table (var, tuple, bitwise)
+    uint32_t n_slots[3] = {0, 0, 0};
+    uint32_t total_slots = 0;
+};
+std::mutex g_bus_mu;
+std::unordered_map<uint64_t, BusPlan> g_bus_plans;
+uint32_t* g_items = nullptr;
+size_t g_items_words = 0;
+
+uint64_t fnv1a64(const void* p, size_t n, uint64_t h) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
 }
 
 }  // namespace
@@ -159,9 +240,81 @@ extern "C" int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
     p.var_bus = var_range_bus_id; p.tuple_bus = tuple2_bus_id; p.bitwise_bus = bitwise_bus_id;
     p.var_hist = d_var_hist; p.tuple_hist = d_tuple2_hist; p.bitwise_hist = d_bitwise_hist;
     p.var_bins = (uint32_t)var_num_bins; p.tuple_sz0 = tuple2_sz0; p.tuple_sz1 = tuple2_sz1;
+    // ---- long traces: binned path ---------------------------------------------------------------
+    const char* env = getenv("POWDR_BUS_BINNED");
+    const bool want_binned = env ? atoi(env) != 0 : num_apc_calls >= 16384;
+    const uint32_t table_bins[3] = {(uint32_t)var_num_bins, tuple2_sz0 * tuple2_sz1, 2u << (2 * POWDR_BITWISE_NUM_BITS)};
+    if (want_binned && table_bins[0] <= (1u << kItemBinBits) && table_bins[1] <= (1u << kItemBinBits)) {
+        std::vector<DevInteraction> h(n_interactions);
+        PW_HIP_TRY(hipMemcpyAsync(h.data(), d_interactions, n_interactions * sizeof(DevInteraction), hipMemcpyDeviceToHost, pw::stream()));
+        PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
+        uint64_t key = fnv1a64(h.data(), h.size() * sizeof(DevInteraction), 1469598103934665603ull);
+        const uint32_t ids[3] = {var_range_bus_id, tuple2_bus_id, bitwise_bus_id};
+        key = fnv1a64(ids, sizeof ids, key);
+        BusPlan* plan;
+        {
+            std::lock_guard<std::mutex> lk(g_bus_mu);
+            auto it = g_bus_plans.find(key);
+            if (it == g_bus_plans.end()) {
+                BusPlan bp;
+                std::vector<int32_t> slot_of(n_interactions, -1);
+                std::vector<uint32_t> per_table[3];
+                for (size_t i = 0; i < n_interactions; ++i) {
+                    int kind = h[i].bus_id == ids[0] ? 0 : h[i].bus_id == ids[1] ? 1 : h[i].bus_id == ids[2] ? 2 : -1;
+                    if (kind < 0) continue;
+                    slot_of[i] = (int32_t)bp.total_slots;
+                    per_table[kind].push_back(bp.total_slots++);
+                }
+                PW_HIP_TRY(hipMalloc(&bp.d_slot_of, n_interactions * 4));
+                PW_HIP_TRY(hipMemcpy(bp.d_slot_of, slot_of.data(), n_interactions * 4, hipMemcpyHostToDevice));
+                for (int t = 0; t < 3; ++t) {
+                    bp.n_slots[t] = (uint32_t)per_table[t].size();
+                    PW_HIP_TRY(hipMalloc(&bp.d_slots[t], (per_table[t].size() + 1) * 4));
+                    if (!per_table[t].empty())
+                        PW_HIP_TRY(hipMemcpy(bp.d_slots[t], per_table[t].data(), per_table[t].size() * 4, hipMemcpyHostToDevice));
+                }
+                it = g_bus_plans.emplace(key, bp).first;
+            }
+            plan = &it->second;
+        }
+        if (plan->total_slots == 0) return (int)hipGetLastError();
+        const size_t stride = ((size_t)num_apc_calls + 3) & ~(size_t)3;
+        const size_t need = (size_t)plan->total_slots * stride;
+        bool have = true;
+        if (need > g_items_words) {
+            if (g_items) (void)hipFree(g_items);
+            g_items = nullptr; g_items_words = 0;
+            if (hipMalloc(&g_items, need * 4) == hipSuccess) g_items_words = need;
+            else { (void)hipGetLastError(); have = false; }
+        }
+        if (have) {
+            {
+                pw::ScopedKernelTimer t("apc_apply_bus_kernel");
+                hipLaunchKernelGGL(apc_apply_bus_kernel<true>, dim3(pw::div_up(stride, kBlock), chunks), dim3(kBlock), 0,
+                                   pw::stream(), d_output, num_apc_calls, d_bytecode, d_interactions, (uint32_t)n_interactions,
+                                   d_arg_spans, p, per_chunk, plan->d_slot_of, g_items, stride);
+            }
+            uint32_t* tables[3] = {d_var_hist, d_tuple2_hist, d_bitwise_hist};
+            unsigned total_parts = 0;
+            for (int t = 0; t < 3; ++t) if (plan->n_slots[t]) total_parts += pw::div_up(table_bins[t], kPartBins);
+            unsigned n_chunks = (512 + total_parts - 1) / (total_parts ? total_parts : 1);
+            const unsigned max_chunks = pw::div_up(stride, 8192);
+            if (n_chunks > max_chunks) n_chunks = max_chunks;
+            if (n_chunks == 0) n_chunks = 1;
+            uint32_t rows_per_chunk = (uint32_t)(((stride + n_chunks - 1) / n_chunks + 3) & ~(size_t)3);
+            n_chunks = pw::div_up(stride, rows_per_chunk);
+            for (int t = 0; t < 3; ++t) {
+                if (!plan->n_slots[t]) continue;
+                pw::ScopedKernelTimer tt("bus_histogram_kernel");
+                hipLaunchKernelGGL(bus_histogram_kernel, dim3(pw::div_up(table_bins[t], kPartBins), n_chunks), dim3(kHistBlock), 0,
+                                   pw::stream(), g_items, stride, plan->d_slots[t], plan->n_slots[t], tables[t], table_bins[t], rows_per_chunk);
+            }
+            return (int)hipGetLastError();
+        }
+    }
     pw::ScopedKernelTimer t("apc_apply_bus_kernel");
-    hipLaunchKernelGGL(apc_apply_bus_kernel, dim3(row_blocks, chunks), dim3(kBlock), 0, pw::stream(),
+    hipLaunchKernelGGL(apc_apply_bus_kernel<false>, dim3(row_blocks, chunks), dim3(kBlock), 0, pw::stream(),
                        d_output, num_apc_calls, d_bytecode, d_interactions,
-                       (uint32_t)n_interactions, d_arg_spans, p, per_chunk);
+                       (uint32_t)n_interactions, d_arg_spans, p, per_chunk, nullptr, nullptr, 0);
     return (int)hipGetLastError();
 }

@@ -266,3 +266,54 @@ def test_large_gather_property(gpu):
     # columns without a substitution (derived ones) are untouched
     untouched = sorted(set(range(W)) - set(gt.subs[:, 3].tolist()))
     assert untouched and all(int((m[c] != 0x55).sum()) == 0 for c in untouched)
+
+
+@pytest.mark.parametrize("shape,num_calls,seed", [("T1", 4096, 5), ("T1", 1001, 6), ("C1", 20000, 7)])
+def test_binned_histogram_path(gpu, shape, num_calls, seed, monkeypatch):
+    """Long traces take the binned path (packed items + LDS partition histograms); force it on
+    short ones too and compare with the oracle and with the direct-atomic path."""
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+
+    s = synth.generate(shape, seed=seed)
+    apc, idx, want, hist, (bufs, dims, gt, order) = run_oracle_gpu_convention(s, num_calls, seed=seed)
+    W, H = want.shape
+    inter, spans, bc = om.compile_bus(apc, idx, H)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("POWDR_BUS_BINNED", mode)
+        out, per = run_gpu(gpu, W, H, num_calls, bufs, dims, gt.air_names, gt.row_block_size, gt.subs,
+                           om.compile_derived(apc, idx, H), (inter, spans, bc))
+        assert (hist_np(per.var_hist) == hist["var"]).all()
+        assert (hist_np(per.tuple_hist) == hist["tuple"]).all()
+        assert (hist_np(per.bitwise_hist) == hist["bitwise"]).all()
+
+
+def test_binned_path_large_multiplicity_and_hot_bins(gpu, monkeypatch):
+    """Multiplicities that do not fit the packed item (>= 4096) fall back to a direct atomic; a
+    constant lookup (every row hits the same bin) is the hot-bin case."""
+    torch, abi, tg = gpu
+    monkeypatch.setenv("POWDR_BUS_BINNED", "1")
+    H, W, calls = 1024, 2, 1000
+    rng = np.random.default_rng(11)
+    trace = np.zeros(H * W, np.uint32)
+    trace[:calls] = rng.integers(0, 256, calls)
+    trace[H : H + calls] = rng.integers(0, 4, calls)
+    PA, PC = om.OP_PUSH_APC, om.OP_PUSH_CONST
+    bc, spans = [], []
+
+    def span(words):
+        spans.append((len(bc), len(words)))
+        bc.extend(words)
+
+    inter = np.array([[3, 2, 0], [3, 2, 3], [6, 4, 6]], np.uint32)
+    span([PC, 5000]); span([PA, 0]); span([PC, 8])          # var: mult 5000, value = col0, bits 8
+    span([PC, 1]); span([PC, 77]); span([PC, 12])             # var: constant lookup, one hot bin
+    span([PA, H]); span([PA, 0]); span([PC, 3]); span([PC, 0]); span([PC, 0])  # bitwise range, mult = col1 (0..3)
+    out = tg.DeviceMatrix.zeros(H, W)
+    out.buf.copy_(to_dev(torch, trace))
+    per = tg.Periphery.fresh()
+    tg.apc_apply_bus(out, calls, bc, inter, spans, per)
+    torch.cuda.synchronize()
+    want = dict(var=np.zeros(1 << 18, np.uint32), tuple=np.zeros(256 * 2048, np.uint32), bitwise=np.zeros(2 * 65536, np.uint32))
+    om.c_apc_apply_bus(trace, calls, np.array(bc, np.uint32), inter, np.array(spans, np.uint32), 3, want["var"], 7, want["tuple"], 256, 2048, 6, want["bitwise"])
+    assert (hist_np(per.var_hist) == want["var"]).all() and want["var"][(1 << 12) + 76] == calls
+    assert (hist_np(per.bitwise_hist) == want["bitwise"]).all()
