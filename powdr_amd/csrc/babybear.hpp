@@ -51,6 +51,16 @@ PW_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
 PW_HD uint32_t to_monty(uint32_t canonical) { return mul(canonical, R2_MOD_P); }
 PW_HD uint32_t from_monty(uint32_t x) { return monty_reduce((uint64_t)x); }
 
+// Lazy product: a in [0, 2p), b in [0, p) -> result in [0, 2p) (a*b < 2p^2 < p * 2^32).
+// Note for the record: lazy ADDITION is not available for this prime in 32-bit lanes — sums of
+// two [0, 2p) values reach 4p > 2^32 — so the NTT butterflies stay fully reduced.
+PW_HD uint32_t mul_lazy(uint32_t a, uint32_t b) {
+    uint64_t t = (uint64_t)a * b;
+    uint32_t m = (uint32_t)t * NEG_PINV;
+    uint64_t u = t + (uint64_t)m * P;
+    return (uint32_t)(u >> 32);
+}
+
 PW_HD uint32_t double_(uint32_t a) { return add(a, a); }
 PW_HD uint32_t halve(uint32_t a) {
     // a/2 mod p: if odd add p (p odd) then shift. a + p < 2^32.

@@ -30,6 +30,7 @@
 #include "common.hpp"
 #include "prover_internal.hpp"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -39,7 +40,7 @@ namespace pw {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kStridedC = 4;  // 16 neighbouring elements = 64-byte segments
+static int kStridedC = 4;  // 2^c neighbouring elements ride along in strided tiles (4: 64-byte segments)
 
 __constant__ uint32_t c_roots16[2][8];  // [0]: w16^r forward, [1]: inverse (Montgomery), r < 8
 
@@ -95,139 +96,125 @@ struct IndexMap {
     }
 };
 
-// One round: LOGR stages on the window [rb, rb+LOGR) of the tile index. x holds EPT elements:
-// x[m * R + rho], R = 2^LOGR, slot sigma = tid + 256 m.
-template <bool DIF, int LOGR, int EPT>
-__device__ __forceinline__ void round_butterflies(uint32_t* x, const IndexMap& im, const GroupParams& gp, int rb,
-                                                  const uint32_t* __restrict__ tw, int tid) {
+// One slot of one round: LOGR stages on the window [rb, rb+LOGR) of the tile index, on the
+// R = 2^LOGR elements v[rho] (fully reduced arithmetic: see the note at bb::mul_lazy).
+template <bool DIF, int LOGR>
+__device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t l0, const IndexMap& im, const GroupParams& gp, int rb,
+                                                 const uint32_t* __restrict__ tw) {
     constexpr int R = 1 << LOGR;
-    constexpr int SLOTS = EPT / R;
     const uint32_t* roots = c_roots16[DIF ? 1 : 0];
+    const size_t g = im.glow(l0, rb);
+    // base[q] = w^(g << shift_q); the smallest shift belongs to q = LOGR-1 and base[q-1] = base[q]^2
+    uint32_t base[LOGR];
+    const int sh_top = DIF ? gp.s0 + gp.k - 1 - (rb + (LOGR - 1) - gp.c)       // stage number s_q
+                           : gp.n - 1 - (gp.s0 + rb + (LOGR - 1) - gp.c);       // n - 1 - s_q
+    base[LOGR - 1] = tw[g << sh_top];
 #pragma unroll
-    for (int m = 0; m < SLOTS; ++m) {
-        const uint32_t sigma = (uint32_t)tid + 256u * m;
-        const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
-        const size_t g = im.glow(l0, rb);
-        // base[q] = w^(g << shift_q)
-        uint32_t base[LOGR];
-        if (DIF) {
-            // s_q = s0 + k - 1 - (rb + q - c); smallest shift at q = LOGR-1; base[q-1] = base[q]^2
-            const int s_top = gp.s0 + gp.k - 1 - (rb + (LOGR - 1) - gp.c);
-            base[LOGR - 1] = tw[g << s_top];
+    for (int q = LOGR - 2; q >= 0; --q) base[q] = bb::sqr(base[q + 1]);
 #pragma unroll
-            for (int q = LOGR - 2; q >= 0; --q) base[q] = bb::sqr(base[q + 1]);
-        } else {
-            // shift_q = n - 1 - (s0 + rb + q - c); smallest at q = LOGR-1; base[q-1] = base[q]^2
-            const int sh_top = gp.n - 1 - (gp.s0 + rb + (LOGR - 1) - gp.c);
-            base[LOGR - 1] = tw[g << sh_top];
+    for (int qi = 0; qi < LOGR; ++qi) {
+        const int q = DIF ? (LOGR - 1 - qi) : qi;
+        // twiddles of this stage: base[q] * w_{2^(q+1)}^r, r < 2^q;  w_{2^(q+1)}^r = w16^(r << (3 - q))
+        uint32_t t[1 << (LOGR - 1)];
 #pragma unroll
-            for (int q = LOGR - 2; q >= 0; --q) base[q] = bb::sqr(base[q + 1]);
-        }
-        uint32_t* v = x + m * R;
+        for (int r = 0; r < (1 << q); ++r) t[r] = r == 0 ? base[q] : bb::mul(base[q], roots[r << (3 - q)]);
 #pragma unroll
-        for (int qi = 0; qi < LOGR; ++qi) {
-            const int q = DIF ? (LOGR - 1 - qi) : qi;
-            // twiddles of this stage: base[q] * w_{2^(q+1)}^r, r < 2^q;  w_{2^(q+1)}^r = w16^(r << (3 - q))
-            uint32_t t[1 << (LOGR - 1)];
-#pragma unroll
-            for (int r = 0; r < (1 << q); ++r) t[r] = r == 0 ? base[q] : bb::mul(base[q], roots[r << (3 - q)]);
-#pragma unroll
-            for (int u = 0; u < R / 2; ++u) {
-                const int lowp = u & ((1 << q) - 1);
-                const int i0 = ((u >> q) << (q + 1)) | lowp;
-                const int i1 = i0 | (1 << q);
-                const uint32_t a = v[i0], b = v[i1];
-                if (DIF) {
-                    v[i0] = bb::add(a, b);
-                    v[i1] = bb::mul(bb::sub(a, b), t[lowp]);
-                } else {
-                    const uint32_t bt = bb::mul(b, t[lowp]);
-                    v[i0] = bb::add(a, bt);
-                    v[i1] = bb::sub(a, bt);
-                }
+        for (int u = 0; u < R / 2; ++u) {
+            const int lowp = u & ((1 << q) - 1);
+            const int i0 = ((u >> q) << (q + 1)) | lowp;
+            const int i1 = i0 | (1 << q);
+            const uint32_t a = v[i0], b = v[i1];
+            if (DIF) {
+                v[i0] = bb::add(a, b);
+                v[i1] = bb::mul(bb::sub(a, b), t[lowp]);
+            } else {
+                const uint32_t bt = bb::mul(b, t[lowp]);
+                v[i0] = bb::add(a, bt);
+                v[i1] = bb::sub(a, bt);
             }
         }
     }
 }
 
-template <int LOGR, int EPT, class F>
-__device__ __forceinline__ void for_each_element(int rb, int tid, F&& f) {
-    constexpr int R = 1 << LOGR;
-    constexpr int SLOTS = EPT / R;
-#pragma unroll
-    for (int m = 0; m < SLOTS; ++m) {
-        const uint32_t sigma = (uint32_t)tid + 256u * m;
-        const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
-#pragma unroll
-        for (int rho = 0; rho < R; ++rho) f(m * R + rho, l0 | ((uint32_t)rho << rb));
-    }
-}
-
+// One round of a group, slot by slot (a slot = the R elements a thread combines). A round is an
+// in-place network: every slot reads and writes the same R tile positions, so slots need no
+// barrier among themselves; barriers separate rounds only. The first round of a group loads from
+// HBM, the last one stores to HBM.
 // EXPAND: `src` is the H-sized bit-reversed coefficient array (n = log2(2H)); element g of the
 // 2H-sized vector is src[g >> 1] * scale_br[g >> 1].
 template <bool DIF, int LOGR, int EPT, bool EXPAND>
-__device__ __forceinline__ void run_round(uint32_t* x, uint32_t* tile, const IndexMap& im, const GroupParams& gp, int round,
+__device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, const GroupParams& gp, int round,
                                           const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
-                                          const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid) {
+                                          const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid,
+                                          bool canon) {
     const int rb = gp.rb[round];
     const bool first = round == 0, last = round == gp.n_rounds - 1;
     constexpr int R = 1 << LOGR;
-    if (first) {
-        if (!EXPAND && rb == 0 && gp.c == 0 && LOGR >= 2) {
-            // the thread's R elements are contiguous in memory: 16-byte loads
-            constexpr int SLOTS = EPT / R;
-#pragma unroll
-            for (int m = 0; m < SLOTS; ++m) {
-                const uint32_t l0 = ((uint32_t)tid + 256u * m) << LOGR;
+    constexpr int SLOTS = EPT / R;
+    const bool vec_plain = rb == 0 && gp.c == 0 && LOGR >= 2;   // the slot's elements are contiguous in HBM
+    const bool vec_expand = EXPAND && rb == 1 && gp.c == 1 && LOGR >= 2;
+#pragma unroll 1
+    for (int m = 0; m < SLOTS; ++m) {
+        uint32_t x[R];
+        const uint32_t sigma = (uint32_t)tid + 256u * m;
+        const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
+        // ---- load ----
+        if (first) {
+            if (EXPAND ? vec_expand : vec_plain) {
                 bool valid;
-                const size_t g = im.global(l0, valid);
-                const uint4* p = reinterpret_cast<const uint4*>(src + g);
+                const size_t g0 = im.global(l0, valid);
+                const uint4* pc = reinterpret_cast<const uint4*>(src + (EXPAND ? (g0 >> 1) : g0));
+                const uint4* ps = reinterpret_cast<const uint4*>(scale_br + (g0 >> 1));
 #pragma unroll
                 for (int v4 = 0; v4 < R / 4; ++v4) {
-                    uint4 d = valid ? p[v4] : make_uint4(0, 0, 0, 0);
-                    x[m * R + 4 * v4 + 0] = d.x; x[m * R + 4 * v4 + 1] = d.y;
-                    x[m * R + 4 * v4 + 2] = d.z; x[m * R + 4 * v4 + 3] = d.w;
+                    uint4 d = make_uint4(0, 0, 0, 0);
+                    if (valid) d = pc[v4];
+                    if (EXPAND) {
+                        uint4 sc = make_uint4(0, 0, 0, 0);
+                        if (valid) sc = ps[v4];
+                        d.x = bb::mul(d.x, sc.x); d.y = bb::mul(d.y, sc.y); d.z = bb::mul(d.z, sc.z); d.w = bb::mul(d.w, sc.w);
+                    }
+                    x[4 * v4 + 0] = d.x; x[4 * v4 + 1] = d.y; x[4 * v4 + 2] = d.z; x[4 * v4 + 3] = d.w;
+                }
+            } else {
+#pragma unroll
+                for (int rho = 0; rho < R; ++rho) {
+                    bool valid;
+                    const size_t g = im.global(l0 | ((uint32_t)rho << rb), valid);
+                    uint32_t v = 0u;
+                    if (valid) v = EXPAND ? bb::mul(src[g >> 1], scale_br[g >> 1]) : src[g];
+                    x[rho] = v;
                 }
             }
         } else {
-            for_each_element<LOGR, EPT>(rb, tid, [&](int reg, uint32_t l) {
-                bool valid;
-                const size_t g = im.global(l, valid);
-                uint32_t v = 0u;
-                if (valid) v = EXPAND ? bb::mul(src[g >> 1], scale_br[g >> 1]) : src[g];
-                x[reg] = v;
-            });
-        }
-    } else {
-        for_each_element<LOGR, EPT>(rb, tid, [&](int reg, uint32_t l) { x[reg] = tile[lds_phys(l)]; });
-        // a middle round overwrites the tile it has just read: every wave must have finished reading
-        if (!last) __syncthreads();
-    }
-    round_butterflies<DIF, LOGR, EPT>(x, im, gp, rb, tw, tid);
-    if (last) {
-        if (rb == 0 && gp.c == 0 && LOGR >= 2) {
-            constexpr int SLOTS = EPT / R;
 #pragma unroll
-            for (int m = 0; m < SLOTS; ++m) {
-                const uint32_t l0 = ((uint32_t)tid + 256u * m) << LOGR;
+            for (int rho = 0; rho < R; ++rho) x[rho] = tile[lds_phys(l0 | ((uint32_t)rho << rb))];
+        }
+        // ---- butterflies ----
+        slot_butterflies<DIF, LOGR>(x, l0, im, gp, rb, tw);
+        // ---- store ----
+        if (last) {
+            (void)canon;
+            if (vec_plain) {
                 bool valid;
-                const size_t g = im.global(l0, valid);
+                const size_t g0 = im.global(l0, valid);
                 if (valid) {
-                    uint4* p = reinterpret_cast<uint4*>(dst + g);
+                    uint4* pd = reinterpret_cast<uint4*>(dst + g0);
 #pragma unroll
-                    for (int v4 = 0; v4 < R / 4; ++v4)
-                        p[v4] = make_uint4(x[m * R + 4 * v4], x[m * R + 4 * v4 + 1], x[m * R + 4 * v4 + 2], x[m * R + 4 * v4 + 3]);
+                    for (int v4 = 0; v4 < R / 4; ++v4) pd[v4] = make_uint4(x[4 * v4], x[4 * v4 + 1], x[4 * v4 + 2], x[4 * v4 + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int rho = 0; rho < R; ++rho) {
+                    bool valid;
+                    const size_t g = im.global(l0 | ((uint32_t)rho << rb), valid);
+                    if (valid) dst[g] = x[rho];
                 }
             }
         } else {
-            for_each_element<LOGR, EPT>(rb, tid, [&](int reg, uint32_t l) {
-                bool valid;
-                const size_t g = im.global(l, valid);
-                if (valid) dst[g] = x[reg];
-            });
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) tile[lds_phys(l0 | ((uint32_t)rho << rb))] = x[rho];
         }
-    } else {
-        for_each_element<LOGR, EPT>(rb, tid, [&](int reg, uint32_t l) { tile[lds_phys(l)] = x[reg]; });
     }
 }
 
@@ -235,10 +222,9 @@ template <bool DIF, int LOGT, bool EXPAND>
 __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                            size_t in_stride, size_t out_stride, GroupParams gp,
                                                            const uint32_t* __restrict__ tw,
-                                                           const uint32_t* __restrict__ scale_br) {
+                                                           const uint32_t* __restrict__ scale_br, int canon) {
     constexpr int EPT = (1 << LOGT) / kBlock;
     __shared__ uint32_t tile[(1 << LOGT) + ((1 << LOGT) >> 5)];
-    uint32_t x[EPT];
     const int tid = threadIdx.x;
     IndexMap im;
     im.B = gp.B; im.c = gp.c; im.lowbits = gp.lowbits; im.k = gp.k;
@@ -249,10 +235,10 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     uint32_t* dst = out + (size_t)blockIdx.y * out_stride;
     for (int r = 0; r < gp.n_rounds; ++r) {
         switch (gp.logr[r]) {
-            case 1: run_round<DIF, 1, EPT, EXPAND>(x, tile, im, gp, r, src, dst, tw, scale_br, tid); break;
-            case 2: run_round<DIF, 2, EPT, EXPAND>(x, tile, im, gp, r, src, dst, tw, scale_br, tid); break;
-            case 3: run_round<DIF, 3, EPT, EXPAND>(x, tile, im, gp, r, src, dst, tw, scale_br, tid); break;
-            default: run_round<DIF, 4, EPT, EXPAND>(x, tile, im, gp, r, src, dst, tw, scale_br, tid); break;
+            case 1: run_round<DIF, 1, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, canon != 0); break;
+            case 2: run_round<DIF, 2, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, canon != 0); break;
+            case 3: run_round<DIF, 3, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, canon != 0); break;
+            default: run_round<DIF, 4, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, canon != 0); break;
         }
         if (r + 1 < gp.n_rounds) __syncthreads();  // the next round reads what this round wrote
     }
@@ -304,6 +290,7 @@ const Tables* tables(int n) {
 // Split stages [first, n) into groups of at most `LOGT - c` stages and each group into rounds.
 std::vector<GroupParams> plan_groups(bool dif, int n, int first, int& logt_out) {
     std::vector<GroupParams> out;
+    if (const char* e = getenv("POWDR_NTT_C")) { int v = atoi(e); if (v >= 0 && v <= 6) kStridedC = v; }
     const int total = n - first;
     // tile size: 2^13 when it saves a pass or the transform is large, else 2^12
     int logt = 12;
@@ -364,7 +351,8 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
             const uint32_t* s_ = src + (size_t)c0 * src_stride;
             uint32_t* d_ = out + (size_t)c0 * out_stride;
             dim3 grid(wgs, cc), block(kBlock);
-#define PW_LAUNCH_NTT(LT, EX) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, EX>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br)
+            const int canon = (&g == &groups.back()) ? 1 : 0;
+#define PW_LAUNCH_NTT(LT, EX) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, EX>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br, canon)
             if (logt == 13) { if (expand) PW_LAUNCH_NTT(13, true); else PW_LAUNCH_NTT(13, false); }
             else            { if (expand) PW_LAUNCH_NTT(12, true); else PW_LAUNCH_NTT(12, false); }
 #undef PW_LAUNCH_NTT
