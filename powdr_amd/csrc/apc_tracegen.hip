@@ -31,6 +31,7 @@
 #include "../../include/powdr_gpu.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -72,10 +73,10 @@ struct Plan {
 };
 
 constexpr int kBlock = 256;
-constexpr int kMaxTileWords = 12 * 1024;  // 48 KB LDS tile -> 3 workgroups / CU
+static int kMaxTileWords = 12 * 1024;  // 48 KB LDS tile -> 3 workgroups / CU (POWDR_GATHER_TILE_WORDS)
 constexpr int kMaxR = 1024;
 constexpr int kMinR = 32;
-constexpr int kMaxChunkJ = kMaxTileWords / kMinR - 1;  // 383
+static int kMaxChunkJ = kMaxTileWords / kMinR - 1;  // 383
 
 __device__ __forceinline__ uint32_t fast_div(uint32_t e, uint32_t magic, uint32_t J) {
     // exact for e < 2^16, J < 2^16 (e*J < 2^32); J == 1 handled by magic == 0
@@ -112,8 +113,8 @@ __global__ __launch_bounds__(kBlock) void apc_gather_tile_kernel(
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4* base4 = reinterpret_cast<const u32x4*>(base);
                 const uint32_t n4 = n >> 2;
-                for (uint32_t q = tid; q < n4; q += kBlock) {
-                    u32x4 v = __builtin_nontemporal_load(base4 + q);
+                // four independent 16-byte loads in flight per lane before any LDS store
+                auto scatter = [&](uint32_t q, u32x4 v) {
                     uint32_t e = q << 2;
                     uint32_t i = fast_div(e, job.magicJ, J);
                     uint32_t j = e - i * (uint32_t)J;
@@ -123,7 +124,16 @@ __global__ __launch_bounds__(kBlock) void apc_gather_tile_kernel(
                         tile[i * pitch + j] = vals[k];
                         if (++j == (uint32_t)J) { j = 0; ++i; }
                     }
+                };
+                uint32_t q = tid;
+                for (; q + 3 * kBlock < n4; q += 4 * kBlock) {
+                    u32x4 v0 = __builtin_nontemporal_load(base4 + q);
+                    u32x4 v1 = __builtin_nontemporal_load(base4 + q + kBlock);
+                    u32x4 v2 = __builtin_nontemporal_load(base4 + q + 2 * kBlock);
+                    u32x4 v3 = __builtin_nontemporal_load(base4 + q + 3 * kBlock);
+                    scatter(q, v0); scatter(q + kBlock, v1); scatter(q + 2 * kBlock, v2); scatter(q + 3 * kBlock, v3);
                 }
+                for (; q < n4; q += kBlock) scatter(q, __builtin_nontemporal_load(base4 + q));
                 for (uint32_t e = (n4 << 2) + tid; e < n; e += kBlock) {
                     uint32_t i = fast_div(e, job.magicJ, J);
                     uint32_t j = e - i * (uint32_t)J;
@@ -199,6 +209,10 @@ int pick_R(int J) {
 }
 
 int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bsize, Plan& plan) {
+    if (const char* e = getenv("POWDR_GATHER_TILE_WORDS")) {
+        int v = atoi(e);
+        if (v >= 4096 && v <= 16384) { kMaxTileWords = v; kMaxChunkJ = kMaxTileWords / kMinR - 1; }
+    }
     const size_t n = subs_in.size();
     // 1. resolve duplicate destinations like the sequential reference loop: last wins
     std::vector<uint32_t> order(n);

@@ -48,21 +48,22 @@ inline void generate_params(Params& p) {
 
 PW_HD uint32_t sbox7(uint32_t x) {
     uint32_t x2 = bb::sqr(x);
-    uint32_t x3 = bb::mul(x2, x);
+    uint32_t x3 = bb::mul_lazy(x2, x);  // in [0, 2p): only ever the lazy operand of the last product
     uint32_t x4 = bb::sqr(x2);
     return bb::mul(x3, x4);
 }
 
 // [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] * (a,b,c,d)
 PW_HD void m4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+    // 11 modular additions
     uint32_t ab = bb::add(a, b), cd = bb::add(c, d);
     uint32_t t = bb::add(ab, cd);
-    uint32_t o0 = bb::add(bb::add(t, ab), b);              // 2a + 3b + c + d
-    uint32_t bc = bb::add(b, c);
-    uint32_t o1 = bb::add(bb::add(t, bc), c);              // a + 2b + 3c + d
-    uint32_t o2 = bb::add(bb::add(t, cd), d);              // a + b + 2c + 3d
-    uint32_t da = bb::add(d, a);
-    uint32_t o3 = bb::add(bb::add(t, da), a);              // 3a + b + c + 2d
+    uint32_t tb = bb::add(t, b);                            // a + 2b + c + d
+    uint32_t td = bb::add(t, d);                            // a + b + c + 2d
+    uint32_t o3 = bb::add(td, bb::double_(a));              // 3a + b + c + 2d
+    uint32_t o1 = bb::add(tb, bb::double_(c));              // a + 2b + 3c + d
+    uint32_t o0 = bb::add(tb, ab);                          // 2a + 3b + c + d
+    uint32_t o2 = bb::add(td, cd);                          // a + b + 2c + 3d
     a = o0; b = o1; c = o2; d = o3;
 }
 
