@@ -73,9 +73,9 @@ struct Plan {
 };
 
 constexpr int kBlock = 256;
-static int kMaxTileWords = 12 * 1024;  // 48 KB LDS tile -> 3 workgroups / CU (POWDR_GATHER_TILE_WORDS)
+static int kMaxTileWords = 5 * 1024;  // <= 20 KB LDS tiles -> 8 workgroups / CU: 24.9 ms vs 35.5 ms with 48 KB tiles at C2 (POWDR_GATHER_TILE_WORDS)
 constexpr int kMaxR = 1024;
-constexpr int kMinR = 32;
+static int kMinR = 16;  // POWDR_GATHER_MIN_R
 static int kMaxChunkJ = kMaxTileWords / kMinR - 1;  // 383
 
 __device__ __forceinline__ uint32_t fast_div(uint32_t e, uint32_t magic, uint32_t J) {
@@ -211,8 +211,10 @@ int pick_R(int J) {
 int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bsize, Plan& plan) {
     if (const char* e = getenv("POWDR_GATHER_TILE_WORDS")) {
         int v = atoi(e);
-        if (v >= 4096 && v <= 16384) { kMaxTileWords = v; kMaxChunkJ = kMaxTileWords / kMinR - 1; }
+        if (v >= 2048 && v <= 16384) kMaxTileWords = v;
     }
+    if (const char* e = getenv("POWDR_GATHER_MIN_R")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) kMinR = v; }
+    kMaxChunkJ = kMaxTileWords / kMinR - 1;
     const size_t n = subs_in.size();
     // 1. resolve duplicate destinations like the sequential reference loop: last wins
     std::vector<uint32_t> order(n);
@@ -386,6 +388,7 @@ extern "C" int _apc_tracegen(PowdrFp* d_output, size_t output_height,
     uint32_t* out = d_output;
     for (const RClass& c : plan->classes) {
         switch (c.R) {
+            case 16: launch_class<16>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
             case 32: launch_class<32>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
             case 64: launch_class<64>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
             case 128: launch_class<128>(c, out, H, d_original_airs, *plan, num_apc_calls); break;

@@ -153,11 +153,18 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
     constexpr int SLOTS = EPT / R;
     const bool vec_plain = rb == 0 && gp.c == 0 && LOGR >= 2;   // the slot's elements are contiguous in HBM
     const bool vec_expand = EXPAND && rb == 1 && gp.c == 1 && LOGR >= 2;
+    const int gshift = rb - gp.c + gp.lowbits;
+    // padded LDS position of element rho of a slot, relative to the slot's base: the window bits and the
+    // slot's bits are disjoint, so lds_phys(l0 | rho << rb) = lds_phys(l0) + lds_off(rho); wave-uniform
+    auto lds_off = [rb](int rho) -> uint32_t {
+        return ((uint32_t)rho << rb) + (rb >= 5 ? ((uint32_t)rho << (rb - 5)) : ((uint32_t)rho >> (5 - rb)));
+    };
 #pragma unroll 1
     for (int m = 0; m < SLOTS; ++m) {
         uint32_t x[R];
         const uint32_t sigma = (uint32_t)tid + 256u * m;
         const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
+        const uint32_t p0 = lds_phys(l0);
         // ---- load ----
         if (first) {
             if (EXPAND ? vec_expand : vec_plain) {
@@ -177,18 +184,26 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
                     x[4 * v4 + 0] = d.x; x[4 * v4 + 1] = d.y; x[4 * v4 + 2] = d.z; x[4 * v4 + 3] = d.w;
                 }
             } else {
+                // window bit (rb + q) of the tile index is bit gshift + q of the global index
+                bool valid;
+                const size_t g0 = im.global(l0, valid);
+                if (EXPAND) {
+                    const size_t q0 = g0 >> 1;
+                    const int qshift = gshift - 1;  // the EXPAND group has lowbits = c = 1, so gshift = rb >= 1
 #pragma unroll
-                for (int rho = 0; rho < R; ++rho) {
-                    bool valid;
-                    const size_t g = im.global(l0 | ((uint32_t)rho << rb), valid);
-                    uint32_t v = 0u;
-                    if (valid) v = EXPAND ? bb::mul(src[g >> 1], scale_br[g >> 1]) : src[g];
-                    x[rho] = v;
+                    for (int rho = 0; rho < R; ++rho) {
+                        const size_t q = q0 + ((size_t)rho << qshift);
+                        x[rho] = valid ? bb::mul(src[q], scale_br[q]) : 0u;
+                    }
+                } else {
+                    const uint32_t* ps = src + g0;
+#pragma unroll
+                    for (int rho = 0; rho < R; ++rho) x[rho] = valid ? ps[(size_t)rho << gshift] : 0u;
                 }
             }
         } else {
 #pragma unroll
-            for (int rho = 0; rho < R; ++rho) x[rho] = tile[lds_phys(l0 | ((uint32_t)rho << rb))];
+            for (int rho = 0; rho < R; ++rho) x[rho] = tile[p0 + lds_off(rho)];
         }
         // ---- butterflies ----
         slot_butterflies<DIF, LOGR>(x, l0, im, gp, rb, tw);
@@ -204,16 +219,17 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
                     for (int v4 = 0; v4 < R / 4; ++v4) pd[v4] = make_uint4(x[4 * v4], x[4 * v4 + 1], x[4 * v4 + 2], x[4 * v4 + 3]);
                 }
             } else {
+                bool valid;
+                const size_t g0 = im.global(l0, valid);
+                if (valid) {
+                    uint32_t* pd = dst + g0;
 #pragma unroll
-                for (int rho = 0; rho < R; ++rho) {
-                    bool valid;
-                    const size_t g = im.global(l0 | ((uint32_t)rho << rb), valid);
-                    if (valid) dst[g] = x[rho];
+                    for (int rho = 0; rho < R; ++rho) pd[(size_t)rho << gshift] = x[rho];
                 }
             }
         } else {
 #pragma unroll
-            for (int rho = 0; rho < R; ++rho) tile[lds_phys(l0 | ((uint32_t)rho << rb))] = x[rho];
+            for (int rho = 0; rho < R; ++rho) tile[p0 + lds_off(rho)] = x[rho];
         }
     }
 }
