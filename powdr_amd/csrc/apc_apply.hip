@@ -295,18 +295,19 @@ extern "C" int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
                                    d_arg_spans, p, per_chunk, plan->d_slot_of, g_items, stride);
             }
             uint32_t* tables[3] = {d_var_hist, d_tuple2_hist, d_bitwise_hist};
-            unsigned total_parts = 0;
-            for (int t = 0; t < 3; ++t) if (plan->n_slots[t]) total_parts += pw::div_up(table_bins[t], kPartBins);
-            unsigned n_chunks = (512 + total_parts - 1) / (total_parts ? total_parts : 1);
-            const unsigned max_chunks = pw::div_up(stride, 8192);
-            if (n_chunks > max_chunks) n_chunks = max_chunks;
-            if (n_chunks == 0) n_chunks = 1;
-            uint32_t rows_per_chunk = (uint32_t)(((stride + n_chunks - 1) / n_chunks + 3) & ~(size_t)3);
-            n_chunks = pw::div_up(stride, rows_per_chunk);
+            // one 128-KB-LDS workgroup fits per CU, and the three launches run one after the other, so each
+            // launch gets ~2 x 256 workgroups of its own: partitions x row chunks
             for (int t = 0; t < 3; ++t) {
                 if (!plan->n_slots[t]) continue;
+                const unsigned parts = pw::div_up(table_bins[t], kPartBins);
+                unsigned n_chunks = (512 + parts - 1) / parts;
+                const unsigned max_chunks = pw::div_up(stride, 4096);
+                if (n_chunks > max_chunks) n_chunks = max_chunks;
+                if (n_chunks == 0) n_chunks = 1;
+                const uint32_t rows_per_chunk = (uint32_t)(((stride + n_chunks - 1) / n_chunks + 3) & ~(size_t)3);
+                n_chunks = pw::div_up(stride, rows_per_chunk);
                 pw::ScopedKernelTimer tt("bus_histogram_kernel");
-                hipLaunchKernelGGL(bus_histogram_kernel, dim3(pw::div_up(table_bins[t], kPartBins), n_chunks), dim3(kHistBlock), 0,
+                hipLaunchKernelGGL(bus_histogram_kernel, dim3(parts, n_chunks), dim3(kHistBlock), 0,
                                    pw::stream(), g_items, stride, plan->d_slots[t], plan->n_slots[t], tables[t], table_bins[t], rows_per_chunk);
             }
             return (int)hipGetLastError();
