@@ -207,16 +207,33 @@ def main():
         if dom:
             cnt, ms = per_kernel[dom]
             launches_per_step = cnt / args.steps
-            # leaf_hash_kernel is launched for the trace LDE (W cols) and the 8-col quotient LDE; the bytes
-            # below are summed over one step's launches and divided by one step's time in that kernel
+            # bytes are summed over one step's launches of that kernel and divided by one step's time in it
             abc = algo_bytes_per_cell.get(dom, 8.0)
             bytes_step = abc * cells_per_step
             achieved = bytes_step / (ms / args.steps * 1e-3) / 1e9
+            traffic = None
+            tf = ROOT / "profiles" / "r01_pmc_traffic_c2.json"
+            if tf.exists() and args.shape == "C2" and log_h == 20:
+                k = json.loads(tf.read_text())["kernels"].get(dom)
+                if k:  # HBM bytes per step from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+                    traffic = k["fetch_bytes_corrected"] + k["write_bytes"]
             roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=None, avg_launch_ms=ms / cnt, launches_per_step=launches_per_step,
-                        algo_bytes_per_cell=abc,
-                        note="leaf_hash_kernel is integer-VALU bound (Poseidon2: ~670 Montgomery products + ~1500 modular adds "
-                             "per permutation, 0.25 permutations per committed cell), not HBM/MFMA bound; see DESIGN.md")
+                        traffic=traffic, traffic_unit="bytes per step (PMC, profiles/r01_pmc_traffic_c2.json)",
+                        algorithmic_bytes_per_step=bytes_step, avg_launch_ms=ms / cnt, launches_per_step=launches_per_step,
+                        algo_bytes_per_cell=abc)
+            if dom == "leaf_hash_kernel":
+                # The dominant kernel is integer-VALU bound, not HBM/MFMA bound. Static count from the gfx950 ISA:
+                # 7089 VALU instructions per Poseidon2 permutation (8 x 552 + 13 x 189 + 216), cross-checked by
+                # SQ_INSTS_VALU (profiles/r01_pmc_sq_counters_h18.tsv); a wave64 VALU instruction issues in 4 cycles.
+                perms = 2 * wl["H"] * ((wl["W"] + 7) // 8) + 2 * wl["H"]  # trace LDE rows + 8-col quotient LDE rows
+                wave_instr = perms * 7089 / 64
+                peak = 1024 * 2.4e9 / 4  # SIMDs x clock / cycles per instruction
+                rate = wave_instr / (ms / args.steps * 1e-3)
+                roof["valu"] = dict(wave_instructions_per_step=wave_instr, achieved_G_wave_instr_s=rate / 1e9,
+                                    peak_G_wave_instr_s=peak / 1e9, frac=rate / peak,
+                                    note="leaf_hash_kernel runs at the VALU issue ceiling (PMC: SQ_ACTIVE_INST_VALU = "
+                                         "SQ_INSTS_VALU quad-cycles = 100% of kernel time); MFMA utilisation is 0 by design "
+                                         "(the Poseidon2 MDS is additions only, DESIGN.md 3.4)")
         cpu = None
         if not args.no_cpu_baseline:
             try:
