@@ -100,14 +100,44 @@ __global__ __launch_bounds__(kBlock) void pow_kernel(const uint32_t* __restrict_
     if ((bb::from_monty(sample) & ((1u << bits) - 1u)) == 0u) atomicMin(best, w);
 }
 
+// The top of a tree (<= 2048 nodes on a level) in ONE launch: a single 1024-thread workgroup walks
+// the levels; the levels live in global memory, the workgroup's own writes are made visible to
+// its other waves by __threadfence_block() + the barrier. Replaces ~11 tiny launches per tree
+// (22 trees per proof).
+constexpr size_t kTailNodes = 2048;
+__global__ __launch_bounds__(1024) void compress_tail_kernel(uint32_t* __restrict__ digests, size_t n_first) {
+    size_t off = 0;
+    for (size_t n = n_first; n > 1; n >>= 1) {
+        const size_t parents = n >> 1;
+        for (size_t i = threadIdx.x; i < parents; i += 1024) {
+            const uint32_t* in = digests + off + i * 16;
+            uint32_t st[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) st[k] = in[k];
+            p2::permute(st, c_params);
+            uint32_t* out = digests + off + n * 8 + i * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out[k] = st[k];
+        }
+        off += n * 8;
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 int build_levels(uint32_t* digests, size_t n_leaves) {
     size_t off = 0;
-    for (size_t n = n_leaves; n > 1; n >>= 1) {
+    size_t n = n_leaves;
+    for (; n > kTailNodes; n >>= 1) {
         size_t parents = n >> 1;
         ScopedKernelTimer t("compress_kernel");
         hipLaunchKernelGGL(compress_kernel, dim3(div_up(parents, kBlock)), dim3(kBlock), 0, stream(), digests + off,
                            parents, digests + off + n * 8);
         off += n * 8;
+    }
+    if (n > 1) {
+        ScopedKernelTimer t("compress_tail_kernel");
+        hipLaunchKernelGGL(compress_tail_kernel, dim3(1), dim3(1024), 0, stream(), digests + off, n);
     }
     return (int)hipGetLastError();
 }
