@@ -23,6 +23,8 @@
 #include "babybear.hpp"
 #include "common.hpp"
 #include "expr_eval.hpp"
+#include "xbc.hpp"
+#include "xbc_compile.hpp"
 #include "../../include/powdr_gpu.h"
 
 #include <cstdlib>
@@ -145,6 +147,62 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
     }
 }
 
+// The same replay on plan-compiled xbc code (xbc.hpp): only periphery interactions are listed,
+// with their table, item slot and the four expression spans resolved on the host.
+struct XInteraction {
+    uint32_t kind;    // 0 var-range, 1 tuple2, 2 bitwise
+    uint32_t slot;    // item slot (binned mode)
+    uint32_t off[4];  // instruction offsets of mult, arg0, arg1, selector
+    uint32_t len[4];
+};
+
+template <bool BINNED>
+__global__ __launch_bounds__(kBlock) void apc_apply_bus_xbc_kernel(
+    const uint32_t* __restrict__ trace, int num_calls, const uint32_t* __restrict__ code,
+    const XInteraction* __restrict__ xint, uint32_t n_xint, BusParams p, uint32_t per_chunk,
+    uint32_t* __restrict__ items, size_t item_stride) {
+    __shared__ uint32_t stack_lds[pw::kStackCap * kBlock];
+    uint32_t* stk = stack_lds + threadIdx.x;
+    const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = r < (size_t)num_calls;
+    if (!BINNED && !live) return;
+    if (BINNED && r >= item_stride) return;
+    const uint32_t i0 = blockIdx.y * per_chunk;
+    const uint32_t i1 = min(n_xint, i0 + per_chunk);
+    for (uint32_t i = i0; i < i1; ++i) {
+        const XInteraction xi = xint[i];
+        uint32_t bin = kItemNone, m = 0u;
+        uint32_t* table = xi.kind == 0 ? p.var_hist : xi.kind == 1 ? p.tuple_hist : p.bitwise_hist;
+        if (live) {
+            m = bb::from_monty(xbc::eval<kBlock, false>(code + 2 * (size_t)xi.off[0], xi.len[0], trace, r, stk));
+            if (m != 0u) {
+                const uint32_t a0 = bb::from_monty(xbc::eval<kBlock, false>(code + 2 * (size_t)xi.off[1], xi.len[1], trace, r, stk));
+                const uint32_t a1 = bb::from_monty(xbc::eval<kBlock, false>(code + 2 * (size_t)xi.off[2], xi.len[2], trace, r, stk));
+                if (xi.kind == 0) {
+                    const uint32_t idx = (a1 < 32u ? (1u << a1) : 0u) + a0 - 1u;
+                    if (idx < p.var_bins) bin = idx;
+                } else if (xi.kind == 1) {
+                    const uint32_t idx = a0 * p.tuple_sz1 + a1;
+                    if (idx < p.tuple_sz0 * p.tuple_sz1) bin = idx;
+                } else {
+                    const uint32_t sel = bb::from_monty(xbc::eval<kBlock, false>(code + 2 * (size_t)xi.off[3], xi.len[3], trace, r, stk));
+                    if (sel <= 1u && a0 < 256u && a1 < 256u) bin = bitwise_index(a0, a1, sel);
+                }
+            }
+        }
+        if (BINNED) {
+            uint32_t item = kItemNone;
+            if (bin != kItemNone) {
+                if (m < kItemMaxMult && bin < (1u << kItemBinBits)) item = bin | (m << kItemBinBits);
+                else atomicAdd(table + bin, m);
+            }
+            items[(size_t)xi.slot * item_stride + r] = item;
+        } else if (bin != kItemNone) {
+            atomicAdd(table + bin, m);
+        }
+    }
+}
+
 constexpr uint32_t kPartBins = 32768;  // 128 KB of LDS counters
 constexpr int kHistBlock = 1024;
 
@@ -182,12 +240,25 @@ struct BusPlan {
     uint32_t* d_slots[3] = {nullptr, nullptr, nullptr};  // slot ids per table (var, tuple, bitwise)
     uint32_t n_slots[3] = {0, 0, 0};
     uint32_t total_slots = 0;
+    // xbc form of the periphery interactions (absent if some expression did not compile)
+    bool has_xbc = false;
+    XInteraction* d_xint = nullptr;
+    uint32_t* d_code = nullptr;
 };
 std::mutex g_bus_mu;
 std::unordered_map<uint64_t, BusPlan> g_bus_plans;
 uint32_t* g_items = nullptr;
 size_t g_items_words = 0;
 
+// 8 bytes per step (the bytecode of an un-optimised APC is megabytes)
+uint64_t hash_words(const void* p, size_t n, uint64_t h) {
+    const uint64_t* w = (const uint64_t*)p;
+    size_t k = n / 8;
+    for (size_t i = 0; i < k; ++i) { h ^= w[i]; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+    const unsigned char* c = (const unsigned char*)p + k * 8;
+    for (size_t i = 0; i < n % 8; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
+}
 uint64_t fnv1a64(const void* p, size_t n, uint64_t h) {
     const unsigned char* c = (const unsigned char*)p;
     for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
@@ -218,66 +289,100 @@ extern "C" int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
                               uint32_t tuple2_bus_id, uint32_t* d_tuple2_hist, uint32_t tuple2_sz0,
                               uint32_t tuple2_sz1, uint32_t bitwise_bus_id,
                               uint32_t* d_bitwise_hist) {
-    (void)bytecode_len;
-    (void)n_arg_spans;
     if (num_apc_calls <= 0) return 0;  // apc_apply_bus.cu:146
     (void)hipGetLastError();
     if (n_interactions == 0) return (int)hipGetLastError();
     const unsigned row_blocks = pw::div_up((size_t)num_apc_calls, kBlock);
     // Enough workgroups to cover 256 CUs x 8 blocks even for short traces.
-    unsigned chunks = 1;
     const unsigned want_blocks = 256u * 8u;
-    if (row_blocks < want_blocks) {
-        chunks = (want_blocks + row_blocks - 1) / row_blocks;
-        const unsigned max_chunks = (unsigned)((n_interactions + 15) / 16);  // >= 16 interactions each
-        if (chunks > max_chunks) chunks = max_chunks;
-        if (chunks > 65535u) chunks = 65535u;
-        if (chunks == 0) chunks = 1;
-    }
-    const uint32_t per_chunk = (uint32_t)((n_interactions + chunks - 1) / chunks);
-    chunks = (unsigned)((n_interactions + per_chunk - 1) / per_chunk);
     BusParams p;
     p.var_bus = var_range_bus_id; p.tuple_bus = tuple2_bus_id; p.bitwise_bus = bitwise_bus_id;
     p.var_hist = d_var_hist; p.tuple_hist = d_tuple2_hist; p.bitwise_hist = d_bitwise_hist;
     p.var_bins = (uint32_t)var_num_bins; p.tuple_sz0 = tuple2_sz0; p.tuple_sz1 = tuple2_sz1;
-    // ---- long traces: binned path ---------------------------------------------------------------
+    // ---- plan: host copy of the (small) tables, cached by content --------------------------------
     const char* env = getenv("POWDR_BUS_BINNED");
     const bool want_binned = env ? atoi(env) != 0 : num_apc_calls >= 16384;
+    const char* env_x = getenv("POWDR_BUS_XBC");
+    const bool want_xbc = env_x ? atoi(env_x) != 0 : true;
     const uint32_t table_bins[3] = {(uint32_t)var_num_bins, tuple2_sz0 * tuple2_sz1, 2u << (2 * POWDR_BITWISE_NUM_BITS)};
-    if (want_binned && table_bins[0] <= (1u << kItemBinBits) && table_bins[1] <= (1u << kItemBinBits)) {
-        std::vector<DevInteraction> h(n_interactions);
-        PW_HIP_TRY(hipMemcpyAsync(h.data(), d_interactions, n_interactions * sizeof(DevInteraction), hipMemcpyDeviceToHost, pw::stream()));
-        PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
-        uint64_t key = fnv1a64(h.data(), h.size() * sizeof(DevInteraction), 1469598103934665603ull);
-        const uint32_t ids[3] = {var_range_bus_id, tuple2_bus_id, bitwise_bus_id};
-        key = fnv1a64(ids, sizeof ids, key);
-        BusPlan* plan;
-        {
-            std::lock_guard<std::mutex> lk(g_bus_mu);
-            auto it = g_bus_plans.find(key);
-            if (it == g_bus_plans.end()) {
-                BusPlan bp;
-                std::vector<int32_t> slot_of(n_interactions, -1);
-                std::vector<uint32_t> per_table[3];
-                for (size_t i = 0; i < n_interactions; ++i) {
-                    int kind = h[i].bus_id == ids[0] ? 0 : h[i].bus_id == ids[1] ? 1 : h[i].bus_id == ids[2] ? 2 : -1;
-                    if (kind < 0) continue;
-                    slot_of[i] = (int32_t)bp.total_slots;
-                    per_table[kind].push_back(bp.total_slots++);
+    std::vector<DevInteraction> h(n_interactions);
+    std::vector<ExprSpan> hs(n_arg_spans);
+    std::vector<uint32_t> hb(bytecode_len);
+    PW_HIP_TRY(hipMemcpyAsync(h.data(), d_interactions, n_interactions * sizeof(DevInteraction), hipMemcpyDeviceToHost, pw::stream()));
+    if (n_arg_spans) PW_HIP_TRY(hipMemcpyAsync(hs.data(), d_arg_spans, n_arg_spans * sizeof(ExprSpan), hipMemcpyDeviceToHost, pw::stream()));
+    if (bytecode_len) PW_HIP_TRY(hipMemcpyAsync(hb.data(), d_bytecode, bytecode_len * 4, hipMemcpyDeviceToHost, pw::stream()));
+    PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
+    uint64_t key = fnv1a64(h.data(), h.size() * sizeof(DevInteraction), 1469598103934665603ull);
+    key = hash_words(hs.data(), hs.size() * sizeof(ExprSpan), key);
+    key = hash_words(hb.data(), hb.size() * 4, key);
+    const uint32_t ids[3] = {var_range_bus_id, tuple2_bus_id, bitwise_bus_id};
+    key = fnv1a64(ids, sizeof ids, key);
+    BusPlan* plan;
+    {
+        std::lock_guard<std::mutex> lk(g_bus_mu);
+        auto it = g_bus_plans.find(key);
+        if (it == g_bus_plans.end()) {
+            BusPlan bp;
+            std::vector<int32_t> slot_of(n_interactions, -1);
+            std::vector<uint32_t> per_table[3];
+            std::vector<XInteraction> xints;
+            std::vector<uint32_t> code;
+            xbc::Compiler cc;
+            bool ok = true;
+            for (size_t i = 0; i < n_interactions; ++i) {
+                int kind = h[i].bus_id == ids[0] ? 0 : h[i].bus_id == ids[1] ? 1 : h[i].bus_id == ids[2] ? 2 : -1;
+                if (kind < 0) continue;
+                slot_of[i] = (int32_t)bp.total_slots;
+                XInteraction xi{};
+                xi.kind = (uint32_t)kind;
+                xi.slot = bp.total_slots;
+                per_table[kind].push_back(bp.total_slots++);
+                const uint32_t which[4] = {0, 1, 2, 4};  // mult, arg0, arg1, (bitwise) selector = arg 3
+                for (int k = 0; k < (kind == 2 ? 4 : 3) && ok; ++k) {
+                    const size_t si = (size_t)h[i].args_index_off + which[k];
+                    if (si >= hs.size() || (size_t)hs[si].off + hs[si].len > hb.size()) { ok = false; break; }
+                    xi.off[k] = (uint32_t)(code.size() / 2);
+                    if (!cc.compile(hb.data() + hs[si].off, hs[si].len, code)) { ok = false; break; }
+                    xi.len[k] = (uint32_t)(code.size() / 2) - xi.off[k];
                 }
-                PW_HIP_TRY(hipMalloc(&bp.d_slot_of, n_interactions * 4));
-                PW_HIP_TRY(hipMemcpy(bp.d_slot_of, slot_of.data(), n_interactions * 4, hipMemcpyHostToDevice));
-                for (int t = 0; t < 3; ++t) {
-                    bp.n_slots[t] = (uint32_t)per_table[t].size();
-                    PW_HIP_TRY(hipMalloc(&bp.d_slots[t], (per_table[t].size() + 1) * 4));
-                    if (!per_table[t].empty())
-                        PW_HIP_TRY(hipMemcpy(bp.d_slots[t], per_table[t].data(), per_table[t].size() * 4, hipMemcpyHostToDevice));
-                }
-                it = g_bus_plans.emplace(key, bp).first;
+                xints.push_back(xi);
             }
-            plan = &it->second;
+            PW_HIP_TRY(hipMalloc(&bp.d_slot_of, (n_interactions + 1) * 4));
+            PW_HIP_TRY(hipMemcpy(bp.d_slot_of, slot_of.data(), n_interactions * 4, hipMemcpyHostToDevice));
+            for (int t = 0; t < 3; ++t) {
+                bp.n_slots[t] = (uint32_t)per_table[t].size();
+                PW_HIP_TRY(hipMalloc(&bp.d_slots[t], (per_table[t].size() + 1) * 4));
+                if (!per_table[t].empty())
+                    PW_HIP_TRY(hipMemcpy(bp.d_slots[t], per_table[t].data(), per_table[t].size() * 4, hipMemcpyHostToDevice));
+            }
+            if (ok && !xints.empty()) {
+                PW_HIP_TRY(hipMalloc(&bp.d_xint, xints.size() * sizeof(XInteraction)));
+                PW_HIP_TRY(hipMemcpy(bp.d_xint, xints.data(), xints.size() * sizeof(XInteraction), hipMemcpyHostToDevice));
+                PW_HIP_TRY(hipMalloc(&bp.d_code, (code.size() + 2) * 4));
+                if (!code.empty()) PW_HIP_TRY(hipMemcpy(bp.d_code, code.data(), code.size() * 4, hipMemcpyHostToDevice));
+                bp.has_xbc = true;
+            }
+            it = g_bus_plans.emplace(key, bp).first;
         }
-        if (plan->total_slots == 0) return (int)hipGetLastError();
+        plan = &it->second;
+    }
+    if (plan->total_slots == 0) return (int)hipGetLastError();
+    const bool use_xbc = want_xbc && plan->has_xbc;
+    // chunking of the interaction list actually walked by the kernel
+    const uint32_t n_list = use_xbc ? plan->total_slots : (uint32_t)n_interactions;
+    unsigned xchunks = 1;
+    if (row_blocks < want_blocks) {
+        xchunks = (want_blocks + row_blocks - 1) / row_blocks;
+        const unsigned max_chunks = (n_list + 15) / 16;
+        if (xchunks > max_chunks) xchunks = max_chunks;
+        if (xchunks > 65535u) xchunks = 65535u;
+        if (xchunks == 0) xchunks = 1;
+    }
+    const uint32_t x_per_chunk = (n_list + xchunks - 1) / xchunks;
+    xchunks = (n_list + x_per_chunk - 1) / x_per_chunk;
+
+    // ---- long traces: binned path ---------------------------------------------------------------
+    if (want_binned && table_bins[0] <= (1u << kItemBinBits) && table_bins[1] <= (1u << kItemBinBits)) {
         const size_t stride = ((size_t)num_apc_calls + 3) & ~(size_t)3;
         const size_t need = (size_t)plan->total_slots * stride;
         bool have = true;
@@ -290,9 +395,14 @@ extern "C" int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
         if (have) {
             {
                 pw::ScopedKernelTimer t("apc_apply_bus_kernel");
-                hipLaunchKernelGGL(apc_apply_bus_kernel<true>, dim3(pw::div_up(stride, kBlock), chunks), dim3(kBlock), 0,
-                                   pw::stream(), d_output, num_apc_calls, d_bytecode, d_interactions, (uint32_t)n_interactions,
-                                   d_arg_spans, p, per_chunk, plan->d_slot_of, g_items, stride);
+                if (use_xbc)
+                    hipLaunchKernelGGL(apc_apply_bus_xbc_kernel<true>, dim3(pw::div_up(stride, kBlock), xchunks), dim3(kBlock), 0,
+                                       pw::stream(), d_output, num_apc_calls, plan->d_code, plan->d_xint, plan->total_slots, p,
+                                       x_per_chunk, g_items, stride);
+                else
+                    hipLaunchKernelGGL(apc_apply_bus_kernel<true>, dim3(pw::div_up(stride, kBlock), xchunks), dim3(kBlock), 0,
+                                       pw::stream(), d_output, num_apc_calls, d_bytecode, d_interactions, (uint32_t)n_interactions,
+                                       d_arg_spans, p, x_per_chunk, plan->d_slot_of, g_items, stride);
             }
             uint32_t* tables[3] = {d_var_hist, d_tuple2_hist, d_bitwise_hist};
             // one 128-KB-LDS workgroup fits per CU, and the three launches run one after the other, so each
@@ -314,8 +424,12 @@ extern "C" int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
         }
     }
     pw::ScopedKernelTimer t("apc_apply_bus_kernel");
-    hipLaunchKernelGGL(apc_apply_bus_kernel<false>, dim3(row_blocks, chunks), dim3(kBlock), 0, pw::stream(),
-                       d_output, num_apc_calls, d_bytecode, d_interactions,
-                       (uint32_t)n_interactions, d_arg_spans, p, per_chunk, nullptr, nullptr, 0);
+    if (use_xbc)
+        hipLaunchKernelGGL(apc_apply_bus_xbc_kernel<false>, dim3(row_blocks, xchunks), dim3(kBlock), 0, pw::stream(),
+                           d_output, num_apc_calls, plan->d_code, plan->d_xint, plan->total_slots, p, x_per_chunk, nullptr, 0);
+    else
+        hipLaunchKernelGGL(apc_apply_bus_kernel<false>, dim3(row_blocks, xchunks), dim3(kBlock), 0, pw::stream(),
+                           d_output, num_apc_calls, d_bytecode, d_interactions,
+                           (uint32_t)n_interactions, d_arg_spans, p, x_per_chunk, nullptr, nullptr, 0);
     return (int)hipGetLastError();
 }

@@ -7,7 +7,9 @@
 // what it needs to run the transcript.
 #include "prover_internal.hpp"
 #include "../../include/powdr_prover.h"
+#include "xbc_compile.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -72,6 +74,7 @@ struct PwProver {
     uint32_t n_constraints;
     uint32_t* d_bytecode = nullptr;
     uint32_t* d_spans = nullptr;
+    bool is_xbc = false;  // d_bytecode/d_spans hold plan-compiled xbc code (xbc.hpp) instead of post-fix code
     // device buffers, grown on demand
     pw::DeviceBuf coef, lde, digests, q, qcoef, qlde, ext_arena, misc;
     std::vector<uint32_t> proof;
@@ -87,13 +90,32 @@ extern "C" PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, 
     p->width = width;
     p->n_constraints = (uint32_t)n_constraints;
     p->h_spans.assign(spans, spans + 2 * n_constraints);
-    size_t bl = bc_len ? bc_len : 1, sl = n_constraints ? 2 * n_constraints : 1;
-    if (hipMalloc(&p->d_bytecode, bl * 4) != hipSuccess || hipMalloc(&p->d_spans, sl * 4) != hipSuccess) {
+    // compile the post-fix constraint programs to xbc (xbc.hpp); fall back to the post-fix interpreter if
+    // any program is malformed or too deep
+    std::vector<uint32_t> code, xspans;
+    bool ok = getenv("POWDR_QUOTIENT_XBC") ? atoi(getenv("POWDR_QUOTIENT_XBC")) != 0 : true;
+    {
+        xbc::Compiler cc;
+        for (size_t k = 0; k < n_constraints && ok; ++k) {
+            const uint32_t off = spans[2 * k], len = spans[2 * k + 1];
+            if ((size_t)off + len > bc_len) { ok = false; break; }
+            const uint32_t o = (uint32_t)(code.size() / 2);
+            if (!cc.compile(bc + off, len, code)) { ok = false; break; }
+            xspans.push_back(o);
+            xspans.push_back((uint32_t)(code.size() / 2) - o);
+        }
+    }
+    const uint32_t* up_bc = ok ? code.data() : bc;
+    const uint32_t* up_sp = ok ? xspans.data() : spans;
+    const size_t up_bc_len = ok ? code.size() : bc_len;
+    p->is_xbc = ok;
+    size_t bl = up_bc_len ? up_bc_len : 1, sl = n_constraints ? 2 * n_constraints : 1;
+    if (hipMalloc(&p->d_bytecode, (bl + 2) * 4) != hipSuccess || hipMalloc(&p->d_spans, sl * 4) != hipSuccess) {
         delete p;
         return nullptr;
     }
-    if (bc_len) (void)hipMemcpy(p->d_bytecode, bc, bc_len * 4, hipMemcpyHostToDevice);
-    if (n_constraints) (void)hipMemcpy(p->d_spans, spans, 2 * n_constraints * 4, hipMemcpyHostToDevice);
+    if (up_bc_len) (void)hipMemcpy(p->d_bytecode, up_bc, up_bc_len * 4, hipMemcpyHostToDevice);
+    if (n_constraints) (void)hipMemcpy(p->d_spans, up_sp, 2 * n_constraints * 4, hipMemcpyHostToDevice);
     return p;
 }
 
@@ -195,7 +217,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const uint32_t one = bb::R_MOD_P;
     const uint32_t zinv_even = bb::inv(bb::sub(sH, one));
     const uint32_t zinv_odd = bb::inv(bb::sub(bb::neg(sH), one));
-    ConstraintProgram prog{p->d_bytecode, p->d_spans, nc};
+    ConstraintProgram prog{p->d_bytecode, p->d_spans, nc, p->is_xbc};
     TRY(quotient_eval(d_lde, N, prog, d_apow, zinv_even, zinv_odd, d_q));
     TRY(intt_dif(d_q, d_q, N, N, 4, logN));
     TRY(quotient_split(d_q, H, (int)log_h, d_qcoef));

@@ -43,9 +43,10 @@ inline size_t merkle_level_offset(size_t n_leaves, int level) {  // in words
 
 // ---- stark_kernels.hip -----------------------------------------------------------------
 struct ConstraintProgram {
-    const uint32_t* d_bytecode;  // PUSH_COL operands = column index
-    const uint32_t* d_spans;     // {off, len} pairs
+    const uint32_t* d_bytecode;  // PUSH_COL operands = column index (reference post-fix encoding) or xbc code
+    const uint32_t* d_spans;     // {off, len} pairs (u32 words, or xbc instructions when is_xbc)
     uint32_t n_constraints;
+    bool is_xbc;
 };
 // q[k*N + j] (k < 4) = coordinate k of  sum_c alpha_pow[c] * C_c(lde row j) * zinv[j & 1]
 int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, const bb::Ext* d_alpha_pows,

@@ -6,6 +6,7 @@
 // constraint bytecode are wave-uniform and arrive through scalar loads.
 #include "prover_internal.hpp"
 #include "expr_eval.hpp"
+#include "xbc.hpp"
 
 namespace pw {
 
@@ -16,6 +17,7 @@ constexpr int kBlock = 256;
 __device__ __forceinline__ bb::Ext load_ext_uniform(const bb::Ext* p) { return *p; }
 
 // ---- quotient ---------------------------------------------------------------------------
+template <bool XBC>
 __global__ __launch_bounds__(kBlock) void quotient_kernel(const uint32_t* __restrict__ lde, size_t N,
                                                            const uint32_t* __restrict__ bytecode,
                                                            const uint32_t* __restrict__ spans, uint32_t n_constraints,
@@ -28,7 +30,8 @@ __global__ __launch_bounds__(kBlock) void quotient_kernel(const uint32_t* __rest
     bb::Ext acc = bb::ext_zero();
     for (uint32_t c = 0; c < n_constraints; ++c) {
         const uint32_t off = spans[2 * c], len = spans[2 * c + 1];
-        const uint32_t v = eval_expr<kBlock, true>(bytecode + off, len, lde, j, stk, N);
+        const uint32_t v = XBC ? xbc::eval<kBlock, true>(bytecode + 2 * (size_t)off, len, lde, j, stk, N)
+                               : eval_expr<kBlock, true>(bytecode + off, len, lde, j, stk, N);
         const bb::Ext a = alpha_pows[c];
         acc.c[0] = bb::add(acc.c[0], bb::mul(a.c[0], v));
         acc.c[1] = bb::add(acc.c[1], bb::mul(a.c[1], v));
@@ -172,8 +175,12 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const uint32_t* __r
 int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, const bb::Ext* d_alpha_pows,
                   uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q) {
     ScopedKernelTimer t("quotient_kernel");
-    hipLaunchKernelGGL(quotient_kernel, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, N, prog.d_bytecode,
-                       prog.d_spans, prog.n_constraints, d_alpha_pows, zinv_even, zinv_odd, q);
+    if (prog.is_xbc)
+        hipLaunchKernelGGL(quotient_kernel<true>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, N, prog.d_bytecode,
+                           prog.d_spans, prog.n_constraints, d_alpha_pows, zinv_even, zinv_odd, q);
+    else
+        hipLaunchKernelGGL(quotient_kernel<false>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, N, prog.d_bytecode,
+                           prog.d_spans, prog.n_constraints, d_alpha_pows, zinv_even, zinv_odd, q);
     return (int)hipGetLastError();
 }
 
