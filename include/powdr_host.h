@@ -89,6 +89,13 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
                                    size_t n_dummy, size_t num_apc_calls, PowdrFp* d_output,
                                    const PowdrPeriphery* periphery);
 
+/* Test hook for the plan-time expression compiler (csrc/xbc.hpp): compiles the reference post-fix
+ * program `postfix` into the accumulator code the kernels run and evaluates it on the host over a
+ * Montgomery-form trace (`trace[operand + r]`). Returns 0, or < 0 if the program is malformed /
+ * deeper than the 16-entry stack (then the kernels fall back to the post-fix interpreter). */
+int powdr_xbc_eval_host(const uint32_t* postfix, uint32_t len, const uint32_t* trace, size_t r,
+                        uint32_t* result, uint32_t* n_instr);
+
 #ifdef __cplusplus
 }
 #endif

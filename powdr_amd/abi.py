@@ -45,6 +45,12 @@ ABI_SYMBOLS = [
 
 
 def _load():
+    # PyTorch-ROCm wheels bundle their own libamdhip64; if libpowdr_gpu.so pulled in /opt/rocm's copy
+    # first, the process would hold two HIP runtimes and the second one reports hipErrorNoDevice.
+    # Importing torch first makes the loader resolve our DT_NEEDED libamdhip64 to the copy torch
+    # loaded, so device pointers and streams are shared. (Rust callers link /opt/rocm directly.)
+    import torch  # noqa: F401
+
     if not _LIBPATH.exists():
         raise ImportError(
             f"{_LIBPATH} is missing: build it with `python -m powdr_amd.build` "

@@ -130,3 +130,61 @@ def test_generate_witness_gpu_matches_oracle(shape, calls):
         assert (per.var_hist.cpu().numpy().view(np.uint32) == hist["var"]).all()
         assert (per.tuple_hist.cpu().numpy().view(np.uint32) == hist["tuple"]).all()
         assert (per.bitwise_hist.cpu().numpy().view(np.uint32) == hist["bitwise"]).all()
+
+
+def test_xbc_compiler_preserves_values():
+    """The plan-time compiler (post-fix -> accumulator code with folding and reordering) against the
+    oracle's evaluator, on random expressions and on the identities it folds."""
+    import ctypes as C
+
+    from powdr_amd import abi
+    from tests.test_oracle_apc import _random_expr
+
+    lib = abi.lib
+    lib.powdr_xbc_eval_host.restype = C.c_int
+    rng = np.random.default_rng(5)
+    W, H = 10, 4
+    ids = list(range(W))
+    idx = {p: p for p in ids}
+    trace = rng.integers(0, om.P, size=W * H, dtype=np.uint32)
+    trace[0:H] = 0  # a zero column: exercises x*0, 0-x, inv_or_zero(0)
+    tm = om.to_monty(trace)
+
+    def check(bc, r):
+        bc = np.array(bc, dtype=np.uint32)
+        try:
+            want = om.c_eval_expr(bc, trace, r)
+        except ValueError:
+            want = None
+        res, n = C.c_uint32(), C.c_uint32()
+        rc = lib.powdr_xbc_eval_host(bc.ctypes.data_as(C.c_void_p), C.c_uint32(len(bc)), tm.ctypes.data_as(C.c_void_p),
+                                     C.c_size_t(r), C.byref(res), C.byref(n))
+        if want is None:
+            assert rc != 0
+            return None
+        assert rc == 0
+        got = int(om.from_monty(np.array([res.value], dtype=np.uint32))[0])
+        assert got == want, (bc.tolist(), r)
+        return n.value
+
+    for depth in (2, 4, 6, 7):
+        for _ in range(150):
+            e = _random_expr(rng, ids, depth)
+            bc = []
+            om.emit_expr(bc, e, idx, H)
+            check(bc, int(rng.integers(H)))
+    A, Cn = om.OP_PUSH_APC, om.OP_PUSH_CONST
+    x, y = [A, 1 * H], [A, 2 * H]
+    cases = [
+        [Cn, 0] + x + [om.OP_ADD], x + [Cn, 0, om.OP_SUB], [Cn, 0] + x + [om.OP_SUB], x + [Cn, 1, om.OP_MUL],
+        x + [Cn, 0, om.OP_MUL], [Cn, 5, Cn, 7, om.OP_MUL, Cn, 3, om.OP_SUB], x + [om.OP_NEG, om.OP_NEG],
+        [Cn, 9] + x + y + [om.OP_ADD, om.OP_SUB], x + y + [om.OP_MUL] + x + y + [om.OP_SUB, om.OP_SUB],
+        [A, 0, om.OP_INV_OR_ZERO] + x + [om.OP_MUL], x + [om.OP_INV_OR_ZERO] + x + [om.OP_MUL], [Cn, 4, om.OP_INV_OR_ZERO],
+    ]
+    for bc in cases:
+        for r in range(H):
+            check(bc, r)
+    assert check(x + [Cn, 1, om.OP_MUL, Cn, 0, om.OP_ADD], 0) == 1  # folds to a single load
+    # malformed programs are rejected (the kernels then keep the post-fix interpreter)
+    for bad in ([om.OP_ADD], x + y, [Cn], [7, 0], x + [om.OP_MUL]):
+        assert check(bad, 0) is None

@@ -40,7 +40,9 @@ def from_dev(t):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_h,W", [(1, 3), (2, 2), (3, 5), (6, 4), (9, 3), (10, 2), (11, 2), (13, 3), (14, 2), (16, 2)])
+@pytest.mark.parametrize("log_h,W", [(1, 3), (2, 2), (3, 5), (4, 1), (5, 2), (6, 4), (7, 1), (8, 2), (9, 3), (10, 2), (11, 2),
+                                      (12, 1), (13, 3), (14, 2), (15, 1), (16, 2), (17, 1), (18, 1), (19, 1), (20, 1),
+                                      (21, 1), (22, 1), (23, 1)])
 def test_lde_matches_oracle(gpu, log_h, W):
     torch, abi, prover = gpu
     rng = np.random.default_rng(log_h)
