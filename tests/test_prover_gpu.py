@@ -205,3 +205,30 @@ def test_multi_air_segment_commitment_merge(gpu):
     assert (merged == np.array(roots)).all()
     d = sharding.commitment_digest(merged)
     assert d.shape == (8,) and (d != sharding.commitment_digest(merged[::-1])).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,log_h,n_cons,nq,pow_bits", [(1, 1, 0, 2, 0), (1, 2, 1, 3, 0), (2, 1, 2, 1, 4), (7, 3, 3, 4, 0), (8, 4, 5, 5, 0),
+                                                         (9, 5, 4, 6, 3), (17, 8, 9, 7, 0), (33, 12, 6, 9, 0), (3, 14, 2, 5, 0)])
+def test_proof_bytes_on_arbitrary_traces(gpu, W, log_h, n_cons, nq, pow_bits):
+    """Byte parity does not depend on the trace satisfying its constraints: random traces, random
+    (unsatisfied) constraint programs, widths that are not multiples of the sponge rate, tiny heights,
+    zero constraints."""
+    torch, abi, prover = gpu
+    rng = np.random.default_rng(W * 100 + log_h)
+    H = 1 << log_h
+    flat = rng.integers(0, P, W * H, dtype=np.uint32)
+    bc, spans = [], []
+    PA, PC = om.OP_PUSH_APC, om.OP_PUSH_CONST
+    for _ in range(n_cons):
+        off = len(bc)
+        a, b, c = (int(x) for x in rng.integers(0, W, 3))
+        bc += [PA, a, PA, b, om.OP_MUL, PC, int(rng.integers(0, P)), om.OP_SUB, PA, c, om.OP_NEG, om.OP_ADD]
+        spans.append((off, len(bc) - off))
+    bc = np.array(bc, np.uint32)
+    spans = np.array(spans, np.uint32).reshape(-1, 2)
+    want = sm.prove(flat, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits)
+    pr = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits)
+    got = pr.prove(to_dev(torch, flat).data_ptr(), log_h)
+    assert len(got) == len(want) and (got == want).all()
+    pr.close()
