@@ -78,10 +78,9 @@ constexpr int kMaxR = 1024;
 static int kMinR = 16;  // POWDR_GATHER_MIN_R
 static int kMaxChunkJ = kMaxTileWords / kMinR - 1;  // 383
 
-__device__ __forceinline__ uint32_t fast_div(uint32_t e, uint32_t magic, uint32_t J) {
-    // exact for e < 2^16, J < 2^16 (e*J < 2^32); J == 1 handled by magic == 0
+__device__ __forceinline__ uint32_t fast_div(uint32_t e, uint32_t magic, uint32_t /*J*/) {
+    // floor(e / J) with magic = ceil(2^32 / J): exact for e < 2^16, J < 2^16; J == 1 is magic == 0
     return magic ? __umulhi(e, magic) : e;
-    (void)J;
 }
 
 template <int R>

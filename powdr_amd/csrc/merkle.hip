@@ -90,13 +90,9 @@ __global__ __launch_bounds__(kBlock) void pow_kernel(const uint32_t* __restrict_
     for (int i = 0; i < 8; ++i)
         if ((uint32_t)i == in_len) st[i] = bb::to_monty(w);
     p2::permute(st, c_params);
-    uint32_t sample;
-    if (in_len == 7) {
-        // the witness filled the rate: duplexing happened inside observe(); sample() pops out[7]
-        sample = st[7];
-    } else {
-        sample = st[7];
-    }
+    // whether the witness filled the rate (duplex inside observe) or not (duplex inside sample), exactly one
+    // permutation follows and sample() pops the last rate word
+    const uint32_t sample = st[7];
     if ((bb::from_monty(sample) & ((1u << bits) - 1u)) == 0u) atomicMin(best, w);
 }
 

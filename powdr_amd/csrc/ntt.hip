@@ -145,8 +145,7 @@ __device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t l0, const
 template <bool DIF, int LOGR, int EPT, bool EXPAND>
 __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, const GroupParams& gp, int round,
                                           const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
-                                          const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid,
-                                          bool canon) {
+                                          const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid) {
     const int rb = gp.rb[round];
     const bool first = round == 0, last = round == gp.n_rounds - 1;
     constexpr int R = 1 << LOGR;
@@ -209,7 +208,6 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
         slot_butterflies<DIF, LOGR>(x, l0, im, gp, rb, tw);
         // ---- store ----
         if (last) {
-            (void)canon;
             if (vec_plain) {
                 bool valid;
                 const size_t g0 = im.global(l0, valid);
@@ -238,7 +236,7 @@ template <bool DIF, int LOGT, bool EXPAND>
 __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                            size_t in_stride, size_t out_stride, GroupParams gp,
                                                            const uint32_t* __restrict__ tw,
-                                                           const uint32_t* __restrict__ scale_br, int canon) {
+                                                           const uint32_t* __restrict__ scale_br) {
     constexpr int EPT = (1 << LOGT) / kBlock;
     __shared__ uint32_t tile[(1 << LOGT) + ((1 << LOGT) >> 5)];
     const int tid = threadIdx.x;
@@ -251,10 +249,10 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     uint32_t* dst = out + (size_t)blockIdx.y * out_stride;
     for (int r = 0; r < gp.n_rounds; ++r) {
         switch (gp.logr[r]) {
-            case 1: run_round<DIF, 1, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, canon != 0); break;
-            case 2: run_round<DIF, 2, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, canon != 0); break;
-            case 3: run_round<DIF, 3, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, canon != 0); break;
-            default: run_round<DIF, 4, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, canon != 0); break;
+            case 1: run_round<DIF, 1, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid); break;
+            case 2: run_round<DIF, 2, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid); break;
+            case 3: run_round<DIF, 3, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid); break;
+            default: run_round<DIF, 4, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid); break;
         }
         if (r + 1 < gp.n_rounds) __syncthreads();  // the next round reads what this round wrote
     }
@@ -367,8 +365,7 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
             const uint32_t* s_ = src + (size_t)c0 * src_stride;
             uint32_t* d_ = out + (size_t)c0 * out_stride;
             dim3 grid(wgs, cc), block(kBlock);
-            const int canon = (&g == &groups.back()) ? 1 : 0;
-#define PW_LAUNCH_NTT(LT, EX) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, EX>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br, canon)
+#define PW_LAUNCH_NTT(LT, EX) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, EX>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br)
             if (logt == 13) { if (expand) PW_LAUNCH_NTT(13, true); else PW_LAUNCH_NTT(13, false); }
             else            { if (expand) PW_LAUNCH_NTT(12, true); else PW_LAUNCH_NTT(12, false); }
 #undef PW_LAUNCH_NTT

@@ -303,7 +303,6 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         uint64_t* d_offs = reinterpret_cast<uint64_t*>(d_qrows + (size_t)nq * 8 + ((nq * (W + 9)) & 1));
         // digest records (8 words) then FRI sibling records (4 words)
         std::vector<uint64_t> dig_offs, ext_offs;
-        const size_t paths_per_query = 2 * (size_t)logN;
         for (uint32_t qi = 0; qi < nq; ++qi) {
             const size_t i = idx[qi];
             for (int tree = 0; tree < 2; ++tree) {
@@ -319,7 +318,6 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
                     dig_offs.push_back(2 * tree_words + tree_off[l] + merkle_level_offset(half, lv) + (((leaf >> lv) ^ 1) * 8));
             }
         }
-        (void)paths_per_query;
         const size_t n_dig = dig_offs.size(), n_ext = ext_offs.size();
         uint64_t* d_dig_offs = d_offs;
         uint64_t* d_ext_offs = d_offs + n_dig;

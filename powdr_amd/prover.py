@@ -14,7 +14,7 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_prover_create", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+PROVER_SYMBOLS = ["pw_verify", "pw_prover_create", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_merkle_commit", "pw_poseidon2_permute_host"]
 
 lib.pw_prover_create.restype = C.c_void_p
@@ -29,6 +29,21 @@ lib.pw_lde_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c
 lib.pw_merkle_commit.restype = C.c_int
 lib.pw_merkle_commit.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
 lib.pw_poseidon2_permute_host.argtypes = [C.c_void_p]
+
+
+lib.pw_verify.restype = C.c_int
+lib.pw_verify.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                          C.c_void_p, C.c_size_t]
+
+
+def verify(proof, width: int, log_height: int, cons_bytecode, cons_spans, num_queries: int = 100, pow_bits: int = 0) -> int:
+    """Host-side verification (no GPU). 0 = valid, otherwise the code of the first failed check."""
+    pr = np.ascontiguousarray(proof, dtype=np.uint32)
+    bc = np.ascontiguousarray(cons_bytecode, dtype=np.uint32)
+    sp = np.ascontiguousarray(cons_spans, dtype=np.uint32).reshape(-1, 2)
+    cfg = PwStarkConfig(num_queries, pow_bits)
+    return int(lib.pw_verify(C.byref(cfg), width, log_height, bc.ctypes.data_as(C.c_void_p), len(bc),
+                             sp.ctypes.data_as(C.c_void_p), len(sp), pr.ctypes.data_as(C.c_void_p), len(pr)))
 
 
 def poseidon2_host(state) -> np.ndarray:

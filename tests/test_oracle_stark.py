@@ -128,3 +128,29 @@ def test_proof_of_work():
     proof = sm.prove(flat, W, 3, bc, spans, num_queries=3, pow_bits=8)
     assert sm.verify(proof, W, 3, bc, spans, num_queries=3, pow_bits=8) == 0
     assert sm.verify(proof, W, 3, bc, spans, num_queries=3, pow_bits=0) != 0
+
+
+@pytest.mark.parametrize("shape,calls,pow_bits", [("T0", 7, 0), ("T0", 33, 6), ("T1", 200, 0)])
+def test_product_verifier_agrees_with_oracle_verifier(shape, calls, pow_bits):
+    """pw_verify (host code of libpowdr_gpu, Montgomery arithmetic, no GPU) against the oracle's
+    verifier: accepts the oracle prover's proofs, rejects every tampering the oracle rejects, with
+    the same verdict code."""
+    from powdr_amd import prover
+
+    s, apc, idx, trace = synthetic_trace(shape, calls, seed=8)
+    W, H = trace.shape
+    log_h = H.bit_length() - 1
+    bc, spans = sm.compile_constraints(apc, idx)
+    flat = np.ascontiguousarray(trace).reshape(-1)
+    proof = sm.prove(flat, W, log_h, bc, spans, num_queries=7, pow_bits=pow_bits)
+    assert prover.verify(proof, W, log_h, bc, spans, num_queries=7, pow_bits=pow_bits) == 0
+    rng = np.random.default_rng(9)
+    for pos in list(rng.choice(len(proof), size=40, replace=False)) + [0, 5, 6, len(proof) - 1]:
+        bad = proof.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        a = sm.verify(bad, W, log_h, bc, spans, num_queries=7, pow_bits=pow_bits)
+        b = prover.verify(bad, W, log_h, bc, spans, num_queries=7, pow_bits=pow_bits)
+        assert a != 0 and a == b, (pos, a, b)
+    assert prover.verify(proof[:-3], W, log_h, bc, spans, num_queries=7, pow_bits=pow_bits) == 10
+    assert prover.verify(np.concatenate([proof, proof[:1]]), W, log_h, bc, spans, num_queries=7, pow_bits=pow_bits) == 9
+    assert prover.verify(proof, W, log_h, bc, spans, num_queries=6, pow_bits=pow_bits) == 1

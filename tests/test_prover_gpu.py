@@ -176,6 +176,7 @@ def test_c2_full_size_trace_generation_and_proof(gpu):
     pr = prover.Prover(W, bc, spans, num_queries=24, pow_bits=12)
     proof = pr.prove(wl["out"].data_ptr(), 20)
     assert sm.verify(proof, W, 20, bc, spans, num_queries=24, pow_bits=12) == 0
+    assert prover.verify(proof, W, 20, bc, spans, num_queries=24, pow_bits=12) == 0  # product-side verifier
     proof2 = proof.copy()
     proof2[len(proof2) // 2] ^= 1
     assert sm.verify(proof2, W, 20, bc, spans, num_queries=24, pow_bits=12) != 0
