@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--pow-bits", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-height", type=int, default=14)
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="host threads / HIP streams proving independent segments concurrently on each GPU "
+                         "(throughput mode; default 1 = one segment at a time, which keeps per-kernel timings clean)")
     ap.add_argument("--exact-source-heights", action="store_true",
                     help="allocate dummy traces with b*calls rows instead of next_pow2 (less HBM)")
     return ap.parse_args()
@@ -156,15 +159,48 @@ def main():
     pr = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits)
     from powdr_amd import sharding
 
-    def step():
-        for t in (wl["per"].var_hist, wl["per"].tuple_hist, wl["per"].bitwise_hist):
+    def run_segment(w):
+        for t in (w["per"].var_hist, w["per"].tuple_hist, w["per"].bitwise_hist):
             t.zero_()
-        wl["apc"].generate_witness_gpu(wl["instr_air"], wl["dummy"], wl["calls"], wl["out"].data_ptr(), wl["per"])
-        proof = pr.prove(wl["out"].data_ptr(), log_h, copy=False)
+        w["apc"].generate_witness_gpu(wl["instr_air"], wl["dummy"], wl["calls"], w["out"].data_ptr(), w["per"])
+        proof = w["pr"].prove(w["out"].data_ptr(), log_h, copy=False)
         if world > 1:
             # the final commitment merge: all-gather of the per-segment trace roots (32 B per segment)
             sharding.merge_commitments([rank], proof[6:14].reshape(1, 8), world)
         return proof
+
+    main_worker = dict(apc=wl["apc"], per=wl["per"], out=wl["out"], pr=pr)
+    workers = [main_worker]
+    if args.pipeline > 1:
+        import threading
+
+        from powdr_amd import host, tracegen as tg
+
+        main_worker["stream"] = torch.cuda.Stream()
+        for _ in range(args.pipeline - 1):
+            workers.append(dict(stream=torch.cuda.Stream(), apc=host.Apc(wl["synth"].doc), per=tg.Periphery.fresh(),
+                                out=torch.empty_like(wl["out"]),
+                                pr=prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits)))
+
+    last = {}
+
+    def run_steps(n):
+        """n segments on this GPU: sequentially, or split over the pipeline's host threads/streams."""
+        if args.pipeline == 1:
+            for _ in range(n):
+                last["proof"] = run_segment(main_worker)
+            return
+
+        def body(w, k):
+            with torch.cuda.stream(w["stream"]):
+                abi.lib.powdr_gpu_set_stream(w["stream"].cuda_stream)
+                for _ in range(k):
+                    last["proof"] = run_segment(w)
+
+        counts = [n // len(workers) + (1 if i < n % len(workers) else 0) for i in range(len(workers))]
+        th = [threading.Thread(target=body, args=(w, k)) for w, k in zip(workers, counts) if k]
+        [t.start() for t in th]
+        [t.join() for t in th]
 
     def barrier():
         if world > 1:
@@ -173,13 +209,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        proof = step()
+    run_steps(max(args.warmup, len(workers) if args.warmup else 0))
     barrier()
     abi.lib.powdr_gpu_timing_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        proof = step()
+    run_steps(args.steps)
     barrier()
     t1 = time.perf_counter()
     timing = abi.timing_report()
@@ -195,6 +229,7 @@ def main():
     total_cells = cells_per_step * args.steps * world
     value = total_cells / elapsed
 
+    proof = last["proof"]
     if rank == 0:
         # dominant kernel + roofline (Merkle leaves read 4*beta = 8 B per trace cell)
         per_kernel = {k: (c, ms) for k, (c, ms) in timing.items()}
@@ -247,7 +282,7 @@ def main():
             config=dict(workload=f"{args.shape} {shape.name} autoprecompile AIR: {wl['W']} cols x 2^{log_h} rows, "
                                  f"{len(wl['cons'][1])} constraints, {wl['apc'].n_bus} bus interactions; trace generation + "
                                  f"pw-stark v0 proof (blow-up 2, {args.queries} queries, {args.pow_bits} PoW bits); one segment per step per GPU",
-                        rows=wl["H"], cols=wl["W"], parallelism=f"segments x{world}",
+                        rows=wl["H"], cols=wl["W"], parallelism=f"segments x{world}" + (f", {args.pipeline} streams per GPU" if args.pipeline > 1 else ""),
                         source_bytes=wl["src_bytes"], proof_bytes=int(len(proof) * 4),
                         prover_device_bytes=pr.device_bytes()),
             roofline=roof, cpu_baseline=cpu, stage_ms=stage_ms,

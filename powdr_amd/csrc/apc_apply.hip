@@ -247,8 +247,9 @@ struct BusPlan {
 };
 std::mutex g_bus_mu;
 std::unordered_map<uint64_t, BusPlan> g_bus_plans;
-uint32_t* g_items = nullptr;
-size_t g_items_words = 0;
+// item buffer of the binned path: one per host thread (= per launch stream)
+thread_local uint32_t* g_items = nullptr;
+thread_local size_t g_items_words = 0;
 
 // 8 bytes per step (the bytecode of an un-optimised APC is megabytes)
 uint64_t hash_words(const void* p, size_t n, uint64_t h) {

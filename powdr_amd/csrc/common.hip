@@ -11,7 +11,9 @@
 
 namespace pw {
 
-static hipStream_t g_stream = nullptr;  // null stream, like the reference (cuda/mod.rs:374-378)
+// Per host thread: a thread that never calls powdr_gpu_set_stream launches on the null stream, like the
+// reference (cuda/mod.rs:374-378); worker threads proving different segments use their own streams.
+static thread_local hipStream_t g_stream = nullptr;
 static bool g_timing = false;
 static std::mutex g_mu;
 struct TimedLaunch {

@@ -10,6 +10,8 @@
 // work — see DESIGN.md §kernels.
 #include "prover_internal.hpp"
 
+#include <mutex>
+
 namespace pw {
 
 namespace {
@@ -141,17 +143,17 @@ int build_levels(uint32_t* digests, size_t n_leaves) {
 }  // namespace
 
 const p2::Params& poseidon2_params_host() {
-    if (!g_params_ready) {
-        p2::generate_params(g_host_params);
-        g_params_ready = true;
-    }
+    static std::once_flag once;
+    std::call_once(once, [] { p2::generate_params(g_host_params); g_params_ready = true; });
     return g_host_params;
 }
 
 int poseidon2_upload_params() {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     if (g_params_uploaded) return 0;
     const p2::Params& p = poseidon2_params_host();
-    PW_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_params), &p, sizeof(p2::Params)));
+    PW_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_params), &p, sizeof(p2::Params)));  // synchronous
     g_params_uploaded = true;
     return 0;
 }

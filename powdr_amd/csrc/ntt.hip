@@ -298,6 +298,8 @@ const Tables* tables(int n) {
     hipLaunchKernelGGL(fill_powers_kernel, dim3(div_up(full, 256)), dim3(256), 0, stream(), t.shift,
                        bb::to_monty(field::kCosetShift), ninv, full);
     hipLaunchKernelGGL(bitrev_copy_kernel, dim3(div_up(full, 256)), dim3(256), 0, stream(), t.shift, t.shift_br, n);
+    // other host threads (other streams) may use the tables as soon as they are published
+    if (hipStreamSynchronize(stream()) != hipSuccess) return nullptr;
     return &g_tables.emplace(n, t).first->second;
 }
 
