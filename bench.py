@@ -63,8 +63,14 @@ def setup_distributed(n):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # test hook: POWDR_DIST_BACKEND=gloo runs the N>1 code path with every rank on GPU 0 (one-GPU boxes)
+        backend = os.environ.get("POWDR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     return rank, local, world
@@ -222,7 +228,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     cells_per_step = wl["W"] * wl["H"]
