@@ -109,6 +109,20 @@ int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
 
 /* ---- extensions (not part of the reference ABI) ------------------------- */
 
+/* The reference encodes PUSH_APC operands as u32 element offsets col*H (cuda/mod.rs:61-63), which cannot
+ * address a trace with width*height >= 2^32 (e.g. 3 731 columns x 2^22 rows). These variants take
+ * COLUMN INDICES as PUSH_APC operands (cell = d_output[operand * output_height + r]); everything else
+ * is as in _apc_apply_derived_expr / _apc_apply_bus. */
+int powdr_apc_apply_derived_expr_cols(PowdrFp* d_output, size_t output_height, int num_apc_calls,
+                                      const DerivedExprSpec* d_specs, size_t n_cols, const uint32_t* d_bytecode);
+int powdr_apc_apply_bus_cols(const PowdrFp* d_output, size_t output_height, int num_apc_calls,
+                             const uint32_t* d_bytecode, size_t bytecode_len,
+                             const DevInteraction* d_interactions, size_t n_interactions,
+                             const ExprSpan* d_arg_spans, size_t n_arg_spans,
+                             uint32_t var_range_bus_id, uint32_t* d_var_hist, size_t var_num_bins,
+                             uint32_t tuple2_bus_id, uint32_t* d_tuple2_hist, uint32_t tuple2_sz0,
+                             uint32_t tuple2_sz1, uint32_t bitwise_bus_id, uint32_t* d_bitwise_hist);
+
 /* All launches of this library go to this stream (default: the null stream,
  * like the reference, cuda/mod.rs:374-378). Pass a hipStream_t as void*. */
 void powdr_gpu_set_stream(void* hip_stream);

@@ -39,6 +39,7 @@ assert C.sizeof(DerivedExprSpec) == 16 and C.sizeof(DevInteraction) == 12
 # every symbol include/powdr_gpu.h declares
 ABI_SYMBOLS = [
     "_apc_tracegen", "_apc_apply_derived_expr", "_apc_apply_bus",
+    "powdr_apc_apply_derived_expr_cols", "powdr_apc_apply_bus_cols",
     "powdr_gpu_set_stream", "powdr_gpu_get_stream", "powdr_gpu_timing_enable",
     "powdr_gpu_timing_report", "powdr_gpu_version",
 ]

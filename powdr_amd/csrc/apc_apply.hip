@@ -36,9 +36,11 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// col_stride = 1: PUSH_APC operands are element offsets col*H (reference encoding); col_stride = H: operands are
+// column indices (extension for traces with W*H >= 2^32, which the u32 offsets cannot address).
 __global__ __launch_bounds__(kBlock) void apc_apply_derived_expr_kernel(
     uint32_t* d_output, size_t H, int num_calls, const DerivedExprSpec* __restrict__ specs,
-    size_t n_cols, const uint32_t* __restrict__ bytecode) {
+    size_t n_cols, const uint32_t* __restrict__ bytecode, size_t col_stride) {
     __shared__ uint32_t stack_lds[pw::kStackCap * kBlock];
     uint32_t* stk = stack_lds + threadIdx.x;
     const size_t total = (size_t)gridDim.x * kBlock;
@@ -48,8 +50,8 @@ __global__ __launch_bounds__(kBlock) void apc_apply_derived_expr_kernel(
                 const DerivedExprSpec spec = specs[i];
                 // later derived columns may read earlier ones of the same row: plain
                 // (non-restrict) accesses by the same thread keep program order.
-                uint32_t v = pw::eval_expr<kBlock>(bytecode + spec.span.off, spec.span.len,
-                                                  d_output, r, stk);
+                uint32_t v = pw::eval_expr<kBlock, true>(bytecode + spec.span.off, spec.span.len,
+                                                        d_output, r, stk, col_stride);
                 d_output[spec.col_base + r] = v;
             }
         } else {
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
     const uint32_t* __restrict__ trace, int num_calls, const uint32_t* __restrict__ bytecode,
     const DevInteraction* __restrict__ interactions, uint32_t n_interactions,
     const ExprSpan* __restrict__ spans, BusParams p, uint32_t per_chunk,
-    const int32_t* __restrict__ slot_of, uint32_t* __restrict__ items, size_t item_stride) {
+    const int32_t* __restrict__ slot_of, uint32_t* __restrict__ items, size_t item_stride, size_t col_stride) {
     __shared__ uint32_t stack_lds[pw::kStackCap * kBlock];
     uint32_t* stk = stack_lds + threadIdx.x;
     const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -112,11 +114,11 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
         if (live) {
             const ExprSpan* sp = spans + intr.args_index_off;
             const ExprSpan ms = sp[0];
-            m = bb::from_monty(pw::eval_expr<kBlock>(bytecode + ms.off, ms.len, trace, r, stk));
+            m = bb::from_monty(pw::eval_expr<kBlock, true>(bytecode + ms.off, ms.len, trace, r, stk, col_stride));
             if (m != 0u) {
                 const ExprSpan s0 = sp[1], s1 = sp[2];
-                const uint32_t a0 = bb::from_monty(pw::eval_expr<kBlock>(bytecode + s0.off, s0.len, trace, r, stk));
-                const uint32_t a1 = bb::from_monty(pw::eval_expr<kBlock>(bytecode + s1.off, s1.len, trace, r, stk));
+                const uint32_t a0 = bb::from_monty(pw::eval_expr<kBlock, true>(bytecode + s0.off, s0.len, trace, r, stk, col_stride));
+                const uint32_t a1 = bb::from_monty(pw::eval_expr<kBlock, true>(bytecode + s1.off, s1.len, trace, r, stk, col_stride));
                 if (kind == 0) {
                     // [value, max_bits] -> bin (1 << max_bits) + value - 1   (apc_apply_bus.cu:74)
                     // (shift counts >= 32 give 0, as PTX shl.b32 does for the reference build)
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
                 } else {
                     // [x, y, x_xor_y, selector]; arg 2 is never read (apc_apply_bus.cu:94-99)
                     const ExprSpan s3 = sp[4];
-                    const uint32_t sel = bb::from_monty(pw::eval_expr<kBlock>(bytecode + s3.off, s3.len, trace, r, stk));
+                    const uint32_t sel = bb::from_monty(pw::eval_expr<kBlock, true>(bytecode + s3.off, s3.len, trace, r, stk, col_stride));
                     if (sel <= 1u && a0 < 256u && a1 < 256u) bin = bitwise_index(a0, a1, sel);
                 }
             }
@@ -160,7 +162,7 @@ template <bool BINNED>
 __global__ __launch_bounds__(kBlock) void apc_apply_bus_xbc_kernel(
     const uint32_t* __restrict__ trace, int num_calls, const uint32_t* __restrict__ code,
     const XInteraction* __restrict__ xint, uint32_t n_xint, BusParams p, uint32_t per_chunk,
-    uint32_t* __restrict__ items, size_t item_stride) {
+    uint32_t* __restrict__ items, size_t item_stride, size_t col_stride) {
     __shared__ uint32_t stack_lds[pw::kStackCap * kBlock];
     uint32_t* stk = stack_lds + threadIdx.x;
     const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -174,10 +176,10 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_xbc_kernel(
         uint32_t bin = kItemNone, m = 0u;
         uint32_t* table = xi.kind == 0 ? p.var_hist : xi.kind == 1 ? p.tuple_hist : p.bitwise_hist;
         if (live) {
-            m = bb::from_monty(xbc::eval<kBlock, false>(code + 2 * (size_t)xi.off[0], xi.len[0], trace, r, stk));
+            m = bb::from_monty(xbc::eval<kBlock, true>(code + 2 * (size_t)xi.off[0], xi.len[0], trace, r, stk, col_stride));
             if (m != 0u) {
-                const uint32_t a0 = bb::from_monty(xbc::eval<kBlock, false>(code + 2 * (size_t)xi.off[1], xi.len[1], trace, r, stk));
-                const uint32_t a1 = bb::from_monty(xbc::eval<kBlock, false>(code + 2 * (size_t)xi.off[2], xi.len[2], trace, r, stk));
+                const uint32_t a0 = bb::from_monty(xbc::eval<kBlock, true>(code + 2 * (size_t)xi.off[1], xi.len[1], trace, r, stk, col_stride));
+                const uint32_t a1 = bb::from_monty(xbc::eval<kBlock, true>(code + 2 * (size_t)xi.off[2], xi.len[2], trace, r, stk, col_stride));
                 if (xi.kind == 0) {
                     const uint32_t idx = (a1 < 32u ? (1u << a1) : 0u) + a0 - 1u;
                     if (idx < p.var_bins) bin = idx;
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_xbc_kernel(
                     const uint32_t idx = a0 * p.tuple_sz1 + a1;
                     if (idx < p.tuple_sz0 * p.tuple_sz1) bin = idx;
                 } else {
-                    const uint32_t sel = bb::from_monty(xbc::eval<kBlock, false>(code + 2 * (size_t)xi.off[3], xi.len[3], trace, r, stk));
+                    const uint32_t sel = bb::from_monty(xbc::eval<kBlock, true>(code + 2 * (size_t)xi.off[3], xi.len[3], trace, r, stk, col_stride));
                     if (sel <= 1u && a0 < 256u && a1 < 256u) bin = bitwise_index(a0, a1, sel);
                 }
             }
@@ -268,9 +270,9 @@ uint64_t fnv1a64(const void* p, size_t n, uint64_t h) {
 
 }  // namespace
 
-extern "C" int _apc_apply_derived_expr(PowdrFp* d_output, size_t H, int num_apc_calls,
-                                       const DerivedExprSpec* d_specs, size_t n_cols,
-                                       const uint32_t* d_bytecode) {
+namespace {
+int apply_derived_impl(PowdrFp* d_output, size_t H, int num_apc_calls, const DerivedExprSpec* d_specs, size_t n_cols,
+                       const uint32_t* d_bytecode, size_t col_stride) {
     if (n_cols == 0) return 0;  // apc_tracegen.cu:114
     (void)hipGetLastError();    // do not report a stale error of an unrelated earlier call
     if (H == 0) return (int)hipGetLastError();
@@ -278,18 +280,32 @@ extern "C" int _apc_apply_derived_expr(PowdrFp* d_output, size_t H, int num_apc_
     if (g > 65535u * 16u) g = 65535u * 16u;
     pw::ScopedKernelTimer t("apc_apply_derived_expr_kernel");
     hipLaunchKernelGGL(apc_apply_derived_expr_kernel, dim3(g), dim3(kBlock), 0, pw::stream(),
-                       d_output, H, num_apc_calls, d_specs, n_cols, d_bytecode);
+                       d_output, H, num_apc_calls, d_specs, n_cols, d_bytecode, col_stride);
     return (int)hipGetLastError();
 }
+}  // namespace
 
-extern "C" int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
-                              const uint32_t* d_bytecode, size_t bytecode_len,
-                              const DevInteraction* d_interactions, size_t n_interactions,
-                              const ExprSpan* d_arg_spans, size_t n_arg_spans,
-                              uint32_t var_range_bus_id, uint32_t* d_var_hist, size_t var_num_bins,
-                              uint32_t tuple2_bus_id, uint32_t* d_tuple2_hist, uint32_t tuple2_sz0,
-                              uint32_t tuple2_sz1, uint32_t bitwise_bus_id,
-                              uint32_t* d_bitwise_hist) {
+extern "C" int _apc_apply_derived_expr(PowdrFp* d_output, size_t H, int num_apc_calls,
+                                       const DerivedExprSpec* d_specs, size_t n_cols,
+                                       const uint32_t* d_bytecode) {
+    return apply_derived_impl(d_output, H, num_apc_calls, d_specs, n_cols, d_bytecode, 1);
+}
+
+extern "C" int powdr_apc_apply_derived_expr_cols(PowdrFp* d_output, size_t H, int num_apc_calls,
+                                                 const DerivedExprSpec* d_specs, size_t n_cols,
+                                                 const uint32_t* d_bytecode) {
+    return apply_derived_impl(d_output, H, num_apc_calls, d_specs, n_cols, d_bytecode, H);
+}
+
+namespace {
+int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
+                   const uint32_t* d_bytecode, size_t bytecode_len,
+                   const DevInteraction* d_interactions, size_t n_interactions,
+                   const ExprSpan* d_arg_spans, size_t n_arg_spans,
+                   uint32_t var_range_bus_id, uint32_t* d_var_hist, size_t var_num_bins,
+                   uint32_t tuple2_bus_id, uint32_t* d_tuple2_hist, uint32_t tuple2_sz0,
+                   uint32_t tuple2_sz1, uint32_t bitwise_bus_id,
+                   uint32_t* d_bitwise_hist, size_t col_stride) {
     if (num_apc_calls <= 0) return 0;  // apc_apply_bus.cu:146
     (void)hipGetLastError();
     if (n_interactions == 0) return (int)hipGetLastError();
@@ -399,11 +415,11 @@ extern "C" int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
                 if (use_xbc)
                     hipLaunchKernelGGL(apc_apply_bus_xbc_kernel<true>, dim3(pw::div_up(stride, kBlock), xchunks), dim3(kBlock), 0,
                                        pw::stream(), d_output, num_apc_calls, plan->d_code, plan->d_xint, plan->total_slots, p,
-                                       x_per_chunk, g_items, stride);
+                                       x_per_chunk, g_items, stride, col_stride);
                 else
                     hipLaunchKernelGGL(apc_apply_bus_kernel<true>, dim3(pw::div_up(stride, kBlock), xchunks), dim3(kBlock), 0,
                                        pw::stream(), d_output, num_apc_calls, d_bytecode, d_interactions, (uint32_t)n_interactions,
-                                       d_arg_spans, p, x_per_chunk, plan->d_slot_of, g_items, stride);
+                                       d_arg_spans, p, x_per_chunk, plan->d_slot_of, g_items, stride, col_stride);
             }
             uint32_t* tables[3] = {d_var_hist, d_tuple2_hist, d_bitwise_hist};
             // one 128-KB-LDS workgroup fits per CU, and the three launches run one after the other, so each
@@ -427,10 +443,37 @@ extern "C" int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
     pw::ScopedKernelTimer t("apc_apply_bus_kernel");
     if (use_xbc)
         hipLaunchKernelGGL(apc_apply_bus_xbc_kernel<false>, dim3(row_blocks, xchunks), dim3(kBlock), 0, pw::stream(),
-                           d_output, num_apc_calls, plan->d_code, plan->d_xint, plan->total_slots, p, x_per_chunk, nullptr, 0);
+                           d_output, num_apc_calls, plan->d_code, plan->d_xint, plan->total_slots, p, x_per_chunk, nullptr, 0, col_stride);
     else
         hipLaunchKernelGGL(apc_apply_bus_kernel<false>, dim3(row_blocks, xchunks), dim3(kBlock), 0, pw::stream(),
                            d_output, num_apc_calls, d_bytecode, d_interactions,
-                           (uint32_t)n_interactions, d_arg_spans, p, x_per_chunk, nullptr, nullptr, 0);
+                           (uint32_t)n_interactions, d_arg_spans, p, x_per_chunk, nullptr, nullptr, 0, col_stride);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int _apc_apply_bus(const PowdrFp* d_output, int num_apc_calls,
+                              const uint32_t* d_bytecode, size_t bytecode_len,
+                              const DevInteraction* d_interactions, size_t n_interactions,
+                              const ExprSpan* d_arg_spans, size_t n_arg_spans,
+                              uint32_t var_range_bus_id, uint32_t* d_var_hist, size_t var_num_bins,
+                              uint32_t tuple2_bus_id, uint32_t* d_tuple2_hist, uint32_t tuple2_sz0,
+                              uint32_t tuple2_sz1, uint32_t bitwise_bus_id,
+                              uint32_t* d_bitwise_hist) {
+    return apply_bus_impl(d_output, num_apc_calls, d_bytecode, bytecode_len, d_interactions, n_interactions, d_arg_spans,
+                          n_arg_spans, var_range_bus_id, d_var_hist, var_num_bins, tuple2_bus_id, d_tuple2_hist, tuple2_sz0,
+                          tuple2_sz1, bitwise_bus_id, d_bitwise_hist, 1);
+}
+
+extern "C" int powdr_apc_apply_bus_cols(const PowdrFp* d_output, size_t output_height, int num_apc_calls,
+                                        const uint32_t* d_bytecode, size_t bytecode_len,
+                                        const DevInteraction* d_interactions, size_t n_interactions,
+                                        const ExprSpan* d_arg_spans, size_t n_arg_spans,
+                                        uint32_t var_range_bus_id, uint32_t* d_var_hist, size_t var_num_bins,
+                                        uint32_t tuple2_bus_id, uint32_t* d_tuple2_hist, uint32_t tuple2_sz0,
+                                        uint32_t tuple2_sz1, uint32_t bitwise_bus_id,
+                                        uint32_t* d_bitwise_hist) {
+    return apply_bus_impl(d_output, num_apc_calls, d_bytecode, bytecode_len, d_interactions, n_interactions, d_arg_spans,
+                          n_arg_spans, var_range_bus_id, d_var_hist, var_num_bins, tuple2_bus_id, d_tuple2_hist, tuple2_sz0,
+                          tuple2_sz1, bitwise_bus_id, d_bitwise_hist, output_height);
 }

@@ -516,23 +516,32 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
     if (rc) return rc;
 
     // ---- derived columns + bus interactions, compiled once per height ----
+    // Traces with width*height >= 2^32 cannot be addressed by the reference's u32 element offsets:
+    // compile with column-index operands and use the *_cols entry points instead.
+    const bool wide = (uint64_t)width * (uint64_t)height > 0xffffffffull;
     auto ct = apc->compiled.find(height);
     if (ct == apc->compiled.end()) {
         PowdrApc::Compiled c;
-        DerivedTables d = compile_derived(*apc, height);
-        BusTables b = compile_bus(*apc, height);
+        DerivedTables d = compile_derived(*apc, wide ? 1 : height);
+        if (wide) for (auto& sp : d.specs) sp.col_base *= height;
+        BusTables b = compile_bus(*apc, wide ? 1 : height);
         c.n_specs = d.specs.size(); c.bbc_len = b.bc.size(); c.n_inter = b.inter.size(); c.n_spans = b.spans.size();
         if ((rc = upload(c.d_specs, d.specs)) || (rc = upload(c.d_dbc, d.bc)) || (rc = upload(c.d_bbc, b.bc)) ||
             (rc = upload(c.d_inter, b.inter)) || (rc = upload(c.d_spans, b.spans))) return rc;
         ct = apc->compiled.emplace(height, c).first;
     }
     const PowdrApc::Compiled& c = ct->second;
-    rc = _apc_apply_derived_expr(d_output, height, (int)num_calls, c.d_specs, c.n_specs, c.d_dbc);
+    rc = wide ? powdr_apc_apply_derived_expr_cols(d_output, height, (int)num_calls, c.d_specs, c.n_specs, c.d_dbc)
+              : _apc_apply_derived_expr(d_output, height, (int)num_calls, c.d_specs, c.n_specs, c.d_dbc);
     if (rc) return rc;
     if (per) {
-        rc = _apc_apply_bus(d_output, (int)num_calls, c.d_bbc, c.bbc_len, c.d_inter, c.n_inter, c.d_spans, c.n_spans,
-                            per->var_range_bus_id, per->d_var_hist, per->var_num_bins, per->tuple2_bus_id, per->d_tuple2_hist,
-                            per->tuple2_sz0, per->tuple2_sz1, per->bitwise_bus_id, per->d_bitwise_hist);
+        rc = wide ? powdr_apc_apply_bus_cols(d_output, height, (int)num_calls, c.d_bbc, c.bbc_len, c.d_inter, c.n_inter, c.d_spans,
+                                             c.n_spans, per->var_range_bus_id, per->d_var_hist, per->var_num_bins,
+                                             per->tuple2_bus_id, per->d_tuple2_hist, per->tuple2_sz0, per->tuple2_sz1,
+                                             per->bitwise_bus_id, per->d_bitwise_hist)
+                  : _apc_apply_bus(d_output, (int)num_calls, c.d_bbc, c.bbc_len, c.d_inter, c.n_inter, c.d_spans, c.n_spans,
+                                   per->var_range_bus_id, per->d_var_hist, per->var_num_bins, per->tuple2_bus_id, per->d_tuple2_hist,
+                                   per->tuple2_sz0, per->tuple2_sz1, per->bitwise_bus_id, per->d_bitwise_hist);
         if (rc) return rc;
     }
     return 0;

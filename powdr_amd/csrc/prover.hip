@@ -150,7 +150,11 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const size_t tree_words = merkle_words(N);
     size_t fri_words = 0;
     for (uint32_t l = 0; l < log_h; ++l) fri_words += merkle_words((N >> l) / 2);
-    TRY(p->coef.ensure((size_t)W * H * 4));
+    // coefficients exist only per column panel (~256 MB): iNTT -> panel -> coset NTT into the resident LDE
+    size_t panel_cols = ((size_t)1 << 26) / H;
+    if (panel_cols < 8) panel_cols = 8;
+    if (panel_cols > W) panel_cols = W;
+    TRY(p->coef.ensure(panel_cols * H * 4));
     TRY(p->lde.ensure((size_t)W * N * 4));
     TRY(p->digests.ensure((2 * tree_words + fri_words) * 4));
     TRY(p->q.ensure(4 * N * 4));
@@ -193,8 +197,11 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     for (uint32_t x : {kMagic, log_h, W, nc, p->cfg.num_queries, p->cfg.pow_bits}) put(x);
 
     // ---- 1. trace: coefficients, LDE, commitment ---------------------------------------------
-    TRY(intt_dif(d_trace, d_coef, H, H, W, (int)log_h));
-    TRY(coset_lde_from_coeffs(d_coef, d_lde, H, N, W, (int)log_h));
+    for (size_t c0 = 0; c0 < W; c0 += panel_cols) {
+        const uint32_t pc = (uint32_t)(W - c0 < panel_cols ? W - c0 : panel_cols);
+        TRY(intt_dif(d_trace + c0 * H, d_coef, H, H, pc, (int)log_h));
+        TRY(coset_lde_from_coeffs(d_coef, d_lde + c0 * N, H, N, pc, (int)log_h));
+    }
     TRY(merkle_commit_matrix(d_lde, N, W, N, d_tdig));
     uint32_t root[8];
     PW_HIP_TRY(hipMemcpyAsync(root, d_tdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
@@ -230,8 +237,11 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
 
     // ---- 3. openings at zeta -------------------------------------------------------------------
     const bb::Ext zeta = ch.sample_ext();
+    // trace columns: barycentric evaluation straight from the caller's trace (natural order on <g_n>);
+    // quotient chunks: from their (small) coefficient arrays
+    TRY(barycentric_weights(zeta, (int)log_h, d_weights));
+    TRY(ext_dot_columns(d_trace, H, W, H, d_weights, d_opened, d_scratch));
     TRY(zeta_weights(zeta, (int)log_h, d_weights));
-    TRY(ext_dot_columns(d_coef, H, W, H, d_weights, d_opened, d_scratch));
     TRY(ext_dot_columns(d_qcoef, H, 8, H, d_weights, d_opened + W, d_scratch));
     std::vector<bb::Ext> opened(K);
     PW_HIP_TRY(hipMemcpyAsync(opened.data(), d_opened, K * sizeof(bb::Ext), hipMemcpyDeviceToHost, st));

@@ -56,6 +56,8 @@ int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, 
 int quotient_split(const uint32_t* cbr, size_t H, int log_h, uint32_t* out);
 // weights[q] = z^(bitrev_n(q)) / 2^n  (Ext), for coefficient vectors as intt_dif leaves them
 int zeta_weights(bb::Ext z, int log_h, bb::Ext* weights);
+// weights[i] = (zeta^H - 1)/H * g^i / (zeta - g^i): f(zeta) = sum_i f(g^i) weights[i] for natural-order evaluations
+int barycentric_weights(bb::Ext zeta, int log_h, bb::Ext* weights);
 // out[c] = sum_q cols[c*stride + q] * weights[q]
 int ext_dot_columns(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t len, const bb::Ext* weights, bb::Ext* out,
                     bb::Ext* scratch);

@@ -68,6 +68,17 @@ __global__ __launch_bounds__(kBlock) void zeta_weights_kernel(bb::Ext z, int log
     w[q] = bb::ext_scale(bb::ext_pow(z, k), ninv);
 }
 
+// w[i] = scale * g^i / (zeta - g^i): Lagrange weights of the order-2^n subgroup at zeta, so that
+// f(zeta) = sum_i f(g^i) w[i] for deg f < 2^n, with scale = (zeta^H - 1) / H.
+__global__ __launch_bounds__(kBlock) void barycentric_weights_kernel(bb::Ext zeta, bb::Ext scale, int log_h, uint32_t g,
+                                                                      bb::Ext* __restrict__ w) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= ((size_t)1 << log_h)) return;
+    const uint32_t gi = bb::pow_u32(g, (uint32_t)i);
+    const bb::Ext den = bb::ext_sub(zeta, bb::ext_from_base(gi));
+    w[i] = bb::ext_mul(bb::ext_scale(scale, gi), bb::ext_inv(den));
+}
+
 constexpr int kDotRowsPerBlock = 8192;
 __global__ __launch_bounds__(kBlock) void ext_dot_partial_kernel(const uint32_t* __restrict__ cols, size_t stride, size_t len,
                                                                   const bb::Ext* __restrict__ weights,
@@ -196,6 +207,16 @@ int zeta_weights(bb::Ext z, int log_h, bb::Ext* weights) {
     const uint32_t ninv = bb::inv(bb::to_monty((uint32_t)(((uint64_t)1 << log_h) % bb::P)));
     ScopedKernelTimer t("zeta_weights_kernel");
     hipLaunchKernelGGL(zeta_weights_kernel, dim3(div_up((size_t)1 << log_h, kBlock)), dim3(kBlock), 0, stream(), z, log_h, ninv, weights);
+    return (int)hipGetLastError();
+}
+
+int barycentric_weights(bb::Ext zeta, int log_h, bb::Ext* weights) {
+    const size_t H = (size_t)1 << log_h;
+    const uint32_t hinv = bb::inv(bb::to_monty((uint32_t)(H % bb::P)));
+    const bb::Ext scale = bb::ext_scale(bb::ext_sub(bb::ext_pow(zeta, H), bb::ext_one()), hinv);
+    ScopedKernelTimer t("barycentric_weights_kernel");
+    hipLaunchKernelGGL(barycentric_weights_kernel, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), zeta, scale, log_h,
+                       field::root_of_unity(log_h), weights);
     return (int)hipGetLastError();
 }
 

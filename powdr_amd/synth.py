@@ -63,6 +63,10 @@ SHAPES = {
                 [("BaseAlu", 36, 318), ("Shift", 53, 116), ("LoadStore", 41, 241), ("BranchEqual", 26, 1), ("JalLui", 18, 1)], config_id=2),
     "C3": Shape("guest-ecrecover", 3731, 22, 3114, 2314,
                 [("BaseAlu", 36, 420), ("Shift", 53, 64), ("LoadStore", 41, 310), ("Mul", 31, 96), ("LessThan", 37, 40), ("BranchEqual", 26, 1)], config_id=3),
+    # C3 with dense gather sources (4 076 source cells per call instead of ~36 000) so that a 2^22-row run fits one
+    # 288 GB GPU: same output shape, constraints and interactions as C3
+    "C3p": Shape("guest-ecrecover (dense sources)", 3731, 22, 3114, 2314,
+                 [("BaseAlu", 36, 30), ("Shift", 53, 20), ("LoadStore", 41, 30), ("Mul", 31, 10), ("LessThan", 37, 10), ("BranchEqual", 26, 1)], config_id=4),
     # small shapes for tests
     "T0": Shape("tiny", 24, 6, 9, 20, [("BaseAlu", 36, 3), ("Shift", 53, 2), ("JalLui", 18, 1)], n_quotient=2, config_id=100),
     "T1": Shape("small", 160, 10, 40, 120, [("BaseAlu", 36, 20), ("Shift", 53, 7), ("LoadStore", 41, 12), ("BranchEqual", 26, 1)], n_quotient=3, config_id=101),

@@ -233,3 +233,21 @@ def test_proof_bytes_on_arbitrary_traces(gpu, W, log_h, n_cons, nq, pow_bits):
     got = pr.prove(to_dev(torch, flat).data_ptr(), log_h)
     assert len(got) == len(want) and (got == want).all()
     pr.close()
+
+
+@pytest.mark.gpu
+def test_c3_scale_trace_and_proof(gpu):
+    """BASELINE configs[2] scale on one GPU: 3 731 columns x 2^22 rows (15.6 G cells, W*H > 2^32, ~190 GB peak):
+    trace generation through the column-operand path, proof, host verification (tools/run_c3_scale.py)."""
+    torch, abi, prover = gpu
+    if torch.cuda.mem_get_info()[0] < 230e9:
+        pytest.skip("needs ~190 GB of free HBM")
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("run_c3_scale", Path(__file__).resolve().parents[1] / "tools" / "run_c3_scale.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.run(22, 16, 8, verbose=False)
+    assert rep["verify_rc"] == 0 and rep["cells"] == 3731 << 22
+    torch.cuda.empty_cache()

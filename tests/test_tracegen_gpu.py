@@ -317,3 +317,39 @@ def test_binned_path_large_multiplicity_and_hot_bins(gpu, monkeypatch):
     om.c_apc_apply_bus(trace, calls, np.array(bc, np.uint32), inter, np.array(spans, np.uint32), 3, want["var"], 7, want["tuple"], 256, 2048, 6, want["bitwise"])
     assert (hist_np(per.var_hist) == want["var"]).all() and want["var"][(1 << 12) + 76] == calls
     assert (hist_np(per.bitwise_hist) == want["bitwise"]).all()
+
+
+def test_column_operand_extensions_match_reference_encoding(gpu):
+    """powdr_apc_apply_derived_expr_cols / powdr_apc_apply_bus_cols (PUSH_APC operand = column index, for
+    traces with W*H >= 2^32) against the reference encoding (operand = col*H) on the same APC."""
+    import ctypes as C
+
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+
+    torch, abi, tg = gpu
+    s = synth.generate("T1", seed=17)
+    calls = 700
+    apc, idx, want, hist, (bufs, dims, gt, order) = run_oracle_gpu_convention(s, calls, seed=17)
+    W, H = want.shape
+    # start from the gathered trace (no derived columns yet)
+    out, _ = run_gpu(gpu, W, H, calls, bufs, dims, gt.air_names, gt.row_block_size, gt.subs, None, None)
+    cb, offs, lens, dbc = om.compile_derived(apc, idx, 1)          # column-index operands
+    specs = np.zeros(len(offs), dtype=[("col_base", "<u8"), ("off", "<u4"), ("len", "<u4")])
+    specs["col_base"], specs["off"], specs["len"] = cb * H, offs, lens
+    d_specs, d_bc = tg._dev(specs, "cuda"), tg._dev(dbc, "cuda")
+    abi.lib.powdr_apc_apply_derived_expr_cols.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+    abi.check(abi.lib.powdr_apc_apply_derived_expr_cols(out.ptr(), H, calls, d_specs.data_ptr(), len(offs), d_bc.data_ptr()), "derived_cols")
+    torch.cuda.synchronize()
+    assert (from_dev(out.buf).reshape(W, H) == want).all()
+    inter, spans, bbc = om.compile_bus(apc, idx, 1)
+    per = tg.Periphery.fresh()
+    d = [tg._dev(np.ascontiguousarray(a), "cuda") for a in (bbc, inter, spans)]
+    vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
+    abi.lib.powdr_apc_apply_bus_cols.argtypes = [vp, sz, C.c_int, vp, sz, vp, sz, vp, sz, u32, vp, sz, u32, vp, u32, u32, u32, vp]
+    abi.check(abi.lib.powdr_apc_apply_bus_cols(out.ptr(), H, calls, d[0].data_ptr(), len(bbc), d[1].data_ptr(), len(inter), d[2].data_ptr(),
+                                               len(spans), per.var_bus, per.var_hist.data_ptr(), per.var_hist.numel(), per.tuple_bus,
+                                               per.tuple_hist.data_ptr(), 256, 2048, per.bitwise_bus, per.bitwise_hist.data_ptr()), "bus_cols")
+    torch.cuda.synchronize()
+    assert (hist_np(per.var_hist) == hist["var"]).all()
+    assert (hist_np(per.tuple_hist) == hist["tuple"]).all()
+    assert (hist_np(per.bitwise_hist) == hist["bitwise"]).all()
