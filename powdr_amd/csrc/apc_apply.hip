@@ -91,13 +91,15 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
     const uint32_t* __restrict__ trace, int num_calls, const uint32_t* __restrict__ bytecode,
     const DevInteraction* __restrict__ interactions, uint32_t n_interactions,
     const ExprSpan* __restrict__ spans, BusParams p, uint32_t per_chunk,
-    const int32_t* __restrict__ slot_of, uint32_t* __restrict__ items, size_t item_stride, size_t col_stride) {
+    const int32_t* __restrict__ slot_of, uint32_t* __restrict__ items, size_t item_stride, size_t col_stride,
+    size_t row0) {
     __shared__ uint32_t stack_lds[pw::kStackCap * kBlock];
     uint32_t* stk = stack_lds + threadIdx.x;
-    const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t rl = (size_t)blockIdx.x * kBlock + threadIdx.x;  // row within this launch's row window
+    const size_t r = row0 + rl;
     const bool live = r < (size_t)num_calls;
     if (!BINNED && !live) return;
-    if (BINNED && r >= item_stride) return;
+    if (BINNED && rl >= item_stride) return;
     const uint32_t i0 = blockIdx.y * per_chunk;
     const uint32_t i1 = min(n_interactions, i0 + per_chunk);
 
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
                 if (m < kItemMaxMult && bin < (1u << kItemBinBits)) item = bin | (m << kItemBinBits);
                 else atomicAdd(table + bin, m);  // does not fit the packed item: rare, direct
             }
-            items[(size_t)slot_of[i] * item_stride + r] = item;
+            items[(size_t)slot_of[i] * item_stride + rl] = item;
         } else if (bin != kItemNone) {
             atomicAdd(table + bin, m);
         }
@@ -162,13 +164,14 @@ template <bool BINNED>
 __global__ __launch_bounds__(kBlock) void apc_apply_bus_xbc_kernel(
     const uint32_t* __restrict__ trace, int num_calls, const uint32_t* __restrict__ code,
     const XInteraction* __restrict__ xint, uint32_t n_xint, BusParams p, uint32_t per_chunk,
-    uint32_t* __restrict__ items, size_t item_stride, size_t col_stride) {
+    uint32_t* __restrict__ items, size_t item_stride, size_t col_stride, size_t row0) {
     __shared__ uint32_t stack_lds[pw::kStackCap * kBlock];
     uint32_t* stk = stack_lds + threadIdx.x;
-    const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t rl = (size_t)blockIdx.x * kBlock + threadIdx.x;  // row within this launch's row window
+    const size_t r = row0 + rl;
     const bool live = r < (size_t)num_calls;
     if (!BINNED && !live) return;
-    if (BINNED && r >= item_stride) return;
+    if (BINNED && rl >= item_stride) return;
     const uint32_t i0 = blockIdx.y * per_chunk;
     const uint32_t i1 = min(n_xint, i0 + per_chunk);
     for (uint32_t i = i0; i < i1; ++i) {
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_xbc_kernel(
                 if (m < kItemMaxMult && bin < (1u << kItemBinBits)) item = bin | (m << kItemBinBits);
                 else atomicAdd(table + bin, m);
             }
-            items[(size_t)xi.slot * item_stride + r] = item;
+            items[(size_t)xi.slot * item_stride + rl] = item;
         } else if (bin != kItemNone) {
             atomicAdd(table + bin, m);
         }
@@ -400,8 +403,11 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
 
     // ---- long traces: binned path ---------------------------------------------------------------
     if (want_binned && table_bins[0] <= (1u << kItemBinBits) && table_bins[1] <= (1u << kItemBinBits)) {
-        const size_t stride = ((size_t)num_apc_calls + 3) & ~(size_t)3;
-        const size_t need = (size_t)plan->total_slots * stride;
+        // rows are processed in windows of at most 2^20 so that the item buffer stays bounded
+        // (slots x 4 MiB): a 2^22-row trace with 1 600 periphery interactions would otherwise need 27 GB
+        const size_t all_rows = ((size_t)num_apc_calls + 3) & ~(size_t)3;
+        const size_t window = all_rows < ((size_t)1 << 20) ? all_rows : ((size_t)1 << 20);
+        const size_t need = (size_t)plan->total_slots * window;
         bool have = true;
         if (need > g_items_words) {
             if (g_items) (void)hipFree(g_items);
@@ -410,32 +416,35 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
             else { (void)hipGetLastError(); have = false; }
         }
         if (have) {
-            {
-                pw::ScopedKernelTimer t("apc_apply_bus_kernel");
-                if (use_xbc)
-                    hipLaunchKernelGGL(apc_apply_bus_xbc_kernel<true>, dim3(pw::div_up(stride, kBlock), xchunks), dim3(kBlock), 0,
-                                       pw::stream(), d_output, num_apc_calls, plan->d_code, plan->d_xint, plan->total_slots, p,
-                                       x_per_chunk, g_items, stride, col_stride);
-                else
-                    hipLaunchKernelGGL(apc_apply_bus_kernel<true>, dim3(pw::div_up(stride, kBlock), xchunks), dim3(kBlock), 0,
-                                       pw::stream(), d_output, num_apc_calls, d_bytecode, d_interactions, (uint32_t)n_interactions,
-                                       d_arg_spans, p, x_per_chunk, plan->d_slot_of, g_items, stride, col_stride);
-            }
             uint32_t* tables[3] = {d_var_hist, d_tuple2_hist, d_bitwise_hist};
-            // one 128-KB-LDS workgroup fits per CU, and the three launches run one after the other, so each
-            // launch gets ~2 x 256 workgroups of its own: partitions x row chunks
-            for (int t = 0; t < 3; ++t) {
-                if (!plan->n_slots[t]) continue;
-                const unsigned parts = pw::div_up(table_bins[t], kPartBins);
-                unsigned n_chunks = (512 + parts - 1) / parts;
-                const unsigned max_chunks = pw::div_up(stride, 4096);
-                if (n_chunks > max_chunks) n_chunks = max_chunks;
-                if (n_chunks == 0) n_chunks = 1;
-                const uint32_t rows_per_chunk = (uint32_t)(((stride + n_chunks - 1) / n_chunks + 3) & ~(size_t)3);
-                n_chunks = pw::div_up(stride, rows_per_chunk);
-                pw::ScopedKernelTimer tt("bus_histogram_kernel");
-                hipLaunchKernelGGL(bus_histogram_kernel, dim3(parts, n_chunks), dim3(kHistBlock), 0,
-                                   pw::stream(), g_items, stride, plan->d_slots[t], plan->n_slots[t], tables[t], table_bins[t], rows_per_chunk);
+            for (size_t row0 = 0; row0 < all_rows; row0 += window) {
+                const size_t stride = all_rows - row0 < window ? all_rows - row0 : window;
+                {
+                    pw::ScopedKernelTimer t("apc_apply_bus_kernel");
+                    if (use_xbc)
+                        hipLaunchKernelGGL(apc_apply_bus_xbc_kernel<true>, dim3(pw::div_up(stride, kBlock), xchunks), dim3(kBlock), 0,
+                                           pw::stream(), d_output, num_apc_calls, plan->d_code, plan->d_xint, plan->total_slots, p,
+                                           x_per_chunk, g_items, stride, col_stride, row0);
+                    else
+                        hipLaunchKernelGGL(apc_apply_bus_kernel<true>, dim3(pw::div_up(stride, kBlock), xchunks), dim3(kBlock), 0,
+                                           pw::stream(), d_output, num_apc_calls, d_bytecode, d_interactions, (uint32_t)n_interactions,
+                                           d_arg_spans, p, x_per_chunk, plan->d_slot_of, g_items, stride, col_stride, row0);
+                }
+                // one 128-KB-LDS workgroup fits per CU, and the three launches run one after the other, so each
+                // launch gets ~2 x 256 workgroups of its own: partitions x row chunks
+                for (int t = 0; t < 3; ++t) {
+                    if (!plan->n_slots[t]) continue;
+                    const unsigned parts = pw::div_up(table_bins[t], kPartBins);
+                    unsigned n_chunks = (512 + parts - 1) / parts;
+                    const unsigned max_chunks = pw::div_up(stride, 4096);
+                    if (n_chunks > max_chunks) n_chunks = max_chunks;
+                    if (n_chunks == 0) n_chunks = 1;
+                    const uint32_t rows_per_chunk = (uint32_t)(((stride + n_chunks - 1) / n_chunks + 3) & ~(size_t)3);
+                    n_chunks = pw::div_up(stride, rows_per_chunk);
+                    pw::ScopedKernelTimer tt("bus_histogram_kernel");
+                    hipLaunchKernelGGL(bus_histogram_kernel, dim3(parts, n_chunks), dim3(kHistBlock), 0,
+                                       pw::stream(), g_items, stride, plan->d_slots[t], plan->n_slots[t], tables[t], table_bins[t], rows_per_chunk);
+                }
             }
             return (int)hipGetLastError();
         }
@@ -443,11 +452,11 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
     pw::ScopedKernelTimer t("apc_apply_bus_kernel");
     if (use_xbc)
         hipLaunchKernelGGL(apc_apply_bus_xbc_kernel<false>, dim3(row_blocks, xchunks), dim3(kBlock), 0, pw::stream(),
-                           d_output, num_apc_calls, plan->d_code, plan->d_xint, plan->total_slots, p, x_per_chunk, nullptr, 0, col_stride);
+                           d_output, num_apc_calls, plan->d_code, plan->d_xint, plan->total_slots, p, x_per_chunk, nullptr, 0, col_stride, 0);
     else
         hipLaunchKernelGGL(apc_apply_bus_kernel<false>, dim3(row_blocks, xchunks), dim3(kBlock), 0, pw::stream(),
                            d_output, num_apc_calls, d_bytecode, d_interactions,
-                           (uint32_t)n_interactions, d_arg_spans, p, x_per_chunk, nullptr, nullptr, 0, col_stride);
+                           (uint32_t)n_interactions, d_arg_spans, p, x_per_chunk, nullptr, nullptr, 0, col_stride, 0);
     return (int)hipGetLastError();
 }
 }  // namespace

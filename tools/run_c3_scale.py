@@ -24,8 +24,7 @@ def run(log_h=22, queries=50, pow_bits=16, verbose=True):
               f"setup {time.perf_counter()-t0:.1f} s", flush=True)
     abi.lib.powdr_gpu_timing_enable(1)
     t1 = time.perf_counter()
-    # bus replay is skipped at this scale (its item buffer would need another 27 GB next to the sources)
-    wl["apc"].generate_witness_gpu(wl["instr_air"], wl["dummy"], wl["calls"], wl["out"].data_ptr(), None)
+    wl["apc"].generate_witness_gpu(wl["instr_air"], wl["dummy"], wl["calls"], wl["out"].data_ptr(), wl["per"])
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t1
     tg_timing = abi.timing_report()
@@ -47,7 +46,8 @@ def run(log_h=22, queries=50, pow_bits=16, verbose=True):
     cells = W * H
     algo = {"apc_gather_tile_kernel": 8.0, "ntt_group_kernel<dif>": 8.0, "ntt_group_kernel<dit>": 16.0, "leaf_hash_kernel": 8.0,
             "deep_kernel": 8.0, "quotient_kernel": 8.0, "ext_dot_partial_kernel": 4.0}
-    report = dict(workload=f"C3p {W} cols x 2^{log_h} rows", cells=cells, trace_gen_ms=t_gen * 1e3, prove_ms=(t3 - t2) * 1e3,
+    hist_mass = [int(t.to(torch.int64).sum()) for t in (wl["per"].var_hist, wl["per"].tuple_hist, wl["per"].bitwise_hist)]
+    report = dict(histogram_mass=hist_mass, workload=f"C3p {W} cols x 2^{log_h} rows", cells=cells, trace_gen_ms=t_gen * 1e3, prove_ms=(t3 - t2) * 1e3,
                   verify_ms=(t4 - t3) * 1e3, verify_rc=rc, cells_per_s_prove=cells / (t3 - t2), cells_per_s_total=cells / (t3 - t2 + t_gen),
                   prover_device_bytes=pr.device_bytes(), proof_bytes=int(len(proof) * 4), kernels={})
     timing.update(tg_timing)
