@@ -161,7 +161,14 @@ def main():
 
     shape = synth.SHAPES[args.shape]
     log_h = args.log_height or shape.log_height
-    wl = build_workload(args.shape, log_h, args.exact_source_heights, seed=rank)
+    try:
+        wl = build_workload(args.shape, log_h, args.exact_source_heights, seed=rank)
+    except torch.cuda.OutOfMemoryError:
+        # power-of-two source heights (like the original chips' traces) need 150 GB at C2; fall back to
+        # b*calls-row sources (115 GB) rather than fail — same kernels, same cells, noted in config.workload
+        torch.cuda.empty_cache()
+        args.exact_source_heights = True
+        wl = build_workload(args.shape, log_h, True, seed=rank)
     pr = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits)
     from powdr_amd import sharding
 
@@ -287,7 +294,8 @@ def main():
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
             config=dict(workload=f"{args.shape} {shape.name} autoprecompile AIR: {wl['W']} cols x 2^{log_h} rows, "
                                  f"{len(wl['cons'][1])} constraints, {wl['apc'].n_bus} bus interactions; trace generation + "
-                                 f"pw-stark v0 proof (blow-up 2, {args.queries} queries, {args.pow_bits} PoW bits); one segment per step per GPU",
+                                 f"pw-stark v0 proof (blow-up 2, {args.queries} queries, {args.pow_bits} PoW bits); one segment per step per GPU"
+                                 + ("; source heights b*calls (not padded to a power of two)" if args.exact_source_heights else ""),
                         rows=wl["H"], cols=wl["W"], parallelism=f"segments x{world}" + (f", {args.pipeline} streams per GPU" if args.pipeline > 1 else ""),
                         source_bytes=wl["src_bytes"], proof_bytes=int(len(proof) * 4),
                         prover_device_bytes=pr.device_bytes()),
