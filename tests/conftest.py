@@ -12,6 +12,14 @@ REFERENCE = Path("/root/reference")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The product has no CPU fallback: make sure the HIP library (and the oracle, the checker) exist.
+    # hipcc cross-compiles gfx950 without a GPU; this is a no-op when everything is up to date.
+    from powdr_amd import build as _build
+
+    _build.build()
+    from oracle import apc_model as _om
+
+    _om.build_c_oracle()
 
 
 @pytest.fixture(scope="session")
