@@ -105,8 +105,9 @@ __global__ __launch_bounds__(kBlock) void apc_gather_tile_kernel(
             air.buffer + (size_t)job.col * (size_t)(uint32_t)air.height;
         const int J = job.J, b = job.b, pitch = job.pitch;
         if (J == b) {
-            // whole block rows: the tile is one contiguous range of the column
-            const uint32_t* base = src + r0 * (size_t)b;
+            // J == b: the per-call segments [j0, j0+b) abut, so the tile is one contiguous range of the column
+            // (j0 != 0 happens when substitutions reach past their own block into the next call's rows)
+            const uint32_t* base = src + r0 * (size_t)b + job.j0;
             const uint32_t n = (uint32_t)valid * (uint32_t)b;
             if ((((uintptr_t)base) & 15u) == 0) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -353,3 +353,129 @@ def test_column_operand_extensions_match_reference_encoding(gpu):
     assert (hist_np(per.var_hist) == hist["var"]).all()
     assert (hist_np(per.tuple_hist) == hist["tuple"]).all()
     assert (hist_np(per.bitwise_hist) == hist["bitwise"]).all()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_gather_fuzz(gpu, seed):
+    """Random OriginalAir / Subst tables: several AIRs, arbitrary block sizes and heights, unsorted and
+    duplicated destinations, block rows beyond row_block_size (the formula reads into the next call's
+    block), partial last tiles — against the oracle's line-by-line restatement of the reference kernel."""
+    torch, abi, tg = gpu
+    rng = np.random.default_rng(1000 + seed)
+    n_airs = int(rng.integers(1, 5))
+    calls = int(rng.integers(1, 3000))
+    H = synth.next_pow2_or_zero(calls)
+    W = int(rng.integers(1, 40))
+    airs, bufs, heights, rbs = [], [], [], []
+    for _ in range(n_airs):
+        w = int(rng.integers(1, 9))
+        b = int(rng.choice([1, 2, 3, 5, 16, 31, 64, 100, 257, 400, 700]))
+        extra = int(rng.integers(0, 4))  # rows a substitution may reach beyond its block
+        h = max(4, synth.next_pow2_or_zero(b * calls + extra + 1))
+        buf = rng.integers(0, om.P, size=w * h, dtype=np.uint32)
+        airs.append((to_dev(torch, buf), w, h, b))
+        bufs.append(buf); heights.append(h); rbs.append(b)
+    n_subs = int(rng.integers(1, 120))
+    recs = []
+    for _ in range(n_subs):
+        a = int(rng.integers(n_airs))
+        _, w, h, b = airs[a]
+        slack = h - b * calls
+        row = int(rng.integers(0, b + min(3, max(0, slack - 1))))
+        recs.append((a, int(rng.integers(w)), row, int(rng.integers(W))))
+    recs = np.array(recs, np.int32)
+    prefill = om.to_monty(rng.integers(0, om.P, size=H * W, dtype=np.uint32))
+    want = om.from_monty(prefill.copy())
+    om.c_apc_tracegen(H, W, bufs, heights, rbs, recs, calls, out=want)
+    out = tg.DeviceMatrix.zeros(H, W)
+    out.buf.copy_(torch.from_numpy(prefill.view(np.int32)))
+    keep = tg.apc_tracegen(out, airs, recs, calls)
+    torch.cuda.synchronize()
+    assert (from_dev(out.buf) == want).all()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_expression_kernels_fuzz(gpu, seed, monkeypatch):
+    """Random derived columns and bus interactions (random expression trees, byte/small/field columns,
+    random multiplicities incl. 0 and large ones) through every evaluator: post-fix interpreter vs xbc,
+    direct atomics vs binned histograms — all against the oracle."""
+    from tests.test_oracle_apc import _random_expr
+
+    torch, abi, tg = gpu
+    rng = np.random.default_rng(7000 + seed)
+    W, calls = int(rng.integers(4, 30)), int(rng.integers(1, 2000))
+    H = synth.next_pow2_or_zero(calls)
+    ids = list(range(W))
+    idx = {p: p for p in ids}
+    trace = np.zeros((W, H), np.uint32)
+    kind = rng.integers(0, 3, W)
+    for c in range(W):
+        hi = [256, 4, om.P][kind[c]]
+        trace[c, :calls] = rng.integers(0, hi, calls)
+    # derived columns: the last few columns, each may read earlier derived ones
+    n_der = int(rng.integers(0, 4))
+    der_cols = list(range(W - n_der, W))
+    col_base, offs, lens, dbc = [], [], [], []
+    for c in der_cols:
+        e = _random_expr(rng, ids[: c], 3)
+        off = len(dbc)
+        if rng.random() < 0.5:
+            om.emit_expr(dbc, _random_expr(rng, ids[: c], 2), idx, H)
+            dbc.append(om.OP_INV_OR_ZERO)
+            om.emit_expr(dbc, e, idx, H)
+            dbc.append(om.OP_MUL)
+        else:
+            om.emit_expr(dbc, e, idx, H)
+        col_base.append(c * H); offs.append(off); lens.append(len(dbc) - off)
+    flat = trace.reshape(-1).copy()
+    derived = (np.array(col_base, np.uint64), np.array(offs, np.uint32), np.array(lens, np.uint32), np.array(dbc, np.uint32))
+    want = flat.copy()
+    if n_der:
+        om.c_apc_apply_derived(want, H, calls, *derived)
+    # bus interactions
+    bytes_cols = [c for c in range(W - n_der) if kind[c] == 0] or [0]
+    small_cols = [c for c in range(W - n_der) if kind[c] == 1] or [0]
+    inter, spans, bc = [], [], []
+
+    def span(e):
+        off = len(bc)
+        om.emit_expr(bc, e, idx, H)
+        spans.append((off, len(bc) - off))
+
+    ref = lambda c: ("ref", "c", int(c))
+    for _ in range(int(rng.integers(1, 40))):
+        bus = int(rng.choice([3, 6, 7, 1, 9]))
+        off_idx = len(spans)
+        r = rng.random()
+        mult = ("num", int(rng.choice([0, 1, 2, 5000]))) if r < 0.3 else ref(rng.choice(small_cols)) if r < 0.7 else _random_expr(rng, ids, 2)
+        span(mult)
+        if bus == 3:
+            val = ref(rng.choice(bytes_cols)) if rng.random() < 0.7 else _random_expr(rng, ids, 2)
+            span(val); span(("num", int(rng.integers(0, 18))))
+            n_args = 2
+        elif bus == 7:
+            span(ref(rng.choice(bytes_cols))); span(("bin", "*", ref(rng.choice(bytes_cols)), ("num", int(rng.integers(1, 9)))))
+            n_args = 2
+        else:
+            span(ref(rng.choice(bytes_cols))); span(ref(rng.choice(bytes_cols)) if rng.random() < 0.8 else _random_expr(rng, ids, 2))
+            span(("num", 0)); span(("num", int(rng.integers(0, 3))) if rng.random() < 0.7 else ref(rng.choice(small_cols)))
+            n_args = 4
+        inter.append((bus, n_args, off_idx))
+    inter = np.array(inter, np.uint32); spans = np.array(spans, np.uint32); bc = np.array(bc, np.uint32)
+    hist = dict(var=np.zeros(1 << 18, np.uint32), tuple=np.zeros(256 * 2048, np.uint32), bitwise=np.zeros(2 * 65536, np.uint32))
+    om.c_apc_apply_bus(want, calls, bc, inter, spans, 3, hist["var"], 7, hist["tuple"], 256, 2048, 6, hist["bitwise"])
+    for binned in ("0", "1"):
+        for xb in ("0", "1"):
+            monkeypatch.setenv("POWDR_BUS_BINNED", binned)
+            monkeypatch.setenv("POWDR_BUS_XBC", xb)
+            out = tg.DeviceMatrix.zeros(H, W)
+            out.buf.copy_(to_dev(torch, flat))
+            if n_der:
+                tg.apc_apply_derived_expr(out, calls, *derived)
+            per = tg.Periphery.fresh()
+            tg.apc_apply_bus(out, calls, bc, inter, spans, per)
+            torch.cuda.synchronize()
+            assert (from_dev(out.buf) == want).all()
+            assert (hist_np(per.var_hist) == hist["var"]).all(), (binned, xb)
+            assert (hist_np(per.tuple_hist) == hist["tuple"]).all(), (binned, xb)
+            assert (hist_np(per.bitwise_hist) == hist["bitwise"]).all(), (binned, xb)
