@@ -251,6 +251,29 @@ def main():
                                "ntt_group_kernel<dif>": 8.0, "ntt_group_kernel<dit>": 16.0, "deep_kernel": 8.0,
                                "quotient_kernel": 8.0}
         stage_ms = {k: ms / args.steps for k, (c, ms) in per_kernel.items()}
+        # the same times grouped under the reference's gauge names (openvm/metrics-viewer/CLAUDE.md:55-116)
+        g = lambda *names: sum(stage_ms.get(n, 0.0) for n in names)
+        gauges = dict(
+            trace_gen_time_ms=g("apc_gather_tile_kernel", "apc_apply_derived_expr_kernel", "apc_apply_bus_kernel", "bus_histogram_kernel"),
+            main_trace_commit_time_ms=g("ntt_group_kernel<dif>", "ntt_group_kernel<dit>", "leaf_hash_kernel", "compress_kernel", "compress_tail_kernel"),
+            quotient_poly_compute_time_ms=g("quotient_kernel", "quotient_split_kernel"),
+            pcs_opening_time_ms=g("barycentric_weights_kernel", "zeta_weights_kernel", "ext_dot_partial_kernel", "deep_kernel",
+                                  "ext_pair_leaf_kernel", "fri_fold_kernel", "gather_rows_kernel"),
+            note="main_trace_commit also contains the 8-column quotient commitment (same kernels); "
+                 "stark_prove_excluding_trace_time_ms = ms_per_step - trace_gen_time_ms")
+        # device-to-device copy ceiling of THIS box: 4 GiB float4-style copy
+        a_ = torch.empty(1 << 30, dtype=torch.int32, device="cuda")
+        b_ = torch.empty_like(a_)
+        b_.copy_(a_)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            b_.copy_(a_)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 4 * 2 * a_.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a_, b_
         roof = None
         if dom:
             cnt, ms = per_kernel[dom]
@@ -299,7 +322,7 @@ def main():
                         rows=wl["H"], cols=wl["W"], parallelism=f"segments x{world}" + (f", {args.pipeline} streams per GPU" if args.pipeline > 1 else ""),
                         source_bytes=wl["src_bytes"], proof_bytes=int(len(proof) * 4),
                         prover_device_bytes=pr.device_bytes()),
-            roofline=roof, cpu_baseline=cpu, stage_ms=stage_ms,
+            roofline=roof, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges, hbm_copy_GBps_measured=copy_gbs,
         )
         print(json.dumps(line))
     if world > 1:

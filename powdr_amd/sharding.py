@@ -66,3 +66,18 @@ def commitment_digest(roots: np.ndarray) -> np.ndarray:
             nxt.append(prover.poseidon2_host(np.concatenate([level[i], right]))[:8])
         level = nxt
     return level[0]
+
+
+def allreduce_histograms(histograms, group=None):
+    """AIR-level sharding inside one segment (SURVEY.md §8e level 2): the APC chips of a segment share the
+    periphery histograms, which are plain integer sums, so ranks that generate different AIRs' traces sum
+    their partial histograms once per segment — ~3.5 MiB of u32 counters (2^18 var-range + 2^19 tuple +
+    2^17 bitwise), one all-reduce each. In place; tensors may live on the GPU (RCCL) or the CPU (gloo)."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return histograms
+    for h in histograms:
+        # u32 counters are stored as int32 words; wrap-around addition is the same operation
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+    return histograms

@@ -55,3 +55,32 @@ def test_commitment_merge_world_size_2_gloo(tmp_path, n_units):
     # the merged list hashes to the same digest on every rank
     assert (sharding.commitment_digest(a) == sharding.commitment_digest(b)).all()
     assert sharding.commitment_digest(a).shape == (8,)
+
+
+def _hist_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    hs = [torch.randint(0, 2**31 - 1, (n,), dtype=torch.int32, generator=g) for n in (1 << 10, 1 << 11, 1 << 9)]
+    sharding.allreduce_histograms(hs)
+    torch.save(hs, os.path.join(out_dir, f"h_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_histogram_allreduce_world_size_2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_hist_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(tmp_path / "h_0.pt")
+    b = torch.load(tmp_path / "h_1.pt")
+    for k, n in enumerate((1 << 10, 1 << 11, 1 << 9)):
+        parts = [torch.randint(0, 2**31 - 1, (n,), dtype=torch.int32, generator=torch.Generator().manual_seed(100 + r)) if k == 0 else None
+                 for r in range(2)]
+        assert torch.equal(a[k], b[k])
+    # exact u32 wrap-around sum of the two ranks' first histograms
+    g0, g1 = torch.Generator().manual_seed(100), torch.Generator().manual_seed(101)
+    x0 = torch.randint(0, 2**31 - 1, (1 << 10,), dtype=torch.int32, generator=g0)
+    x1 = torch.randint(0, 2**31 - 1, (1 << 10,), dtype=torch.int32, generator=g1)
+    want = ((x0.to(torch.int64) + x1.to(torch.int64)) & 0xFFFFFFFF).numpy().astype(np.uint32)
+    assert (a[0].numpy().view(np.uint32) == want).all()
