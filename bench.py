@@ -305,6 +305,20 @@ def main():
                                     note="leaf_hash_kernel runs at the VALU issue ceiling (PMC: SQ_ACTIVE_INST_VALU = "
                                          "SQ_INSTS_VALU quad-cycles = 100% of kernel time); MFMA utilisation is 0 by design "
                                          "(the Poseidon2 MDS is additions only, DESIGN.md 3.4)")
+        # every major kernel against the HBM roofline: algorithmic bytes (SURVEY.md 8d x cells) / its time per step,
+        # and the PMC-measured HBM traffic where a profile of this exact workload is committed
+        traffic_db = {}
+        tf = ROOT / "profiles" / "r01_pmc_traffic_c2.json"
+        if tf.exists() and args.shape == "C2" and log_h == 20:
+            for k, v in json.loads(tf.read_text())["kernels"].items():
+                base = k.split("<")[0]
+                traffic_db[base] = traffic_db.get(base, 0.0) + v["fetch_bytes_corrected"] + v["write_bytes"]
+        by_kernel = {}
+        for k, ms in stage_ms.items():
+            if k in algo_bytes_per_cell and ms > 0:
+                gbs = algo_bytes_per_cell[k] * cells_per_step / (ms * 1e-3) / 1e9
+                by_kernel[k] = dict(ms=ms, algorithmic_GBps=gbs, frac_of_peak=gbs / HBM_PEAK_GBS,
+                                    pmc_traffic_bytes=traffic_db.get(k.split("<")[0]))
         cpu = None
         if not args.no_cpu_baseline:
             try:
@@ -322,7 +336,7 @@ def main():
                         rows=wl["H"], cols=wl["W"], parallelism=f"segments x{world}" + (f", {args.pipeline} streams per GPU" if args.pipeline > 1 else ""),
                         source_bytes=wl["src_bytes"], proof_bytes=int(len(proof) * 4),
                         prover_device_bytes=pr.device_bytes()),
-            roofline=roof, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges, hbm_copy_GBps_measured=copy_gbs,
+            roofline=roof, roofline_by_kernel=by_kernel, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges, hbm_copy_GBps_measured=copy_gbs,
         )
         print(json.dumps(line))
     if world > 1:
