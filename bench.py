@@ -312,13 +312,15 @@ def main():
         if tf.exists() and args.shape == "C2" and log_h == 20:
             for k, v in json.loads(tf.read_text())["kernels"].items():
                 base = k.split("<")[0]
+                if base == "ntt_group_kernel":  # the library times DIF (inverse) and DIT (forward) launches separately
+                    base += "<dif>" if k.split("<")[1].startswith("true") else "<dit>"
                 traffic_db[base] = traffic_db.get(base, 0.0) + v["fetch_bytes_corrected"] + v["write_bytes"]
         by_kernel = {}
         for k, ms in stage_ms.items():
             if k in algo_bytes_per_cell and ms > 0:
                 gbs = algo_bytes_per_cell[k] * cells_per_step / (ms * 1e-3) / 1e9
                 by_kernel[k] = dict(ms=ms, algorithmic_GBps=gbs, frac_of_peak=gbs / HBM_PEAK_GBS,
-                                    pmc_traffic_bytes=traffic_db.get(k.split("<")[0]))
+                                    pmc_traffic_bytes=traffic_db.get(k, traffic_db.get(k.split("<")[0])))
         cpu = None
         if not args.no_cpu_baseline:
             try:
