@@ -50,6 +50,13 @@ void pw_prover_destroy(PwProver* p);
 int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t log_height, const uint32_t** proof_words,
                     size_t* n_words);
 
+/* "Mock prover": evaluate every constraint on every row of the trace on the device and report violations —
+ * the counterpart of the reference's `debug_proving_ctx` used by its `prove_mock` tests
+ * (openvm-riscv/src/lib.rs:288-294). *n_violations = number of (row, constraint) pairs that are non-zero;
+ * if any, *first_row / *first_constraint name the first one in row-major order. */
+int pw_prover_check_constraints(PwProver* p, const uint32_t* d_trace, uint32_t log_height, uint64_t* n_violations,
+                                uint64_t* first_row, uint32_t* first_constraint);
+
 /* Verify a proof on the host (no GPU): the counterpart of the reference's CPU verification step
  * `verify_app_proof::<BabyBearPoseidon2CpuEngine>` (openvm-riscv/src/lib.rs:337-341). Constraint
  * programs as for pw_prover_create (post-fix, column-index operands, no INV_OR_ZERO).

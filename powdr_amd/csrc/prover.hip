@@ -368,6 +368,29 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     return (int)hipGetLastError();
 }
 
+// ---- mock prover -------------------------------------------------------------------------------------
+
+extern "C" int pw_prover_check_constraints(PwProver* p, const uint32_t* d_trace, uint32_t log_h, uint64_t* n_violations,
+                                           uint64_t* first_row, uint32_t* first_constraint) {
+    if (!p || !d_trace || log_h > 40) return -1;
+    (void)hipGetLastError();
+    const size_t H = (size_t)1 << log_h;
+    TRY(p->misc.ensure(4096));
+    unsigned long long* d = p->misc.as<unsigned long long>();
+    unsigned long long init[2] = {~0ull, 0ull}, res[2];
+    PW_HIP_TRY(hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, stream()));
+    ConstraintProgram prog{p->d_bytecode, p->d_spans, p->n_constraints, p->is_xbc};
+    if (p->n_constraints) TRY(check_constraints(d_trace, H, prog, d));
+    PW_HIP_TRY(hipMemcpyAsync(res, d, sizeof res, hipMemcpyDeviceToHost, stream()));
+    PW_HIP_TRY(hipStreamSynchronize(stream()));
+    if (n_violations) *n_violations = res[1];
+    if (res[1] && p->n_constraints) {
+        if (first_row) *first_row = res[0] / p->n_constraints;
+        if (first_constraint) *first_constraint = (uint32_t)(res[0] % p->n_constraints);
+    }
+    return (int)hipGetLastError();
+}
+
 // ---- single stages -----------------------------------------------------------------------------------
 
 extern "C" int pw_lde_batch(const uint32_t* d_trace, uint32_t width, uint32_t log_h, uint32_t* d_coeffs, uint32_t* d_lde) {

@@ -51,6 +51,9 @@ struct ConstraintProgram {
 // q[k*N + j] (k < 4) = coordinate k of  sum_c alpha_pow[c] * C_c(lde row j) * zinv[j & 1]
 int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, const bb::Ext* d_alpha_pows,
                   uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q);
+// evaluate all constraints on all trace rows; d_first_and_count[0] = min(row * nc + c) over violations
+// (caller initialises to ~0), [1] = number of violations
+int check_constraints(const uint32_t* trace, size_t H, const ConstraintProgram& prog, unsigned long long* d_first_and_count);
 // chunk coefficients from the unscaled DIF-iNTT of q over N = 2H points:
 // out[(4*ch + k)*H + q'] = cbr[k*N + 2q' + ch] * s^-(bitrev(q') + ch*H) / 2   (H-scaled bit-reversed coefficients)
 int quotient_split(const uint32_t* cbr, size_t H, int log_h, uint32_t* out);

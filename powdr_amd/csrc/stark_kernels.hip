@@ -43,6 +43,28 @@ __global__ __launch_bounds__(kBlock) void quotient_kernel(const uint32_t* __rest
     for (int k = 0; k < 4; ++k) q[(size_t)k * N + j] = bb::mul(acc.c[k], zi);
 }
 
+// "mock prover": evaluate every constraint on every TRACE row; first[0] <- min over violations of row * nc + c
+template <bool XBC>
+__global__ __launch_bounds__(kBlock) void check_constraints_kernel(const uint32_t* __restrict__ trace, size_t H,
+                                                                    const uint32_t* __restrict__ bytecode,
+                                                                    const uint32_t* __restrict__ spans, uint32_t n_constraints,
+                                                                    unsigned long long* __restrict__ first,
+                                                                    unsigned long long* __restrict__ count) {
+    __shared__ uint32_t stack_lds[kStackCap * kBlock];
+    uint32_t* stk = stack_lds + threadIdx.x;
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= H) return;
+    for (uint32_t c = 0; c < n_constraints; ++c) {
+        const uint32_t off = spans[2 * c], len = spans[2 * c + 1];
+        const uint32_t v = XBC ? xbc::eval<kBlock, true>(bytecode + 2 * (size_t)off, len, trace, j, stk, H)
+                               : eval_expr<kBlock, true>(bytecode + off, len, trace, j, stk, H);
+        if (v != 0u) {
+            atomicMin(first, (unsigned long long)j * n_constraints + c);
+            atomicAdd(count, 1ull);
+        }
+    }
+}
+
 // out[(4*ch + k)*H + q'] = cbr[k*N + 2q' + ch] * s^-(bitrev(q') + ch*H) / 2
 __global__ __launch_bounds__(kBlock) void quotient_split_kernel(const uint32_t* __restrict__ cbr, size_t H, int log_h,
                                                                  uint32_t sinv, uint32_t half_m, uint32_t* __restrict__ out) {
@@ -192,6 +214,17 @@ int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, 
     else
         hipLaunchKernelGGL(quotient_kernel<false>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, N, prog.d_bytecode,
                            prog.d_spans, prog.n_constraints, d_alpha_pows, zinv_even, zinv_odd, q);
+    return (int)hipGetLastError();
+}
+
+int check_constraints(const uint32_t* trace, size_t H, const ConstraintProgram& prog, unsigned long long* d_first_and_count) {
+    ScopedKernelTimer t("check_constraints_kernel");
+    if (prog.is_xbc)
+        hipLaunchKernelGGL(check_constraints_kernel<true>, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), trace, H,
+                           prog.d_bytecode, prog.d_spans, prog.n_constraints, d_first_and_count, d_first_and_count + 1);
+    else
+        hipLaunchKernelGGL(check_constraints_kernel<false>, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), trace, H,
+                           prog.d_bytecode, prog.d_spans, prog.n_constraints, d_first_and_count, d_first_and_count + 1);
     return (int)hipGetLastError();
 }
 

@@ -14,7 +14,7 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_verify", "pw_prover_create", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_merkle_commit", "pw_poseidon2_permute_host"]
 
 lib.pw_prover_create.restype = C.c_void_p
@@ -22,6 +22,9 @@ lib.pw_prover_create.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_void_
 lib.pw_prover_destroy.argtypes = [C.c_void_p]
 lib.pw_prover_prove.restype = C.c_int
 lib.pw_prover_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]
+lib.pw_prover_check_constraints.restype = C.c_int
+lib.pw_prover_check_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint32)]
 lib.pw_prover_device_bytes.restype = C.c_size_t
 lib.pw_prover_device_bytes.argtypes = [C.c_void_p]
 lib.pw_lde_batch.restype = C.c_int
@@ -72,6 +75,13 @@ class Prover:
         abi.check(rc, "pw_prover_prove")
         a = np.ctypeslib.as_array(words, shape=(n.value,))
         return a.copy() if copy else a
+
+    def check_constraints(self, d_trace_ptr: int, log_height: int):
+        """Mock prover: (number of violated (row, constraint) pairs, first row, first constraint)."""
+        n, row, c = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        rc = lib.pw_prover_check_constraints(self._h, d_trace_ptr, log_height, C.byref(n), C.byref(row), C.byref(c))
+        abi.check(rc, "pw_prover_check_constraints")
+        return (n.value, row.value, c.value) if n.value else (0, None, None)
 
     def device_bytes(self) -> int:
         return int(lib.pw_prover_device_bytes(self._h))

@@ -251,3 +251,27 @@ def test_c3_scale_trace_and_proof(gpu):
     rep = mod.run(22, 16, 8, verbose=False)
     assert rep["verify_rc"] == 0 and rep["cells"] == 3731 << 22
     torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_mock_prover_reports_violations(gpu):
+    """pw_prover_check_constraints = the reference's prove_mock / debug_proving_ctx: a generated trace has no
+    violation (padding rows included); a corrupted cell is located exactly."""
+    torch, abi, prover = gpu
+    s, flat, (W, H), bc, spans = _synthetic("T1", 500, seed=5)
+    log_h = H.bit_length() - 1
+    pr = prover.Prover(W, bc, spans, num_queries=2)
+    d_t = to_dev(torch, flat)
+    assert pr.check_constraints(d_t.data_ptr(), log_h) == (0, None, None)
+    apc = om.load_apc(s.doc)
+    idx = apc.poly_id_to_index()
+    valid_col = idx[[q for q, k in s.kinds.items() if k[0] == "valid"][0]]
+    d_t[valid_col * H + 123] = int(om.to_monty(np.array([2], np.uint32))[0])
+    n, row, c = pr.check_constraints(d_t.data_ptr(), log_h)
+    assert n >= 1 and row == 123
+    # the oracle's view of the same row: constraint c is the first non-zero one
+    trace = flat.reshape(W, H).copy()
+    trace[valid_col, 123] = 2
+    vals = [om.eval_ast(e, lambda pid: int(trace[idx[pid], 123])) for e in apc.constraints]
+    assert vals[c] != 0 and all(v == 0 for v in vals[:c])
+    pr.close()
