@@ -14,6 +14,8 @@ P = om.P
 def _lib():
     lib = om.c_oracle()
     lib.or_prove.restype = C.c_size_t
+    lib.or_prove_logup.restype = C.c_size_t
+    lib.or_verify_logup.restype = C.c_int
     lib.or_verify.restype = C.c_int
     lib.or_root_of_unity.restype = C.c_uint32
     return lib
@@ -115,3 +117,31 @@ def verify(proof, width, log_h, cons_bc, cons_spans, num_queries=8, pow_bits=0) 
     sp = np.ascontiguousarray(cons_spans, dtype=np.uint32)
     return int(_lib().or_verify(C.c_uint32(num_queries), C.c_uint32(pow_bits), _p(pr), C.c_size_t(len(pr)), C.c_uint32(width),
                                 C.c_uint32(log_h), _p(bc), _p(sp), C.c_size_t(len(sp))))
+
+
+def compile_interactions(apc: om.Apc, idx: dict):
+    """All bus interactions with column-index operands: (inter[n,3], spans[m,2], bytecode) — compile_bus at height 1."""
+    return om.compile_bus(apc, idx, 1)
+
+
+def prove_logup(trace_cm, width, log_h, cons_bc, cons_spans, inter, ispans, ibc, num_queries=8, pow_bits=0) -> np.ndarray:
+    lib = _lib()
+    arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in (trace_cm, cons_bc, cons_spans, inter, ispans, ibc)]
+    t, bc, sp, it, isp, ib = arrs
+    args = (C.c_uint32(num_queries), C.c_uint32(pow_bits), _p(t), C.c_uint32(width), C.c_uint32(log_h), _p(bc), _p(sp),
+            C.c_size_t(len(sp.reshape(-1, 2))), _p(it), C.c_size_t(len(it.reshape(-1, 3))), _p(isp), _p(ib))
+    cap = 1 << 18
+    while True:
+        buf = np.zeros(cap, np.uint32)
+        n = lib.or_prove_logup(*args, _p(buf), C.c_size_t(cap))
+        if n <= cap:
+            return buf[:n].copy()
+        cap = int(n)
+
+
+def verify_logup(proof, width, log_h, cons_bc, cons_spans, inter, ispans, ibc, num_queries=8, pow_bits=0) -> int:
+    arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in (proof, cons_bc, cons_spans, inter, ispans, ibc)]
+    pr, bc, sp, it, isp, ib = arrs
+    return int(_lib().or_verify_logup(C.c_uint32(num_queries), C.c_uint32(pow_bits), _p(pr), C.c_size_t(len(pr)), C.c_uint32(width),
+                                      C.c_uint32(log_h), _p(bc), _p(sp), C.c_size_t(len(sp.reshape(-1, 2))), _p(it),
+                                      C.c_size_t(len(it.reshape(-1, 3))), _p(isp), _p(ib)))

@@ -586,6 +586,400 @@ int verify(const Config& cfg, const u32* proof, size_t len, u32 width, u32 log_h
     return 0;
 }
 
+
+/* ================================================================== pw-stark v0 + LogUp
+ * Optional extension that also proves the AIR's bus interactions (PowdrAir::eval pushes them with
+ * `builder.push_interaction(id, args, mult, 1)`, openvm/src/powdr_extension/chip.rs:117-129), in the
+ * committed-column LogUp style of the OpenVM-1 generation of the backend (metrics `perm_cols`,
+ * `generate_perm_trace_time_ms`, openvm/metrics-viewer/CLAUDE.md:62-73,114). Parity unpinned like the
+ * rest of the prover. Differences from v0:
+ *   after the trace root: al, bl <- transcript (extension field)
+ *   perm matrix (4 (n_int + 1) base columns): for interaction i,
+ *        d_i = al + bus_i + sum_j bl^(j+1) a_ij,   q_i = m_i / d_i,
+ *        phi(row r) = sum_{r' <= r} sum_i q_i(r');  S = phi(last row) goes into the proof
+ *   extra (extension-valued) constraints, folded after the base ones:
+ *        q_i d_i - m_i                                      (every row)
+ *        is_first (phi - sum_i q_i)
+ *        is_transition (phi' - phi - sum_i q_i')            (' = next row)
+ *        is_last (phi - S)
+ *     with is_first = Z_H/(x-1), is_last = Z_H/(x-g^-1), is_transition = x - g^-1
+ *   openings: main, perm, quotient at zeta; perm also at g*zeta; DEEP with both points.
+ */
+constexpr u32 MAGIC2 = 0x32535750u; /* "PWS2" */
+
+struct Interactions { const u32* inter; size_t n; const u32* spans; const u32* bc; };  /* inter = n x {bus, n_args, span index} */
+
+struct LogupRow {  /* per-row evaluation shared by prover (base values) and verifier (ext values) */
+    static Ext denom_base(const Interactions& I, size_t i, const u32* m, size_t stride, size_t row, const Ext& al, const Ext* blpow) {
+        const u32* it = I.inter + 3 * i;
+        const u32* sp = I.spans + 2 * (size_t)it[2];
+        Ext d = ext_add(al, ext_from(it[0] % P));
+        for (u32 j = 0; j < it[1]; ++j) {
+            u32 a = eval_base(I.bc + sp[2 + 2 * j], sp[3 + 2 * j], m, stride, row);
+            d = ext_add(d, ext_scale(blpow[j + 1], a));
+        }
+        return d;
+    }
+    static u32 mult_base(const Interactions& I, size_t i, const u32* m, size_t stride, size_t row) {
+        const u32* it = I.inter + 3 * i;
+        const u32* sp = I.spans + 2 * (size_t)it[2];
+        return eval_base(I.bc + sp[0], sp[1], m, stride, row);
+    }
+};
+
+size_t max_args(const Interactions& I) { size_t k = 0; for (size_t i = 0; i < I.n; ++i) if (I.inter[3 * i + 1] > k) k = I.inter[3 * i + 1]; return k; }
+
+void observe_instance2(Challenger& ch, u32 log_h, u32 width, u32 nc, u32 n_int, const Config& cfg) {
+    ch.observe(MAGIC2 % P); ch.observe(log_h); ch.observe(width); ch.observe(nc); ch.observe(n_int);
+    ch.observe(cfg.num_queries); ch.observe(cfg.pow_bits);
+}
+
+std::vector<u32> prove_logup(const Config& cfg, const u32* trace, u32 width, u32 log_h, const Program& prog, const Interactions& I) {
+    const size_t H = (size_t)1 << log_h, N = 2 * H;
+    const int logN = (int)log_h + 1;
+    const u32 n_int = (u32)I.n;
+    const size_t Wp = 4 * ((size_t)n_int + 1);
+    Writer pf;
+    Challenger ch;
+    observe_instance2(ch, log_h, width, (u32)prog.n, n_int, cfg);
+    pf.put(MAGIC2); pf.put(log_h); pf.put(width); pf.put((u32)prog.n); pf.put(n_int); pf.put(cfg.num_queries); pf.put(cfg.pow_bits);
+
+    /* 1. main trace */
+    std::vector<u32> coef((size_t)width * H), lde((size_t)width * N);
+#pragma omp parallel for schedule(dynamic)
+    for (long c = 0; c < (long)width; ++c) {
+        memcpy(&coef[c * H], trace + c * H, H * 4);
+        idft(&coef[c * H], (int)log_h);
+        coset_lde_from_coeffs(&coef[c * H], (int)log_h, &lde[c * N]);
+    }
+    Merkle t_tree;
+    commit_matrix(lde.data(), N, width, t_tree);
+    pf.put(t_tree.root());
+    ch.observe_digest(t_tree.root());
+
+    /* 2. permutation (LogUp) trace */
+    Ext al = ch.sample_ext(), bl = ch.sample_ext();
+    std::vector<Ext> blpow(max_args(I) + 2);
+    { Ext b = ext_one(); for (auto& x : blpow) { x = b; b = ext_mul(b, bl); } }
+    std::vector<u32> perm(Wp * H);
+    std::vector<Ext> rowsum(H);
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < (long)H; ++r) {
+        Ext acc = ext_zero();
+        for (size_t i = 0; i < n_int; ++i) {
+            Ext d = LogupRow::denom_base(I, i, trace, H, (size_t)r, al, blpow.data());
+            u32 m = LogupRow::mult_base(I, i, trace, H, (size_t)r);
+            Ext q = ext_scale(ext_inv(d), m);
+            for (int k = 0; k < 4; ++k) perm[(4 * i + k) * H + r] = q.c[k];
+            acc = ext_add(acc, q);
+        }
+        rowsum[r] = acc;
+    }
+    Ext run = ext_zero();
+    for (size_t r = 0; r < H; ++r) { run = ext_add(run, rowsum[r]); for (int k = 0; k < 4; ++k) perm[(4 * (size_t)n_int + k) * H + r] = run.c[k]; }
+    const Ext S = run;
+    std::vector<u32> pcoef(Wp * H), plde(Wp * N);
+#pragma omp parallel for schedule(dynamic)
+    for (long c = 0; c < (long)Wp; ++c) {
+        memcpy(&pcoef[c * H], &perm[c * H], H * 4);
+        idft(&pcoef[c * H], (int)log_h);
+        coset_lde_from_coeffs(&pcoef[c * H], (int)log_h, &plde[c * N]);
+    }
+    Merkle p_tree;
+    commit_matrix(plde.data(), N, Wp, p_tree);
+    pf.put(p_tree.root());
+    ch.observe_digest(p_tree.root());
+    pf.put(S);
+    ch.observe_ext(S);
+
+    /* 3. quotient */
+    Ext alpha = ch.sample_ext();
+    const size_t M = prog.n + n_int + 3;
+    std::vector<Ext> apow(M);
+    { Ext a = ext_one(); for (size_t j = M; j-- > 0;) { apow[j] = a; a = ext_mul(a, alpha); } }
+    u32 sH = or_pow(COSET_SHIFT, H);
+    u32 zval[2] = {or_sub(sH, 1), or_sub(or_neg(sH), 1)};
+    u32 zinv[2] = {or_inv(zval[0]), or_inv(zval[1])};
+    u32 g = root_of_unity((int)log_h), ginv = or_inv(g);
+    u32 wN = root_of_unity(logN);
+    std::vector<u32> xs(N);
+    { u32 x = COSET_SHIFT; for (size_t j = 0; j < N; ++j) { xs[j] = x; x = or_mul(x, wN); } }
+    std::vector<u32> q(4 * N);
+#pragma omp parallel for schedule(static)
+    for (long j = 0; j < (long)N; ++j) {
+        const size_t jn = ((size_t)j + 2) & (N - 1);  /* next row: g * x_j = x_{j+2} */
+        Ext acc = ext_zero();
+        for (size_t k = 0; k < prog.n; ++k) {
+            u32 v = eval_base(prog.bc + prog.spans[2 * k], prog.spans[2 * k + 1], lde.data(), N, (size_t)j);
+            acc = ext_add(acc, ext_scale(apow[k], v));
+        }
+        Ext sumq = ext_zero(), sumq_next = ext_zero();
+        for (size_t i = 0; i < n_int; ++i) {
+            Ext qi, qn;
+            for (int k = 0; k < 4; ++k) { qi.c[k] = plde[(4 * i + k) * N + j]; qn.c[k] = plde[(4 * i + k) * N + jn]; }
+            sumq = ext_add(sumq, qi);
+            sumq_next = ext_add(sumq_next, qn);
+            Ext d = LogupRow::denom_base(I, i, lde.data(), N, (size_t)j, al, blpow.data());
+            u32 m = LogupRow::mult_base(I, i, lde.data(), N, (size_t)j);
+            Ext c = ext_sub(ext_mul(qi, d), ext_from(m));
+            acc = ext_add(acc, ext_mul(apow[prog.n + i], c));
+        }
+        Ext phi, phin;
+        for (int k = 0; k < 4; ++k) { phi.c[k] = plde[(4 * (size_t)n_int + k) * N + j]; phin.c[k] = plde[(4 * (size_t)n_int + k) * N + jn]; }
+        u32 x = xs[j], Z = zval[j & 1];
+        u32 is_first = or_mul(Z, or_inv(or_sub(x, 1)));
+        u32 is_last = or_mul(Z, or_inv(or_sub(x, ginv)));
+        u32 is_trans = or_sub(x, ginv);
+        acc = ext_add(acc, ext_mul(apow[prog.n + n_int], ext_scale(ext_sub(phi, sumq), is_first)));
+        acc = ext_add(acc, ext_mul(apow[prog.n + n_int + 1], ext_scale(ext_sub(ext_sub(phin, phi), sumq_next), is_trans)));
+        acc = ext_add(acc, ext_mul(apow[prog.n + n_int + 2], ext_scale(ext_sub(phi, S), is_last)));
+        acc = ext_scale(acc, zinv[j & 1]);
+        for (int k = 0; k < 4; ++k) q[k * N + j] = acc.c[k];
+    }
+    std::vector<u32> qcoef(8 * H), qlde(8 * N);
+    u32 sinv = or_inv(COSET_SHIFT);
+    for (int k = 0; k < 4; ++k) {
+        idft(&q[k * N], logN);
+        u32 sp = 1;
+        for (size_t i = 0; i < N; ++i) { q[k * N + i] = or_mul(q[k * N + i], sp); sp = or_mul(sp, sinv); }
+        memcpy(&qcoef[(size_t)k * H], &q[k * N], H * 4);
+        memcpy(&qcoef[(size_t)(4 + k) * H], &q[k * N + H], H * 4);
+    }
+    for (int c = 0; c < 8; ++c) coset_lde_from_coeffs(&qcoef[(size_t)c * H], (int)log_h, &qlde[(size_t)c * N]);
+    Merkle q_tree;
+    commit_matrix(qlde.data(), N, 8, q_tree);
+    pf.put(q_tree.root());
+    ch.observe_digest(q_tree.root());
+
+    /* 4. openings */
+    Ext zeta = ch.sample_ext();
+    Ext gzeta = ext_scale(zeta, g);
+    const size_t K1 = width + Wp + 8, K = K1 + Wp;
+    std::vector<Ext> opened(K);
+#pragma omp parallel for schedule(dynamic)
+    for (long c = 0; c < (long)width; ++c) opened[c] = eval_poly_at(&coef[c * H], H, zeta);
+#pragma omp parallel for schedule(dynamic)
+    for (long c = 0; c < (long)Wp; ++c) {
+        opened[width + c] = eval_poly_at(&pcoef[c * H], H, zeta);
+        opened[K1 + c] = eval_poly_at(&pcoef[c * H], H, gzeta);
+    }
+    for (int c = 0; c < 8; ++c) opened[width + Wp + c] = eval_poly_at(&qcoef[(size_t)c * H], H, zeta);
+    /* proof order: main, perm@zeta, perm@g zeta, quotient */
+    for (size_t c = 0; c < width + Wp; ++c) { pf.put(opened[c]); ch.observe_ext(opened[c]); }
+    for (size_t c = 0; c < Wp; ++c) { pf.put(opened[K1 + c]); ch.observe_ext(opened[K1 + c]); }
+    for (int c = 0; c < 8; ++c) { pf.put(opened[width + Wp + c]); ch.observe_ext(opened[width + Wp + c]); }
+
+    /* 5. DEEP vector */
+    Ext gamma = ch.sample_ext();
+    std::vector<Ext> gpow(K);
+    { Ext gg = ext_one(); for (size_t k = 0; k < K; ++k) { gpow[k] = gg; gg = ext_mul(gg, gamma); } }
+    Ext sum1 = ext_zero(), sum2 = ext_zero();
+    for (size_t k = 0; k < K1; ++k) sum1 = ext_add(sum1, ext_mul(gpow[k], opened[k]));
+    for (size_t k = K1; k < K; ++k) sum2 = ext_add(sum2, ext_mul(gpow[k], opened[k]));
+    std::vector<Ext> v(N);
+#pragma omp parallel for schedule(static)
+    for (long j = 0; j < (long)N; ++j) {
+        Ext a1 = ext_zero(), a2 = ext_zero();
+        for (size_t k = 0; k < width; ++k) a1 = ext_add(a1, ext_scale(gpow[k], lde[k * N + j]));
+        for (size_t k = 0; k < Wp; ++k) {
+            u32 pv = plde[k * N + j];
+            a1 = ext_add(a1, ext_scale(gpow[width + k], pv));
+            a2 = ext_add(a2, ext_scale(gpow[K1 + k], pv));
+        }
+        for (size_t k = 0; k < 8; ++k) a1 = ext_add(a1, ext_scale(gpow[width + Wp + k], qlde[k * N + j]));
+        Ext t1 = ext_mul(ext_sub(a1, sum1), ext_inv(ext_sub(ext_from(xs[j]), zeta)));
+        Ext t2 = ext_mul(ext_sub(a2, sum2), ext_inv(ext_sub(ext_from(xs[j]), gzeta)));
+        v[j] = ext_add(t1, t2);
+    }
+
+    /* 6. FRI, PoW, queries: as v0 plus the perm matrix openings */
+    std::vector<std::vector<Ext>> layers;
+    std::vector<Merkle> fri_trees;
+    u32 shift = COSET_SHIFT, inv2 = or_inv(2);
+    for (int l = 0; l < (int)log_h; ++l) {
+        size_t Nl = N >> l, half = Nl / 2;
+        std::vector<Digest> leaves(half);
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)half; ++i) {
+            u32 row[8];
+            memcpy(row, v[i].c, 16);
+            memcpy(row + 4, v[i + half].c, 16);
+            leaves[i] = hash_row(row, 8);
+        }
+        Merkle t;
+        t.build(std::move(leaves));
+        pf.put(t.root());
+        ch.observe_digest(t.root());
+        Ext beta = ch.sample_ext();
+        u32 wl = root_of_unity(logN - l);
+        std::vector<Ext> nv(half);
+        std::vector<u32> xl(half);
+        { u32 x = shift; for (size_t i = 0; i < half; ++i) { xl[i] = x; x = or_mul(x, wl); } }
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)half; ++i) {
+            Ext a = v[i], b = v[i + half];
+            Ext s2 = ext_scale(ext_add(a, b), inv2);
+            Ext d = ext_scale(ext_sub(a, b), or_mul(inv2, or_inv(xl[i])));
+            nv[i] = ext_add(s2, ext_mul(beta, d));
+        }
+        layers.push_back(std::move(v));
+        fri_trees.push_back(std::move(t));
+        v = std::move(nv);
+        shift = or_mul(shift, shift);
+    }
+    pf.put(v[0]);
+    ch.observe_ext(v[0]);
+    u32 witness = 0;
+    if (cfg.pow_bits) {
+        for (;; ++witness) { Challenger c2 = ch; c2.observe(witness); if (c2.sample_bits((int)cfg.pow_bits) == 0) break; }
+    }
+    pf.put(witness);
+    ch.observe(witness);
+    if (cfg.pow_bits) (void)ch.sample_bits((int)cfg.pow_bits);
+    for (u32 qi = 0; qi < cfg.num_queries; ++qi) {
+        size_t idx = ch.sample_bits(logN);
+        pf.put((u32)idx);
+        for (size_t c = 0; c < width; ++c) pf.put(lde[c * N + idx]);
+        t_tree.path(idx, pf.w);
+        for (size_t c = 0; c < Wp; ++c) pf.put(plde[c * N + idx]);
+        p_tree.path(idx, pf.w);
+        for (size_t c = 0; c < 8; ++c) pf.put(qlde[c * N + idx]);
+        q_tree.path(idx, pf.w);
+        for (int l = 0; l < (int)log_h; ++l) {
+            size_t Nl = N >> l, half = Nl / 2, p = idx & (Nl - 1);
+            pf.put(layers[l][p ^ half]);
+            fri_trees[l].path(p & (half - 1), pf.w);
+        }
+    }
+    return pf.w;
+}
+
+int verify_logup(const Config& cfg, const u32* proof, size_t len, u32 width, u32 log_h, const Program& prog, const Interactions& I) {
+    const size_t H = (size_t)1 << log_h, N = 2 * H;
+    const int logN = (int)log_h + 1;
+    const u32 n_int = (u32)I.n;
+    const size_t Wp = 4 * ((size_t)n_int + 1);
+    size_t pos = 0;
+    auto need = [&](size_t k) { if (pos + k > len) throw std::runtime_error("short proof"); };
+    auto get = [&]() { need(1); return proof[pos++]; };
+    auto get_digest = [&]() { need(8); Digest d; memcpy(d.data(), proof + pos, 32); pos += 8; return d; };
+    auto get_ext = [&]() { need(4); Ext e; memcpy(e.c, proof + pos, 16); pos += 4; return e; };
+    try {
+        if (get() != MAGIC2 || get() != log_h || get() != width || get() != prog.n || get() != n_int || get() != cfg.num_queries ||
+            get() != cfg.pow_bits) return 1;
+        Challenger ch;
+        observe_instance2(ch, log_h, width, (u32)prog.n, n_int, cfg);
+        Digest t_root = get_digest();
+        ch.observe_digest(t_root);
+        Ext al = ch.sample_ext(), bl = ch.sample_ext();
+        Digest p_root = get_digest();
+        ch.observe_digest(p_root);
+        Ext S = get_ext();
+        ch.observe_ext(S);
+        Ext alpha = ch.sample_ext();
+        Digest q_root = get_digest();
+        ch.observe_digest(q_root);
+        Ext zeta = ch.sample_ext();
+        u32 g = root_of_unity((int)log_h), ginv = or_inv(g);
+        Ext gzeta = ext_scale(zeta, g);
+        const size_t K1 = width + Wp + 8, K = K1 + Wp;
+        std::vector<Ext> opened(K);
+        for (size_t c = 0; c < width + Wp; ++c) { opened[c] = get_ext(); ch.observe_ext(opened[c]); }
+        for (size_t c = 0; c < Wp; ++c) { opened[K1 + c] = get_ext(); ch.observe_ext(opened[K1 + c]); }
+        for (int c = 0; c < 8; ++c) { opened[width + Wp + c] = get_ext(); ch.observe_ext(opened[width + Wp + c]); }
+        /* constraints at zeta */
+        Ext basis[4] = {{{1, 0, 0, 0}}, {{0, 1, 0, 0}}, {{0, 0, 1, 0}}, {{0, 0, 0, 1}}};
+        auto ext_col = [&](size_t base) { Ext r = ext_zero(); for (int k = 0; k < 4; ++k) r = ext_add(r, ext_mul(basis[k], opened[base + k])); return r; };
+        std::vector<Ext> blpow(max_args(I) + 2);
+        { Ext b = ext_one(); for (auto& x : blpow) { x = b; b = ext_mul(b, bl); } }
+        Ext acc = ext_zero();
+        for (size_t k = 0; k < prog.n; ++k)
+            acc = ext_add(ext_mul(acc, alpha), eval_ext(prog.bc + prog.spans[2 * k], prog.spans[2 * k + 1], opened.data()));
+        Ext sumq = ext_zero(), sumq_next = ext_zero();
+        for (size_t i = 0; i < n_int; ++i) {
+            const u32* it = I.inter + 3 * i;
+            const u32* sp = I.spans + 2 * (size_t)it[2];
+            Ext d = ext_add(al, ext_from(it[0] % P));
+            for (u32 j = 0; j < it[1]; ++j) d = ext_add(d, ext_mul(blpow[j + 1], eval_ext(I.bc + sp[2 + 2 * j], sp[3 + 2 * j], opened.data())));
+            Ext m = eval_ext(I.bc + sp[0], sp[1], opened.data());
+            Ext qi = ext_col(width + 4 * i), qn = ext_col(K1 + 4 * i);
+            sumq = ext_add(sumq, qi);
+            sumq_next = ext_add(sumq_next, qn);
+            acc = ext_add(ext_mul(acc, alpha), ext_sub(ext_mul(qi, d), m));
+        }
+        Ext phi = ext_col(width + 4 * (size_t)n_int), phin = ext_col(K1 + 4 * (size_t)n_int);
+        Ext zH = ext_pow(zeta, H);
+        Ext Z = ext_sub(zH, ext_one());
+        Ext is_first = ext_mul(Z, ext_inv(ext_sub(zeta, ext_one())));
+        Ext is_last = ext_mul(Z, ext_inv(ext_sub(zeta, ext_from(ginv))));
+        Ext is_trans = ext_sub(zeta, ext_from(ginv));
+        acc = ext_add(ext_mul(acc, alpha), ext_mul(is_first, ext_sub(phi, sumq)));
+        acc = ext_add(ext_mul(acc, alpha), ext_mul(is_trans, ext_sub(ext_sub(phin, phi), sumq_next)));
+        acc = ext_add(ext_mul(acc, alpha), ext_mul(is_last, ext_sub(phi, S)));
+        Ext qlo = ext_col(width + Wp), qhi = ext_col(width + Wp + 4);
+        if (!ext_eq(acc, ext_mul(Z, ext_add(qlo, ext_mul(zH, qhi))))) return 2;
+
+        Ext gamma = ch.sample_ext();
+        std::vector<Ext> gpow(K);
+        { Ext gg = ext_one(); for (size_t k = 0; k < K; ++k) { gpow[k] = gg; gg = ext_mul(gg, gamma); } }
+        Ext sum1 = ext_zero(), sum2 = ext_zero();
+        for (size_t k = 0; k < K1; ++k) sum1 = ext_add(sum1, ext_mul(gpow[k], opened[k]));
+        for (size_t k = K1; k < K; ++k) sum2 = ext_add(sum2, ext_mul(gpow[k], opened[k]));
+        std::vector<Digest> fri_roots(log_h);
+        std::vector<Ext> betas(log_h);
+        for (u32 l = 0; l < log_h; ++l) { fri_roots[l] = get_digest(); ch.observe_digest(fri_roots[l]); betas[l] = ch.sample_ext(); }
+        Ext final_poly = get_ext();
+        ch.observe_ext(final_poly);
+        u32 witness = get();
+        ch.observe(witness);
+        if (cfg.pow_bits && ch.sample_bits((int)cfg.pow_bits) != 0) return 3;
+        auto check_path = [&](Digest leaf, size_t idx, int depth, const Digest& root) {
+            for (int l = 0; l < depth; ++l) { Digest sib = get_digest(); leaf = ((idx >> l) & 1) ? compress(sib, leaf) : compress(leaf, sib); }
+            return leaf == root;
+        };
+        u32 wN = root_of_unity(logN), inv2 = or_inv(2);
+        for (u32 qi = 0; qi < cfg.num_queries; ++qi) {
+            size_t idx = ch.sample_bits(logN);
+            if (get() != idx) return 4;
+            need(width);
+            const u32* trow = proof + pos; pos += width;
+            if (!check_path(hash_row(trow, width), idx, logN, t_root)) return 5;
+            need(Wp);
+            const u32* prow = proof + pos; pos += Wp;
+            if (!check_path(hash_row(prow, Wp), idx, logN, p_root)) return 11;
+            need(8);
+            const u32* qrow = proof + pos; pos += 8;
+            if (!check_path(hash_row(qrow, 8), idx, logN, q_root)) return 6;
+            u32 x = or_mul(COSET_SHIFT, or_pow(wN, idx));
+            Ext a1 = ext_zero(), a2 = ext_zero();
+            for (size_t k = 0; k < width; ++k) a1 = ext_add(a1, ext_scale(gpow[k], trow[k]));
+            for (size_t k = 0; k < Wp; ++k) { a1 = ext_add(a1, ext_scale(gpow[width + k], prow[k])); a2 = ext_add(a2, ext_scale(gpow[K1 + k], prow[k])); }
+            for (size_t k = 0; k < 8; ++k) a1 = ext_add(a1, ext_scale(gpow[width + Wp + k], qrow[k]));
+            Ext cur = ext_add(ext_mul(ext_sub(a1, sum1), ext_inv(ext_sub(ext_from(x), zeta))),
+                              ext_mul(ext_sub(a2, sum2), ext_inv(ext_sub(ext_from(x), gzeta))));
+            u32 shift = COSET_SHIFT;
+            for (u32 l = 0; l < log_h; ++l) {
+                size_t Nl = N >> l, half = Nl / 2, p = idx & (Nl - 1);
+                Ext sib = get_ext();
+                Ext lo = (p < half) ? cur : sib, hi = (p < half) ? sib : cur;
+                u32 row[8];
+                memcpy(row, lo.c, 16); memcpy(row + 4, hi.c, 16);
+                if (!check_path(hash_row(row, 8), p & (half - 1), logN - 1 - (int)l, fri_roots[l])) return 7;
+                u32 xi = or_mul(shift, or_pow(root_of_unity(logN - (int)l), p & (half - 1)));
+                Ext s2 = ext_scale(ext_add(lo, hi), inv2);
+                Ext d = ext_scale(ext_sub(lo, hi), or_mul(inv2, or_inv(xi)));
+                cur = ext_add(s2, ext_mul(betas[l], d));
+                shift = or_mul(shift, shift);
+            }
+            if (!ext_eq(cur, final_poly)) return 8;
+        }
+        if (pos != len) return 9;
+    } catch (const std::exception&) {
+        return 10;
+    }
+    return 0;
+}
+
 }  // namespace
 
 /* ---------------------------------------------------------------- C entry points for tests */
@@ -644,6 +1038,28 @@ int or_verify(uint32_t num_queries, uint32_t pow_bits, const uint32_t* proof, si
     Config cfg{num_queries, pow_bits};
     Program pr{cons_bc, cons_spans, n_constraints};
     return verify(cfg, proof, len, width, log_h, pr);
+}
+
+
+/* ---- pw-stark v0 + LogUp: interactions = n x {bus id, n_args, first span index}; spans = {off,len} pairs laid out
+ * [mult, arg0, arg1, ...] per interaction; bytecode with column-index operands (compile_bus with height 1). */
+size_t or_prove_logup(uint32_t num_queries, uint32_t pow_bits, const uint32_t* trace, uint32_t width, uint32_t log_h,
+                      const uint32_t* cons_bc, const uint32_t* cons_spans, size_t n_constraints, const uint32_t* inter,
+                      size_t n_inter, const uint32_t* ispans, const uint32_t* ibc, uint32_t* proof, size_t cap) {
+    Config cfg{num_queries, pow_bits};
+    Program pr{cons_bc, cons_spans, n_constraints};
+    Interactions I{inter, n_inter, ispans, ibc};
+    std::vector<u32> w = prove_logup(cfg, trace, width, log_h, pr, I);
+    if (w.size() <= cap) memcpy(proof, w.data(), w.size() * 4);
+    return w.size();
+}
+int or_verify_logup(uint32_t num_queries, uint32_t pow_bits, const uint32_t* proof, size_t len, uint32_t width, uint32_t log_h,
+                    const uint32_t* cons_bc, const uint32_t* cons_spans, size_t n_constraints, const uint32_t* inter,
+                    size_t n_inter, const uint32_t* ispans, const uint32_t* ibc) {
+    Config cfg{num_queries, pow_bits};
+    Program pr{cons_bc, cons_spans, n_constraints};
+    Interactions I{inter, n_inter, ispans, ibc};
+    return verify_logup(cfg, proof, len, width, log_h, pr, I);
 }
 
 }  // extern "C"

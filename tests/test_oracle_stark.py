@@ -154,3 +154,30 @@ def test_product_verifier_agrees_with_oracle_verifier(shape, calls, pow_bits):
     assert prover.verify(proof[:-3], W, log_h, bc, spans, num_queries=7, pow_bits=pow_bits) == 10
     assert prover.verify(np.concatenate([proof, proof[:1]]), W, log_h, bc, spans, num_queries=7, pow_bits=pow_bits) == 9
     assert prover.verify(proof, W, log_h, bc, spans, num_queries=6, pow_bits=pow_bits) == 1
+
+
+@pytest.mark.parametrize("shape,calls", [("T0", 5), ("T0", 64), ("T1", 90)])
+def test_logup_extension_accepts_and_rejects(shape, calls):
+    """pw-stark v0 + LogUp (bus interactions inside the proof): honest proofs verify; tampering, a broken
+    constraint, and a perturbed interaction operand (which breaks q_i * d_i = m_i) are rejected."""
+    s, apc, idx, trace = synthetic_trace(shape, calls, seed=12)
+    W, H = trace.shape
+    log_h = H.bit_length() - 1
+    bc, spans = sm.compile_constraints(apc, idx)
+    inter, ispans, ibc = sm.compile_interactions(apc, idx)
+    flat = np.ascontiguousarray(trace).reshape(-1)
+    proof = sm.prove_logup(flat, W, log_h, bc, spans, inter, ispans, ibc, num_queries=5)
+    assert sm.verify_logup(proof, W, log_h, bc, spans, inter, ispans, ibc, num_queries=5) == 0
+    assert (sm.prove_logup(flat, W, log_h, bc, spans, inter, ispans, ibc, num_queries=5) == proof).all()
+    rng = np.random.default_rng(3)
+    for pos in rng.choice(len(proof), size=16, replace=False):
+        bad = proof.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        assert sm.verify_logup(bad, W, log_h, bc, spans, inter, ispans, ibc, num_queries=5) != 0
+    # a verifier that believes in a different interaction list rejects the proof
+    inter2 = inter.copy()
+    inter2[0, 0] = (int(inter2[0, 0]) + 1) % 16
+    assert sm.verify_logup(proof, W, log_h, bc, spans, inter2, ispans, ibc, num_queries=5) != 0
+    # the proof is longer than the constraints-only one by the permutation matrix openings
+    base = sm.prove(flat, W, log_h, bc, spans, num_queries=5)
+    assert len(proof) > len(base) + 8 * (len(inter) + 1)
