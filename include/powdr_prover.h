@@ -43,6 +43,15 @@ typedef struct {
  * spans = {off, len} pairs in u32 words. Host pointers; copied. */
 PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, const uint32_t* cons_bytecode,
                            size_t bytecode_len, const uint32_t* cons_spans, size_t n_constraints);
+/* The same AIR including its bus interactions (PowdrAir::eval's `push_interaction`, chip.rs:117-129), proven
+ * with committed LogUp columns ("pw-stark v0 + LogUp", oracle/stark_oracle.cpp): interactions = n x {bus id,
+ * n_args, first span index}, spans = {off,len} pairs laid out [mult, arg0, arg1, ...] per interaction into
+ * `inter_bytecode` (post-fix, column-index operands) — i.e. powdr_apc_compile_bus(apc, 1, ...). The proof then
+ * also carries the permutation-matrix commitment, the cumulative sum S and the extra openings. */
+PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t width, const uint32_t* cons_bytecode,
+                                 size_t bytecode_len, const uint32_t* cons_spans, size_t n_constraints,
+                                 const uint32_t* interactions, size_t n_interactions, const uint32_t* inter_spans,
+                                 size_t n_inter_spans, const uint32_t* inter_bytecode, size_t inter_bytecode_len);
 void pw_prover_destroy(PwProver* p);
 
 /* Prove one trace (column-major, width x 2^log_height, Montgomery words, device).

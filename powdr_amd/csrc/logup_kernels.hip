@@ -1,0 +1,243 @@
+// Kernels of the LogUp extension of pw-stark v0 (protocol: oracle/stark_oracle.cpp, "pw-stark v0 + LogUp"):
+// permutation-trace generation, running-sum scan, the extended quotient and DEEP kernels.
+// One lane per row everywhere; interaction programs are xbc code with column-index operands.
+#include "prover_internal.hpp"
+#include "xbc.hpp"
+#include "expr_eval.hpp"
+
+namespace pw {
+
+namespace {
+
+constexpr int kBlock = 256;
+using bb::Ext;
+
+// d_i = al + bus_i + sum_j bl^(j+1) a_ij on row r of matrix `m` (column stride `stride`)
+__device__ __forceinline__ Ext interaction_denominator(const LogupInteraction& it, const uint32_t* __restrict__ xspans,
+                                                       const uint32_t* __restrict__ code, const uint32_t* __restrict__ m,
+                                                       size_t stride, size_t r, uint32_t* stk, const Ext& al,
+                                                       const Ext* __restrict__ blpow) {
+    Ext d = al;
+    d.c[0] = bb::add(d.c[0], it.bus_monty);
+    for (uint32_t j = 0; j < it.n_args; ++j) {
+        const uint32_t off = xspans[2 * (it.first_span + 1 + j)], len = xspans[2 * (it.first_span + 1 + j) + 1];
+        const uint32_t a = xbc::eval<kBlock, true>(code + 2 * (size_t)off, len, m, r, stk, stride);
+        const Ext b = blpow[j + 1];
+        d.c[0] = bb::add(d.c[0], bb::mul(b.c[0], a));
+        d.c[1] = bb::add(d.c[1], bb::mul(b.c[1], a));
+        d.c[2] = bb::add(d.c[2], bb::mul(b.c[2], a));
+        d.c[3] = bb::add(d.c[3], bb::mul(b.c[3], a));
+    }
+    return d;
+}
+__device__ __forceinline__ uint32_t interaction_mult(const LogupInteraction& it, const uint32_t* __restrict__ xspans,
+                                                     const uint32_t* __restrict__ code, const uint32_t* __restrict__ m,
+                                                     size_t stride, size_t r, uint32_t* stk) {
+    const uint32_t off = xspans[2 * it.first_span], len = xspans[2 * it.first_span + 1];
+    return xbc::eval<kBlock, true>(code + 2 * (size_t)off, len, m, r, stk, stride);
+}
+
+// perm[(4i+k)*H + r] = coordinate k of q_i(r) = m_i(r) / d_i(r);  rowsum[r] = sum_i q_i(r)
+__global__ __launch_bounds__(kBlock) void logup_perm_kernel(const uint32_t* __restrict__ trace, size_t H, LogupProgram lp, Ext al,
+                                                             const Ext* __restrict__ blpow, uint32_t* __restrict__ perm,
+                                                             Ext* __restrict__ rowsum) {
+    __shared__ uint32_t stack_lds[kStackCap * kBlock];
+    uint32_t* stk = stack_lds + threadIdx.x;
+    const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= H) return;
+    Ext acc = bb::ext_zero();
+    for (uint32_t i = 0; i < lp.n; ++i) {
+        const LogupInteraction it = lp.d_inter[i];
+        const uint32_t m = interaction_mult(it, lp.d_xspans, lp.d_code, trace, H, r, stk);
+        Ext q = bb::ext_zero();
+        if (m != 0u) {
+            const Ext d = interaction_denominator(it, lp.d_xspans, lp.d_code, trace, H, r, stk, al, blpow);
+            q = bb::ext_scale(bb::ext_inv(d), m);
+        }
+        uint32_t* out = perm + (size_t)(4 * i) * H + r;
+        out[0] = q.c[0]; out[H] = q.c[1]; out[2 * H] = q.c[2]; out[3 * H] = q.c[3];
+        acc = bb::ext_add(acc, q);
+    }
+    rowsum[r] = acc;
+}
+
+// ---- inclusive scan of an Ext vector (length H, power of two) into the 4 phi columns -------------------
+constexpr int kScanPerThread = 16;
+constexpr int kScanChunk = kBlock * kScanPerThread;  // rows per workgroup
+
+__device__ __forceinline__ Ext block_exclusive_scan(Ext v, Ext* lds, Ext& total) {
+    // Hillis-Steele over 256 threads in LDS
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {
+        Ext x = lds[t];
+        if (t >= off) x = bb::ext_add(x, lds[t - off]);
+        __syncthreads();
+        lds[t] = x;
+        __syncthreads();
+    }
+    total = lds[kBlock - 1];
+    Ext incl = lds[t];
+    __syncthreads();
+    return bb::ext_sub(incl, v);
+}
+
+__global__ __launch_bounds__(kBlock) void scan_block_totals_kernel(const Ext* __restrict__ in, size_t H, Ext* __restrict__ totals) {
+    __shared__ Ext lds[kBlock];
+    const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanPerThread;
+    Ext s = bb::ext_zero();
+    for (int k = 0; k < kScanPerThread; ++k)
+        if (base + k < H) s = bb::ext_add(s, in[base + k]);
+    Ext total;
+    (void)block_exclusive_scan(s, lds, total);
+    if (threadIdx.x == 0) totals[blockIdx.x] = total;
+}
+__global__ void scan_totals_kernel(Ext* totals, uint32_t n) {  // tiny: n <= 2^22 / 4096 = 1024 blocks
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        Ext run = bb::ext_zero();
+        for (uint32_t i = 0; i < n; ++i) { Ext t = totals[i]; totals[i] = run; run = bb::ext_add(run, t); }
+    }
+}
+__global__ __launch_bounds__(kBlock) void scan_write_kernel(const Ext* __restrict__ in, size_t H, const Ext* __restrict__ offsets,
+                                                             uint32_t* __restrict__ phi_cols /* 4 columns of H */) {
+    __shared__ Ext lds[kBlock];
+    const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanPerThread;
+    Ext s = bb::ext_zero();
+    for (int k = 0; k < kScanPerThread; ++k)
+        if (base + k < H) s = bb::ext_add(s, in[base + k]);
+    Ext total;
+    Ext run = bb::ext_add(block_exclusive_scan(s, lds, total), offsets[blockIdx.x]);
+    for (int k = 0; k < kScanPerThread; ++k) {
+        if (base + k < H) {
+            run = bb::ext_add(run, in[base + k]);
+            phi_cols[base + k] = run.c[0]; phi_cols[H + base + k] = run.c[1];
+            phi_cols[2 * H + base + k] = run.c[2]; phi_cols[3 * H + base + k] = run.c[3];
+        }
+    }
+}
+
+// ---- quotient with the LogUp constraints ---------------------------------------------------------------
+// acc = sum_k apow[k] C_k + sum_i apow[nc+i] (q_i d_i - m_i) + apow[nc+n] is_first (phi - sum q)
+//       + apow[nc+n+1] is_trans (phi' - phi - sum q') + apow[nc+n+2] is_last (phi - S);  q = acc / Z_H
+template <bool XBC>
+__global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* __restrict__ lde, const uint32_t* __restrict__ plde,
+                                                                 size_t N, const uint32_t* __restrict__ bytecode,
+                                                                 const uint32_t* __restrict__ spans, uint32_t nc, LogupProgram lp,
+                                                                 const Ext* __restrict__ apow, Ext al, const Ext* __restrict__ blpow,
+                                                                 Ext S, uint32_t zval_even, uint32_t zval_odd, uint32_t shift,
+                                                                 uint32_t wN, uint32_t ginv, uint32_t* __restrict__ q) {
+    __shared__ uint32_t stack_lds[kStackCap * kBlock];
+    uint32_t* stk = stack_lds + threadIdx.x;
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= N) return;
+    const size_t jn = (j + 2) & (N - 1);
+    Ext acc = bb::ext_zero();
+    for (uint32_t c = 0; c < nc; ++c) {
+        const uint32_t off = spans[2 * c], len = spans[2 * c + 1];
+        const uint32_t v = XBC ? xbc::eval<kBlock, true>(bytecode + 2 * (size_t)off, len, lde, j, stk, N)
+                               : eval_expr<kBlock, true>(bytecode + off, len, lde, j, stk, N);
+        acc = bb::ext_add(acc, bb::ext_scale(apow[c], v));
+    }
+    Ext sumq = bb::ext_zero(), sumq_next = bb::ext_zero();
+    for (uint32_t i = 0; i < lp.n; ++i) {
+        const LogupInteraction it = lp.d_inter[i];
+        const uint32_t* pc = plde + (size_t)(4 * i) * N;
+        const Ext qi = {{pc[j], pc[N + j], pc[2 * N + j], pc[3 * N + j]}};
+        const Ext qn = {{pc[jn], pc[N + jn], pc[2 * N + jn], pc[3 * N + jn]}};
+        sumq = bb::ext_add(sumq, qi);
+        sumq_next = bb::ext_add(sumq_next, qn);
+        const Ext d = interaction_denominator(it, lp.d_xspans, lp.d_code, lde, N, j, stk, al, blpow);
+        const uint32_t m = interaction_mult(it, lp.d_xspans, lp.d_code, lde, N, j, stk);
+        Ext c = bb::ext_mul(qi, d);
+        c.c[0] = bb::sub(c.c[0], m);
+        acc = bb::ext_add(acc, bb::ext_mul(apow[nc + i], c));
+    }
+    const uint32_t* pp = plde + (size_t)(4 * lp.n) * N;
+    const Ext phi = {{pp[j], pp[N + j], pp[2 * N + j], pp[3 * N + j]}};
+    const Ext phin = {{pp[jn], pp[N + jn], pp[2 * N + jn], pp[3 * N + jn]}};
+    const uint32_t x = bb::mul(shift, bb::pow_u32(wN, (uint32_t)j));
+    const uint32_t Z = (j & 1) ? zval_odd : zval_even;
+    const uint32_t one = bb::R_MOD_P;
+    const uint32_t is_first = bb::mul(Z, bb::inv(bb::sub(x, one)));
+    const uint32_t is_last = bb::mul(Z, bb::inv(bb::sub(x, ginv)));
+    const uint32_t is_trans = bb::sub(x, ginv);
+    acc = bb::ext_add(acc, bb::ext_mul(apow[nc + lp.n], bb::ext_scale(bb::ext_sub(phi, sumq), is_first)));
+    acc = bb::ext_add(acc, bb::ext_mul(apow[nc + lp.n + 1], bb::ext_scale(bb::ext_sub(bb::ext_sub(phin, phi), sumq_next), is_trans)));
+    acc = bb::ext_add(acc, bb::ext_mul(apow[nc + lp.n + 2], bb::ext_scale(bb::ext_sub(phi, S), is_last)));
+    const uint32_t zi = bb::inv(Z);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[(size_t)k * N + j] = bb::mul(acc.c[k], zi);
+}
+
+// ---- DEEP with two opening points ------------------------------------------------------------------------
+// v[j] = (sum_{k<K1} g^k f_k(x_j) - sum1) / (x_j - zeta) + (sum_{k<Wp} g^(K1+k) p_k(x_j) - sum2) / (x_j - g zeta)
+__global__ __launch_bounds__(kBlock) void deep_logup_kernel(const uint32_t* __restrict__ lde, uint32_t W, const uint32_t* __restrict__ plde,
+                                                             uint32_t Wp, const uint32_t* __restrict__ qlde, size_t N,
+                                                             const Ext* __restrict__ gpow, Ext sum1, Ext sum2, Ext zeta, Ext gzeta,
+                                                             uint32_t shift, uint32_t wN, Ext* __restrict__ v) {
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= N) return;
+    Ext a1 = bb::ext_zero(), a2 = bb::ext_zero();
+    auto fma1 = [&](const Ext& g, uint32_t x) {
+        a1.c[0] = bb::add(a1.c[0], bb::mul(g.c[0], x)); a1.c[1] = bb::add(a1.c[1], bb::mul(g.c[1], x));
+        a1.c[2] = bb::add(a1.c[2], bb::mul(g.c[2], x)); a1.c[3] = bb::add(a1.c[3], bb::mul(g.c[3], x));
+    };
+    for (uint32_t k = 0; k < W; ++k) fma1(gpow[k], lde[(size_t)k * N + j]);
+    const uint32_t K1 = W + Wp + 8;
+    for (uint32_t k = 0; k < Wp; ++k) {
+        const uint32_t x = plde[(size_t)k * N + j];
+        fma1(gpow[W + k], x);
+        const Ext g2 = gpow[K1 + k];
+        a2.c[0] = bb::add(a2.c[0], bb::mul(g2.c[0], x)); a2.c[1] = bb::add(a2.c[1], bb::mul(g2.c[1], x));
+        a2.c[2] = bb::add(a2.c[2], bb::mul(g2.c[2], x)); a2.c[3] = bb::add(a2.c[3], bb::mul(g2.c[3], x));
+    }
+    for (uint32_t k = 0; k < 8; ++k) fma1(gpow[W + Wp + k], qlde[(size_t)k * N + j]);
+    const uint32_t xj = bb::mul(shift, bb::pow_u32(wN, (uint32_t)j));
+    const Ext xe = bb::ext_from_base(xj);
+    const Ext t1 = bb::ext_mul(bb::ext_sub(a1, sum1), bb::ext_inv(bb::ext_sub(xe, zeta)));
+    const Ext t2 = bb::ext_mul(bb::ext_sub(a2, sum2), bb::ext_inv(bb::ext_sub(xe, gzeta)));
+    v[j] = bb::ext_add(t1, t2);
+}
+
+}  // namespace
+
+int logup_perm_trace(const uint32_t* trace, size_t H, const LogupProgram& lp, bb::Ext al, const bb::Ext* d_blpow, uint32_t* perm,
+                     bb::Ext* d_rowsum, bb::Ext* d_block_totals) {
+    {
+        ScopedKernelTimer t("logup_perm_kernel");
+        hipLaunchKernelGGL(logup_perm_kernel, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), trace, H, lp, al, d_blpow, perm, d_rowsum);
+    }
+    const uint32_t blocks = div_up(H, kScanChunk);
+    ScopedKernelTimer t("logup_scan_kernels");
+    hipLaunchKernelGGL(scan_block_totals_kernel, dim3(blocks), dim3(kBlock), 0, stream(), d_rowsum, H, d_block_totals);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(64), 0, stream(), d_block_totals, blocks);
+    hipLaunchKernelGGL(scan_write_kernel, dim3(blocks), dim3(kBlock), 0, stream(), d_rowsum, H, d_block_totals,
+                       perm + (size_t)(4 * lp.n) * H);
+    return (int)hipGetLastError();
+}
+
+int quotient_eval_logup(const uint32_t* lde, const uint32_t* plde, size_t N, int logN, const ConstraintProgram& prog,
+                        const LogupProgram& lp, const bb::Ext* d_apow, bb::Ext al, const bb::Ext* d_blpow, bb::Ext S,
+                        uint32_t zval_even, uint32_t zval_odd, uint32_t* q) {
+    const uint32_t shift = bb::to_monty(field::kCosetShift), wN = field::root_of_unity(logN);
+    const uint32_t ginv = bb::inv(field::root_of_unity(logN - 1));
+    ScopedKernelTimer t("quotient_logup_kernel");
+    if (prog.is_xbc)
+        hipLaunchKernelGGL(quotient_logup_kernel<true>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, plde, N, prog.d_bytecode,
+                           prog.d_spans, prog.n_constraints, lp, d_apow, al, d_blpow, S, zval_even, zval_odd, shift, wN, ginv, q);
+    else
+        hipLaunchKernelGGL(quotient_logup_kernel<false>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, plde, N, prog.d_bytecode,
+                           prog.d_spans, prog.n_constraints, lp, d_apow, al, d_blpow, S, zval_even, zval_odd, shift, wN, ginv, q);
+    return (int)hipGetLastError();
+}
+
+int deep_quotient_logup(const uint32_t* lde, uint32_t W, const uint32_t* plde, uint32_t Wp, const uint32_t* qlde, size_t N, int logN,
+                        const bb::Ext* d_gpow, bb::Ext sum1, bb::Ext sum2, bb::Ext zeta, bb::Ext gzeta, bb::Ext* v) {
+    ScopedKernelTimer t("deep_logup_kernel");
+    hipLaunchKernelGGL(deep_logup_kernel, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, W, plde, Wp, qlde, N, d_gpow, sum1,
+                       sum2, zeta, gzeta, bb::to_monty(field::kCosetShift), field::root_of_unity(logN), v);
+    return (int)hipGetLastError();
+}
+
+}  // namespace pw

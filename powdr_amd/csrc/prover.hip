@@ -17,7 +17,8 @@ namespace pw {
 
 namespace {
 
-constexpr uint32_t kMagic = 0x31535750u;  // "PWS1"
+constexpr uint32_t kMagic = 0x31535750u;   // "PWS1"
+constexpr uint32_t kMagic2 = 0x32535750u;  // "PWS2": with the LogUp extension
 
 // ---- duplex-sponge challenger on Montgomery words (spec: oracle/stark_oracle.cpp Challenger) ----
 struct Challenger {
@@ -75,12 +76,21 @@ struct PwProver {
     uint32_t* d_bytecode = nullptr;
     uint32_t* d_spans = nullptr;
     bool is_xbc = false;  // d_bytecode/d_spans hold plan-compiled xbc code (xbc.hpp) instead of post-fix code
+    // LogUp extension (pw_prover_create_logup): the AIR's bus interactions as xbc programs
+    bool logup = false;
+    uint32_t n_inter = 0, max_args = 0;
+    pw::LogupInteraction* d_inter = nullptr;
+    uint32_t* d_ixspans = nullptr;
+    uint32_t* d_icode = nullptr;
+    pw::DeviceBuf perm, plde;
     // device buffers, grown on demand
     pw::DeviceBuf coef, lde, digests, q, qcoef, qlde, ext_arena, misc;
     std::vector<uint32_t> proof;
 };
 
 using namespace pw;
+
+extern "C" void pw_prover_destroy(PwProver* p);
 
 extern "C" PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, const uint32_t* bc, size_t bc_len,
                                       const uint32_t* spans, size_t n_constraints) {
@@ -119,9 +129,48 @@ extern "C" PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, 
     return p;
 }
 
+extern "C" PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t width, const uint32_t* bc, size_t bc_len,
+                                            const uint32_t* spans, size_t n_constraints, const uint32_t* inter, size_t n_inter,
+                                            const uint32_t* ispans, size_t n_ispans, const uint32_t* ibc, size_t ibc_len) {
+    PwProver* p = pw_prover_create(cfg, width, bc, bc_len, spans, n_constraints);
+    if (!p) return nullptr;
+    // interactions: {bus, n_args, first span}; spans [mult, arg0, ...] into ibc (post-fix, column operands)
+    std::vector<pw::LogupInteraction> li(n_inter);
+    std::vector<uint32_t> xspans, code;
+    xbc::Compiler cc;
+    bool ok = true;
+    for (size_t i = 0; i < n_inter && ok; ++i) {
+        const uint32_t bus = inter[3 * i], na = inter[3 * i + 1], first = inter[3 * i + 2];
+        if ((size_t)first + 1 + na > n_ispans) { ok = false; break; }
+        li[i] = {bb::to_monty(bus % bb::P), na, (uint32_t)(xspans.size() / 2)};
+        if (na > p->max_args) p->max_args = na;
+        for (uint32_t k = 0; k <= na && ok; ++k) {
+            const uint32_t off = ispans[2 * (first + k)], len = ispans[2 * (first + k) + 1];
+            if ((size_t)off + len > ibc_len) { ok = false; break; }
+            const uint32_t o = (uint32_t)(code.size() / 2);
+            if (!cc.compile(ibc + off, len, code)) { ok = false; break; }
+            xspans.push_back(o);
+            xspans.push_back((uint32_t)(code.size() / 2) - o);
+        }
+    }
+    auto up = [&](void** d, const void* h, size_t bytes) {
+        if (hipMalloc(d, bytes ? bytes : 4) != hipSuccess) return false;
+        return !bytes || hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!ok || !up((void**)&p->d_inter, li.data(), li.size() * sizeof(pw::LogupInteraction)) ||
+        !up((void**)&p->d_ixspans, xspans.data(), xspans.size() * 4) || !up((void**)&p->d_icode, code.data(), code.size() * 4)) {
+        pw_prover_destroy(p);
+        return nullptr;
+    }
+    p->logup = true;
+    p->n_inter = (uint32_t)n_inter;
+    return p;
+}
+
 extern "C" void pw_prover_destroy(PwProver* p) {
     if (!p) return;
-    for (DeviceBuf* b : {&p->coef, &p->lde, &p->digests, &p->q, &p->qcoef, &p->qlde, &p->ext_arena, &p->misc}) b->release();
+    for (DeviceBuf* b : {&p->coef, &p->lde, &p->digests, &p->q, &p->qcoef, &p->qlde, &p->ext_arena, &p->misc, &p->perm, &p->plde}) b->release();
+    for (void* q : {(void*)p->d_inter, (void*)p->d_ixspans, (void*)p->d_icode}) if (q) (void)hipFree(q);
     if (p->d_bytecode) (void)hipFree(p->d_bytecode);
     if (p->d_spans) (void)hipFree(p->d_spans);
     delete p;
@@ -129,7 +178,7 @@ extern "C" void pw_prover_destroy(PwProver* p) {
 
 extern "C" size_t pw_prover_device_bytes(const PwProver* p) {
     return p->coef.bytes + p->lde.bytes + p->digests.bytes + p->q.bytes + p->qcoef.bytes + p->qlde.bytes +
-           p->ext_arena.bytes + p->misc.bytes;
+           p->ext_arena.bytes + p->misc.bytes + p->perm.bytes + p->plde.bytes;
 }
 
 #define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
@@ -141,7 +190,12 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const uint32_t W = p->width, nc = p->n_constraints;
     const size_t H = (size_t)1 << log_h, N = 2 * H;
     const int logN = (int)log_h + 1;
-    const uint32_t K = W + 8;
+    const bool lg = p->logup;
+    const uint32_t n_int = lg ? p->n_inter : 0;
+    const uint32_t Wp = lg ? 4 * (n_int + 1) : 0;   // permutation matrix: q_i coordinates, then phi
+    const uint32_t K1 = W + Wp + 8;                  // polynomials opened at zeta: main | perm | quotient
+    const uint32_t K = K1 + Wp;                      // + perm opened at g*zeta
+    const uint32_t M = nc + (lg ? n_int + 3 : 0);    // folded constraints
     hipStream_t st = stream();
     TRY(poseidon2_upload_params());
 
@@ -156,17 +210,24 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     if (panel_cols > W) panel_cols = W;
     TRY(p->coef.ensure(panel_cols * H * 4));
     TRY(p->lde.ensure((size_t)W * N * 4));
-    TRY(p->digests.ensure((2 * tree_words + fri_words) * 4));
+    const size_t n_trees = lg ? 3 : 2;  // trace | quotient | (perm) | FRI
+    TRY(p->digests.ensure((n_trees * tree_words + fri_words) * 4));
+    if (lg) {
+        TRY(p->perm.ensure((size_t)Wp * H * 4));
+        TRY(p->plde.ensure((size_t)Wp * N * 4));
+    }
     TRY(p->q.ensure(4 * N * 4));
     TRY(p->qcoef.ensure(8 * H * 4));
     TRY(p->qlde.ensure(8 * N * 4));
     // ext arena: FRI layer vectors v_0 (N) .. v_log_h (2): 2N ext; weights (H)
-    TRY(p->ext_arena.ensure((2 * N + H + 16) * sizeof(bb::Ext)));
+    // ext arena: FRI layer vectors v_0 (N) .. v_log_h (2): 2N ext; weights (H); LogUp: second weights, row sums
+    TRY(p->ext_arena.ensure((2 * N + (lg ? 3 : 1) * H + H / 4096 + 32) * sizeof(bb::Ext)));
     const uint32_t n_chunks = div_up(H, 8192);
-    const size_t misc_ext = (size_t)K * n_chunks + K + K + nc + 64;
+    const uint32_t dot_cols = Wp > W ? Wp : W;
+    const size_t misc_ext = (size_t)dot_cols * n_chunks + K + K + M + p->max_args + 64;
     const uint32_t nq = p->cfg.num_queries;
-    const size_t path_records = (size_t)nq * (2 * (size_t)logN + (size_t)log_h * logN) + 16;
-    size_t misc_bytes = misc_ext * sizeof(bb::Ext) + (size_t)nq * 4 + (size_t)nq * (W + 8) * 4 + path_records * (8 + 32) +
+    const size_t path_records = (size_t)nq * (n_trees * (size_t)logN + (size_t)log_h * logN) + 16;
+    size_t misc_bytes = misc_ext * sizeof(bb::Ext) + (size_t)nq * 4 + (size_t)nq * (W + Wp + 8) * 4 + path_records * (8 + 32) +
                         (size_t)nq * log_h * (8 + 16) + 4096;
     TRY(p->misc.ensure(misc_bytes));
 
@@ -175,17 +236,23 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     uint32_t* d_dig = p->digests.as<uint32_t>();
     uint32_t* d_tdig = d_dig;
     uint32_t* d_qdig = d_dig + tree_words;
-    uint32_t* d_fdig = d_dig + 2 * tree_words;
+    uint32_t* d_pdig = d_dig + 2 * tree_words;          // LogUp only
+    uint32_t* d_fdig = d_dig + n_trees * tree_words;
+    uint32_t* d_perm = p->perm.as<uint32_t>();
+    uint32_t* d_plde = p->plde.as<uint32_t>();
     uint32_t* d_q = p->q.as<uint32_t>();
     uint32_t* d_qcoef = p->qcoef.as<uint32_t>();
     uint32_t* d_qlde = p->qlde.as<uint32_t>();
     bb::Ext* d_v = p->ext_arena.as<bb::Ext>();          // FRI layers, consecutive
     bb::Ext* d_weights = d_v + 2 * N;
-    bb::Ext* d_scratch = p->misc.as<bb::Ext>();          // K * n_chunks
-    bb::Ext* d_opened = d_scratch + (size_t)K * n_chunks; // K
+    bb::Ext* d_weights2 = d_weights + H;                   // LogUp: weights at g*zeta
+    bb::Ext* d_rowsum = d_weights2 + H;                    // LogUp: per-row sums, then block totals
+    bb::Ext* d_scratch = p->misc.as<bb::Ext>();            // dot_cols * n_chunks
+    bb::Ext* d_opened = d_scratch + (size_t)dot_cols * n_chunks;  // K
     bb::Ext* d_gpow = d_opened + K;                        // K
-    bb::Ext* d_apow = d_gpow + K;                          // nc
-    uint8_t* d_tail = reinterpret_cast<uint8_t*>(d_apow + nc + 8);
+    bb::Ext* d_apow = d_gpow + K;                          // M
+    bb::Ext* d_blpow = d_apow + M + 4;                     // max_args + 2
+    uint8_t* d_tail = reinterpret_cast<uint8_t*>(d_blpow + p->max_args + 8);
 
     std::vector<uint32_t>& pf = p->proof;
     pf.clear();
@@ -193,15 +260,24 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     auto put_monty = [&](const uint32_t* w, size_t n) { for (size_t i = 0; i < n; ++i) pf.push_back(bb::from_monty(w[i])); };
 
     Challenger ch;
-    for (uint32_t x : {kMagic % bb::P, log_h, W, nc, p->cfg.num_queries, p->cfg.pow_bits}) ch.observe_canonical(x);
-    for (uint32_t x : {kMagic, log_h, W, nc, p->cfg.num_queries, p->cfg.pow_bits}) put(x);
+    if (lg) {
+        for (uint32_t x : {kMagic2 % bb::P, log_h, W, nc, n_int, p->cfg.num_queries, p->cfg.pow_bits}) ch.observe_canonical(x);
+        for (uint32_t x : {kMagic2, log_h, W, nc, n_int, p->cfg.num_queries, p->cfg.pow_bits}) put(x);
+    } else {
+        for (uint32_t x : {kMagic % bb::P, log_h, W, nc, p->cfg.num_queries, p->cfg.pow_bits}) ch.observe_canonical(x);
+        for (uint32_t x : {kMagic, log_h, W, nc, p->cfg.num_queries, p->cfg.pow_bits}) put(x);
+    }
 
     // ---- 1. trace: coefficients, LDE, commitment ---------------------------------------------
-    for (size_t c0 = 0; c0 < W; c0 += panel_cols) {
-        const uint32_t pc = (uint32_t)(W - c0 < panel_cols ? W - c0 : panel_cols);
-        TRY(intt_dif(d_trace + c0 * H, d_coef, H, H, pc, (int)log_h));
-        TRY(coset_lde_from_coeffs(d_coef, d_lde + c0 * N, H, N, pc, (int)log_h));
-    }
+    auto lde_matrix = [&](const uint32_t* m, uint32_t cols, uint32_t* out) -> int {
+        for (size_t c0 = 0; c0 < cols; c0 += panel_cols) {
+            const uint32_t pc = (uint32_t)(cols - c0 < panel_cols ? cols - c0 : panel_cols);
+            TRY(intt_dif(m + c0 * H, d_coef, H, H, pc, (int)log_h));
+            TRY(coset_lde_from_coeffs(d_coef, out + c0 * N, H, N, pc, (int)log_h));
+        }
+        return 0;
+    };
+    TRY(lde_matrix(d_trace, W, d_lde));
     TRY(merkle_commit_matrix(d_lde, N, W, N, d_tdig));
     uint32_t root[8];
     PW_HIP_TRY(hipMemcpyAsync(root, d_tdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
@@ -209,13 +285,38 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     put_monty(root, 8);
     ch.observe_words(root, 8);
 
+    // ---- 1b. LogUp: permutation trace, its LDE and commitment ---------------------------------------
+    bb::Ext al = bb::ext_zero(), S = bb::ext_zero();
+    LogupProgram lp{p->d_inter, n_int, p->d_ixspans, p->d_icode};
+    if (lg) {
+        al = ch.sample_ext();
+        const bb::Ext bl = ch.sample_ext();
+        std::vector<bb::Ext> blpow(p->max_args + 2);
+        { bb::Ext b = bb::ext_one(); for (auto& x : blpow) { x = b; b = bb::ext_mul(b, bl); } }
+        PW_HIP_TRY(hipMemcpyAsync(d_blpow, blpow.data(), blpow.size() * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
+        PW_HIP_TRY(hipStreamSynchronize(st));
+        TRY(logup_perm_trace(d_trace, H, lp, al, d_blpow, d_perm, d_rowsum, d_rowsum + H));
+        TRY(lde_matrix(d_perm, Wp, d_plde));
+        TRY(merkle_commit_matrix(d_plde, N, Wp, N, d_pdig));
+        uint32_t sw[4];
+        PW_HIP_TRY(hipMemcpyAsync(root, d_pdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
+        for (int k = 0; k < 4; ++k)  // S = phi(last row)
+            PW_HIP_TRY(hipMemcpyAsync(&sw[k], d_perm + ((size_t)(4 * n_int + k) * H + (H - 1)), 4, hipMemcpyDeviceToHost, st));
+        PW_HIP_TRY(hipStreamSynchronize(st));
+        put_monty(root, 8);
+        ch.observe_words(root, 8);
+        for (int k = 0; k < 4; ++k) S.c[k] = sw[k];
+        put_monty(S.c, 4);
+        ch.observe_ext(S);
+    }
+
     // ---- 2. quotient ---------------------------------------------------------------------------
     const bb::Ext alpha = ch.sample_ext();
     {
-        std::vector<bb::Ext> apow(nc ? nc : 1);
+        std::vector<bb::Ext> apow(M ? M : 1);
         bb::Ext a = bb::ext_one();
-        for (size_t j = nc; j-- > 0;) { apow[j] = a; a = bb::ext_mul(a, alpha); }
-        if (nc) PW_HIP_TRY(hipMemcpyAsync(d_apow, apow.data(), nc * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
+        for (size_t j = M; j-- > 0;) { apow[j] = a; a = bb::ext_mul(a, alpha); }
+        if (M) PW_HIP_TRY(hipMemcpyAsync(d_apow, apow.data(), M * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
         PW_HIP_TRY(hipStreamSynchronize(st));  // apow is a stack-local vector
     }
     const uint32_t s_m = bb::to_monty(field::kCosetShift);
@@ -225,7 +326,10 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const uint32_t zinv_even = bb::inv(bb::sub(sH, one));
     const uint32_t zinv_odd = bb::inv(bb::sub(bb::neg(sH), one));
     ConstraintProgram prog{p->d_bytecode, p->d_spans, nc, p->is_xbc};
-    TRY(quotient_eval(d_lde, N, prog, d_apow, zinv_even, zinv_odd, d_q));
+    if (lg)
+        TRY(quotient_eval_logup(d_lde, d_plde, N, logN, prog, lp, d_apow, al, d_blpow, S, bb::sub(sH, one), bb::sub(bb::neg(sH), one), d_q));
+    else
+        TRY(quotient_eval(d_lde, N, prog, d_apow, zinv_even, zinv_odd, d_q));
     TRY(intt_dif(d_q, d_q, N, N, 4, logN));
     TRY(quotient_split(d_q, H, (int)log_h, d_qcoef));
     TRY(coset_lde_from_coeffs(d_qcoef, d_qlde, H, N, 8, (int)log_h));
@@ -239,27 +343,44 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const bb::Ext zeta = ch.sample_ext();
     // trace columns: barycentric evaluation straight from the caller's trace (natural order on <g_n>);
     // quotient chunks: from their (small) coefficient arrays
+    // internal order of `opened` (= order of the gamma powers): main | perm@zeta | quotient | perm@g*zeta
+    const bb::Ext gzeta = bb::ext_scale(zeta, field::root_of_unity((int)log_h));
     TRY(barycentric_weights(zeta, (int)log_h, d_weights));
     TRY(ext_dot_columns(d_trace, H, W, H, d_weights, d_opened, d_scratch));
+    if (lg) {
+        TRY(ext_dot_columns(d_perm, H, Wp, H, d_weights, d_opened + W, d_scratch));
+        TRY(barycentric_weights(gzeta, (int)log_h, d_weights2));
+        TRY(ext_dot_columns(d_perm, H, Wp, H, d_weights2, d_opened + K1, d_scratch));
+    }
     TRY(zeta_weights(zeta, (int)log_h, d_weights));
-    TRY(ext_dot_columns(d_qcoef, H, 8, H, d_weights, d_opened + W, d_scratch));
+    TRY(ext_dot_columns(d_qcoef, H, 8, H, d_weights, d_opened + W + Wp, d_scratch));
     std::vector<bb::Ext> opened(K);
     PW_HIP_TRY(hipMemcpyAsync(opened.data(), d_opened, K * sizeof(bb::Ext), hipMemcpyDeviceToHost, st));
     PW_HIP_TRY(hipStreamSynchronize(st));
-    for (auto& e : opened) { put_monty(e.c, 4); ch.observe_ext(e); }
+    {
+        // proof / transcript order: main, perm@zeta, perm@g*zeta, quotient
+        auto emit = [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) { put_monty(opened[k].c, 4); ch.observe_ext(opened[k]); } };
+        emit(0, (size_t)W + Wp);
+        emit(K1, K);
+        emit((size_t)W + Wp, K1);
+    }
 
     // ---- 4. reduced-opening vector -------------------------------------------------------------
     const bb::Ext gamma = ch.sample_ext();
-    bb::Ext opened_sum = bb::ext_zero();
+    bb::Ext opened_sum = bb::ext_zero(), opened_sum2 = bb::ext_zero();
     {
         std::vector<bb::Ext> gpow(K);
         bb::Ext g = bb::ext_one();
         for (uint32_t k = 0; k < K; ++k) { gpow[k] = g; g = bb::ext_mul(g, gamma); }
-        for (uint32_t k = 0; k < K; ++k) opened_sum = bb::ext_add(opened_sum, bb::ext_mul(gpow[k], opened[k]));
+        for (uint32_t k = 0; k < K1; ++k) opened_sum = bb::ext_add(opened_sum, bb::ext_mul(gpow[k], opened[k]));
+        for (uint32_t k = K1; k < K; ++k) opened_sum2 = bb::ext_add(opened_sum2, bb::ext_mul(gpow[k], opened[k]));
         PW_HIP_TRY(hipMemcpyAsync(d_gpow, gpow.data(), K * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
         PW_HIP_TRY(hipStreamSynchronize(st));
     }
-    TRY(deep_quotient(d_lde, W, d_qlde, 8, N, logN, d_gpow, opened_sum, zeta, d_v));
+    if (lg)
+        TRY(deep_quotient_logup(d_lde, W, d_plde, Wp, d_qlde, N, logN, d_gpow, opened_sum, opened_sum2, zeta, gzeta, d_v));
+    else
+        TRY(deep_quotient(d_lde, W, d_qlde, 8, N, logN, d_gpow, opened_sum, zeta, d_v));
 
     // ---- 5. FRI commit phase --------------------------------------------------------------------
     std::vector<size_t> layer_off(log_h + 1), tree_off(log_h);  // offsets in Ext / in words
@@ -309,14 +430,17 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         // layout of the tail buffer
         uint32_t* d_idx = reinterpret_cast<uint32_t*>(d_tail);
         uint32_t* d_trows = d_idx + nq;
-        uint32_t* d_qrows = d_trows + (size_t)nq * W;
-        uint64_t* d_offs = reinterpret_cast<uint64_t*>(d_qrows + (size_t)nq * 8 + ((nq * (W + 9)) & 1));
+        uint32_t* d_prows = d_trows + (size_t)nq * W;
+        uint32_t* d_qrows = d_prows + (size_t)nq * Wp;
+        uint64_t* d_offs = reinterpret_cast<uint64_t*>(d_qrows + (size_t)nq * 8 + (((size_t)nq * (W + Wp + 9)) & 1));
         // digest records (8 words) then FRI sibling records (4 words)
         std::vector<uint64_t> dig_offs, ext_offs;
         for (uint32_t qi = 0; qi < nq; ++qi) {
             const size_t i = idx[qi];
-            for (int tree = 0; tree < 2; ++tree) {
-                const size_t base = tree ? tree_words : 0;
+            // proof order: trace path, (perm path), quotient path; arena order: trace | quotient | perm
+            for (int tree : {0, 2, 1}) {
+                if (tree == 2 && !lg) continue;
+                const size_t base = (size_t)tree * tree_words;
                 for (int l = 0; l < logN; ++l)
                     dig_offs.push_back(base + merkle_level_offset(N, l) + (((i >> l) ^ 1) * 8));
             }
@@ -325,7 +449,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
                 ext_offs.push_back((layer_off[l] + (pp ^ half)) * 4);
                 const size_t leaf = pp & (half - 1);
                 for (int lv = 0; lv < logN - 1 - (int)l; ++lv)
-                    dig_offs.push_back(2 * tree_words + tree_off[l] + merkle_level_offset(half, lv) + (((leaf >> lv) ^ 1) * 8));
+                    dig_offs.push_back(n_trees * tree_words + tree_off[l] + merkle_level_offset(half, lv) + (((leaf >> lv) ^ 1) * 8));
             }
         }
         const size_t n_dig = dig_offs.size(), n_ext = ext_offs.size();
@@ -337,14 +461,16 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         PW_HIP_TRY(hipMemcpyAsync(d_dig_offs, dig_offs.data(), n_dig * 8, hipMemcpyHostToDevice, st));
         if (n_ext) PW_HIP_TRY(hipMemcpyAsync(d_ext_offs, ext_offs.data(), n_ext * 8, hipMemcpyHostToDevice, st));
         TRY(gather_rows(d_lde, N, W, d_idx, nq, d_trows));
+        if (lg) TRY(gather_rows(d_plde, N, Wp, d_idx, nq, d_prows));
         TRY(gather_rows(d_qlde, N, 8, d_idx, nq, d_qrows));
         hipLaunchKernelGGL(gather_records_kernel, dim3(div_up(n_dig * 8, 256)), dim3(256), 0, st, d_dig, d_dig_offs, 8u,
                            (uint32_t)n_dig, d_dig_out);
         if (n_ext)
             hipLaunchKernelGGL(gather_records_kernel, dim3(div_up(n_ext * 4, 256)), dim3(256), 0, st,
                                reinterpret_cast<const uint32_t*>(d_v), d_ext_offs, 4u, (uint32_t)n_ext, d_ext_out);
-        std::vector<uint32_t> trows((size_t)nq * W), qrows((size_t)nq * 8), dig(n_dig * 8), ext(n_ext * 4 + 1);
+        std::vector<uint32_t> trows((size_t)nq * W), prows((size_t)nq * Wp + 1), qrows((size_t)nq * 8), dig(n_dig * 8), ext(n_ext * 4 + 1);
         PW_HIP_TRY(hipMemcpyAsync(trows.data(), d_trows, trows.size() * 4, hipMemcpyDeviceToHost, st));
+        if (lg) PW_HIP_TRY(hipMemcpyAsync(prows.data(), d_prows, (size_t)nq * Wp * 4, hipMemcpyDeviceToHost, st));
         PW_HIP_TRY(hipMemcpyAsync(qrows.data(), d_qrows, qrows.size() * 4, hipMemcpyDeviceToHost, st));
         PW_HIP_TRY(hipMemcpyAsync(dig.data(), d_dig_out, n_dig * 32, hipMemcpyDeviceToHost, st));
         if (n_ext) PW_HIP_TRY(hipMemcpyAsync(ext.data(), d_ext_out, n_ext * 16, hipMemcpyDeviceToHost, st));
@@ -354,6 +480,10 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
             put(idx[qi]);
             put_monty(&trows[(size_t)qi * W], W);
             put_monty(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
+            if (lg) {
+                put_monty(&prows[(size_t)qi * Wp], Wp);
+                put_monty(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
+            }
             put_monty(&qrows[(size_t)qi * 8], 8);
             put_monty(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
             for (uint32_t l = 0; l < log_h; ++l) {

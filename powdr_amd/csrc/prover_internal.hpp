@@ -71,6 +71,27 @@ int deep_quotient(const uint32_t* lde_a, uint32_t wa, const uint32_t* lde_b, uin
 int fri_fold(const bb::Ext* v, size_t half, int log_size, uint32_t shift, bb::Ext beta, bb::Ext* out);
 // gather row `idx` of a column-major matrix into out[0..width)
 int gather_rows(const uint32_t* m, size_t height, uint32_t width, const uint32_t* d_indices, uint32_t n_idx, uint32_t* out);
+// ---- logup_kernels.hip (pw-stark v0 + LogUp) ----------------------------------------------------------
+struct LogupInteraction {
+    uint32_t bus_monty;   // bus id as a field element (Montgomery)
+    uint32_t n_args;
+    uint32_t first_span;  // index into xspans: [mult, arg0, arg1, ...]
+};
+struct LogupProgram {
+    const LogupInteraction* d_inter;
+    uint32_t n;
+    const uint32_t* d_xspans;  // {off, len} in xbc instructions
+    const uint32_t* d_code;    // xbc code, column-index operands
+};
+// perm (4(n+1) columns x H): q_i coordinates then phi; d_rowsum: H Ext scratch; d_block_totals: H/4096+1 Ext scratch
+int logup_perm_trace(const uint32_t* trace, size_t H, const LogupProgram& lp, bb::Ext al, const bb::Ext* d_blpow, uint32_t* perm,
+                     bb::Ext* d_rowsum, bb::Ext* d_block_totals);
+int quotient_eval_logup(const uint32_t* lde, const uint32_t* plde, size_t N, int logN, const ConstraintProgram& prog,
+                        const LogupProgram& lp, const bb::Ext* d_apow, bb::Ext al, const bb::Ext* d_blpow, bb::Ext S,
+                        uint32_t zval_even, uint32_t zval_odd, uint32_t* q);
+int deep_quotient_logup(const uint32_t* lde, uint32_t W, const uint32_t* plde, uint32_t Wp, const uint32_t* qlde, size_t N, int logN,
+                        const bb::Ext* d_gpow, bb::Ext sum1, bb::Ext sum2, bb::Ext zeta, bb::Ext gzeta, bb::Ext* v);
+
 // proof-of-work search: smallest witness w (checked in blocks) such that the transcript state,
 // after observing w, samples a value with `bits` low zero bits. state = 16 words sponge state,
 // in_len = number of pending absorbed words (they are in pending[]).

@@ -14,11 +14,14 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_merkle_commit", "pw_poseidon2_permute_host"]
 
 lib.pw_prover_create.restype = C.c_void_p
 lib.pw_prover_create.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+lib.pw_prover_create_logup.restype = C.c_void_p
+lib.pw_prover_create_logup.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
 lib.pw_prover_destroy.argtypes = [C.c_void_p]
 lib.pw_prover_prove.restype = C.c_int
 lib.pw_prover_prove.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]
@@ -56,15 +59,26 @@ def poseidon2_host(state) -> np.ndarray:
 
 
 class Prover:
-    """One AIR = one prover (constraint programs fixed at construction)."""
+    """One AIR = one prover (constraint programs fixed at construction).
 
-    def __init__(self, width: int, cons_bytecode, cons_spans, num_queries: int = 100, pow_bits: int = 0):
+    interactions = (inter[n x 3] = {bus, n_args, first span}, spans[m x 2], bytecode) — the output of
+    host.compile_bus(apc, 1) — switches the prover to "pw-stark v0 + LogUp" (proof magic PWS2)."""
+
+    def __init__(self, width: int, cons_bytecode, cons_spans, num_queries: int = 100, pow_bits: int = 0, interactions=None):
         bc = np.ascontiguousarray(cons_bytecode, dtype=np.uint32)
         sp = np.ascontiguousarray(cons_spans, dtype=np.uint32).reshape(-1, 2)
         cfg = PwStarkConfig(num_queries, pow_bits)
         self.width = width
-        self._h = lib.pw_prover_create(C.byref(cfg), width, bc.ctypes.data_as(C.c_void_p), len(bc),
-                                       sp.ctypes.data_as(C.c_void_p), len(sp))
+        if interactions is None:
+            self._h = lib.pw_prover_create(C.byref(cfg), width, bc.ctypes.data_as(C.c_void_p), len(bc),
+                                           sp.ctypes.data_as(C.c_void_p), len(sp))
+        else:
+            it = np.ascontiguousarray(interactions[0], dtype=np.uint32).reshape(-1, 3)
+            isp = np.ascontiguousarray(interactions[1], dtype=np.uint32).reshape(-1, 2)
+            ibc = np.ascontiguousarray(interactions[2], dtype=np.uint32)
+            self._h = lib.pw_prover_create_logup(C.byref(cfg), width, bc.ctypes.data_as(C.c_void_p), len(bc),
+                                                 sp.ctypes.data_as(C.c_void_p), len(sp), it.ctypes.data_as(C.c_void_p), len(it),
+                                                 isp.ctypes.data_as(C.c_void_p), len(isp), ibc.ctypes.data_as(C.c_void_p), len(ibc))
         if not self._h:
             raise RuntimeError("pw_prover_create failed")
 

@@ -105,6 +105,37 @@ def test_proof_bytes_match_oracle(gpu, shape, calls, nq, pow_bits):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,calls,nq,pow_bits", [("T0", 2, 3, 0), ("T0", 7, 4, 0), ("T0", 64, 5, 5), ("T1", 100, 6, 0), ("T1", 1000, 8, 0),
+                                                      ("T1", 5000, 10, 0)])
+def test_logup_proof_bytes_match_oracle(gpu, shape, calls, nq, pow_bits):
+    """pw-stark v0 + LogUp: the HIP proof (permutation columns, prefix scan, extended quotient, openings at
+    zeta and g*zeta, third Merkle tree) equals the oracle's byte for byte, and the oracle's verifier accepts it."""
+    torch, abi, prover = gpu
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+
+    s = synth.generate(shape, seed=13)
+    apc, idx, trace, _, _ = run_oracle_gpu_convention(s, calls, seed=13)
+    W, H = trace.shape
+    log_h = H.bit_length() - 1
+    bc, spans = sm.compile_constraints(apc, idx)
+    inter, ispans, ibc = sm.compile_interactions(apc, idx)
+    flat = np.ascontiguousarray(trace).reshape(-1)
+    want = sm.prove_logup(flat, W, log_h, bc, spans, inter, ispans, ibc, num_queries=nq, pow_bits=pow_bits)
+    assert sm.verify_logup(want, W, log_h, bc, spans, inter, ispans, ibc, num_queries=nq, pow_bits=pow_bits) == 0
+    pr = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits, interactions=(inter, ispans, ibc))
+    d_t = to_dev(torch, flat)
+    got = pr.prove(d_t.data_ptr(), log_h)
+    assert len(got) == len(want)
+    assert (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
+    assert (pr.prove(d_t.data_ptr(), log_h) == want).all()
+    pr.close()
+    # the constraints-only prover is unaffected
+    pr0 = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits)
+    assert (pr0.prove(d_t.data_ptr(), log_h) == sm.prove(flat, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits)).all()
+    pr0.close()
+
+
+@pytest.mark.gpu
 def test_large_proof_verifies(gpu):
     """2^16-row, 160-column trace: too slow to prove on the CPU oracle in a test, so the HIP
     proof is checked with the oracle's VERIFIER (accept) and a corrupted trace (reject)."""
