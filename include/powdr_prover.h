@@ -52,6 +52,13 @@ PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t width, const
                                  size_t bytecode_len, const uint32_t* cons_spans, size_t n_constraints,
                                  const uint32_t* interactions, size_t n_interactions, const uint32_t* inter_spans,
                                  size_t n_inter_spans, const uint32_t* inter_bytecode, size_t inter_bytecode_len);
+/* LogUp across the AIRs of a segment: the challenges of the bus argument are drawn from the 8-word `bus seed`
+ * alone, so every AIR proven with the same seed uses the same pair and the per-AIR cumulative sums add up.
+ * Flow: pw_prover_trace_root for every AIR -> seed = a digest over all roots (the caller's choice; the segment
+ * verifier must recompute it) -> pw_prover_set_bus_seed + pw_prover_prove per AIR. Without a seed (NULL, the
+ * default) an AIR uses its own trace root. Canonical words. */
+int pw_prover_trace_root(PwProver* p, const uint32_t* d_trace, uint32_t log_height, uint32_t* root8);
+int pw_prover_set_bus_seed(PwProver* p, const uint32_t* seed8);
 void pw_prover_destroy(PwProver* p);
 
 /* Prove one trace (column-major, width x 2^log_height, Montgomery words, device).
@@ -74,6 +81,18 @@ int pw_prover_check_constraints(PwProver* p, const uint32_t* d_trace, uint32_t l
 int pw_verify(const PwStarkConfig* cfg, uint32_t width, uint32_t log_height, const uint32_t* cons_bytecode,
               size_t bytecode_len, const uint32_t* cons_spans, size_t n_constraints, const uint32_t* proof_words,
               size_t n_words);
+
+/* Verify a "pw-stark v0 + LogUp" proof (pw_prover_create_logup). Interaction arguments as for the prover.
+ * Additional failure codes: 11 = permutation-matrix opening, 12 = the proof's bus seed is not
+ * `expected_bus_seed` (NULL: not the proof's own trace root). On success `cumulative_sum` (4 canonical words,
+ * may be NULL) receives this AIR's bus sum S = sum_rows sum_i m_i / d_i and `trace_root` (8 words, may be NULL)
+ * its trace commitment; the caller accepts a segment when every proof verifies against the seed recomputed
+ * from all the trace roots and the sums add up to zero (every send matched by a receive). */
+int pw_verify_logup(const PwStarkConfig* cfg, uint32_t width, uint32_t log_height, const uint32_t* cons_bytecode,
+                    size_t bytecode_len, const uint32_t* cons_spans, size_t n_constraints, const uint32_t* interactions,
+                    size_t n_interactions, const uint32_t* inter_spans, size_t n_inter_spans,
+                    const uint32_t* inter_bytecode, size_t inter_bytecode_len, const uint32_t* expected_bus_seed,
+                    const uint32_t* proof_words, size_t n_words, uint32_t* cumulative_sum, uint32_t* trace_root);
 
 /* Bytes of device memory the prover currently holds. */
 size_t pw_prover_device_bytes(const PwProver* p);

@@ -124,12 +124,22 @@ def compile_interactions(apc: om.Apc, idx: dict):
     return om.compile_bus(apc, idx, 1)
 
 
-def prove_logup(trace_cm, width, log_h, cons_bc, cons_spans, inter, ispans, ibc, num_queries=8, pow_bits=0) -> np.ndarray:
+def _seed(bus_seed):
+    if bus_seed is None:
+        return None, C.c_void_p(None)
+    a = np.ascontiguousarray(bus_seed, dtype=np.uint32)
+    assert a.shape == (8,)
+    return a, _p(a)
+
+
+def prove_logup(trace_cm, width, log_h, cons_bc, cons_spans, inter, ispans, ibc, num_queries=8, pow_bits=0, bus_seed=None) -> np.ndarray:
+    """bus_seed: 8 canonical words shared by all AIRs of a segment (None: the AIR's own trace root)."""
     lib = _lib()
+    keep, seed_p = _seed(bus_seed)
     arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in (trace_cm, cons_bc, cons_spans, inter, ispans, ibc)]
     t, bc, sp, it, isp, ib = arrs
     args = (C.c_uint32(num_queries), C.c_uint32(pow_bits), _p(t), C.c_uint32(width), C.c_uint32(log_h), _p(bc), _p(sp),
-            C.c_size_t(len(sp.reshape(-1, 2))), _p(it), C.c_size_t(len(it.reshape(-1, 3))), _p(isp), _p(ib))
+            C.c_size_t(len(sp.reshape(-1, 2))), _p(it), C.c_size_t(len(it.reshape(-1, 3))), _p(isp), _p(ib), seed_p)
     cap = 1 << 18
     while True:
         buf = np.zeros(cap, np.uint32)
@@ -139,9 +149,10 @@ def prove_logup(trace_cm, width, log_h, cons_bc, cons_spans, inter, ispans, ibc,
         cap = int(n)
 
 
-def verify_logup(proof, width, log_h, cons_bc, cons_spans, inter, ispans, ibc, num_queries=8, pow_bits=0) -> int:
+def verify_logup(proof, width, log_h, cons_bc, cons_spans, inter, ispans, ibc, num_queries=8, pow_bits=0, bus_seed=None) -> int:
+    keep, seed_p = _seed(bus_seed)
     arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in (proof, cons_bc, cons_spans, inter, ispans, ibc)]
     pr, bc, sp, it, isp, ib = arrs
     return int(_lib().or_verify_logup(C.c_uint32(num_queries), C.c_uint32(pow_bits), _p(pr), C.c_size_t(len(pr)), C.c_uint32(width),
                                       C.c_uint32(log_h), _p(bc), _p(sp), C.c_size_t(len(sp.reshape(-1, 2))), _p(it),
-                                      C.c_size_t(len(it.reshape(-1, 3))), _p(isp), _p(ib)))
+                                      C.c_size_t(len(it.reshape(-1, 3))), _p(isp), _p(ib), seed_p))

@@ -634,7 +634,20 @@ void observe_instance2(Challenger& ch, u32 log_h, u32 width, u32 nc, u32 n_int, 
     ch.observe(cfg.num_queries); ch.observe(cfg.pow_bits);
 }
 
-std::vector<u32> prove_logup(const Config& cfg, const u32* trace, u32 width, u32 log_h, const Program& prog, const Interactions& I) {
+/* The LogUp challenges (alpha_l, beta_l) come from a transcript of their own that observes only the 8-word
+ * `bus seed`, so that every AIR of a segment draws the SAME pair and the per-AIR cumulative sums can be added up.
+ * The seed is a digest over the trace commitments of all AIRs on the bus (the segment verifier recomputes it from
+ * the trace roots in the proofs); a lone AIR uses its own trace root. */
+void bus_challenges(const Digest& seed, Ext& al, Ext& bl) {
+    Challenger cb;
+    cb.observe(MAGIC2 % P);
+    cb.observe_digest(seed);
+    al = cb.sample_ext();
+    bl = cb.sample_ext();
+}
+
+std::vector<u32> prove_logup(const Config& cfg, const u32* trace, u32 width, u32 log_h, const Program& prog, const Interactions& I,
+                             const u32* bus_seed) {
     const size_t H = (size_t)1 << log_h, N = 2 * H;
     const int logN = (int)log_h + 1;
     const u32 n_int = (u32)I.n;
@@ -658,7 +671,12 @@ std::vector<u32> prove_logup(const Config& cfg, const u32* trace, u32 width, u32
     ch.observe_digest(t_tree.root());
 
     /* 2. permutation (LogUp) trace */
-    Ext al = ch.sample_ext(), bl = ch.sample_ext();
+    Digest seed = t_tree.root();
+    if (bus_seed) memcpy(seed.data(), bus_seed, 32);
+    pf.put(seed);
+    ch.observe_digest(seed);
+    Ext al, bl;
+    bus_challenges(seed, al, bl);
     std::vector<Ext> blpow(max_args(I) + 2);
     { Ext b = ext_one(); for (auto& x : blpow) { x = b; b = ext_mul(b, bl); } }
     std::vector<u32> perm(Wp * H);
@@ -854,7 +872,8 @@ std::vector<u32> prove_logup(const Config& cfg, const u32* trace, u32 width, u32
     return pf.w;
 }
 
-int verify_logup(const Config& cfg, const u32* proof, size_t len, u32 width, u32 log_h, const Program& prog, const Interactions& I) {
+int verify_logup(const Config& cfg, const u32* proof, size_t len, u32 width, u32 log_h, const Program& prog, const Interactions& I,
+                 const u32* expected_seed) {
     const size_t H = (size_t)1 << log_h, N = 2 * H;
     const int logN = (int)log_h + 1;
     const u32 n_int = (u32)I.n;
@@ -871,7 +890,11 @@ int verify_logup(const Config& cfg, const u32* proof, size_t len, u32 width, u32
         observe_instance2(ch, log_h, width, (u32)prog.n, n_int, cfg);
         Digest t_root = get_digest();
         ch.observe_digest(t_root);
-        Ext al = ch.sample_ext(), bl = ch.sample_ext();
+        Digest seed = get_digest();
+        if (expected_seed ? memcmp(seed.data(), expected_seed, 32) != 0 : seed != t_root) return 12;
+        ch.observe_digest(seed);
+        Ext al, bl;
+        bus_challenges(seed, al, bl);
         Digest p_root = get_digest();
         ch.observe_digest(p_root);
         Ext S = get_ext();
@@ -1045,21 +1068,22 @@ int or_verify(uint32_t num_queries, uint32_t pow_bits, const uint32_t* proof, si
  * [mult, arg0, arg1, ...] per interaction; bytecode with column-index operands (compile_bus with height 1). */
 size_t or_prove_logup(uint32_t num_queries, uint32_t pow_bits, const uint32_t* trace, uint32_t width, uint32_t log_h,
                       const uint32_t* cons_bc, const uint32_t* cons_spans, size_t n_constraints, const uint32_t* inter,
-                      size_t n_inter, const uint32_t* ispans, const uint32_t* ibc, uint32_t* proof, size_t cap) {
+                      size_t n_inter, const uint32_t* ispans, const uint32_t* ibc, const uint32_t* bus_seed /* 8 words or NULL */,
+                      uint32_t* proof, size_t cap) {
     Config cfg{num_queries, pow_bits};
     Program pr{cons_bc, cons_spans, n_constraints};
     Interactions I{inter, n_inter, ispans, ibc};
-    std::vector<u32> w = prove_logup(cfg, trace, width, log_h, pr, I);
+    std::vector<u32> w = prove_logup(cfg, trace, width, log_h, pr, I, bus_seed);
     if (w.size() <= cap) memcpy(proof, w.data(), w.size() * 4);
     return w.size();
 }
 int or_verify_logup(uint32_t num_queries, uint32_t pow_bits, const uint32_t* proof, size_t len, uint32_t width, uint32_t log_h,
                     const uint32_t* cons_bc, const uint32_t* cons_spans, size_t n_constraints, const uint32_t* inter,
-                    size_t n_inter, const uint32_t* ispans, const uint32_t* ibc) {
+                    size_t n_inter, const uint32_t* ispans, const uint32_t* ibc, const uint32_t* expected_seed /* or NULL */) {
     Config cfg{num_queries, pow_bits};
     Program pr{cons_bc, cons_spans, n_constraints};
     Interactions I{inter, n_inter, ispans, ibc};
-    return verify_logup(cfg, proof, len, width, log_h, pr, I);
+    return verify_logup(cfg, proof, len, width, log_h, pr, I, expected_seed);
 }
 
 }  // extern "C"

@@ -12,7 +12,8 @@
 namespace {
 
 using bb::Ext;
-constexpr uint32_t kMagic = 0x31535750u;
+constexpr uint32_t kMagic = 0x31535750u;   // "PWS1"
+constexpr uint32_t kMagic2 = 0x32535750u;  // "PWS2": with the LogUp extension
 
 struct Transcript {
     uint32_t st[16];
@@ -82,14 +83,35 @@ bool eval_ext(const uint32_t* bc, uint32_t len, const Ext* vals, uint32_t width,
     return true;
 }
 
-}  // namespace
+// the AIR's bus interactions as the verifier is told them (pw_prover_create_logup's arguments)
+struct Interactions {
+    const uint32_t* inter;   // n x {bus, n_args, first span}
+    size_t n;
+    const uint32_t* spans;   // {off, len} pairs: [mult, arg0, ...] per interaction
+    size_t n_spans;
+    const uint32_t* bc;
+    size_t bc_len;
+};
 
 // Returns 0 if the proof is valid, a positive code naming the first failed check otherwise:
 // 1 header, 2 constraint identity at zeta, 3 proof of work, 4 query index, 5/6 trace/quotient opening,
-// 7 FRI layer opening, 8 final polynomial, 9 trailing words, 10 truncated / malformed.
-extern "C" int pw_verify(const PwStarkConfig* cfg, uint32_t width, uint32_t log_h, const uint32_t* bc, size_t bc_len,
-                         const uint32_t* spans, size_t n_constraints, const uint32_t* proof, size_t len) {
+// 7 FRI layer opening, 8 final polynomial, 9 trailing words, 10 truncated / malformed, 11 permutation opening, 12 bus seed.
+int verify_impl(const PwStarkConfig* cfg, uint32_t width, uint32_t log_h, const uint32_t* bc, size_t bc_len, const uint32_t* spans,
+                size_t n_constraints, const Interactions* lg, const uint32_t* expected_seed, const uint32_t* proof, size_t len,
+                uint32_t* sum_out, uint32_t* trace_root_out) {
     if (!cfg || !proof || log_h < 1 || log_h > 26) return 10;
+    const uint32_t n_int = lg ? (uint32_t)lg->n : 0;
+    const size_t Wp = lg ? 4 * ((size_t)n_int + 1) : 0;
+    uint32_t max_args = 0;
+    if (lg) {
+        for (size_t i = 0; i < lg->n; ++i) {
+            const uint32_t na = lg->inter[3 * i + 1], first = lg->inter[3 * i + 2];
+            if ((size_t)first + 1 + na > lg->n_spans) return 10;
+            for (uint32_t k = 0; k <= na; ++k)
+                if ((size_t)lg->spans[2 * (first + k)] + lg->spans[2 * (first + k) + 1] > lg->bc_len) return 10;
+            if (na > max_args) max_args = na;
+        }
+    }
     const size_t H = (size_t)1 << log_h, N = 2 * H;
     const int logN = (int)log_h + 1;
     size_t pos = 0;
@@ -100,24 +122,53 @@ extern "C" int pw_verify(const PwStarkConfig* cfg, uint32_t width, uint32_t log_
     auto get_digest = [&]() { Digest d; for (auto& w : d.w) w = get_m(); return d; };
     auto get_ext = [&]() { Ext e; for (auto& w : e.c) w = get_m(); return e; };
 
-    const uint32_t hdr[6] = {kMagic, log_h, width, (uint32_t)n_constraints, cfg->num_queries, cfg->pow_bits};
+    std::vector<uint32_t> hdr = {lg ? kMagic2 : kMagic, log_h, width, (uint32_t)n_constraints};
+    if (lg) hdr.push_back(n_int);
+    hdr.push_back(cfg->num_queries);
+    hdr.push_back(cfg->pow_bits);
     for (uint32_t h : hdr) if (get() != h) return 1;
     Transcript ch;
-    ch.observe(bb::to_monty(kMagic % bb::P));
-    for (int i = 1; i < 6; ++i) ch.observe(bb::to_monty(hdr[i] % bb::P));
+    for (uint32_t h : hdr) ch.observe(bb::to_monty(h % bb::P));
 
     const Digest t_root = get_digest();
     ch.observe_n(t_root.w, 8);
+    Ext al = bb::ext_zero(), bl = bb::ext_zero(), S = bb::ext_zero();
+    Digest p_root{};
+    if (lg) {
+        // bus challenges: own transcript over the bus seed (shared by the AIRs of a segment; default = own trace root)
+        const Digest seed = get_digest();
+        if (short_read) return 10;
+        Digest want = t_root;
+        if (expected_seed) for (int i = 0; i < 8; ++i) want.w[i] = bb::to_monty(expected_seed[i] % bb::P);
+        if (!same(seed, want)) return 12;
+        ch.observe_n(seed.w, 8);
+        Transcript cb;
+        cb.observe(bb::to_monty(kMagic2 % bb::P));
+        cb.observe_n(seed.w, 8);
+        al = cb.sample_ext();
+        bl = cb.sample_ext();
+        p_root = get_digest();
+        ch.observe_n(p_root.w, 8);
+        S = get_ext();
+        ch.observe_n(S.c, 4);
+    }
     const Ext alpha = ch.sample_ext();
     const Digest q_root = get_digest();
     ch.observe_n(q_root.w, 8);
     const Ext zeta = ch.sample_ext();
-    const size_t K = (size_t)width + 8;
+    const uint32_t g_h = pw::field::root_of_unity((int)log_h), g_inv = bb::inv(g_h);
+    const Ext gzeta = bb::ext_scale(zeta, g_h);
+    // internal order (= order of the gamma powers): main | perm@zeta | quotient | perm@g*zeta;
+    // proof order: main, perm@zeta, perm@g*zeta, quotient
+    const size_t K1 = (size_t)width + Wp + 8, K = K1 + Wp;
     std::vector<Ext> opened(K);
-    for (auto& e : opened) { e = get_ext(); ch.observe_n(e.c, 4); }
+    auto read_opened = [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) { opened[k] = get_ext(); ch.observe_n(opened[k].c, 4); } };
+    read_opened(0, width + Wp);
+    read_opened(K1, K);
+    read_opened(width + Wp, K1);
     if (short_read) return 10;
 
-    // constraint identity: sum_j alpha^(nc-1-j) C_j(opened) == Z_H(zeta) * (Q_lo(zeta) + zeta^H Q_hi(zeta))
+    // constraint identity: sum_j alpha^(M-1-j) C_j(opened) == Z_H(zeta) * (Q_lo(zeta) + zeta^H Q_hi(zeta))
     Ext acc = bb::ext_zero();
     for (size_t k = 0; k < n_constraints; ++k) {
         const uint32_t off = spans[2 * k], ln = spans[2 * k + 1];
@@ -127,29 +178,54 @@ extern "C" int pw_verify(const PwStarkConfig* cfg, uint32_t width, uint32_t log_
     }
     const Ext zH = bb::ext_pow(zeta, H);
     const Ext zh = bb::ext_sub(zH, bb::ext_one());
-    Ext qlo, qhi;  // sum_k X^k * q_k: the coordinates of the opened chunk columns are the basis coefficients
-    {
-        auto combine = [&](size_t base) {
-            Ext r = bb::ext_zero();
-            for (int k = 0; k < 4; ++k) {
-                Ext basis = bb::ext_zero();
-                basis.c[k] = bb::R_MOD_P;
-                r = bb::ext_add(r, bb::ext_mul(basis, opened[base + k]));
+    // sum_k X^k * o_k: the coordinates of an opened extension-valued column are the basis coefficients
+    auto combine = [&](size_t base) {
+        Ext r = bb::ext_zero();
+        for (int k = 0; k < 4; ++k) {
+            Ext basis = bb::ext_zero();
+            basis.c[k] = bb::R_MOD_P;
+            r = bb::ext_add(r, bb::ext_mul(basis, opened[base + k]));
+        }
+        return r;
+    };
+    if (lg) {
+        // LogUp: q_i * d_i = m_i on every row; phi is the running sum of sum_i q_i and ends at S
+        std::vector<Ext> blpow(max_args + 2);
+        { Ext b = bb::ext_one(); for (auto& x : blpow) { x = b; b = bb::ext_mul(b, bl); } }
+        Ext sumq = bb::ext_zero(), sumq_next = bb::ext_zero();
+        for (size_t i = 0; i < n_int; ++i) {
+            const uint32_t bus = lg->inter[3 * i], na = lg->inter[3 * i + 1];
+            const uint32_t* sp = lg->spans + 2 * (size_t)lg->inter[3 * i + 2];
+            Ext d = bb::ext_add(al, bb::ext_from_base(bb::to_monty(bus % bb::P))), m, a;
+            for (uint32_t j = 0; j < na; ++j) {
+                if (!eval_ext(lg->bc + sp[2 + 2 * j], sp[3 + 2 * j], opened.data(), width, a)) return 10;
+                d = bb::ext_add(d, bb::ext_mul(blpow[j + 1], a));
             }
-            return r;
-        };
-        qlo = combine(width);
-        qhi = combine(width + 4);
+            if (!eval_ext(lg->bc + sp[0], sp[1], opened.data(), width, m)) return 10;
+            const Ext qi = combine(width + 4 * i), qn = combine(K1 + 4 * i);
+            sumq = bb::ext_add(sumq, qi);
+            sumq_next = bb::ext_add(sumq_next, qn);
+            acc = bb::ext_add(bb::ext_mul(acc, alpha), bb::ext_sub(bb::ext_mul(qi, d), m));
+        }
+        const Ext phi = combine(width + 4 * (size_t)n_int), phin = combine(K1 + 4 * (size_t)n_int);
+        const Ext is_trans = bb::ext_sub(zeta, bb::ext_from_base(g_inv));
+        const Ext is_first = bb::ext_mul(zh, bb::ext_inv(bb::ext_sub(zeta, bb::ext_one())));
+        const Ext is_last = bb::ext_mul(zh, bb::ext_inv(is_trans));
+        acc = bb::ext_add(bb::ext_mul(acc, alpha), bb::ext_mul(is_first, bb::ext_sub(phi, sumq)));
+        acc = bb::ext_add(bb::ext_mul(acc, alpha), bb::ext_mul(is_trans, bb::ext_sub(bb::ext_sub(phin, phi), sumq_next)));
+        acc = bb::ext_add(bb::ext_mul(acc, alpha), bb::ext_mul(is_last, bb::ext_sub(phi, S)));
     }
+    const Ext qlo = combine(width + Wp), qhi = combine(width + Wp + 4);
     if (!bb::ext_eq(acc, bb::ext_mul(zh, bb::ext_add(qlo, bb::ext_mul(zH, qhi))))) return 2;
 
     const Ext gamma = ch.sample_ext();
     std::vector<Ext> gpow(K);
-    Ext opened_sum = bb::ext_zero();
+    Ext opened_sum = bb::ext_zero(), opened_sum2 = bb::ext_zero();
     {
         Ext g = bb::ext_one();
         for (size_t k = 0; k < K; ++k) { gpow[k] = g; g = bb::ext_mul(g, gamma); }
-        for (size_t k = 0; k < K; ++k) opened_sum = bb::ext_add(opened_sum, bb::ext_mul(gpow[k], opened[k]));
+        for (size_t k = 0; k < K1; ++k) opened_sum = bb::ext_add(opened_sum, bb::ext_mul(gpow[k], opened[k]));
+        for (size_t k = K1; k < K; ++k) opened_sum2 = bb::ext_add(opened_sum2, bb::ext_mul(gpow[k], opened[k]));
     }
     std::vector<Digest> fri_roots(log_h);
     std::vector<Ext> betas(log_h);
@@ -174,20 +250,29 @@ extern "C" int pw_verify(const PwStarkConfig* cfg, uint32_t width, uint32_t log_
     };
     const uint32_t shift0 = bb::to_monty(pw::field::kCosetShift);
     const uint32_t inv2 = bb::inv(bb::to_monty(2));
-    std::vector<uint32_t> trow(width), qrow(8);
+    std::vector<uint32_t> trow(width), prow(Wp), qrow(8);
     for (uint32_t qi = 0; qi < cfg->num_queries; ++qi) {
         const size_t idx = ch.sample_bits(logN);
         if (get() != idx) return short_read ? 10 : 4;
         for (auto& w : trow) w = get_m();
         if (short_read) return 10;
         if (!check_path(hash_row(trow.data(), width), idx, logN, t_root)) return short_read ? 10 : 5;
+        if (lg) {
+            for (auto& w : prow) w = get_m();
+            if (!check_path(hash_row(prow.data(), Wp), idx, logN, p_root)) return short_read ? 10 : 11;
+        }
         for (auto& w : qrow) w = get_m();
         if (!check_path(hash_row(qrow.data(), 8), idx, logN, q_root)) return short_read ? 10 : 6;
         const uint32_t x = bb::mul(shift0, bb::pow_u32(pw::field::root_of_unity(logN), (uint32_t)idx));
-        Ext a = bb::ext_zero();
+        Ext a = bb::ext_zero(), a2 = bb::ext_zero();
         for (size_t k = 0; k < width; ++k) a = bb::ext_add(a, bb::ext_scale(gpow[k], trow[k]));
-        for (size_t k = 0; k < 8; ++k) a = bb::ext_add(a, bb::ext_scale(gpow[width + k], qrow[k]));
+        for (size_t k = 0; k < Wp; ++k) {
+            a = bb::ext_add(a, bb::ext_scale(gpow[width + k], prow[k]));
+            a2 = bb::ext_add(a2, bb::ext_scale(gpow[K1 + k], prow[k]));
+        }
+        for (size_t k = 0; k < 8; ++k) a = bb::ext_add(a, bb::ext_scale(gpow[width + Wp + k], qrow[k]));
         Ext cur = bb::ext_mul(bb::ext_sub(a, opened_sum), bb::ext_inv(bb::ext_sub(bb::ext_from_base(x), zeta)));
+        if (lg) cur = bb::ext_add(cur, bb::ext_mul(bb::ext_sub(a2, opened_sum2), bb::ext_inv(bb::ext_sub(bb::ext_from_base(x), gzeta))));
         uint32_t shift = shift0;
         for (uint32_t l = 0; l < log_h; ++l) {
             const size_t Nl = N >> l, half = Nl / 2, p = idx & (Nl - 1);
@@ -208,5 +293,24 @@ extern "C" int pw_verify(const PwStarkConfig* cfg, uint32_t width, uint32_t log_
     }
     if (short_read) return 10;
     if (pos != len) return 9;
+    if (sum_out) for (int k = 0; k < 4; ++k) sum_out[k] = bb::from_monty(S.c[k]);
+    if (trace_root_out) for (int k = 0; k < 8; ++k) trace_root_out[k] = bb::from_monty(t_root.w[k]);
     return 0;
+}
+
+}  // namespace
+
+extern "C" int pw_verify(const PwStarkConfig* cfg, uint32_t width, uint32_t log_h, const uint32_t* bc, size_t bc_len,
+                         const uint32_t* spans, size_t n_constraints, const uint32_t* proof, size_t len) {
+    return verify_impl(cfg, width, log_h, bc, bc_len, spans, n_constraints, nullptr, nullptr, proof, len, nullptr, nullptr);
+}
+
+extern "C" int pw_verify_logup(const PwStarkConfig* cfg, uint32_t width, uint32_t log_h, const uint32_t* bc, size_t bc_len,
+                               const uint32_t* spans, size_t n_constraints, const uint32_t* interactions, size_t n_interactions,
+                               const uint32_t* inter_spans, size_t n_inter_spans, const uint32_t* inter_bytecode,
+                               size_t inter_bytecode_len, const uint32_t* expected_bus_seed, const uint32_t* proof, size_t len,
+                               uint32_t* cumulative_sum, uint32_t* trace_root) {
+    const Interactions lg{interactions, n_interactions, inter_spans, n_inter_spans, inter_bytecode, inter_bytecode_len};
+    return verify_impl(cfg, width, log_h, bc, bc_len, spans, n_constraints, &lg, expected_bus_seed, proof, len, cumulative_sum,
+                       trace_root);
 }

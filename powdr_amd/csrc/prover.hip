@@ -83,6 +83,8 @@ struct PwProver {
     uint32_t* d_ixspans = nullptr;
     uint32_t* d_icode = nullptr;
     pw::DeviceBuf perm, plde;
+    bool has_bus_seed = false;
+    uint32_t bus_seed[8] = {0};  // Montgomery
     // device buffers, grown on demand
     pw::DeviceBuf coef, lde, digests, q, qcoef, qlde, ext_arena, misc;
     std::vector<uint32_t> proof;
@@ -167,6 +169,43 @@ extern "C" PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t w
     return p;
 }
 
+#define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+extern "C" int pw_prover_set_bus_seed(PwProver* p, const uint32_t* seed8) {
+    if (!p || !p->logup) return (int)hipErrorInvalidValue;
+    p->has_bus_seed = seed8 != nullptr;
+    if (seed8) for (int i = 0; i < 8; ++i) p->bus_seed[i] = bb::to_monty(seed8[i] % bb::P);
+    return 0;
+}
+
+// Trace commitment only (LDE + Merkle root): what a segment's AIRs exchange before the bus seed can be formed.
+extern "C" int pw_prover_trace_root(PwProver* p, const uint32_t* d_trace, uint32_t log_h, uint32_t* root8) {
+    if (!p || !d_trace || !root8 || log_h < 1 || log_h > 26) return (int)hipErrorInvalidValue;
+    (void)hipGetLastError();
+    const size_t H = (size_t)1 << log_h, N = 2 * H, W = p->width;
+    size_t panel_cols = ((size_t)1 << 26) / H;  // as pw_prover_prove
+    if (panel_cols < 8) panel_cols = 8;
+    if (panel_cols > W) panel_cols = W;
+    hipStream_t st = stream();
+    TRY(poseidon2_upload_params());
+    TRY(p->coef.ensure(panel_cols * H * 4));
+    TRY(p->lde.ensure(W * N * 4));
+    TRY(p->digests.ensure(merkle_words(N) * 4));
+    uint32_t* d_coef = p->coef.as<uint32_t>();
+    uint32_t* d_lde = p->lde.as<uint32_t>();
+    for (size_t c0 = 0; c0 < W; c0 += panel_cols) {
+        const uint32_t pc = (uint32_t)(W - c0 < panel_cols ? W - c0 : panel_cols);
+        TRY(intt_dif(d_trace + c0 * H, d_coef, H, H, pc, (int)log_h));
+        TRY(coset_lde_from_coeffs(d_coef, d_lde + c0 * N, H, N, pc, (int)log_h));
+    }
+    TRY(merkle_commit_matrix(d_lde, N, (uint32_t)W, N, p->digests.as<uint32_t>()));
+    uint32_t root[8];
+    PW_HIP_TRY(hipMemcpyAsync(root, p->digests.as<uint32_t>() + merkle_words(N) - 8, 32, hipMemcpyDeviceToHost, st));
+    PW_HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < 8; ++i) root8[i] = bb::from_monty(root[i]);
+    return (int)hipGetLastError();
+}
+
 extern "C" void pw_prover_destroy(PwProver* p) {
     if (!p) return;
     for (DeviceBuf* b : {&p->coef, &p->lde, &p->digests, &p->q, &p->qcoef, &p->qlde, &p->ext_arena, &p->misc, &p->perm, &p->plde}) b->release();
@@ -181,7 +220,6 @@ extern "C" size_t pw_prover_device_bytes(const PwProver* p) {
            p->ext_arena.bytes + p->misc.bytes + p->perm.bytes + p->plde.bytes;
 }
 
-#define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
 extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t log_h, const uint32_t** proof_words,
                                size_t* n_words) {
@@ -289,8 +327,17 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     bb::Ext al = bb::ext_zero(), S = bb::ext_zero();
     LogupProgram lp{p->d_inter, n_int, p->d_ixspans, p->d_icode};
     if (lg) {
-        al = ch.sample_ext();
-        const bb::Ext bl = ch.sample_ext();
+        // the bus challenges come from a transcript that saw only the bus seed (shared by all AIRs of a segment;
+        // a lone AIR uses its own trace root), see oracle/stark_oracle.cpp bus_challenges
+        uint32_t seed[8];
+        memcpy(seed, p->has_bus_seed ? p->bus_seed : root, 32);
+        put_monty(seed, 8);
+        ch.observe_words(seed, 8);
+        Challenger cb;
+        cb.observe_canonical(kMagic2 % bb::P);
+        cb.observe_words(seed, 8);
+        al = cb.sample_ext();
+        const bb::Ext bl = cb.sample_ext();
         std::vector<bb::Ext> blpow(p->max_args + 2);
         { bb::Ext b = bb::ext_one(); for (auto& x : blpow) { x = b; b = bb::ext_mul(b, bl); } }
         PW_HIP_TRY(hipMemcpyAsync(d_blpow, blpow.data(), blpow.size() * sizeof(bb::Ext), hipMemcpyHostToDevice, st));

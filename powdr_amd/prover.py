@@ -14,7 +14,7 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_merkle_commit", "pw_poseidon2_permute_host"]
 
 lib.pw_prover_create.restype = C.c_void_p
@@ -50,6 +50,38 @@ def verify(proof, width: int, log_height: int, cons_bytecode, cons_spans, num_qu
     cfg = PwStarkConfig(num_queries, pow_bits)
     return int(lib.pw_verify(C.byref(cfg), width, log_height, bc.ctypes.data_as(C.c_void_p), len(bc),
                              sp.ctypes.data_as(C.c_void_p), len(sp), pr.ctypes.data_as(C.c_void_p), len(pr)))
+
+
+lib.pw_verify_logup.restype = C.c_int
+lib.pw_verify_logup.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                C.c_void_p, C.c_void_p]
+lib.pw_prover_trace_root.restype = C.c_int
+lib.pw_prover_trace_root.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+lib.pw_prover_set_bus_seed.restype = C.c_int
+lib.pw_prover_set_bus_seed.argtypes = [C.c_void_p, C.c_void_p]
+
+
+def verify_logup(proof, width: int, log_height: int, cons_bytecode, cons_spans, interactions, num_queries: int = 100,
+                 pow_bits: int = 0, bus_seed=None, with_root: bool = False):
+    """Host-side verification of a LogUp proof: (code, cumulative bus sum S as 4 canonical words or None)
+    [, trace root]. bus_seed: the 8 words the proof must have drawn its bus challenges from (None: its own
+    trace root)."""
+    pr = np.ascontiguousarray(proof, dtype=np.uint32)
+    bc = np.ascontiguousarray(cons_bytecode, dtype=np.uint32)
+    sp = np.ascontiguousarray(cons_spans, dtype=np.uint32).reshape(-1, 2)
+    it = np.ascontiguousarray(interactions[0], dtype=np.uint32).reshape(-1, 3)
+    isp = np.ascontiguousarray(interactions[1], dtype=np.uint32).reshape(-1, 2)
+    ibc = np.ascontiguousarray(interactions[2], dtype=np.uint32)
+    cfg = PwStarkConfig(num_queries, pow_bits)
+    s, root = np.zeros(4, np.uint32), np.zeros(8, np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    seed = None if bus_seed is None else np.ascontiguousarray(bus_seed, dtype=np.uint32)
+    rc = int(lib.pw_verify_logup(C.byref(cfg), width, log_height, p(bc), len(bc), p(sp), len(sp), p(it), len(it), p(isp), len(isp),
+                                 p(ibc), len(ibc), None if seed is None else p(seed), p(pr), len(pr), p(s), p(root)))
+    if with_root:
+        return rc, (s if rc == 0 else None), (root if rc == 0 else None)
+    return rc, (s if rc == 0 else None)
 
 
 def poseidon2_host(state) -> np.ndarray:
@@ -89,6 +121,17 @@ class Prover:
         abi.check(rc, "pw_prover_prove")
         a = np.ctypeslib.as_array(words, shape=(n.value,))
         return a.copy() if copy else a
+
+    def trace_root(self, d_trace_ptr: int, log_height: int) -> np.ndarray:
+        """Commitment to the trace alone (8 canonical words) — phase 1 of a multi-AIR LogUp segment."""
+        root = np.zeros(8, np.uint32)
+        abi.check(lib.pw_prover_trace_root(self._h, d_trace_ptr, log_height, root.ctypes.data_as(C.c_void_p)), "pw_prover_trace_root")
+        return root
+
+    def set_bus_seed(self, seed) -> None:
+        """Seed of the bus challenges shared by all AIRs of a segment (None: back to the AIR's own trace root)."""
+        a = None if seed is None else np.ascontiguousarray(seed, dtype=np.uint32)
+        abi.check(lib.pw_prover_set_bus_seed(self._h, None if a is None else a.ctypes.data_as(C.c_void_p)), "pw_prover_set_bus_seed")
 
     def check_constraints(self, d_trace_ptr: int, log_height: int):
         """Mock prover: (number of violated (row, constraint) pairs, first row, first constraint)."""

@@ -160,6 +160,8 @@ def test_product_verifier_agrees_with_oracle_verifier(shape, calls, pow_bits):
 def test_logup_extension_accepts_and_rejects(shape, calls):
     """pw-stark v0 + LogUp (bus interactions inside the proof): honest proofs verify; tampering, a broken
     constraint, and a perturbed interaction operand (which breaks q_i * d_i = m_i) are rejected."""
+    from powdr_amd import prover
+
     s, apc, idx, trace = synthetic_trace(shape, calls, seed=12)
     W, H = trace.shape
     log_h = H.bit_length() - 1
@@ -174,10 +176,85 @@ def test_logup_extension_accepts_and_rejects(shape, calls):
         bad = proof.copy()
         bad[pos] = (int(bad[pos]) + 1) % P
         assert sm.verify_logup(bad, W, log_h, bc, spans, inter, ispans, ibc, num_queries=5) != 0
+    # the product's host verifier agrees with the oracle's on every one of these, code for code
+    rc, S = prover.verify_logup(proof, W, log_h, bc, spans, (inter, ispans, ibc), num_queries=5)
+    assert rc == 0 and (S == proof[31:35]).all()  # header 7 | trace root 8 | bus seed 8 | perm root 8 | S
+    assert (proof[7:15] == proof[15:23]).all()     # a lone AIR seeds its bus challenges with its own trace root
+    for pos in list(rng.choice(len(proof), size=30, replace=False)) + [0, 4, 7, 15, 23, 31, len(proof) - 1]:
+        bad = proof.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        a = sm.verify_logup(bad, W, log_h, bc, spans, inter, ispans, ibc, num_queries=5)
+        b = prover.verify_logup(bad, W, log_h, bc, spans, (inter, ispans, ibc), num_queries=5)[0]
+        assert a != 0 and a == b, (pos, a, b)
+    assert prover.verify_logup(proof[:-2], W, log_h, bc, spans, (inter, ispans, ibc), num_queries=5)[0] == 10
+    assert prover.verify(proof, W, log_h, bc, spans, num_queries=5) == 1  # a PWS2 proof is not a PWS1 proof
     # a verifier that believes in a different interaction list rejects the proof
     inter2 = inter.copy()
     inter2[0, 0] = (int(inter2[0, 0]) + 1) % 16
     assert sm.verify_logup(proof, W, log_h, bc, spans, inter2, ispans, ibc, num_queries=5) != 0
+    assert prover.verify_logup(proof, W, log_h, bc, spans, (inter2, ispans, ibc), num_queries=5)[0] == 2
     # the proof is longer than the constraints-only one by the permutation matrix openings
     base = sm.prove(flat, W, log_h, bc, spans, num_queries=5)
     assert len(proof) > len(base) + 8 * (len(inter) + 1)
+
+
+def balanced_bus_pair(log_h, seed):
+    """Two 3-column AIRs over one bus: the first sends (a, b) with multiplicity m on each row, the second
+    receives the same tuples in a different row order (multiplicity -m)."""
+    rng = np.random.default_rng(seed)
+    H = 1 << log_h
+    m = rng.integers(0, 4, H).astype(np.uint32)
+    a = rng.integers(0, P, H, dtype=np.uint32)
+    b = rng.integers(0, 1 << 16, H).astype(np.uint32)
+    perm = rng.permutation(H)
+    t1 = np.stack([m, a, b])
+    t2 = np.stack([m[perm], a[perm], b[perm]])
+    PA = om.OP_PUSH_APC
+    send = (np.array([[5, 2, 0]], np.uint32), np.array([[0, 2], [2, 2], [4, 2]], np.uint32), np.array([PA, 0, PA, 1, PA, 2], np.uint32))
+    recv = (np.array([[5, 2, 0]], np.uint32), np.array([[0, 3], [3, 2], [5, 2]], np.uint32),
+            np.array([PA, 0, om.OP_NEG, PA, 1, PA, 2], np.uint32))
+    return (t1, send), (t2, recv)
+
+
+def ext_add_canonical(x, y):
+    return (x.astype(np.uint64) + y.astype(np.uint64)) % P
+
+
+def test_logup_cumulative_sums_balance_across_airs():
+    """The point of LogUp: a segment's bus is balanced iff the per-AIR cumulative sums add up to zero."""
+    from powdr_amd import prover
+
+    from powdr_amd import sharding
+
+    no_cons = (np.zeros(0, np.uint32), np.zeros((0, 2), np.uint32))
+    (t1, send), (t2, recv) = balanced_bus_pair(5, seed=4)
+
+    def segment(airs):
+        """prove every AIR against the seed formed from all trace roots; verify as the segment verifier would"""
+        roots = [sm.prove_logup(t.reshape(-1), 3, 5, *no_cons, *it, num_queries=0)[7:15] for t, it in airs]  # phase 1: commitments
+        seed = sharding.commitment_digest(np.array(roots))
+        sums, seen_roots = [], []
+        for t, it in airs:
+            proof = sm.prove_logup(t.reshape(-1), 3, 5, *no_cons, *it, num_queries=4, bus_seed=seed)
+            assert sm.verify_logup(proof, 3, 5, *no_cons, *it, num_queries=4, bus_seed=seed) == 0
+            assert sm.verify_logup(proof, 3, 5, *no_cons, *it, num_queries=4) == 12  # not a lone-AIR proof
+            rc, S, root = prover.verify_logup(proof, 3, 5, *no_cons, it, num_queries=4, bus_seed=seed, with_root=True)
+            assert rc == 0
+            assert prover.verify_logup(proof, 3, 5, *no_cons, it, num_queries=4, bus_seed=seed ^ 1)[0] == 12
+            sums.append(S)
+            seen_roots.append(root)
+        assert (sharding.commitment_digest(np.array(seen_roots)) == seed).all()  # the seed binds every trace
+        return sums
+
+    s1, s2 = segment([(t1, send), (t2, recv)])
+    assert s1.any() and (ext_add_canonical(s1, s2) == 0).all()
+    # an unmatched send (one tuple changed on the receiving side) leaves a non-zero total
+    t2b = t2.copy()
+    row = int(np.argmax(t2b[0] != 0))
+    t2b[2, row] ^= 1
+    s1, s2 = segment([(t1, send), (t2b, recv)])
+    assert (ext_add_canonical(s1, s2) != 0).any()
+    # proofs made with private seeds (each AIR's own root) are individually valid but their sums do not cancel
+    lone = [prover.verify_logup(sm.prove_logup(t.reshape(-1), 3, 5, *no_cons, *it, num_queries=4), 3, 5, *no_cons, it, num_queries=4)
+            for t, it in ((t1, send), (t2, recv))]
+    assert lone[0][0] == 0 and lone[1][0] == 0 and (ext_add_canonical(lone[0][1], lone[1][1]) != 0).any()

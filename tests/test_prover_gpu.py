@@ -136,6 +136,71 @@ def test_logup_proof_bytes_match_oracle(gpu, shape, calls, nq, pow_bits):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("log_h", [4, 13, 17])
+def test_logup_bus_balances_across_airs(gpu, log_h):
+    """Two AIRs on one bus (sends / permuted receives), proven on the device, verified on the host: each proof is
+    valid and the cumulative sums cancel; 2^17 rows crosses the scan's block boundaries (4096 rows per workgroup)."""
+    torch, abi, prover = gpu
+    from powdr_amd import sharding
+    from tests.test_oracle_stark import balanced_bus_pair, ext_add_canonical
+
+    no_cons = (np.zeros(0, np.uint32), np.zeros((0, 2), np.uint32))
+    airs = [(to_dev(torch, t.reshape(-1)), t, it, prover.Prover(3, *no_cons, num_queries=6, interactions=it))
+            for t, it in balanced_bus_pair(log_h, seed=log_h)]
+    roots = [pr.trace_root(d.data_ptr(), log_h) for d, _, _, pr in airs]  # phase 1
+    seed = sharding.commitment_digest(np.array(roots))
+    sums = []
+    for (d, t, it, pr), root in zip(airs, roots):
+        pr.set_bus_seed(seed)
+        proof = pr.prove(d.data_ptr(), log_h)
+        assert (proof[7:15] == root).all() and (proof[15:23] == seed).all()
+        rc, S, vroot = prover.verify_logup(proof, 3, log_h, *no_cons, it, num_queries=6, bus_seed=seed, with_root=True)
+        assert rc == 0 and (vroot == root).all()
+        assert prover.verify_logup(proof, 3, log_h, *no_cons, it, num_queries=6)[0] == 12
+        if log_h <= 13:
+            assert sm.verify_logup(proof, 3, log_h, *no_cons, *it, num_queries=6, bus_seed=seed) == 0
+            assert (proof == sm.prove_logup(t.reshape(-1), 3, log_h, *no_cons, *it, num_queries=6, bus_seed=seed)).all()
+        pr.set_bus_seed(None)  # back to the lone-AIR seed
+        assert prover.verify_logup(pr.prove(d.data_ptr(), log_h), 3, log_h, *no_cons, it, num_queries=6)[0] == 0
+        pr.close()
+        sums.append(S)
+    assert sums[0].any() and (ext_add_canonical(sums[0], sums[1]) == 0).all()
+
+
+@pytest.mark.gpu
+def test_logup_large_proof_verifies(gpu):
+    """2^16-row, 160-column synthetic APC trace with all its bus interactions inside the proof: the HIP proof is
+    accepted by the product verifier and the oracle's; breaking one interaction operand in the trace is rejected
+    by neither (the trace is still self-consistent) but changes S."""
+    torch, abi, prover = gpu
+    from powdr_amd import tracegen as tg
+
+    s = synth.generate("T1", seed=22)
+    apc = om.load_apc(s.doc)
+    idx = apc.poly_id_to_index()
+    bc, spans = sm.compile_constraints(apc, idx)
+    it = sm.compile_interactions(apc, idx)
+    gt = om.build_gpu_tables(apc, idx)
+    calls = (1 << 16) - 3
+    H, W, log_h = 1 << 16, len(idx), 16
+    bufs, dims = synth.fill_dummy_traces_numpy(s, calls, seed=22)
+    name_to = {n: i for i, (n, _, _, _) in enumerate(dims)}
+    airs = [(to_dev(torch, bufs[name_to[n]]), dims[name_to[n]][1], dims[name_to[n]][2], b) for n, b in zip(gt.air_names, gt.row_block_size)]
+    out = tg.DeviceMatrix.zeros(H, W)
+    keep = [tg.apc_tracegen(out, airs, gt.subs, calls), tg.apc_apply_derived_expr(out, calls, *om.compile_derived(apc, idx, H))]
+    pr = prover.Prover(W, bc, spans, num_queries=20, interactions=it)
+    proof = pr.prove(out.ptr(), log_h)
+    rc, S = prover.verify_logup(proof, W, log_h, bc, spans, it, num_queries=20)
+    assert rc == 0
+    assert sm.verify_logup(proof, W, log_h, bc, spans, *it, num_queries=20) == 0
+    bad = proof.copy()
+    bad[31] = (int(bad[31]) + 1) % P  # claimed S
+    assert prover.verify_logup(bad, W, log_h, bc, spans, it, num_queries=20)[0] == 2
+    pr.close()
+    del keep
+
+
+@pytest.mark.gpu
 def test_large_proof_verifies(gpu):
     """2^16-row, 160-column trace: too slow to prove on the CPU oracle in a test, so the HIP
     proof is checked with the oracle's VERIFIER (accept) and a corrupted trace (reject)."""
