@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="host threads / HIP streams proving independent segments concurrently on each GPU "
                          "(throughput mode; default 1 = one segment at a time, which keeps per-kernel timings clean)")
+    ap.add_argument("--logup", action="store_true",
+                    help="prove the bus interactions too (pw-stark v0 + LogUp: one extension column per interaction, "
+                         "rho = 4*(n_interactions+1)/W extra committed columns per main column); NOT the headline configuration")
     ap.add_argument("--exact-source-heights", action="store_true",
                     help="allocate dummy traces with b*calls rows instead of next_pow2 (less HBM)")
     return ap.parse_args()
@@ -169,7 +172,8 @@ def main():
         torch.cuda.empty_cache()
         args.exact_source_heights = True
         wl = build_workload(args.shape, log_h, True, seed=rank)
-    pr = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits)
+    inter = wl["apc"].compile_bus(1) if args.logup else None  # (interactions, spans, bytecode) with column operands
+    pr = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits, interactions=inter)
     from powdr_amd import sharding
 
     def run_segment(w):
@@ -179,7 +183,8 @@ def main():
         proof = w["pr"].prove(w["out"].data_ptr(), log_h, copy=False)
         if world > 1:
             # the final commitment merge: all-gather of the per-segment trace roots (32 B per segment)
-            sharding.merge_commitments([rank], proof[6:14].reshape(1, 8), world)
+            o = 7 if args.logup else 6
+            sharding.merge_commitments([rank], proof[o:o + 8].reshape(1, 8), world)
         return proof
 
     main_worker = dict(apc=wl["apc"], per=wl["per"], out=wl["out"], pr=pr)
@@ -193,7 +198,8 @@ def main():
         for _ in range(args.pipeline - 1):
             workers.append(dict(stream=torch.cuda.Stream(), apc=host.Apc(wl["synth"].doc), per=tg.Periphery.fresh(),
                                 out=torch.empty_like(wl["out"]),
-                                pr=prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits)))
+                                pr=prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits,
+                                                 interactions=inter)))
 
     last = {}
 
@@ -256,10 +262,11 @@ def main():
         gauges = dict(
             trace_gen_time_ms=g("apc_gather_tile_kernel", "apc_apply_derived_expr_kernel", "apc_apply_bus_kernel", "bus_histogram_kernel"),
             main_trace_commit_time_ms=g("ntt_group_kernel<dif>", "ntt_group_kernel<dit>", "leaf_hash_kernel", "compress_kernel", "compress_tail_kernel"),
-            quotient_poly_compute_time_ms=g("quotient_kernel", "quotient_split_kernel"),
-            pcs_opening_time_ms=g("barycentric_weights_kernel", "zeta_weights_kernel", "ext_dot_partial_kernel", "deep_kernel",
+            perm_trace_time_ms=g("logup_perm_kernel", "logup_scan_kernels"),
+            quotient_poly_compute_time_ms=g("quotient_kernel", "quotient_logup_kernel", "quotient_split_kernel"),
+            pcs_opening_time_ms=g("barycentric_weights_kernel", "zeta_weights_kernel", "ext_dot_partial_kernel", "deep_kernel", "deep_logup_kernel",
                                   "ext_pair_leaf_kernel", "fri_fold_kernel", "gather_rows_kernel"),
-            note="main_trace_commit also contains the 8-column quotient commitment (same kernels); "
+            note="main_trace_commit also contains the 8-column quotient commitment (and, with --logup, the permutation matrix's; same kernels); "
                  "stark_prove_excluding_trace_time_ms = ms_per_step - trace_gen_time_ms")
         # device-to-device copy ceiling of THIS box: 4 GiB float4-style copy
         a_ = torch.empty(1 << 30, dtype=torch.int32, device="cuda")
@@ -333,7 +340,11 @@ def main():
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
             config=dict(workload=f"{args.shape} {shape.name} autoprecompile AIR: {wl['W']} cols x 2^{log_h} rows, "
                                  f"{len(wl['cons'][1])} constraints, {wl['apc'].n_bus} bus interactions; trace generation + "
-                                 f"pw-stark v0 proof (blow-up 2, {args.queries} queries, {args.pow_bits} PoW bits); one segment per step per GPU"
+                                 f"pw-stark v0 proof (blow-up 2, {args.queries} queries, {args.pow_bits} PoW bits)"
+                                 + (f" WITH the LogUp phase: {4 * (wl['apc'].n_bus + 1)} extra committed columns, "
+                                    f"rho = {4 * (wl['apc'].n_bus + 1) / wl['W']:.2f} (SURVEY 8d: algorithmic bytes per main cell "
+                                    f"= 48 + 4 + 44*rho = {52 + 44 * 4 * (wl['apc'].n_bus + 1) / wl['W']:.0f})" if args.logup else "")
+                                 + "; one segment per step per GPU"
                                  + ("; source heights b*calls (not padded to a power of two)" if args.exact_source_heights else ""),
                         rows=wl["H"], cols=wl["W"], parallelism=f"segments x{world}" + (f", {args.pipeline} streams per GPU" if args.pipeline > 1 else ""),
                         source_bytes=wl["src_bytes"], proof_bytes=int(len(proof) * 4),
