@@ -123,6 +123,19 @@ int powdr_apc_apply_bus_cols(const PowdrFp* d_output, size_t output_height, int 
                              uint32_t tuple2_bus_id, uint32_t* d_tuple2_hist, uint32_t tuple2_sz0,
                              uint32_t tuple2_sz1, uint32_t bitwise_bus_id, uint32_t* d_bitwise_hist);
 
+/* Traces of the shared periphery chips (the RECEIVE side of the three lookup buses) from the histograms
+ * _apc_apply_bus filled. The chips are EXTERNAL (openvm-circuit-primitives; instantiated in
+ * openvm/src/powdr_extension/trace_generator/cuda/periphery.rs:33-85); in-repo is how a lookup becomes a histogram
+ * index (openvm/cuda/src/apc_apply_bus.cu:74,89,104) and these functions invert that map: row i carries the tuple
+ * with index i and its count as multiplicity. Column-major Montgomery matrices, layouts ours:
+ *   var range : n_bins rows (power of two) x [value, bits, mult],        i = (1 << bits) + value - 1
+ *   tuple2    : sz0*sz1 rows (power of two) x [v0, v1, mult],            i = v0 * sz1 + v1
+ *   bitwise   : 65 536 rows x [x, y, x ^ y, mult_range, mult_xor],       i = x * 256 + y, hist = [range | xor]
+ * All pointers are device pointers; return value as above. */
+int powdr_periphery_var_range_trace(const uint32_t* d_var_hist, size_t var_num_bins, PowdrFp* d_out);
+int powdr_periphery_tuple2_trace(const uint32_t* d_tuple2_hist, uint32_t tuple2_sz0, uint32_t tuple2_sz1, PowdrFp* d_out);
+int powdr_periphery_bitwise_trace(const uint32_t* d_bitwise_hist, PowdrFp* d_out);
+
 /* All launches of this library go to this stream (default: the null stream,
  * like the reference, cuda/mod.rs:374-378). Pass a hipStream_t as void*. */
 void powdr_gpu_set_stream(void* hip_stream);

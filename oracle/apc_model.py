@@ -499,3 +499,26 @@ def c_generate_witness(apc: Apc, cpu: CpuTables, id_to_index, dummy_rowmajor: li
     if rc:
         raise ValueError(f"or_generate_witness failed: {rc}")
     return values[: height * width].reshape(height, width)
+
+
+# ---- periphery chips' traces from the histograms (include/powdr_gpu.h powdr_periphery_*_trace) --------------------
+# The tuple <-> index maps are the reference's (openvm/cuda/src/apc_apply_bus.cu:74,89,104; cpu/periphery.rs:176-237)
+# inverted; canonical values, column-major (one numpy row per column).
+
+def var_range_trace(hist: np.ndarray) -> np.ndarray:
+    i = np.arange(len(hist), dtype=np.uint64) + 1
+    bits = np.floor(np.log2(i.astype(np.float64))).astype(np.uint64)
+    bits = np.where((np.uint64(1) << bits) > i, bits - 1, bits)  # guard the float log at exact powers of two
+    bits = np.where((np.uint64(2) << bits) <= i, bits + 1, bits)
+    return np.stack([i - (np.uint64(1) << bits), bits, hist.astype(np.uint64) % P]).astype(np.uint32)
+
+
+def tuple2_trace(hist: np.ndarray, sz0: int, sz1: int) -> np.ndarray:
+    i = np.arange(sz0 * sz1, dtype=np.uint64)
+    return np.stack([i // sz1, i % sz1, hist.astype(np.uint64) % P]).astype(np.uint32)
+
+
+def bitwise_trace(hist: np.ndarray) -> np.ndarray:
+    i = np.arange(65536, dtype=np.uint64)
+    x, y = i >> 8, i & 255
+    return np.stack([x, y, x ^ y, hist[:65536].astype(np.uint64) % P, hist[65536:].astype(np.uint64) % P]).astype(np.uint32)
