@@ -98,17 +98,28 @@ struct IndexMap {
 
 // One slot of one round: LOGR stages on the window [rb, rb+LOGR) of the tile index, on the
 // R = 2^LOGR elements v[rho] (fully reduced arithmetic: see the note at bb::mul_lazy).
+// The twiddle base of slot m of a round: w^(g << shift) for the slot's low global index bits g and the round's
+// smallest shift (the one of window bit logr-1). A table lookup with global-memory latency on the critical path
+// of the slot's butterflies, so callers fetch it one slot (or one round) ahead.
+template <bool DIF>
+__device__ __forceinline__ uint32_t load_twiddle_base(const IndexMap& im, const GroupParams& gp, int round, int m, int tid,
+                                                      const uint32_t* __restrict__ tw) {
+    const int rb = gp.rb[round], logr = gp.logr[round];
+    const uint32_t sigma = (uint32_t)tid + 256u * m;
+    const uint32_t l0 = ((sigma >> rb) << (rb + logr)) | (sigma & ((1u << rb) - 1u));
+    const size_t g = im.glow(l0, rb);
+    const int sh_top = DIF ? gp.s0 + gp.k - 1 - (rb + (logr - 1) - gp.c)       // stage number s_q
+                           : gp.n - 1 - (gp.s0 + rb + (logr - 1) - gp.c);       // n - 1 - s_q
+    return tw[g << sh_top];
+}
+
 template <bool DIF, int LOGR>
-__device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t l0, const IndexMap& im, const GroupParams& gp, int rb,
-                                                 const uint32_t* __restrict__ tw) {
+__device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t base_top) {
     constexpr int R = 1 << LOGR;
     const uint32_t* roots = c_roots16[DIF ? 1 : 0];
-    const size_t g = im.glow(l0, rb);
     // base[q] = w^(g << shift_q); the smallest shift belongs to q = LOGR-1 and base[q-1] = base[q]^2
     uint32_t base[LOGR];
-    const int sh_top = DIF ? gp.s0 + gp.k - 1 - (rb + (LOGR - 1) - gp.c)       // stage number s_q
-                           : gp.n - 1 - (gp.s0 + rb + (LOGR - 1) - gp.c);       // n - 1 - s_q
-    base[LOGR - 1] = tw[g << sh_top];
+    base[LOGR - 1] = base_top;
 #pragma unroll
     for (int q = LOGR - 2; q >= 0; --q) base[q] = bb::sqr(base[q + 1]);
 #pragma unroll
@@ -142,10 +153,12 @@ __device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t l0, const
 // HBM, the last one stores to HBM.
 // EXPAND: `src` is the H-sized bit-reversed coefficient array (n = log2(2H)); element g of the
 // 2H-sized vector is src[g >> 1] * scale_br[g >> 1].
+// `tw_base` enters as the twiddle base of this round's slot 0 and leaves as the one of the next round's slot 0.
 template <bool DIF, int LOGR, int EPT, bool EXPAND>
 __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, const GroupParams& gp, int round,
                                           const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
-                                          const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid) {
+                                          const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid,
+                                          uint32_t& tw_base) {
     const int rb = gp.rb[round];
     const bool first = round == 0, last = round == gp.n_rounds - 1;
     constexpr int R = 1 << LOGR;
@@ -164,6 +177,10 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
         const uint32_t sigma = (uint32_t)tid + 256u * m;
         const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
         const uint32_t p0 = lds_phys(l0);
+        // fetch the next slot's (or the next round's first) twiddle base while this slot computes
+        const uint32_t cur_base = tw_base;
+        if (m + 1 < SLOTS) tw_base = load_twiddle_base<DIF>(im, gp, round, m + 1, tid, tw);
+        else if (!last) tw_base = load_twiddle_base<DIF>(im, gp, round + 1, 0, tid, tw);
         // ---- load ----
         if (first) {
             if (EXPAND ? vec_expand : vec_plain) {
@@ -205,7 +222,7 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
             for (int rho = 0; rho < R; ++rho) x[rho] = tile[p0 + lds_off(rho)];
         }
         // ---- butterflies ----
-        slot_butterflies<DIF, LOGR>(x, l0, im, gp, rb, tw);
+        slot_butterflies<DIF, LOGR>(x, cur_base);
         // ---- store ----
         if (last) {
             if (vec_plain) {
@@ -247,12 +264,13 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     im.n_tiles = (size_t)gp.n_tiles;
     const uint32_t* src = in + (size_t)blockIdx.y * in_stride;
     uint32_t* dst = out + (size_t)blockIdx.y * out_stride;
+    uint32_t tw_base = load_twiddle_base<DIF>(im, gp, 0, 0, tid, tw);
     for (int r = 0; r < gp.n_rounds; ++r) {
         switch (gp.logr[r]) {
-            case 1: run_round<DIF, 1, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid); break;
-            case 2: run_round<DIF, 2, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid); break;
-            case 3: run_round<DIF, 3, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid); break;
-            default: run_round<DIF, 4, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid); break;
+            case 1: run_round<DIF, 1, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            case 2: run_round<DIF, 2, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            case 3: run_round<DIF, 3, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            default: run_round<DIF, 4, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
         }
         if (r + 1 < gp.n_rounds) __syncthreads();  // the next round reads what this round wrote
     }

@@ -11,6 +11,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 namespace pw {
@@ -261,7 +262,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     // ext arena: FRI layer vectors v_0 (N) .. v_log_h (2): 2N ext; weights (H); LogUp: second weights, row sums
     TRY(p->ext_arena.ensure((2 * N + (lg ? 3 : 1) * H + H / 4096 + 32) * sizeof(bb::Ext)));
     const uint32_t n_chunks = div_up(H, 8192);
-    const uint32_t dot_cols = Wp > W ? Wp : W;
+    const uint32_t dot_cols = std::max({W, Wp, 8u});  // widest matrix ext_dot_columns sees (the quotient has 8 columns)
     const size_t misc_ext = (size_t)dot_cols * n_chunks + K + K + M + p->max_args + 64;
     const uint32_t nq = p->cfg.num_queries;
     const size_t path_records = (size_t)nq * (n_trees * (size_t)logN + (size_t)log_h * logN) + 16;
