@@ -336,8 +336,12 @@ def test_c3_scale_trace_and_proof(gpu):
     """BASELINE configs[2] scale on one GPU: 3 731 columns x 2^22 rows (15.6 G cells, W*H > 2^32, ~190 GB peak):
     trace generation through the column-operand path, proof, host verification (tools/run_c3_scale.py)."""
     torch, abi, prover = gpu
+    import gc
+
+    gc.collect()  # provers of earlier tests release their device buffers in __del__
+    torch.cuda.empty_cache()
     if torch.cuda.mem_get_info()[0] < 230e9:
-        pytest.skip("needs ~190 GB of free HBM")
+        pytest.skip(f"needs ~190 GB of free HBM, {torch.cuda.mem_get_info()[0] / 1e9:.0f} GB free")
     import importlib.util
     from pathlib import Path
 
