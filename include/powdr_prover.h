@@ -94,6 +94,45 @@ int pw_verify_logup(const PwStarkConfig* cfg, uint32_t width, uint32_t log_heigh
                     const uint32_t* inter_bytecode, size_t inter_bytecode_len, const uint32_t* expected_bus_seed,
                     const uint32_t* proof_words, size_t n_words, uint32_t* cumulative_sum, uint32_t* trace_root);
 
+/* ---- one segment = many AIRs -------------------------------------------------------------------------------------
+ * The engine call the reference makes once per segment with all chips' traces, `engine.prove(pk, ProvingContext{
+ * per_trace})` (openvm/src/trace_generation.rs:97-139, openvm-riscv/src/lib.rs:327-341). */
+typedef struct PwSegmentAir {
+    PwProver* prover;        /* one per AIR (pw_prover_create / _create_logup), reused from segment to segment */
+    const uint32_t* d_trace; /* device, column-major width x 2^log_height, Montgomery */
+    uint32_t log_height;
+} PwSegmentAir;
+
+/* Proves every AIR. `n_workers` host threads (0 = 4), each with its own HIP stream on the caller's device, take
+ * the AIRs largest first (small proofs are latency bound; concurrency fills the GPU); n_workers = 1 runs inline on
+ * the calling thread's stream. shared_bus_seed != 0: every prover must come from pw_prover_create_logup; phase 1
+ * commits all traces, the bus seed is pw_commitment_digest over the trace roots in AIR order, phase 2 proves every
+ * AIR with it (each prover reuses its phase-1 LDE and tree). proofs[i] / n_words[i] are owned by airs[i].prover and
+ * valid until its next proof; bus_seed8 (may be NULL) receives the seed. Returns 0 or the first error. */
+int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int shared_bus_seed, unsigned n_workers,
+                     const uint32_t** proofs, size_t* n_words, uint32_t* bus_seed8);
+
+typedef struct PwAirDescription {
+    uint32_t width, log_height;
+    uint32_t logup;                                          /* 0: constraints-only ("PWS1") proof, interaction fields unused */
+    const uint32_t* cons_bytecode; size_t bytecode_len;
+    const uint32_t* cons_spans; size_t n_constraints;
+    const uint32_t* interactions; size_t n_interactions;
+    const uint32_t* inter_spans; size_t n_inter_spans;
+    const uint32_t* inter_bytecode; size_t inter_bytecode_len;
+} PwAirDescription;
+
+/* Host verification of a segment. With shared_bus_seed the seed is recomputed from the trace roots inside the
+ * proofs and every proof must have used it. Returns 0; ((air index + 1) << 8) | code of the first failing proof
+ * (codes as pw_verify / pw_verify_logup); or 14 when check_balance is set and the cumulative bus sums of all AIRs
+ * do not add up to zero. total_sum4 (may be NULL) receives that sum. */
+int pw_verify_segment(const PwStarkConfig* cfg, const PwAirDescription* airs, size_t n_airs,
+                      const uint32_t* const* proofs, const size_t* n_words, int shared_bus_seed, int check_balance,
+                      uint32_t* total_sum4);
+
+/* Digest over an ordered list of 8-word commitments (binary Poseidon2 tree; canonical words). */
+void pw_commitment_digest(const uint32_t* roots8, size_t n, uint32_t* digest8);
+
 /* Bytes of device memory the prover currently holds. */
 size_t pw_prover_device_bytes(const PwProver* p);
 

@@ -156,3 +156,18 @@ def verify_logup(proof, width, log_h, cons_bc, cons_spans, inter, ispans, ibc, n
     return int(_lib().or_verify_logup(C.c_uint32(num_queries), C.c_uint32(pow_bits), _p(pr), C.c_size_t(len(pr)), C.c_uint32(width),
                                       C.c_uint32(log_h), _p(bc), _p(sp), C.c_size_t(len(sp.reshape(-1, 2))), _p(it),
                                       C.c_size_t(len(it.reshape(-1, 3))), _p(isp), _p(ib), seed_p))
+
+
+def commitment_digest(roots) -> np.ndarray:
+    """Restatement of pw_commitment_digest: binary Poseidon2 tree over the ordered 8-word commitments, an odd node is
+    paired with zeros, a single commitment is its own digest, none gives zeros."""
+    level = [np.asarray(r, dtype=np.uint32) for r in np.asarray(roots, dtype=np.uint32).reshape(-1, 8)]
+    if not level:
+        return np.zeros(8, np.uint32)
+    while len(level) > 1:
+        nxt = []
+        for i in range(0, len(level), 2):
+            right = level[i + 1] if i + 1 < len(level) else np.zeros(8, np.uint32)
+            nxt.append(poseidon2(np.concatenate([level[i], right]))[:8])
+        level = nxt
+    return level[0]

@@ -86,6 +86,11 @@ struct PwProver {
     pw::DeviceBuf perm, plde;
     bool has_bus_seed = false;
     uint32_t bus_seed[8] = {0};  // Montgomery
+    // pw_prover_trace_root leaves the trace's LDE and Merkle tree in `lde` / `digests`; a pw_prover_prove of the
+    // same (pointer, height) right after it starts from them instead of recomputing (one-shot)
+    const uint32_t* committed_trace = nullptr;
+    uint32_t committed_log_h = 0;
+    uint32_t committed_root[8] = {0};  // Montgomery
     // device buffers, grown on demand
     pw::DeviceBuf coef, lde, digests, q, qcoef, qlde, ext_arena, misc;
     std::vector<uint32_t> proof;
@@ -179,31 +184,66 @@ extern "C" int pw_prover_set_bus_seed(PwProver* p, const uint32_t* seed8) {
     return 0;
 }
 
+namespace {
+
+struct CommitLayout {
+    size_t H, N, tree_words, fri_words, n_trees, panel_cols;
+};
+
+// Buffers of the trace commitment, sized as pw_prover_prove needs them (so that a later prove does not reallocate)
+int ensure_commit_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
+    L.H = (size_t)1 << log_h;
+    L.N = 2 * L.H;
+    L.tree_words = merkle_words(L.N);
+    L.fri_words = 0;
+    for (uint32_t l = 0; l < log_h; ++l) L.fri_words += merkle_words((L.N >> l) / 2);
+    L.n_trees = p->logup ? 3 : 2;  // trace | quotient | (perm) | FRI
+    // coefficients exist only per column panel (~256 MB): iNTT -> panel -> coset NTT into the resident LDE
+    L.panel_cols = ((size_t)1 << 26) / L.H;
+    if (L.panel_cols < 8) L.panel_cols = 8;
+    const size_t widest = p->logup ? std::max<size_t>(p->width, 4 * ((size_t)p->n_inter + 1)) : p->width;
+    if (L.panel_cols > widest) L.panel_cols = widest;
+    TRY(p->coef.ensure(L.panel_cols * L.H * 4));
+    TRY(p->lde.ensure((size_t)p->width * L.N * 4));
+    TRY(p->digests.ensure((L.n_trees * L.tree_words + L.fri_words) * 4));
+    return 0;
+}
+
+int lde_matrix(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_t* m, uint32_t cols, uint32_t* out) {
+    uint32_t* d_coef = p->coef.as<uint32_t>();
+    for (size_t c0 = 0; c0 < cols; c0 += L.panel_cols) {
+        const uint32_t pc = (uint32_t)(cols - c0 < L.panel_cols ? cols - c0 : L.panel_cols);
+        TRY(intt_dif(m + c0 * L.H, d_coef, L.H, L.H, pc, (int)log_h));
+        TRY(coset_lde_from_coeffs(d_coef, out + c0 * L.N, L.H, L.N, pc, (int)log_h));
+    }
+    return 0;
+}
+
+// LDE + Merkle tree of the trace into p->lde / the first tree of p->digests; root (Montgomery) to the host
+int commit_trace(PwProver* p, const CommitLayout& L, const uint32_t* d_trace, uint32_t log_h, uint32_t* root) {
+    hipStream_t st = stream();
+    uint32_t* d_tdig = p->digests.as<uint32_t>();
+    TRY(lde_matrix(p, L, log_h, d_trace, p->width, p->lde.as<uint32_t>()));
+    TRY(merkle_commit_matrix(p->lde.as<uint32_t>(), L.N, p->width, L.N, d_tdig));
+    PW_HIP_TRY(hipMemcpyAsync(root, d_tdig + L.tree_words - 8, 32, hipMemcpyDeviceToHost, st));
+    PW_HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // namespace
+
 // Trace commitment only (LDE + Merkle root): what a segment's AIRs exchange before the bus seed can be formed.
 extern "C" int pw_prover_trace_root(PwProver* p, const uint32_t* d_trace, uint32_t log_h, uint32_t* root8) {
     if (!p || !d_trace || !root8 || log_h < 1 || log_h > 26) return (int)hipErrorInvalidValue;
     (void)hipGetLastError();
-    const size_t H = (size_t)1 << log_h, N = 2 * H, W = p->width;
-    size_t panel_cols = ((size_t)1 << 26) / H;  // as pw_prover_prove
-    if (panel_cols < 8) panel_cols = 8;
-    if (panel_cols > W) panel_cols = W;
-    hipStream_t st = stream();
     TRY(poseidon2_upload_params());
-    TRY(p->coef.ensure(panel_cols * H * 4));
-    TRY(p->lde.ensure(W * N * 4));
-    TRY(p->digests.ensure(merkle_words(N) * 4));
-    uint32_t* d_coef = p->coef.as<uint32_t>();
-    uint32_t* d_lde = p->lde.as<uint32_t>();
-    for (size_t c0 = 0; c0 < W; c0 += panel_cols) {
-        const uint32_t pc = (uint32_t)(W - c0 < panel_cols ? W - c0 : panel_cols);
-        TRY(intt_dif(d_trace + c0 * H, d_coef, H, H, pc, (int)log_h));
-        TRY(coset_lde_from_coeffs(d_coef, d_lde + c0 * N, H, N, pc, (int)log_h));
-    }
-    TRY(merkle_commit_matrix(d_lde, N, (uint32_t)W, N, p->digests.as<uint32_t>()));
-    uint32_t root[8];
-    PW_HIP_TRY(hipMemcpyAsync(root, p->digests.as<uint32_t>() + merkle_words(N) - 8, 32, hipMemcpyDeviceToHost, st));
-    PW_HIP_TRY(hipStreamSynchronize(st));
-    for (int i = 0; i < 8; ++i) root8[i] = bb::from_monty(root[i]);
+    CommitLayout L;
+    p->committed_trace = nullptr;
+    TRY(ensure_commit_buffers(p, log_h, L));
+    TRY(commit_trace(p, L, d_trace, log_h, p->committed_root));
+    for (int i = 0; i < 8; ++i) root8[i] = bb::from_monty(p->committed_root[i]);
+    p->committed_trace = d_trace;
+    p->committed_log_h = log_h;
     return (int)hipGetLastError();
 }
 
@@ -239,18 +279,12 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     TRY(poseidon2_upload_params());
 
     // ---- buffers --------------------------------------------------------------------------
-    // digest arena: trace tree | quotient tree | FRI trees
-    const size_t tree_words = merkle_words(N);
-    size_t fri_words = 0;
-    for (uint32_t l = 0; l < log_h; ++l) fri_words += merkle_words((N >> l) / 2);
-    // coefficients exist only per column panel (~256 MB): iNTT -> panel -> coset NTT into the resident LDE
-    size_t panel_cols = ((size_t)1 << 26) / H;
-    if (panel_cols < 8) panel_cols = 8;
-    if (panel_cols > W) panel_cols = W;
-    TRY(p->coef.ensure(panel_cols * H * 4));
-    TRY(p->lde.ensure((size_t)W * N * 4));
-    const size_t n_trees = lg ? 3 : 2;  // trace | quotient | (perm) | FRI
-    TRY(p->digests.ensure((n_trees * tree_words + fri_words) * 4));
+    // digest arena: trace tree | quotient tree | (perm tree) | FRI trees
+    const bool have_commitment = p->committed_trace == d_trace && p->committed_log_h == log_h;
+    p->committed_trace = nullptr;  // one-shot
+    CommitLayout L;
+    TRY(ensure_commit_buffers(p, log_h, L));
+    const size_t tree_words = L.tree_words, n_trees = L.n_trees;
     if (lg) {
         TRY(p->perm.ensure((size_t)Wp * H * 4));
         TRY(p->plde.ensure((size_t)Wp * N * 4));
@@ -270,10 +304,8 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
                         (size_t)nq * log_h * (8 + 16) + 4096;
     TRY(p->misc.ensure(misc_bytes));
 
-    uint32_t* d_coef = p->coef.as<uint32_t>();
     uint32_t* d_lde = p->lde.as<uint32_t>();
     uint32_t* d_dig = p->digests.as<uint32_t>();
-    uint32_t* d_tdig = d_dig;
     uint32_t* d_qdig = d_dig + tree_words;
     uint32_t* d_pdig = d_dig + 2 * tree_words;          // LogUp only
     uint32_t* d_fdig = d_dig + n_trees * tree_words;
@@ -308,19 +340,9 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     }
 
     // ---- 1. trace: coefficients, LDE, commitment ---------------------------------------------
-    auto lde_matrix = [&](const uint32_t* m, uint32_t cols, uint32_t* out) -> int {
-        for (size_t c0 = 0; c0 < cols; c0 += panel_cols) {
-            const uint32_t pc = (uint32_t)(cols - c0 < panel_cols ? cols - c0 : panel_cols);
-            TRY(intt_dif(m + c0 * H, d_coef, H, H, pc, (int)log_h));
-            TRY(coset_lde_from_coeffs(d_coef, out + c0 * N, H, N, pc, (int)log_h));
-        }
-        return 0;
-    };
-    TRY(lde_matrix(d_trace, W, d_lde));
-    TRY(merkle_commit_matrix(d_lde, N, W, N, d_tdig));
     uint32_t root[8];
-    PW_HIP_TRY(hipMemcpyAsync(root, d_tdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
-    PW_HIP_TRY(hipStreamSynchronize(st));
+    if (have_commitment) memcpy(root, p->committed_root, 32);  // pw_prover_trace_root already did this step
+    else TRY(commit_trace(p, L, d_trace, log_h, root));
     put_monty(root, 8);
     ch.observe_words(root, 8);
 
@@ -344,7 +366,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         PW_HIP_TRY(hipMemcpyAsync(d_blpow, blpow.data(), blpow.size() * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
         PW_HIP_TRY(hipStreamSynchronize(st));
         TRY(logup_perm_trace(d_trace, H, lp, al, d_blpow, d_perm, d_rowsum, d_rowsum + H));
-        TRY(lde_matrix(d_perm, Wp, d_plde));
+        TRY(lde_matrix(p, L, log_h, d_perm, Wp, d_plde));
         TRY(merkle_commit_matrix(d_plde, N, Wp, N, d_pdig));
         uint32_t sw[4];
         PW_HIP_TRY(hipMemcpyAsync(root, d_pdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));

@@ -14,7 +14,7 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_merkle_commit", "pw_poseidon2_permute_host"]
 
 lib.pw_prover_create.restype = C.c_void_p
@@ -82,6 +82,81 @@ def verify_logup(proof, width: int, log_height: int, cons_bytecode, cons_spans, 
     if with_root:
         return rc, (s if rc == 0 else None), (root if rc == 0 else None)
     return rc, (s if rc == 0 else None)
+
+
+class PwSegmentAir(C.Structure):
+    _fields_ = [("prover", C.c_void_p), ("d_trace", C.c_void_p), ("log_height", C.c_uint32)]
+
+
+class PwAirDescription(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("log_height", C.c_uint32), ("logup", C.c_uint32),
+                ("cons_bytecode", C.c_void_p), ("bytecode_len", C.c_size_t), ("cons_spans", C.c_void_p), ("n_constraints", C.c_size_t),
+                ("interactions", C.c_void_p), ("n_interactions", C.c_size_t), ("inter_spans", C.c_void_p), ("n_inter_spans", C.c_size_t),
+                ("inter_bytecode", C.c_void_p), ("inter_bytecode_len", C.c_size_t)]
+
+
+lib.pw_prove_segment.restype = C.c_int
+lib.pw_prove_segment.argtypes = [C.POINTER(PwSegmentAir), C.c_size_t, C.c_int, C.c_uint, C.POINTER(C.POINTER(C.c_uint32)),
+                                 C.POINTER(C.c_size_t), C.c_void_p]
+lib.pw_verify_segment.restype = C.c_int
+lib.pw_verify_segment.argtypes = [C.POINTER(PwStarkConfig), C.POINTER(PwAirDescription), C.c_size_t, C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_void_p]
+lib.pw_commitment_digest.restype = None
+lib.pw_commitment_digest.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+
+
+def commitment_digest(roots) -> np.ndarray:
+    """Digest over an ordered list of 8-word commitments (canonical words)."""
+    r = np.ascontiguousarray(roots, dtype=np.uint32).reshape(-1, 8)
+    out = np.zeros(8, np.uint32)
+    lib.pw_commitment_digest(r.ctypes.data_as(C.c_void_p), len(r), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def prove_segment(airs, shared_bus_seed: bool = False, n_workers: int = 0, copy: bool = True):
+    """airs: [(Prover, device trace pointer, log_height)] -> ([proof words per AIR], bus seed).
+    One call proves all AIRs of a segment on `n_workers` host threads / HIP streams (0 = 4)."""
+    n = len(airs)
+    recs = (PwSegmentAir * max(n, 1))()
+    for i, (pr, ptr, lh) in enumerate(airs):
+        recs[i] = PwSegmentAir(pr._h, ptr, lh)
+    proofs = (C.POINTER(C.c_uint32) * max(n, 1))()
+    lens = (C.c_size_t * max(n, 1))()
+    seed = np.zeros(8, np.uint32)
+    rc = lib.pw_prove_segment(recs, n, int(shared_bus_seed), n_workers, proofs, lens, seed.ctypes.data_as(C.c_void_p))
+    abi.check(rc, "pw_prove_segment")
+    out = []
+    for i in range(n):
+        a = np.ctypeslib.as_array(proofs[i], shape=(lens[i],))
+        out.append(a.copy() if copy else a)
+    return out, seed
+
+
+def verify_segment(descs, proofs, num_queries: int = 100, pow_bits: int = 0, shared_bus_seed: bool = False, check_balance: bool = False):
+    """descs: [(width, log_height, cons_bytecode, cons_spans, interactions-or-None)] -> (code, total bus sum).
+    code 0 = every proof valid (and balanced if asked); ((i+1) << 8) | c = proof i failed check c; 14 = unbalanced."""
+    n = len(descs)
+    keep, recs = [], (PwAirDescription * max(n, 1))()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for i, (w, lh, bc, sp, it) in enumerate(descs):
+        bc = np.ascontiguousarray(bc, dtype=np.uint32)
+        sp = np.ascontiguousarray(sp, dtype=np.uint32).reshape(-1, 2)
+        keep += [bc, sp]
+        if it is None:
+            recs[i] = PwAirDescription(w, lh, 0, vp(bc), len(bc), vp(sp), len(sp), None, 0, None, 0, None, 0)
+        else:
+            a = np.ascontiguousarray(it[0], dtype=np.uint32).reshape(-1, 3)
+            b = np.ascontiguousarray(it[1], dtype=np.uint32).reshape(-1, 2)
+            c = np.ascontiguousarray(it[2], dtype=np.uint32)
+            keep += [a, b, c]
+            recs[i] = PwAirDescription(w, lh, 1, vp(bc), len(bc), vp(sp), len(sp), vp(a), len(a), vp(b), len(b), vp(c), len(c))
+    prs = [np.ascontiguousarray(p, dtype=np.uint32) for p in proofs]
+    ptrs = (C.c_void_p * max(n, 1))(*[p.ctypes.data for p in prs])
+    lens = (C.c_size_t * max(n, 1))(*[len(p) for p in prs])
+    cfg = PwStarkConfig(num_queries, pow_bits)
+    total = np.zeros(4, np.uint32)
+    rc = int(lib.pw_verify_segment(C.byref(cfg), recs, n, ptrs, lens, int(shared_bus_seed), int(check_balance), vp(total)))
+    return rc, total
 
 
 def poseidon2_host(state) -> np.ndarray:

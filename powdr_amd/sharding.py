@@ -52,20 +52,11 @@ def merge_commitments(local_units, local_roots, n_units: int, group=None) -> np.
 
 
 def commitment_digest(roots: np.ndarray) -> np.ndarray:
-    """One 8-word digest over the ordered list of commitments (binary Poseidon2 tree, the host
-    transcript permutation of libpowdr_gpu; canonical words)."""
+    """One 8-word digest over the ordered list of commitments (binary Poseidon2 tree, an odd node paired with
+    zeros; `pw_commitment_digest` of libpowdr_gpu, host code; canonical words). Also the bus seed of a segment."""
     from . import prover
 
-    level = [np.asarray(r, dtype=np.uint32) for r in roots]
-    if not level:
-        return np.zeros(8, np.uint32)
-    while len(level) > 1:
-        nxt = []
-        for i in range(0, len(level), 2):
-            right = level[i + 1] if i + 1 < len(level) else np.zeros(8, np.uint32)
-            nxt.append(prover.poseidon2_host(np.concatenate([level[i], right]))[:8])
-        level = nxt
-    return level[0]
+    return prover.commitment_digest(roots)
 
 
 def allreduce_histograms(histograms, group=None):

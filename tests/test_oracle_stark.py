@@ -258,3 +258,54 @@ def test_logup_cumulative_sums_balance_across_airs():
     lone = [prover.verify_logup(sm.prove_logup(t.reshape(-1), 3, 5, *no_cons, *it, num_queries=4), 3, 5, *no_cons, it, num_queries=4)
             for t, it in ((t1, send), (t2, recv))]
     assert lone[0][0] == 0 and lone[1][0] == 0 and (ext_add_canonical(lone[0][1], lone[1][1]) != 0).any()
+
+
+def test_commitment_digest_matches_restatement():
+    from powdr_amd import prover, sharding
+
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 2, 3, 5, 8, 13):
+        r = rng.integers(0, P, (n, 8), dtype=np.uint32)
+        assert (prover.commitment_digest(r) == sm.commitment_digest(r)).all()
+        assert (sharding.commitment_digest(r) == sm.commitment_digest(r)).all()
+    one = rng.integers(0, P, (1, 8), dtype=np.uint32)
+    assert (prover.commitment_digest(one) == one[0]).all()
+
+
+def test_verify_segment_on_oracle_proofs():
+    """pw_verify_segment (host): recomputes the bus seed from the trace roots inside the proofs, verifies every
+    proof against it, adds up the cumulative sums."""
+    from powdr_amd import prover
+
+    no_cons = (np.zeros(0, np.uint32), np.zeros((0, 2), np.uint32))
+    (t1, send), (t2, recv) = balanced_bus_pair(4, seed=9)
+
+    def proofs_for(airs):
+        roots = [sm.prove_logup(t.reshape(-1), 3, 4, *no_cons, *it, num_queries=0)[7:15] for t, it in airs]
+        seed = sm.commitment_digest(np.array(roots))
+        return [sm.prove_logup(t.reshape(-1), 3, 4, *no_cons, *it, num_queries=5, bus_seed=seed) for t, it in airs]
+
+    descs = [(3, 4, *no_cons, send), (3, 4, *no_cons, recv)]
+    proofs = proofs_for([(t1, send), (t2, recv)])
+    rc, total = prover.verify_segment(descs, proofs, num_queries=5, shared_bus_seed=True, check_balance=True)
+    assert rc == 0 and (total == 0).all()
+    # the order of the AIRs is part of the seed
+    assert prover.verify_segment(descs[::-1], proofs[::-1], num_queries=5, shared_bus_seed=True)[0] == (1 << 8) | 12
+    # a tampered opening in the second proof
+    bad = [proofs[0], proofs[1].copy()]
+    bad[1][40] = (int(bad[1][40]) + 1) % P
+    assert prover.verify_segment(descs, bad, num_queries=5, shared_bus_seed=True)[0] >> 8 == 2
+    # an unmatched tuple: every proof is valid, the segment is not balanced
+    t2b = t2.copy()
+    t2b[1, int(np.argmax(t2b[0] != 0))] ^= 1
+    proofs = proofs_for([(t1, send), (t2b, recv)])
+    assert prover.verify_segment(descs, proofs, num_queries=5, shared_bus_seed=True, check_balance=False)[0] == 0
+    rc, total = prover.verify_segment(descs, proofs, num_queries=5, shared_bus_seed=True, check_balance=True)
+    assert rc == 14 and total.any()
+    # constraints-only proofs ("PWS1") go through the same entry point
+    s, apc, idx, trace = synthetic_trace("T0", 9, seed=3)
+    W, H = trace.shape
+    bc, spans = sm.compile_constraints(apc, idx)
+    pf = sm.prove(np.ascontiguousarray(trace).reshape(-1), W, H.bit_length() - 1, bc, spans, num_queries=5)
+    assert prover.verify_segment([(W, H.bit_length() - 1, bc, spans, None)] * 2, [pf, pf], num_queries=5)[0] == 0
+    assert prover.verify_segment([(W, H.bit_length() - 1, bc, spans, None)], [pf[:-1]], num_queries=5)[0] == (1 << 8) | 10

@@ -141,3 +141,74 @@ def test_bitwise_bus_balances(gpu):
     sums = prove_segment(gpu, airs, [log_h, 16])
     assert sums[0].any() and (ext_sum(sums) == 0).all()
     del keep
+
+
+@pytest.mark.parametrize("workers", [1, 3])
+def test_prove_segment_matches_the_per_air_flow(gpu, workers):
+    """pw_prove_segment (one call, host threads + streams, phase-1 commitments reused in phase 2) produces exactly the
+    proofs of the explicit trace_root -> seed -> prove flow, and pw_verify_segment accepts them as a balanced segment."""
+    torch, periphery, prover, sharding, tg = gpu
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+    from tests.test_tracegen_gpu import run_gpu
+
+    s = synth.generate("T1", seed=6)
+    apc, idx, want, hist, (bufs, dims, gt, order) = run_oracle_gpu_convention(s, 3000, seed=6)
+    W, H = want.shape
+    log_h = H.bit_length() - 1
+    out, per = run_gpu((torch, None, tg), W, H, 3000, bufs, dims, gt.air_names, gt.row_block_size, gt.subs,
+                       om.compile_derived(apc, idx, H), om.compile_bus(apc, idx, H))
+    cons = sm.compile_constraints(apc, idx)
+    sends = periphery.select_buses(sm.compile_interactions(apc, idx), {per.var_bus, per.tuple_bus})
+    airs = [(out.buf, W, cons, sends, log_h),
+            (periphery.var_range_trace(per.var_hist), 3, NO_CONS, periphery.var_range_interactions(per.var_bus), per.var_hist.numel().bit_length() - 1),
+            (periphery.tuple2_trace(per.tuple_hist, per.tuple_sizes), 3, NO_CONS, periphery.tuple2_interactions(per.tuple_bus),
+             per.tuple_hist.numel().bit_length() - 1)]
+    nq = 7
+    provers = [prover.Prover(w, *c, num_queries=nq, interactions=it) for (_, w, c, it, _) in airs]
+    # explicit flow
+    roots = [pr.trace_root(t.data_ptr(), lh) for pr, (t, _, _, _, lh) in zip(provers, airs)]
+    seed = sharding.commitment_digest(np.array(roots))
+    ref = []
+    for pr, (t, _, _, _, lh) in zip(provers, airs):
+        pr.set_bus_seed(seed)
+        ref.append(pr.prove(t.data_ptr(), lh))
+    # one call
+    got, seed2 = prover.prove_segment([(pr, t.data_ptr(), lh) for pr, (t, _, _, _, lh) in zip(provers, airs)], shared_bus_seed=True,
+                                      n_workers=workers)
+    assert (seed2 == seed).all()
+    for a, b in zip(got, ref):
+        assert len(a) == len(b) and (a == b).all()
+    descs = [(w, lh, *c, it) for (_, w, c, it, lh) in airs]
+    rc, total = prover.verify_segment(descs, got, num_queries=nq, shared_bus_seed=True, check_balance=True)
+    assert rc == 0 and (total == 0).all()
+    for pr in provers:
+        pr.close()
+
+
+def test_prove_segment_many_airs_of_mixed_heights(gpu):
+    """A reth-shaped segment: many AIRs, heights 2^4..2^15, constraints only; four workers produce
+    the same bytes as proving the AIRs one by one, whatever order the workers finish in."""
+    torch, periphery, prover, sharding, tg = gpu
+    rng = np.random.default_rng(8)
+    PA, PC = om.OP_PUSH_APC, om.OP_PUSH_CONST
+    airs, provers = [], []
+    for k in range(14):
+        log_h = int(rng.integers(4, 16))
+        W = int(rng.integers(2, 40))
+        a, b = (int(x) for x in rng.integers(0, W, 2))
+        bc = np.array([PA, a, PA, b, om.OP_MUL, PC, int(rng.integers(0, P)), om.OP_SUB], np.uint32)  # unsatisfied: parity does not care
+        spans = np.array([[0, len(bc)]], np.uint32)
+        t = to_dev(torch, rng.integers(0, P, W << log_h, dtype=np.uint32))
+        airs.append((t, W, log_h, bc, spans))
+        provers.append(prover.Prover(W, bc, spans, num_queries=6, pow_bits=3))
+    ref = [pr.prove(t.data_ptr(), lh) for pr, (t, _, lh, _, _) in zip(provers, airs)]
+    for workers in (4, 0, 1):
+        got, _ = prover.prove_segment([(pr, t.data_ptr(), lh) for pr, (t, _, lh, _, _) in zip(provers, airs)], n_workers=workers)
+        for a, b in zip(got, ref):
+            assert len(a) == len(b) and (a == b).all()
+    for k in (0, 5, 13):
+        t, W, lh, bc, spans = airs[k]
+        if lh <= 10:
+            assert (ref[k] == sm.prove(from_dev(t), W, lh, bc, spans, num_queries=6, pow_bits=3)).all()
+    for pr in provers:
+        pr.close()
