@@ -173,6 +173,7 @@ def main():
         args.exact_source_heights = True
         wl = build_workload(args.shape, log_h, True, seed=rank)
     inter = wl["apc"].compile_bus(1) if args.logup else None  # (interactions, spans, bytecode) with column operands
+    perm_cols = 4 * len(prover.logup_group_starts(inter)) if args.logup else 0  # 4 * (groups + 1)
     pr = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits, interactions=inter)
     from powdr_amd import sharding
 
@@ -341,9 +342,9 @@ def main():
             config=dict(workload=f"{args.shape} {shape.name} autoprecompile AIR: {wl['W']} cols x 2^{log_h} rows, "
                                  f"{len(wl['cons'][1])} constraints, {wl['apc'].n_bus} bus interactions; trace generation + "
                                  f"pw-stark v0 proof (blow-up 2, {args.queries} queries, {args.pow_bits} PoW bits)"
-                                 + (f" WITH the LogUp phase: {4 * (wl['apc'].n_bus + 1)} extra committed columns, "
-                                    f"rho = {4 * (wl['apc'].n_bus + 1) / wl['W']:.2f} (SURVEY 8d: algorithmic bytes per main cell "
-                                    f"= 48 + 4 + 44*rho = {52 + 44 * 4 * (wl['apc'].n_bus + 1) / wl['W']:.0f})" if args.logup else "")
+                                 + (f" WITH the LogUp phase: {perm_cols // 4 - 1} interaction groups = {perm_cols} extra committed "
+                                    f"columns, rho = {perm_cols / wl['W']:.2f} (SURVEY 8d: algorithmic bytes per main cell "
+                                    f"= 48 + 4 + 44*rho = {52 + 44 * perm_cols / wl['W']:.0f})" if args.logup else "")
                                  + "; one segment per step per GPU"
                                  + ("; source heights b*calls (not padded to a power of two)" if args.exact_source_heights else ""),
                         rows=wl["H"], cols=wl["W"], parallelism=f"segments x{world}" + (f", {args.pipeline} streams per GPU" if args.pipeline > 1 else ""),

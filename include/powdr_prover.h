@@ -94,6 +94,14 @@ int pw_verify_logup(const PwStarkConfig* cfg, uint32_t width, uint32_t log_heigh
                     const uint32_t* inter_bytecode, size_t inter_bytecode_len, const uint32_t* expected_bus_seed,
                     const uint32_t* proof_words, size_t n_words, uint32_t* cumulative_sum, uint32_t* trace_root);
 
+/* How pw_prover_create_logup / pw_verify_logup pack the interactions into committed columns: consecutive
+ * interactions share one extension column ("group") while the group's constraint keeps degree <= 3. Writes up to
+ * `cap` group boundaries (interaction indices) to `out`, returns their number (n_groups + 1; 0 = malformed table).
+ * The permutation matrix has 4 * (n_groups + 1) base columns. */
+size_t pw_logup_group_starts(const uint32_t* interactions, size_t n_interactions, const uint32_t* inter_spans,
+                             size_t n_inter_spans, const uint32_t* inter_bytecode, size_t inter_bytecode_len,
+                             uint32_t* out, size_t cap);
+
 /* ---- one segment = many AIRs -------------------------------------------------------------------------------------
  * The engine call the reference makes once per segment with all chips' traces, `engine.prove(pk, ProvingContext{
  * per_trace})` (openvm/src/trace_generation.rs:97-139, openvm-riscv/src/lib.rs:327-341). */

@@ -124,6 +124,17 @@ def compile_interactions(apc: om.Apc, idx: dict):
     return om.compile_bus(apc, idx, 1)
 
 
+def group_starts(inter, ispans, ibc) -> np.ndarray:
+    """Boundaries of the LogUp groups (n_groups + 1 interaction indices)."""
+    it, isp, ib = (np.ascontiguousarray(a, dtype=np.uint32) for a in (inter, ispans, ibc))
+    n = len(it.reshape(-1, 3))
+    out = np.zeros(n + 2, np.uint32)
+    lib = _lib()
+    lib.or_group_starts.restype = C.c_size_t
+    k = lib.or_group_starts(_p(it), C.c_size_t(n), _p(isp), _p(ib), _p(out), C.c_size_t(len(out)))
+    return out[:k].copy()
+
+
 def _seed(bus_seed):
     if bus_seed is None:
         return None, C.c_void_p(None)

@@ -594,13 +594,15 @@ int verify(const Config& cfg, const u32* proof, size_t len, u32 width, u32 log_h
  * `generate_perm_trace_time_ms`, openvm/metrics-viewer/CLAUDE.md:62-73,114). Parity unpinned like the
  * rest of the prover. Differences from v0:
  *   after the trace root: al, bl <- transcript (extension field)
- *   perm matrix (4 (n_int + 1) base columns): for interaction i,
- *        d_i = al + bus_i + sum_j bl^(j+1) a_ij,   q_i = m_i / d_i,
- *        phi(row r) = sum_{r' <= r} sum_i q_i(r');  S = phi(last row) goes into the proof
+ *   interactions are packed, in order, into groups (the backend's "chunks"): a group is extended while its
+ *        constraint below keeps degree <= 3 (group_starts); n_g groups
+ *   perm matrix (4 (n_g + 1) base columns): for interaction i, d_i = al + bus_i + sum_j bl^(j+1) a_ij; for group g
+ *        q_g = sum_{i in g} m_i / d_i  (one extension column),
+ *        phi(row r) = sum_{r' <= r} sum_g q_g(r');  S = phi(last row) goes into the proof
  *   extra (extension-valued) constraints, folded after the base ones:
- *        q_i d_i - m_i                                      (every row)
- *        is_first (phi - sum_i q_i)
- *        is_transition (phi' - phi - sum_i q_i')            (' = next row)
+ *        q_g prod_{i in g} d_i - sum_{i in g} m_i prod_{j in g, j != i} d_j      (every row)
+ *        is_first (phi - sum_g q_g)
+ *        is_transition (phi' - phi - sum_g q_g')            (' = next row)
  *        is_last (phi - S)
  *     with is_first = Z_H/(x-1), is_last = Z_H/(x-g^-1), is_transition = x - g^-1
  *   openings: main, perm, quotient at zeta; perm also at g*zeta; DEEP with both points.
@@ -629,6 +631,46 @@ struct LogupRow {  /* per-row evaluation shared by prover (base values) and veri
 
 size_t max_args(const Interactions& I) { size_t k = 0; for (size_t i = 0; i < I.n; ++i) if (I.inter[3 * i + 1] > k) k = I.inter[3 * i + 1]; return k; }
 
+/* degree in the trace columns of a post-fix program */
+int expr_degree(const u32* bc, u32 len) {
+    int st[16], sp = 0;
+    for (u32 ip = 0; ip < len;) {
+        u32 op = bc[ip++];
+        if (op == OP_PUSH_COL || op == OP_PUSH_CONST) { if (sp >= 16 || ip >= len) return 99; st[sp++] = op == OP_PUSH_COL ? 1 : 0; ++ip; }
+        else if (op == OP_ADD || op == OP_SUB) { if (sp < 2) return 99; --sp; st[sp - 1] = st[sp - 1] > st[sp] ? st[sp - 1] : st[sp]; }
+        else if (op == OP_MUL) { if (sp < 2) return 99; --sp; st[sp - 1] += st[sp]; }
+        else if (op == OP_NEG) { if (sp < 1) return 99; }
+        else return 99;
+    }
+    return sp == 1 ? st[0] : 99;
+}
+
+/* Group boundaries (n_g + 1 entries): interactions are taken in order; interaction i joins the current group while
+ *   1 + sum_{j in g} deg d_j <= 3   and   deg m_j + sum_{k in g, k != j} deg d_k <= 3 for every member j,
+ * i.e. while the group's constraint stays within the degree the blow-up-2 quotient can carry; otherwise it opens a
+ * new group (a single interaction is always accepted: an over-degree one simply cannot be proven). */
+std::vector<u32> group_starts(const Interactions& I) {
+    std::vector<u32> starts{0};
+    std::vector<int> dm, dd;
+    int sum_den = 0;
+    for (size_t i = 0; i < I.n; ++i) {
+        const u32* it = I.inter + 3 * i;
+        const u32* sp = I.spans + 2 * (size_t)it[2];
+        int m = expr_degree(I.bc + sp[0], sp[1]), d = 0;
+        for (u32 j = 0; j < it[1]; ++j) { int a = expr_degree(I.bc + sp[2 + 2 * j], sp[3 + 2 * j]); if (a > d) d = a; }
+        bool ok = !dm.empty();
+        if (ok) {
+            const int ns = sum_den + d;
+            ok = 1 + ns <= 3 && m + ns - d <= 3;
+            for (size_t k = 0; ok && k < dm.size(); ++k) ok = dm[k] + ns - dd[k] <= 3;
+        }
+        if (!ok && !dm.empty()) { starts.push_back((u32)i); dm.clear(); dd.clear(); sum_den = 0; }
+        dm.push_back(m); dd.push_back(d); sum_den += d;
+    }
+    if (I.n) starts.push_back((u32)I.n);
+    return starts;
+}
+
 void observe_instance2(Challenger& ch, u32 log_h, u32 width, u32 nc, u32 n_int, const Config& cfg) {
     ch.observe(MAGIC2 % P); ch.observe(log_h); ch.observe(width); ch.observe(nc); ch.observe(n_int);
     ch.observe(cfg.num_queries); ch.observe(cfg.pow_bits);
@@ -651,7 +693,19 @@ std::vector<u32> prove_logup(const Config& cfg, const u32* trace, u32 width, u32
     const size_t H = (size_t)1 << log_h, N = 2 * H;
     const int logN = (int)log_h + 1;
     const u32 n_int = (u32)I.n;
-    const size_t Wp = 4 * ((size_t)n_int + 1);
+    const std::vector<u32> gs = group_starts(I);
+    const size_t n_g = gs.size() - 1;
+    const size_t Wp = 4 * (n_g + 1);
+    /* (num, den) of group g at one row: q_g = num / den with num = sum_i m_i prod_{j != i} d_j, den = prod_i d_i */
+    auto group_fraction = [&](size_t g, const u32* m, size_t stride, size_t row, const Ext& al, const Ext* blpow, Ext& num, Ext& den) {
+        num = ext_zero(); den = ext_one();
+        for (size_t i = gs[g]; i < gs[g + 1]; ++i) {
+            Ext d = LogupRow::denom_base(I, i, m, stride, row, al, blpow);
+            u32 mu = LogupRow::mult_base(I, i, m, stride, row);
+            num = ext_add(ext_mul(num, d), ext_scale(den, mu));
+            den = ext_mul(den, d);
+        }
+    };
     Writer pf;
     Challenger ch;
     observe_instance2(ch, log_h, width, (u32)prog.n, n_int, cfg);
@@ -684,17 +738,17 @@ std::vector<u32> prove_logup(const Config& cfg, const u32* trace, u32 width, u32
 #pragma omp parallel for schedule(static)
     for (long r = 0; r < (long)H; ++r) {
         Ext acc = ext_zero();
-        for (size_t i = 0; i < n_int; ++i) {
-            Ext d = LogupRow::denom_base(I, i, trace, H, (size_t)r, al, blpow.data());
-            u32 m = LogupRow::mult_base(I, i, trace, H, (size_t)r);
-            Ext q = ext_scale(ext_inv(d), m);
-            for (int k = 0; k < 4; ++k) perm[(4 * i + k) * H + r] = q.c[k];
+        for (size_t g = 0; g < n_g; ++g) {
+            Ext num, den;
+            group_fraction(g, trace, H, (size_t)r, al, blpow.data(), num, den);
+            Ext q = ext_mul(num, ext_inv(den));
+            for (int k = 0; k < 4; ++k) perm[(4 * g + k) * H + r] = q.c[k];
             acc = ext_add(acc, q);
         }
         rowsum[r] = acc;
     }
     Ext run = ext_zero();
-    for (size_t r = 0; r < H; ++r) { run = ext_add(run, rowsum[r]); for (int k = 0; k < 4; ++k) perm[(4 * (size_t)n_int + k) * H + r] = run.c[k]; }
+    for (size_t r = 0; r < H; ++r) { run = ext_add(run, rowsum[r]); for (int k = 0; k < 4; ++k) perm[(4 * n_g + k) * H + r] = run.c[k]; }
     const Ext S = run;
     std::vector<u32> pcoef(Wp * H), plde(Wp * N);
 #pragma omp parallel for schedule(dynamic)
@@ -712,7 +766,7 @@ std::vector<u32> prove_logup(const Config& cfg, const u32* trace, u32 width, u32
 
     /* 3. quotient */
     Ext alpha = ch.sample_ext();
-    const size_t M = prog.n + n_int + 3;
+    const size_t M = prog.n + n_g + 3;
     std::vector<Ext> apow(M);
     { Ext a = ext_one(); for (size_t j = M; j-- > 0;) { apow[j] = a; a = ext_mul(a, alpha); } }
     u32 sH = or_pow(COSET_SHIFT, H);
@@ -732,25 +786,24 @@ std::vector<u32> prove_logup(const Config& cfg, const u32* trace, u32 width, u32
             acc = ext_add(acc, ext_scale(apow[k], v));
         }
         Ext sumq = ext_zero(), sumq_next = ext_zero();
-        for (size_t i = 0; i < n_int; ++i) {
-            Ext qi, qn;
-            for (int k = 0; k < 4; ++k) { qi.c[k] = plde[(4 * i + k) * N + j]; qn.c[k] = plde[(4 * i + k) * N + jn]; }
+        for (size_t g = 0; g < n_g; ++g) {
+            Ext qi, qn, num, den;
+            for (int k = 0; k < 4; ++k) { qi.c[k] = plde[(4 * g + k) * N + j]; qn.c[k] = plde[(4 * g + k) * N + jn]; }
             sumq = ext_add(sumq, qi);
             sumq_next = ext_add(sumq_next, qn);
-            Ext d = LogupRow::denom_base(I, i, lde.data(), N, (size_t)j, al, blpow.data());
-            u32 m = LogupRow::mult_base(I, i, lde.data(), N, (size_t)j);
-            Ext c = ext_sub(ext_mul(qi, d), ext_from(m));
-            acc = ext_add(acc, ext_mul(apow[prog.n + i], c));
+            group_fraction(g, lde.data(), N, (size_t)j, al, blpow.data(), num, den);
+            Ext c = ext_sub(ext_mul(qi, den), num);
+            acc = ext_add(acc, ext_mul(apow[prog.n + g], c));
         }
         Ext phi, phin;
-        for (int k = 0; k < 4; ++k) { phi.c[k] = plde[(4 * (size_t)n_int + k) * N + j]; phin.c[k] = plde[(4 * (size_t)n_int + k) * N + jn]; }
+        for (int k = 0; k < 4; ++k) { phi.c[k] = plde[(4 * n_g + k) * N + j]; phin.c[k] = plde[(4 * n_g + k) * N + jn]; }
         u32 x = xs[j], Z = zval[j & 1];
         u32 is_first = or_mul(Z, or_inv(or_sub(x, 1)));
         u32 is_last = or_mul(Z, or_inv(or_sub(x, ginv)));
         u32 is_trans = or_sub(x, ginv);
-        acc = ext_add(acc, ext_mul(apow[prog.n + n_int], ext_scale(ext_sub(phi, sumq), is_first)));
-        acc = ext_add(acc, ext_mul(apow[prog.n + n_int + 1], ext_scale(ext_sub(ext_sub(phin, phi), sumq_next), is_trans)));
-        acc = ext_add(acc, ext_mul(apow[prog.n + n_int + 2], ext_scale(ext_sub(phi, S), is_last)));
+        acc = ext_add(acc, ext_mul(apow[prog.n + n_g], ext_scale(ext_sub(phi, sumq), is_first)));
+        acc = ext_add(acc, ext_mul(apow[prog.n + n_g + 1], ext_scale(ext_sub(ext_sub(phin, phi), sumq_next), is_trans)));
+        acc = ext_add(acc, ext_mul(apow[prog.n + n_g + 2], ext_scale(ext_sub(phi, S), is_last)));
         acc = ext_scale(acc, zinv[j & 1]);
         for (int k = 0; k < 4; ++k) q[k * N + j] = acc.c[k];
     }
@@ -877,7 +930,9 @@ int verify_logup(const Config& cfg, const u32* proof, size_t len, u32 width, u32
     const size_t H = (size_t)1 << log_h, N = 2 * H;
     const int logN = (int)log_h + 1;
     const u32 n_int = (u32)I.n;
-    const size_t Wp = 4 * ((size_t)n_int + 1);
+    const std::vector<u32> gs = group_starts(I);
+    const size_t n_g = gs.size() - 1;
+    const size_t Wp = 4 * (n_g + 1);
     size_t pos = 0;
     auto need = [&](size_t k) { if (pos + k > len) throw std::runtime_error("short proof"); };
     auto get = [&]() { need(1); return proof[pos++]; };
@@ -919,18 +974,23 @@ int verify_logup(const Config& cfg, const u32* proof, size_t len, u32 width, u32
         for (size_t k = 0; k < prog.n; ++k)
             acc = ext_add(ext_mul(acc, alpha), eval_ext(prog.bc + prog.spans[2 * k], prog.spans[2 * k + 1], opened.data()));
         Ext sumq = ext_zero(), sumq_next = ext_zero();
-        for (size_t i = 0; i < n_int; ++i) {
-            const u32* it = I.inter + 3 * i;
-            const u32* sp = I.spans + 2 * (size_t)it[2];
-            Ext d = ext_add(al, ext_from(it[0] % P));
-            for (u32 j = 0; j < it[1]; ++j) d = ext_add(d, ext_mul(blpow[j + 1], eval_ext(I.bc + sp[2 + 2 * j], sp[3 + 2 * j], opened.data())));
-            Ext m = eval_ext(I.bc + sp[0], sp[1], opened.data());
-            Ext qi = ext_col(width + 4 * i), qn = ext_col(K1 + 4 * i);
+        for (size_t g = 0; g < n_g; ++g) {
+            Ext num = ext_zero(), den = ext_one();
+            for (size_t i = gs[g]; i < gs[g + 1]; ++i) {
+                const u32* it = I.inter + 3 * i;
+                const u32* sp = I.spans + 2 * (size_t)it[2];
+                Ext d = ext_add(al, ext_from(it[0] % P));
+                for (u32 j = 0; j < it[1]; ++j) d = ext_add(d, ext_mul(blpow[j + 1], eval_ext(I.bc + sp[2 + 2 * j], sp[3 + 2 * j], opened.data())));
+                Ext m = eval_ext(I.bc + sp[0], sp[1], opened.data());
+                num = ext_add(ext_mul(num, d), ext_mul(den, m));
+                den = ext_mul(den, d);
+            }
+            Ext qi = ext_col(width + 4 * g), qn = ext_col(K1 + 4 * g);
             sumq = ext_add(sumq, qi);
             sumq_next = ext_add(sumq_next, qn);
-            acc = ext_add(ext_mul(acc, alpha), ext_sub(ext_mul(qi, d), m));
+            acc = ext_add(ext_mul(acc, alpha), ext_sub(ext_mul(qi, den), num));
         }
-        Ext phi = ext_col(width + 4 * (size_t)n_int), phin = ext_col(K1 + 4 * (size_t)n_int);
+        Ext phi = ext_col(width + 4 * n_g), phin = ext_col(K1 + 4 * n_g);
         Ext zH = ext_pow(zeta, H);
         Ext Z = ext_sub(zH, ext_one());
         Ext is_first = ext_mul(Z, ext_inv(ext_sub(zeta, ext_one())));
@@ -1076,6 +1136,13 @@ size_t or_prove_logup(uint32_t num_queries, uint32_t pow_bits, const uint32_t* t
     std::vector<u32> w = prove_logup(cfg, trace, width, log_h, pr, I, bus_seed);
     if (w.size() <= cap) memcpy(proof, w.data(), w.size() * 4);
     return w.size();
+}
+/* group boundaries of the LogUp packing: writes up to cap entries, returns the number of entries (n_groups + 1) */
+size_t or_group_starts(const uint32_t* inter, size_t n_inter, const uint32_t* ispans, const uint32_t* ibc, uint32_t* out, size_t cap) {
+    Interactions I{inter, n_inter, ispans, ibc};
+    std::vector<u32> g = group_starts(I);
+    for (size_t i = 0; i < g.size() && i < cap; ++i) out[i] = g[i];
+    return g.size();
 }
 int or_verify_logup(uint32_t num_queries, uint32_t pow_bits, const uint32_t* proof, size_t len, uint32_t width, uint32_t log_h,
                     const uint32_t* cons_bc, const uint32_t* cons_spans, size_t n_constraints, const uint32_t* inter,

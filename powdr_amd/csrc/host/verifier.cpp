@@ -3,6 +3,7 @@
 // /root/reference/openvm-riscv/src/lib.rs:337-341). Protocol: oracle/stark_oracle.cpp header / DESIGN.md §5.
 // Independent of the oracle's verifier (different arithmetic representation, own transcript code).
 #include "../prover_internal.hpp"
+#include "../logup_groups.hpp"
 #include "../../../include/powdr_prover.h"
 #include "../../../include/powdr_gpu.h"
 
@@ -101,8 +102,8 @@ int verify_impl(const PwStarkConfig* cfg, uint32_t width, uint32_t log_h, const 
                 uint32_t* sum_out, uint32_t* trace_root_out) {
     if (!cfg || !proof || log_h < 1 || log_h > 26) return 10;
     const uint32_t n_int = lg ? (uint32_t)lg->n : 0;
-    const size_t Wp = lg ? 4 * ((size_t)n_int + 1) : 0;
     uint32_t max_args = 0;
+    std::vector<uint32_t> gstarts{0};
     if (lg) {
         for (size_t i = 0; i < lg->n; ++i) {
             const uint32_t na = lg->inter[3 * i + 1], first = lg->inter[3 * i + 2];
@@ -111,7 +112,10 @@ int verify_impl(const PwStarkConfig* cfg, uint32_t width, uint32_t log_h, const 
                 if ((size_t)lg->spans[2 * (first + k)] + lg->spans[2 * (first + k) + 1] > lg->bc_len) return 10;
             if (na > max_args) max_args = na;
         }
+        gstarts = pw::logup_group_starts(lg->inter, lg->n, lg->spans, lg->bc);
     }
+    const size_t n_g = gstarts.size() - 1;
+    const size_t Wp = lg ? 4 * (n_g + 1) : 0;
     const size_t H = (size_t)1 << log_h, N = 2 * H;
     const int logN = (int)log_h + 1;
     size_t pos = 0;
@@ -189,25 +193,31 @@ int verify_impl(const PwStarkConfig* cfg, uint32_t width, uint32_t log_h, const 
         return r;
     };
     if (lg) {
-        // LogUp: q_i * d_i = m_i on every row; phi is the running sum of sum_i q_i and ends at S
+        // LogUp: per group q_g * prod d_i = sum_i m_i prod_{j != i} d_j on every row (i.e. q_g = sum_i m_i / d_i);
+        // phi is the running sum of sum_g q_g and ends at S
         std::vector<Ext> blpow(max_args + 2);
         { Ext b = bb::ext_one(); for (auto& x : blpow) { x = b; b = bb::ext_mul(b, bl); } }
         Ext sumq = bb::ext_zero(), sumq_next = bb::ext_zero();
-        for (size_t i = 0; i < n_int; ++i) {
-            const uint32_t bus = lg->inter[3 * i], na = lg->inter[3 * i + 1];
-            const uint32_t* sp = lg->spans + 2 * (size_t)lg->inter[3 * i + 2];
-            Ext d = bb::ext_add(al, bb::ext_from_base(bb::to_monty(bus % bb::P))), m, a;
-            for (uint32_t j = 0; j < na; ++j) {
-                if (!eval_ext(lg->bc + sp[2 + 2 * j], sp[3 + 2 * j], opened.data(), width, a)) return 10;
-                d = bb::ext_add(d, bb::ext_mul(blpow[j + 1], a));
+        for (size_t g = 0; g < n_g; ++g) {
+            Ext num = bb::ext_zero(), den = bb::ext_one();
+            for (size_t i = gstarts[g]; i < gstarts[g + 1]; ++i) {
+                const uint32_t bus = lg->inter[3 * i], na = lg->inter[3 * i + 1];
+                const uint32_t* sp = lg->spans + 2 * (size_t)lg->inter[3 * i + 2];
+                Ext d = bb::ext_add(al, bb::ext_from_base(bb::to_monty(bus % bb::P))), m, a;
+                for (uint32_t j = 0; j < na; ++j) {
+                    if (!eval_ext(lg->bc + sp[2 + 2 * j], sp[3 + 2 * j], opened.data(), width, a)) return 10;
+                    d = bb::ext_add(d, bb::ext_mul(blpow[j + 1], a));
+                }
+                if (!eval_ext(lg->bc + sp[0], sp[1], opened.data(), width, m)) return 10;
+                num = bb::ext_add(bb::ext_mul(num, d), bb::ext_mul(den, m));
+                den = bb::ext_mul(den, d);
             }
-            if (!eval_ext(lg->bc + sp[0], sp[1], opened.data(), width, m)) return 10;
-            const Ext qi = combine(width + 4 * i), qn = combine(K1 + 4 * i);
+            const Ext qi = combine(width + 4 * g), qn = combine(K1 + 4 * g);
             sumq = bb::ext_add(sumq, qi);
             sumq_next = bb::ext_add(sumq_next, qn);
-            acc = bb::ext_add(bb::ext_mul(acc, alpha), bb::ext_sub(bb::ext_mul(qi, d), m));
+            acc = bb::ext_add(bb::ext_mul(acc, alpha), bb::ext_sub(bb::ext_mul(qi, den), num));
         }
-        const Ext phi = combine(width + 4 * (size_t)n_int), phin = combine(K1 + 4 * (size_t)n_int);
+        const Ext phi = combine(width + 4 * n_g), phin = combine(K1 + 4 * n_g);
         const Ext is_trans = bb::ext_sub(zeta, bb::ext_from_base(g_inv));
         const Ext is_first = bb::ext_mul(zh, bb::ext_inv(bb::ext_sub(zeta, bb::ext_one())));
         const Ext is_last = bb::ext_mul(zh, bb::ext_inv(is_trans));
@@ -313,4 +323,20 @@ extern "C" int pw_verify_logup(const PwStarkConfig* cfg, uint32_t width, uint32_
     const Interactions lg{interactions, n_interactions, inter_spans, n_inter_spans, inter_bytecode, inter_bytecode_len};
     return verify_impl(cfg, width, log_h, bc, bc_len, spans, n_constraints, &lg, expected_bus_seed, proof, len, cumulative_sum,
                        trace_root);
+}
+
+// Boundaries of the LogUp groups the prover and the verifier derive from an interaction table (logup_groups.hpp):
+// writes up to `cap` entries, returns the number of entries (n_groups + 1), 0 if the table is malformed.
+extern "C" size_t pw_logup_group_starts(const uint32_t* interactions, size_t n_interactions, const uint32_t* inter_spans,
+                                        size_t n_inter_spans, const uint32_t* inter_bytecode, size_t inter_bytecode_len,
+                                        uint32_t* out, size_t cap) {
+    for (size_t i = 0; i < n_interactions; ++i) {
+        const uint32_t na = interactions[3 * i + 1], first = interactions[3 * i + 2];
+        if ((size_t)first + 1 + na > n_inter_spans) return 0;
+        for (uint32_t k = 0; k <= na; ++k)
+            if ((size_t)inter_spans[2 * (first + k)] + inter_spans[2 * (first + k) + 1] > inter_bytecode_len) return 0;
+    }
+    const std::vector<uint32_t> g = pw::logup_group_starts(interactions, n_interactions, inter_spans, inter_bytecode);
+    for (size_t i = 0; i < g.size() && i < cap; ++i) out[i] = g[i];
+    return g.size();
 }

@@ -37,7 +37,9 @@ __device__ __forceinline__ uint32_t interaction_mult(const LogupInteraction& it,
     return xbc::eval<kBlock, true>(code + 2 * (size_t)off, len, m, r, stk, stride);
 }
 
-// perm[(4i+k)*H + r] = coordinate k of q_i(r) = m_i(r) / d_i(r);  rowsum[r] = sum_i q_i(r)
+// perm[(4g+k)*H + r] = coordinate k of q_g(r) = sum_{i in g} m_i(r) / d_i(r);  rowsum[r] = sum_g q_g(r).
+// Only interactions with a non-zero multiplicity on the row contribute (padding rows cost no inversion at all); the
+// active ones of a group share one inversion: q = num / den, (num, den) <- (num d_i + m_i den, den d_i).
 __global__ __launch_bounds__(kBlock) void logup_perm_kernel(const uint32_t* __restrict__ trace, size_t H, LogupProgram lp, Ext al,
                                                              const Ext* __restrict__ blpow, uint32_t* __restrict__ perm,
                                                              Ext* __restrict__ rowsum) {
@@ -46,15 +48,25 @@ __global__ __launch_bounds__(kBlock) void logup_perm_kernel(const uint32_t* __re
     const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= H) return;
     Ext acc = bb::ext_zero();
-    for (uint32_t i = 0; i < lp.n; ++i) {
-        const LogupInteraction it = lp.d_inter[i];
-        const uint32_t m = interaction_mult(it, lp.d_xspans, lp.d_code, trace, H, r, stk);
-        Ext q = bb::ext_zero();
-        if (m != 0u) {
+    for (uint32_t g = 0; g < lp.n_groups; ++g) {
+        Ext num = bb::ext_zero(), den = bb::ext_one();
+        bool any = false;
+        for (uint32_t i = lp.d_gstarts[g]; i < lp.d_gstarts[g + 1]; ++i) {
+            const LogupInteraction it = lp.d_inter[i];
+            const uint32_t m = interaction_mult(it, lp.d_xspans, lp.d_code, trace, H, r, stk);
+            if (m == 0u) continue;
             const Ext d = interaction_denominator(it, lp.d_xspans, lp.d_code, trace, H, r, stk, al, blpow);
-            q = bb::ext_scale(bb::ext_inv(d), m);
+            if (any) {
+                num = bb::ext_add(bb::ext_mul(num, d), bb::ext_scale(den, m));
+                den = bb::ext_mul(den, d);
+            } else {
+                num = bb::ext_from_base(m);
+                den = d;
+                any = true;
+            }
         }
-        uint32_t* out = perm + (size_t)(4 * i) * H + r;
+        const Ext q = any ? bb::ext_mul(num, bb::ext_inv(den)) : bb::ext_zero();
+        uint32_t* out = perm + (size_t)(4 * g) * H + r;
         out[0] = q.c[0]; out[H] = q.c[1]; out[2 * H] = q.c[2]; out[3 * H] = q.c[3];
         acc = bb::ext_add(acc, q);
     }
@@ -118,8 +130,9 @@ __global__ __launch_bounds__(kBlock) void scan_write_kernel(const Ext* __restric
 }
 
 // ---- quotient with the LogUp constraints ---------------------------------------------------------------
-// acc = sum_k apow[k] C_k + sum_i apow[nc+i] (q_i d_i - m_i) + apow[nc+n] is_first (phi - sum q)
-//       + apow[nc+n+1] is_trans (phi' - phi - sum q') + apow[nc+n+2] is_last (phi - S);  q = acc / Z_H
+// acc = sum_k apow[k] C_k + sum_g apow[nc+g] (q_g den_g - num_g) + apow[nc+G] is_first (phi - sum q)
+//       + apow[nc+G+1] is_trans (phi' - phi - sum q') + apow[nc+G+2] is_last (phi - S);  q = acc / Z_H
+// with den_g = prod_{i in g} d_i, num_g = sum_{i in g} m_i prod_{j != i} d_j, G = number of groups
 template <bool XBC>
 __global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* __restrict__ lde, const uint32_t* __restrict__ plde,
                                                                  size_t N, const uint32_t* __restrict__ bytecode,
@@ -140,20 +153,30 @@ __global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* 
         acc = bb::ext_add(acc, bb::ext_scale(apow[c], v));
     }
     Ext sumq = bb::ext_zero(), sumq_next = bb::ext_zero();
-    for (uint32_t i = 0; i < lp.n; ++i) {
-        const LogupInteraction it = lp.d_inter[i];
-        const uint32_t* pc = plde + (size_t)(4 * i) * N;
+    for (uint32_t g = 0; g < lp.n_groups; ++g) {
+        const uint32_t* pc = plde + (size_t)(4 * g) * N;
         const Ext qi = {{pc[j], pc[N + j], pc[2 * N + j], pc[3 * N + j]}};
         const Ext qn = {{pc[jn], pc[N + jn], pc[2 * N + jn], pc[3 * N + jn]}};
         sumq = bb::ext_add(sumq, qi);
         sumq_next = bb::ext_add(sumq_next, qn);
-        const Ext d = interaction_denominator(it, lp.d_xspans, lp.d_code, lde, N, j, stk, al, blpow);
-        const uint32_t m = interaction_mult(it, lp.d_xspans, lp.d_code, lde, N, j, stk);
-        Ext c = bb::ext_mul(qi, d);
-        c.c[0] = bb::sub(c.c[0], m);
-        acc = bb::ext_add(acc, bb::ext_mul(apow[nc + i], c));
+        const uint32_t i0 = lp.d_gstarts[g], i1 = lp.d_gstarts[g + 1];
+        Ext num, den;
+        for (uint32_t i = i0; i < i1; ++i) {
+            const LogupInteraction it = lp.d_inter[i];
+            const Ext d = interaction_denominator(it, lp.d_xspans, lp.d_code, lde, N, j, stk, al, blpow);
+            const uint32_t m = interaction_mult(it, lp.d_xspans, lp.d_code, lde, N, j, stk);
+            if (i == i0) {
+                num = bb::ext_from_base(m);
+                den = d;
+            } else {
+                num = bb::ext_add(bb::ext_mul(num, d), bb::ext_scale(den, m));
+                den = bb::ext_mul(den, d);
+            }
+        }
+        const Ext c = bb::ext_sub(bb::ext_mul(qi, den), num);
+        acc = bb::ext_add(acc, bb::ext_mul(apow[nc + g], c));
     }
-    const uint32_t* pp = plde + (size_t)(4 * lp.n) * N;
+    const uint32_t* pp = plde + (size_t)(4 * lp.n_groups) * N;
     const Ext phi = {{pp[j], pp[N + j], pp[2 * N + j], pp[3 * N + j]}};
     const Ext phin = {{pp[jn], pp[N + jn], pp[2 * N + jn], pp[3 * N + jn]}};
     const uint32_t x = bb::mul(shift, bb::pow_u32(wN, (uint32_t)j));
@@ -162,9 +185,9 @@ __global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* 
     const uint32_t is_first = bb::mul(Z, bb::inv(bb::sub(x, one)));
     const uint32_t is_last = bb::mul(Z, bb::inv(bb::sub(x, ginv)));
     const uint32_t is_trans = bb::sub(x, ginv);
-    acc = bb::ext_add(acc, bb::ext_mul(apow[nc + lp.n], bb::ext_scale(bb::ext_sub(phi, sumq), is_first)));
-    acc = bb::ext_add(acc, bb::ext_mul(apow[nc + lp.n + 1], bb::ext_scale(bb::ext_sub(bb::ext_sub(phin, phi), sumq_next), is_trans)));
-    acc = bb::ext_add(acc, bb::ext_mul(apow[nc + lp.n + 2], bb::ext_scale(bb::ext_sub(phi, S), is_last)));
+    acc = bb::ext_add(acc, bb::ext_mul(apow[nc + lp.n_groups], bb::ext_scale(bb::ext_sub(phi, sumq), is_first)));
+    acc = bb::ext_add(acc, bb::ext_mul(apow[nc + lp.n_groups + 1], bb::ext_scale(bb::ext_sub(bb::ext_sub(phin, phi), sumq_next), is_trans)));
+    acc = bb::ext_add(acc, bb::ext_mul(apow[nc + lp.n_groups + 2], bb::ext_scale(bb::ext_sub(phi, S), is_last)));
     const uint32_t zi = bb::inv(Z);
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[(size_t)k * N + j] = bb::mul(acc.c[k], zi);
@@ -213,7 +236,7 @@ int logup_perm_trace(const uint32_t* trace, size_t H, const LogupProgram& lp, bb
     hipLaunchKernelGGL(scan_block_totals_kernel, dim3(blocks), dim3(kBlock), 0, stream(), d_rowsum, H, d_block_totals);
     hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(64), 0, stream(), d_block_totals, blocks);
     hipLaunchKernelGGL(scan_write_kernel, dim3(blocks), dim3(kBlock), 0, stream(), d_rowsum, H, d_block_totals,
-                       perm + (size_t)(4 * lp.n) * H);
+                       perm + (size_t)(4 * lp.n_groups) * H);
     return (int)hipGetLastError();
 }
 

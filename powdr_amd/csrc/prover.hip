@@ -6,6 +6,7 @@
 // 32-byte roots, the W+8 opened values and the query answers (a few hundred KB), which is
 // what it needs to run the transcript.
 #include "prover_internal.hpp"
+#include "logup_groups.hpp"
 #include "../../include/powdr_prover.h"
 #include "xbc_compile.hpp"
 
@@ -79,7 +80,8 @@ struct PwProver {
     bool is_xbc = false;  // d_bytecode/d_spans hold plan-compiled xbc code (xbc.hpp) instead of post-fix code
     // LogUp extension (pw_prover_create_logup): the AIR's bus interactions as xbc programs
     bool logup = false;
-    uint32_t n_inter = 0, max_args = 0;
+    uint32_t n_inter = 0, n_groups = 0, max_args = 0;
+    uint32_t* d_gstarts = nullptr;  // group boundaries (logup_groups.hpp)
     pw::LogupInteraction* d_inter = nullptr;
     uint32_t* d_ixspans = nullptr;
     uint32_t* d_icode = nullptr;
@@ -165,13 +167,17 @@ extern "C" PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t w
         if (hipMalloc(d, bytes ? bytes : 4) != hipSuccess) return false;
         return !bytes || hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
-    if (!ok || !up((void**)&p->d_inter, li.data(), li.size() * sizeof(pw::LogupInteraction)) ||
+    std::vector<uint32_t> gstarts{0};
+    if (ok) gstarts = pw::logup_group_starts(inter, n_inter, ispans, ibc);
+    if (!ok || !up((void**)&p->d_gstarts, gstarts.data(), gstarts.size() * 4) ||
+        !up((void**)&p->d_inter, li.data(), li.size() * sizeof(pw::LogupInteraction)) ||
         !up((void**)&p->d_ixspans, xspans.data(), xspans.size() * 4) || !up((void**)&p->d_icode, code.data(), code.size() * 4)) {
         pw_prover_destroy(p);
         return nullptr;
     }
     p->logup = true;
     p->n_inter = (uint32_t)n_inter;
+    p->n_groups = (uint32_t)gstarts.size() - 1;
     return p;
 }
 
@@ -201,7 +207,7 @@ int ensure_commit_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
     // coefficients exist only per column panel (~256 MB): iNTT -> panel -> coset NTT into the resident LDE
     L.panel_cols = ((size_t)1 << 26) / L.H;
     if (L.panel_cols < 8) L.panel_cols = 8;
-    const size_t widest = p->logup ? std::max<size_t>(p->width, 4 * ((size_t)p->n_inter + 1)) : p->width;
+    const size_t widest = p->logup ? std::max<size_t>(p->width, 4 * ((size_t)p->n_groups + 1)) : p->width;
     if (L.panel_cols > widest) L.panel_cols = widest;
     TRY(p->coef.ensure(L.panel_cols * L.H * 4));
     TRY(p->lde.ensure((size_t)p->width * L.N * 4));
@@ -250,7 +256,7 @@ extern "C" int pw_prover_trace_root(PwProver* p, const uint32_t* d_trace, uint32
 extern "C" void pw_prover_destroy(PwProver* p) {
     if (!p) return;
     for (DeviceBuf* b : {&p->coef, &p->lde, &p->digests, &p->q, &p->qcoef, &p->qlde, &p->ext_arena, &p->misc, &p->perm, &p->plde}) b->release();
-    for (void* q : {(void*)p->d_inter, (void*)p->d_ixspans, (void*)p->d_icode}) if (q) (void)hipFree(q);
+    for (void* q : {(void*)p->d_inter, (void*)p->d_ixspans, (void*)p->d_icode, (void*)p->d_gstarts}) if (q) (void)hipFree(q);
     if (p->d_bytecode) (void)hipFree(p->d_bytecode);
     if (p->d_spans) (void)hipFree(p->d_spans);
     delete p;
@@ -271,10 +277,11 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const int logN = (int)log_h + 1;
     const bool lg = p->logup;
     const uint32_t n_int = lg ? p->n_inter : 0;
-    const uint32_t Wp = lg ? 4 * (n_int + 1) : 0;   // permutation matrix: q_i coordinates, then phi
+    const uint32_t n_g = lg ? p->n_groups : 0;
+    const uint32_t Wp = lg ? 4 * (n_g + 1) : 0;     // permutation matrix: q_g coordinates per group, then phi
     const uint32_t K1 = W + Wp + 8;                  // polynomials opened at zeta: main | perm | quotient
     const uint32_t K = K1 + Wp;                      // + perm opened at g*zeta
-    const uint32_t M = nc + (lg ? n_int + 3 : 0);    // folded constraints
+    const uint32_t M = nc + (lg ? n_g + 3 : 0);      // folded constraints
     hipStream_t st = stream();
     TRY(poseidon2_upload_params());
 
@@ -348,7 +355,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
 
     // ---- 1b. LogUp: permutation trace, its LDE and commitment ---------------------------------------
     bb::Ext al = bb::ext_zero(), S = bb::ext_zero();
-    LogupProgram lp{p->d_inter, n_int, p->d_ixspans, p->d_icode};
+    LogupProgram lp{p->d_inter, n_int, p->d_ixspans, p->d_icode, p->d_gstarts, n_g};
     if (lg) {
         // the bus challenges come from a transcript that saw only the bus seed (shared by all AIRs of a segment;
         // a lone AIR uses its own trace root), see oracle/stark_oracle.cpp bus_challenges
@@ -371,7 +378,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         uint32_t sw[4];
         PW_HIP_TRY(hipMemcpyAsync(root, d_pdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
         for (int k = 0; k < 4; ++k)  // S = phi(last row)
-            PW_HIP_TRY(hipMemcpyAsync(&sw[k], d_perm + ((size_t)(4 * n_int + k) * H + (H - 1)), 4, hipMemcpyDeviceToHost, st));
+            PW_HIP_TRY(hipMemcpyAsync(&sw[k], d_perm + ((size_t)(4 * n_g + k) * H + (H - 1)), 4, hipMemcpyDeviceToHost, st));
         PW_HIP_TRY(hipStreamSynchronize(st));
         put_monty(root, 8);
         ch.observe_words(root, 8);

@@ -82,8 +82,10 @@ struct LogupProgram {
     uint32_t n;
     const uint32_t* d_xspans;  // {off, len} in xbc instructions
     const uint32_t* d_code;    // xbc code, column-index operands
+    const uint32_t* d_gstarts; // n_groups + 1 interaction indices (logup_groups.hpp)
+    uint32_t n_groups;
 };
-// perm (4(n+1) columns x H): q_i coordinates then phi; d_rowsum: H Ext scratch; d_block_totals: H/4096+1 Ext scratch
+// perm (4(n_groups+1) columns x H): q_g coordinates then phi; d_rowsum: H Ext scratch; d_block_totals: H/4096+1 Ext scratch
 int logup_perm_trace(const uint32_t* trace, size_t H, const LogupProgram& lp, bb::Ext al, const bb::Ext* d_blpow, uint32_t* perm,
                      bb::Ext* d_rowsum, bb::Ext* d_block_totals);
 int quotient_eval_logup(const uint32_t* lde, const uint32_t* plde, size_t N, int logN, const ConstraintProgram& prog,

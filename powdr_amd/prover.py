@@ -14,7 +14,7 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_merkle_commit", "pw_poseidon2_permute_host"]
 
 lib.pw_prover_create.restype = C.c_void_p
@@ -103,6 +103,23 @@ lib.pw_verify_segment.argtypes = [C.POINTER(PwStarkConfig), C.POINTER(PwAirDescr
                                   C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_void_p]
 lib.pw_commitment_digest.restype = None
 lib.pw_commitment_digest.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+
+
+lib.pw_logup_group_starts.restype = C.c_size_t
+lib.pw_logup_group_starts.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+
+
+def logup_group_starts(interactions) -> np.ndarray:
+    """Boundaries of the LogUp groups (one committed extension column each) for an interaction table."""
+    it = np.ascontiguousarray(interactions[0], dtype=np.uint32).reshape(-1, 3)
+    isp = np.ascontiguousarray(interactions[1], dtype=np.uint32).reshape(-1, 2)
+    ibc = np.ascontiguousarray(interactions[2], dtype=np.uint32)
+    out = np.zeros(len(it) + 2, np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    k = lib.pw_logup_group_starts(p(it), len(it), p(isp), len(isp), p(ibc), len(ibc), p(out), len(out))
+    if k == 0:
+        raise ValueError("malformed interaction table")
+    return out[:k].copy()
 
 
 def commitment_digest(roots) -> np.ndarray:

@@ -309,3 +309,38 @@ def test_verify_segment_on_oracle_proofs():
     pf = sm.prove(np.ascontiguousarray(trace).reshape(-1), W, H.bit_length() - 1, bc, spans, num_queries=5)
     assert prover.verify_segment([(W, H.bit_length() - 1, bc, spans, None)] * 2, [pf, pf], num_queries=5)[0] == 0
     assert prover.verify_segment([(W, H.bit_length() - 1, bc, spans, None)], [pf[:-1]], num_queries=5)[0] == (1 << 8) | 10
+
+
+def test_logup_grouping_is_the_same_in_oracle_and_product():
+    """Which interactions share a committed column is part of the protocol: prover, verifier and oracle must agree.
+    Degree-1 arguments pair up (q d1 d2 has degree 3); a degree-2 argument or a degree-3 multiplicity stays alone."""
+    from powdr_amd import prover
+
+    for shape, seed in (("T0", 1), ("T1", 2), ("C1", 3)):
+        s, apc, idx, trace = synthetic_trace(shape, 4, seed=seed)
+        it = sm.compile_interactions(apc, idx)
+        a, b = sm.group_starts(*it), prover.logup_group_starts(it)
+        assert (a == b).all() and a[0] == 0 and a[-1] == len(it[0])
+        assert (np.diff(a) >= 1).all() and (np.diff(a) <= 2).all() and len(a) - 1 < len(it[0])
+    PA, PC, MUL = om.OP_PUSH_APC, om.OP_PUSH_CONST, om.OP_MUL
+    lin, quad, const = [PA, 0], [PA, 0, PA, 1, MUL], [PC, 7]
+    cube = [PA, 0, PA, 1, MUL, PA, 2, MUL]
+
+    def table(rows):  # rows: (mult program, [arg programs])
+        inter, spans, bc = [], [], []
+        for m, args in rows:
+            inter.append((3, len(args), len(spans)))
+            for prog in [m] + args:
+                spans.append((len(bc), len(prog)))
+                bc += prog
+        return np.array(inter, np.uint32), np.array(spans, np.uint32), np.array(bc, np.uint32)
+
+    cases = [([(lin, [lin]), (lin, [lin]), (lin, [lin])], [0, 2, 3]),          # pairs
+             ([(lin, [quad]), (lin, [lin])], [0, 1, 2]),                       # 1 + 2 + 1 > 3
+             ([(lin, [const]), (lin, [const]), (quad, [lin, const]), (lin, [lin])], [0, 4]),  # constant denominators are free
+             ([(cube, [lin]), (lin, [lin])], [0, 1, 2]),                        # m1 d2 would have degree 4
+             ([(quad, [lin]), (quad, [lin])], [0, 2]),                          # 2 + 1 = 3
+             ([], [0])]
+    for rows, want in cases:
+        t = table(rows)
+        assert sm.group_starts(*t).tolist() == want and prover.logup_group_starts(t).tolist() == want
