@@ -72,3 +72,34 @@ def allreduce_histograms(histograms, group=None):
         # u32 counters are stored as int32 words; wrap-around addition is the same operation
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
     return histograms
+
+
+def prove_segment_sharded(my_units, n_units: int, commit, prove, group=None):
+    """AIR-level sharding of ONE segment whose AIRs share buses (SURVEY.md 8e level 2; the single-process form is
+    `pw_prove_segment(shared_bus_seed=1)`). Every rank owns the AIRs `my_units` (see `assign_units`).
+
+      phase 1  commit(u) -> 8-word trace root of AIR u           (rank-local: LDE + Merkle tree stay on the GPU)
+      exchange all-gather of the roots, 32 bytes per AIR          (the only collective on this path)
+      seed     commitment_digest(roots in AIR order)              (identical on every rank)
+      phase 2  prove(u, seed) -> proof words of AIR u             (rank-local)
+
+    Returns (seed, {u: proof}). `commit` / `prove` are callables so that the same orchestration drives the GPU
+    provers (`gpu_segment_callables`) and, in the CPU tests, a stand-in prover. The verifier needs nothing from this
+    exchange: `pw_verify_segment` recomputes the seed from the trace roots inside the proofs."""
+    roots = np.array([commit(u) for u in my_units], dtype=np.uint32).reshape(-1, 8)
+    merged = merge_commitments(my_units, roots, n_units, group=group)
+    seed = commitment_digest(merged)
+    return seed, {u: prove(u, seed) for u in my_units}
+
+
+def gpu_segment_callables(provers, trace_ptrs, log_heights):
+    """commit / prove callables over `prover.Prover` objects created with `interactions=` (one per AIR index)."""
+
+    def commit(u):
+        return provers[u].trace_root(trace_ptrs[u], log_heights[u])
+
+    def prove(u, seed):
+        provers[u].set_bus_seed(seed)
+        return provers[u].prove(trace_ptrs[u], log_heights[u])
+
+    return commit, prove

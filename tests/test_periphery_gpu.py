@@ -181,6 +181,10 @@ def test_prove_segment_matches_the_per_air_flow(gpu, workers):
     descs = [(w, lh, *c, it) for (_, w, c, it, lh) in airs]
     rc, total = prover.verify_segment(descs, got, num_queries=nq, shared_bus_seed=True, check_balance=True)
     assert rc == 0 and (total == 0).all()
+    # the rank-sharded orchestration (here with one rank owning every AIR) gives the same bytes again
+    commit, prove = sharding.gpu_segment_callables(provers, [t.data_ptr() for t, *_ in airs], [lh for *_, lh in airs])
+    seed3, proofs3 = sharding.prove_segment_sharded([0, 1, 2], 3, commit, prove)
+    assert (seed3 == seed).all() and all((proofs3[u] == ref[u]).all() for u in range(3))
     for pr in provers:
         pr.close()
 

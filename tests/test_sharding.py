@@ -84,3 +84,49 @@ def test_histogram_allreduce_world_size_2_gloo(tmp_path):
     x1 = torch.randint(0, 2**31 - 1, (1 << 10,), dtype=torch.int32, generator=g1)
     want = ((x0.to(torch.int64) + x1.to(torch.int64)) & 0xFFFFFFFF).numpy().astype(np.uint32)
     assert (a[0].numpy().view(np.uint32) == want).all()
+
+
+def _segment_worker(rank, world, port, out_dir):
+    """One LogUp segment, two AIRs on one bus, one AIR per rank; the oracle stands in for the GPU prover."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import stark_model as sm
+    from tests.test_oracle_stark import balanced_bus_pair
+
+    no_cons = (np.zeros(0, np.uint32), np.zeros((0, 2), np.uint32))
+    airs = balanced_bus_pair(4, seed=21)
+    mine = sharding.assign_units([3 << 4, 3 << 4], world)[rank]
+
+    def commit(u):
+        t, it = airs[u]
+        return sm.prove_logup(t.reshape(-1), 3, 4, *no_cons, *it, num_queries=0)[7:15]
+
+    def prove(u, seed):
+        t, it = airs[u]
+        return sm.prove_logup(t.reshape(-1), 3, 4, *no_cons, *it, num_queries=4, bus_seed=seed)
+
+    seed, proofs = sharding.prove_segment_sharded(mine, 2, commit, prove)
+    for u, pf in proofs.items():
+        np.save(os.path.join(out_dir, f"proof_{u}.npy"), pf)
+    np.save(os.path.join(out_dir, f"seed_{rank}.npy"), seed)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_logup_segment_sharded_over_two_ranks_gloo(tmp_path):
+    """N>1 path of a bus-sharing segment: trace roots all-gathered, same seed on both ranks, the host verifier
+    accepts the two proofs as one balanced segment."""
+    from powdr_amd import prover
+    from tests.test_oracle_stark import balanced_bus_pair
+
+    port = _free_port()
+    mp.spawn(_segment_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    s0, s1 = np.load(tmp_path / "seed_0.npy"), np.load(tmp_path / "seed_1.npy")
+    assert (s0 == s1).all() and s0.any()
+    proofs = [np.load(tmp_path / f"proof_{u}.npy") for u in range(2)]
+    no_cons = (np.zeros(0, np.uint32), np.zeros((0, 2), np.uint32))
+    descs = [(3, 4, *no_cons, it) for _, it in balanced_bus_pair(4, seed=21)]
+    rc, total = prover.verify_segment(descs, proofs, num_queries=4, shared_bus_seed=True, check_balance=True)
+    assert rc == 0 and (total == 0).all()
+    assert (proofs[0][15:23] == s0).all() and (proofs[1][15:23] == s0).all()
