@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--logup", action="store_true",
                     help="prove the bus interactions too (pw-stark v0 + LogUp: one extension column per interaction, "
                          "rho = 4*(n_interactions+1)/W extra committed columns per main column); NOT the headline configuration")
+    ap.add_argument("--calls-fraction", type=float, default=1.0,
+                    help="APC calls as a fraction of the trace height (SURVEY 8d asks for a 0.75 run: the rest is zero padding)")
     ap.add_argument("--exact-source-heights", action="store_true",
                     help="allocate dummy traces with b*calls rows instead of next_pow2 (less HBM)")
     return ap.parse_args()
@@ -79,13 +81,13 @@ def setup_distributed(n):
     return rank, local, world
 
 
-def build_workload(shape_name, log_h, exact_heights, seed):
+def build_workload(shape_name, log_h, exact_heights, seed, calls_fraction=1.0):
     from powdr_amd import host, synth, tracegen as tg
 
     s = synth.generate(shape_name, seed=seed)
     apc = host.Apc(s.doc)
     H = 1 << log_h
-    calls = H
+    calls = max(1, int(H * calls_fraction))
     # AIR ids by first appearance among instructions with substitutions
     order, instr_air = [], []
     for n in s.instr_air:
@@ -165,13 +167,13 @@ def main():
     shape = synth.SHAPES[args.shape]
     log_h = args.log_height or shape.log_height
     try:
-        wl = build_workload(args.shape, log_h, args.exact_source_heights, seed=rank)
+        wl = build_workload(args.shape, log_h, args.exact_source_heights, seed=rank, calls_fraction=args.calls_fraction)
     except torch.cuda.OutOfMemoryError:
         # power-of-two source heights (like the original chips' traces) need 150 GB at C2; fall back to
         # b*calls-row sources (115 GB) rather than fail — same kernels, same cells, noted in config.workload
         torch.cuda.empty_cache()
         args.exact_source_heights = True
-        wl = build_workload(args.shape, log_h, True, seed=rank)
+        wl = build_workload(args.shape, log_h, True, seed=rank, calls_fraction=args.calls_fraction)
     inter = wl["apc"].compile_bus(1) if args.logup else None  # (interactions, spans, bytecode) with column operands
     perm_cols = 4 * len(prover.logup_group_starts(inter)) if args.logup else 0  # 4 * (groups + 1)
     pr = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits, interactions=inter)
@@ -345,6 +347,7 @@ def main():
                                  + (f" WITH the LogUp phase: {perm_cols // 4 - 1} interaction groups = {perm_cols} extra committed "
                                     f"columns, rho = {perm_cols / wl['W']:.2f} (SURVEY 8d: algorithmic bytes per main cell "
                                     f"= 48 + 4 + 44*rho = {52 + 44 * perm_cols / wl['W']:.0f})" if args.logup else "")
+                                 + (f"; {wl['calls']} APC calls, the remaining rows are zero padding" if wl["calls"] != wl["H"] else "")
                                  + "; one segment per step per GPU"
                                  + ("; source heights b*calls (not padded to a power of two)" if args.exact_source_heights else ""),
                         rows=wl["H"], cols=wl["W"], parallelism=f"segments x{world}" + (f", {args.pipeline} streams per GPU" if args.pipeline > 1 else ""),
