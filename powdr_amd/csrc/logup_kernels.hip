@@ -201,21 +201,16 @@ __global__ __launch_bounds__(kBlock) void deep_logup_kernel(const uint32_t* __re
                                                              uint32_t shift, uint32_t wN, Ext* __restrict__ v) {
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= N) return;
-    Ext a1 = bb::ext_zero(), a2 = bb::ext_zero();
-    auto fma1 = [&](const Ext& g, uint32_t x) {
-        a1.c[0] = bb::add(a1.c[0], bb::mul(g.c[0], x)); a1.c[1] = bb::add(a1.c[1], bb::mul(g.c[1], x));
-        a1.c[2] = bb::add(a1.c[2], bb::mul(g.c[2], x)); a1.c[3] = bb::add(a1.c[3], bb::mul(g.c[3], x));
-    };
-    for (uint32_t k = 0; k < W; ++k) fma1(gpow[k], lde[(size_t)k * N + j]);
+    bb::ExtWideAcc w1, w2;
+    for (uint32_t k = 0; k < W; ++k) w1.fma(gpow[k], lde[(size_t)k * N + j]);
     const uint32_t K1 = W + Wp + 8;
     for (uint32_t k = 0; k < Wp; ++k) {
         const uint32_t x = plde[(size_t)k * N + j];
-        fma1(gpow[W + k], x);
-        const Ext g2 = gpow[K1 + k];
-        a2.c[0] = bb::add(a2.c[0], bb::mul(g2.c[0], x)); a2.c[1] = bb::add(a2.c[1], bb::mul(g2.c[1], x));
-        a2.c[2] = bb::add(a2.c[2], bb::mul(g2.c[2], x)); a2.c[3] = bb::add(a2.c[3], bb::mul(g2.c[3], x));
+        w1.fma(gpow[W + k], x);
+        w2.fma(gpow[K1 + k], x);
     }
-    for (uint32_t k = 0; k < 8; ++k) fma1(gpow[W + Wp + k], qlde[(size_t)k * N + j]);
+    for (uint32_t k = 0; k < 8; ++k) w1.fma(gpow[W + Wp + k], qlde[(size_t)k * N + j]);
+    const Ext a1 = w1.result(), a2 = w2.result();
     const uint32_t xj = bb::mul(shift, bb::pow_u32(wN, (uint32_t)j));
     const Ext xe = bb::ext_from_base(xj);
     const Ext t1 = bb::ext_mul(bb::ext_sub(a1, sum1), bb::ext_inv(bb::ext_sub(xe, zeta)));

@@ -102,44 +102,53 @@ __global__ __launch_bounds__(kBlock) void barycentric_weights_kernel(bb::Ext zet
 }
 
 constexpr int kDotRowsPerBlock = 8192;
+constexpr int kDotColsPerBlock = 4;  // columns that share one pass over the weights
 __global__ __launch_bounds__(kBlock) void ext_dot_partial_kernel(const uint32_t* __restrict__ cols, size_t stride, size_t len,
-                                                                  const bb::Ext* __restrict__ weights,
+                                                                  uint32_t n_cols, const bb::Ext* __restrict__ weights,
                                                                   bb::Ext* __restrict__ partial, uint32_t n_chunks) {
-    __shared__ uint32_t red[4][kBlock / 64];
-    const uint32_t* col = cols + (size_t)blockIdx.y * stride;
+    __shared__ uint32_t red[kDotColsPerBlock][4][kBlock / 64];
+    const uint32_t c0 = blockIdx.y * kDotColsPerBlock;
+    const uint32_t nc = n_cols - c0 < (uint32_t)kDotColsPerBlock ? n_cols - c0 : (uint32_t)kDotColsPerBlock;  // block-uniform
+    const uint32_t* col = cols + (size_t)c0 * stride;
     const size_t q0 = (size_t)blockIdx.x * kDotRowsPerBlock;
     const size_t q1 = q0 + kDotRowsPerBlock < len ? q0 + kDotRowsPerBlock : len;
-    uint64_t acc[4] = {0, 0, 0, 0};  // sums of reduced products: < 32 * p < 2^36
-    for (size_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
-        const uint32_t v = col[q];
-        const bb::Ext w = weights[q];
+    bb::ExtWideAcc wide[kDotColsPerBlock];
+    if (nc == kDotColsPerBlock) {
+        for (size_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
+            const bb::Ext w = weights[q];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] += bb::mul(w.c[k], v);
-    }
-    uint32_t r[4];
+            for (int c = 0; c < kDotColsPerBlock; ++c) wide[c].fma(w, col[(size_t)c * stride + q]);
+        }
+    } else {
+        for (size_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
+            const bb::Ext w = weights[q];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = (uint32_t)(acc[k] % bb::P);
-    // wave reduction
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) r[k] = bb::add(r[k], __shfl_down(r[k], off, 64));
+            for (int c = 0; c < kDotColsPerBlock; ++c)
+                if ((uint32_t)c < nc) wide[c].fma(w, col[(size_t)c * stride + q]);
+        }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) red[k][wave] = r[k];
+    for (int c = 0; c < kDotColsPerBlock; ++c) {
+        const bb::Ext part = wide[c].result();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t r = part.c[k];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) r = bb::add(r, __shfl_down(r, off, 64));  // wave reduction
+            if (lane == 0) red[c][k][wave] = r;
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < nc) {
         bb::Ext o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint32_t s = red[k][0];
-            for (int w = 1; w < kBlock / 64; ++w) s = bb::add(s, red[k][w]);
-            o.c[k] = s;
+            uint32_t s_ = red[threadIdx.x][k][0];
+            for (int w = 1; w < kBlock / 64; ++w) s_ = bb::add(s_, red[threadIdx.x][k][w]);
+            o.c[k] = s_;
         }
-        partial[(size_t)blockIdx.y * n_chunks + blockIdx.x] = o;
+        partial[(size_t)(c0 + threadIdx.x) * n_chunks + blockIdx.x] = o;
     }
 }
 __global__ void ext_dot_final_kernel(const bb::Ext* __restrict__ partial, uint32_t n_cols, uint32_t n_chunks, bb::Ext* __restrict__ out) {
@@ -157,27 +166,14 @@ __global__ __launch_bounds__(kBlock) void deep_kernel(const uint32_t* __restrict
                                                        uint32_t shift, uint32_t wN, bb::Ext* __restrict__ v) {
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= N) return;
-    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    // gpow[k] is wave-uniform (scalar loads); the column value is the only vector operand of the multiply-adds
+    bb::ExtWideAcc wide;
     const uint32_t* pa = ma + j;
 #pragma unroll 4
-    for (uint32_t k = 0; k < wa; ++k) {
-        const uint32_t x = pa[(size_t)k * N];
-        const bb::Ext g = gpow[k];
-        a0 = bb::add(a0, bb::mul(g.c[0], x));
-        a1 = bb::add(a1, bb::mul(g.c[1], x));
-        a2 = bb::add(a2, bb::mul(g.c[2], x));
-        a3 = bb::add(a3, bb::mul(g.c[3], x));
-    }
+    for (uint32_t k = 0; k < wa; ++k) wide.fma(gpow[k], pa[(size_t)k * N]);
     const uint32_t* pb = mb + j;
-    for (uint32_t k = 0; k < wb; ++k) {
-        const uint32_t x = pb[(size_t)k * N];
-        const bb::Ext g = gpow[wa + k];
-        a0 = bb::add(a0, bb::mul(g.c[0], x));
-        a1 = bb::add(a1, bb::mul(g.c[1], x));
-        a2 = bb::add(a2, bb::mul(g.c[2], x));
-        a3 = bb::add(a3, bb::mul(g.c[3], x));
-    }
-    const bb::Ext acc = {{a0, a1, a2, a3}};
+    for (uint32_t k = 0; k < wb; ++k) wide.fma(gpow[wa + k], pb[(size_t)k * N]);
+    const bb::Ext acc = wide.result();
     const uint32_t xj = bb::mul(shift, bb::pow_u32(wN, (uint32_t)j));
     const bb::Ext den = bb::ext_sub(bb::ext_from_base(xj), zeta);
     v[j] = bb::ext_mul(bb::ext_sub(acc, opened_sum), bb::ext_inv(den));
@@ -256,11 +252,12 @@ int barycentric_weights(bb::Ext zeta, int log_h, bb::Ext* weights) {
 int ext_dot_columns(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t len, const bb::Ext* weights, bb::Ext* out,
                     bb::Ext* scratch) {
     const uint32_t n_chunks = div_up(len, kDotRowsPerBlock);
-    for (uint32_t c0 = 0; c0 < n_cols; c0 += 65535u) {
-        uint32_t cc = n_cols - c0 < 65535u ? n_cols - c0 : 65535u;
+    const uint32_t max_cols = 65535u * kDotColsPerBlock;
+    for (uint32_t c0 = 0; c0 < n_cols; c0 += max_cols) {
+        uint32_t cc = n_cols - c0 < max_cols ? n_cols - c0 : max_cols;
         ScopedKernelTimer t("ext_dot_partial_kernel");
-        hipLaunchKernelGGL(ext_dot_partial_kernel, dim3(n_chunks, cc), dim3(kBlock), 0, stream(), cols + (size_t)c0 * stride,
-                           stride, len, weights, scratch + (size_t)c0 * n_chunks, n_chunks);
+        hipLaunchKernelGGL(ext_dot_partial_kernel, dim3(n_chunks, div_up(cc, kDotColsPerBlock)), dim3(kBlock), 0, stream(),
+                           cols + (size_t)c0 * stride, stride, len, cc, weights, scratch + (size_t)c0 * n_chunks, n_chunks);
     }
     hipLaunchKernelGGL(ext_dot_final_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, stream(), scratch, n_cols, n_chunks, out);
     return (int)hipGetLastError();
