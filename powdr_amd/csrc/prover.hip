@@ -204,8 +204,10 @@ int ensure_commit_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
     L.fri_words = 0;
     for (uint32_t l = 0; l < log_h; ++l) L.fri_words += merkle_words((L.N >> l) / 2);
     L.n_trees = p->logup ? 3 : 2;  // trace | quotient | (perm) | FRI
-    // coefficients exist only per column panel (~256 MB): iNTT -> panel -> coset NTT into the resident LDE
-    L.panel_cols = ((size_t)1 << 26) / L.H;
+    // coefficients exist only per column panel (1 GB by default; larger panels = fewer, larger launches): iNTT -> panel ->
+    // coset NTT into the resident LDE
+    static const int panel_log_words = [] { const char* e = getenv("POWDR_PANEL_LOG_WORDS"); int v = e ? atoi(e) : 28; return v < 20 || v > 32 ? 28 : v; }();
+    L.panel_cols = ((size_t)1 << panel_log_words) / L.H;
     if (L.panel_cols < 8) L.panel_cols = 8;
     const size_t widest = p->logup ? std::max<size_t>(p->width, 4 * ((size_t)p->n_groups + 1)) : p->width;
     if (L.panel_cols > widest) L.panel_cols = widest;
