@@ -61,6 +61,59 @@ PW_HD uint32_t mul_lazy(uint32_t a, uint32_t b) {
     return (uint32_t)(u >> 32);
 }
 
+// Sums of many field elements without intermediate reductions: a 64-bit accumulator takes one instruction per term
+// (v_mad_u64_u32 with the multiplier 1 is a 32+64-bit add; a modular addition is 3), reduced once by reduce_sum.
+PW_HD uint64_t wide_add(uint64_t acc, uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t out;
+    asm("v_mad_u64_u32 %0, vcc, %1, 1, %2" : "=v"(out) : "v"(x), "v"(acc) : "vcc");
+    return out;
+#else
+    return acc + x;
+#endif
+}
+// acc + k * x in one instruction (k a small constant)
+PW_HD uint64_t wide_fma(uint64_t acc, uint32_t x, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t out;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(out) : "v"(x), "n"(k), "v"(acc) : "vcc");
+    return out;
+#else
+    return acc + (uint64_t)x * k;
+#endif
+}
+// c + k * x for a wave-uniform 64-bit c (the compiler keeps it in an SGPR pair: no copy into vector registers)
+PW_HD uint64_t wide_fma_uniform(uint64_t c, uint32_t x, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t out;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(out) : "v"(x), "n"(k), "s"(c) : "vcc");
+    return out;
+#else
+    return c + (uint64_t)x * k;
+#endif
+}
+// k * x as a 64-bit value
+PW_HD uint64_t wide_mul(uint32_t x, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t out;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(out) : "v"(x), "n"(k) : "vcc");
+    return out;
+#else
+    return (uint64_t)x * k;
+#endif
+}
+// x < 64 p  ->  x mod p.  q = floor((x >> 5) * 68 / 2^32) with 68 = floor(2^37 / p): q <= x / p and
+// x - q p < (1 - 68 / 68.27) x + p + 68 * 32 < 1.26 p.
+PW_HD uint32_t reduce_wide(uint64_t x) {
+    const uint32_t q = (uint32_t)(((x >> 5) & 0xffffffffull) * 68u >> 32);
+    return reduce_2p((uint32_t)x - q * P);
+}
+// x < 16 p  ->  x mod p.  q = floor(x / 2^31) <= x / p, and x - q p < x (2^27 - 1) / 2^31 + p < 2p for x < 16 p.
+PW_HD uint32_t reduce_sum(uint64_t x) {
+    const uint32_t q = (uint32_t)(x >> 31);
+    return reduce_2p((uint32_t)x - q * P);
+}
+
 PW_HD uint32_t double_(uint32_t a) { return add(a, a); }
 PW_HD uint32_t halve(uint32_t a) {
     // a/2 mod p: if odd add p (p odd) then shift. a + p < 2^32.

@@ -19,6 +19,10 @@ struct Params {
     uint32_t ext_rc[8][16];
     uint32_t int_rc[13];
     uint32_t diag[16];
+    // ext_rc[r] folded into the external linear layer that precedes round r (external_layer_fold): the layer adds
+    // to every output the sum of its column over the four blocks, so the constant that enters block q, column i is
+    // c[q][i] - (sum_q' c[q'][i]) / 5; 64-bit words because they seed 64-bit accumulators from a scalar register pair
+    uint64_t ext_fold[8][16];
 };
 
 // host-side generation (Montgomery form)
@@ -44,6 +48,14 @@ inline void generate_params(Params& p) {
                             bb::neg(m(4)), inv2k(8), inv2k(2), inv2k(3), inv2k(27), bb::neg(inv2k(8)),
                             bb::neg(inv2k(4)), bb::neg(inv2k(27))};
     for (int i = 0; i < 16; ++i) p.diag[i] = d[i];
+    const uint32_t inv5 = bb::inv(m(5));
+    for (int r = 0; r < 8; ++r)
+        for (int i = 0; i < 4; ++i) {
+            uint32_t col = 0;
+            for (int q = 0; q < 4; ++q) col = bb::add(col, p.ext_rc[r][4 * q + i]);
+            const uint32_t t = bb::mul(col, inv5);
+            for (int q = 0; q < 4; ++q) p.ext_fold[r][4 * q + i] = bb::sub(p.ext_rc[r][4 * q + i], t);
+        }
 }
 
 PW_HD uint32_t sbox7(uint32_t x) {
@@ -78,25 +90,49 @@ PW_HD void external_layer(uint32_t* s) {
     }
 }
 
+// The same layer followed by the addition of the next round's constants, in 64-bit accumulators: every output is
+// 2x_i + 3x_{i+1} + x_{i+2} + x_{i+3} (four multiply-adds seeded with the folded constant) plus the column sum
+// (64-bit adds), reduced once (< 40 p) — 188 instructions instead of 72 modular additions + 16 constant additions.
+template <bool FOLD>
+PW_HD void external_layer_fold(uint32_t* s, const uint64_t* fold) {
+    uint64_t y[16];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t x0 = s[4 * b + i], x1 = s[4 * b + ((i + 1) & 3)], x2 = s[4 * b + ((i + 2) & 3)], x3 = s[4 * b + ((i + 3) & 3)];
+            uint64_t a = FOLD ? bb::wide_fma_uniform(fold[4 * b + i], x0, 2) : bb::wide_mul(x0, 2);
+            a = bb::wide_fma(a, x1, 3);
+            a = bb::wide_add(a, x2);
+            y[4 * b + i] = bb::wide_add(a, x3);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t col = (y[i] + y[4 + i]) + (y[8 + i] + y[12 + i]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s[4 * b + i] = bb::reduce_wide(y[4 * b + i] + col);
+    }
+}
+
 // s_i <- sum + mu_i * s_i with mu = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/4, 1/8, 2^-27, -2^-8, -1/16, -2^-27]
 PW_HD void internal_layer(uint32_t* s, const uint32_t* diag) {
-    uint32_t sum = s[0];
+    uint64_t wide = s[0];  // 16 terms < p: one reduction at the end instead of 15
 #pragma unroll
-    for (int i = 1; i < 16; ++i) sum = bb::add(sum, s[i]);
-    uint32_t d2, h;
+    for (int i = 1; i < 16; ++i) wide = bb::wide_add(wide, s[i]);
+    const uint32_t sum = bb::reduce_sum(wide);
+    uint32_t h;
     s[0] = bb::sub(sum, bb::double_(s[0]));
     s[1] = bb::add(sum, s[1]);
     s[2] = bb::add(sum, bb::double_(s[2]));
     h = bb::halve(s[3]);
     s[3] = bb::add(sum, h);
-    d2 = bb::double_(s[4]);
-    s[4] = bb::add(sum, bb::add(d2, s[4]));
-    s[5] = bb::add(sum, bb::double_(bb::double_(s[5])));
+    s[4] = bb::reduce_sum(bb::wide_fma(sum, s[4], 3));  // sum + 3 s4 < 4p: one multiply-add and one reduction
+    s[5] = bb::reduce_sum(bb::wide_fma(sum, s[5], 4));
     h = bb::halve(s[6]);
     s[6] = bb::sub(sum, h);
-    d2 = bb::double_(s[7]);
-    s[7] = bb::sub(sum, bb::add(d2, s[7]));
-    s[8] = bb::sub(sum, bb::double_(bb::double_(s[8])));
+    s[7] = bb::reduce_sum(bb::wide_fma(sum, bb::P - s[7], 3));  // sum - 3 s7 = sum + 3 (p - s7)
+    s[8] = bb::reduce_sum(bb::wide_fma(sum, bb::P - s[8], 4));
 #pragma unroll
     for (int i = 9; i < 16; ++i) s[i] = bb::add(sum, bb::mul(diag[i], s[i]));
 }
@@ -105,25 +141,35 @@ PW_HD void internal_layer(uint32_t* s, const uint32_t* diag) {
 // ~1 K instructions (8 KB) and stays resident in the instruction cache shared by a CU pair;
 // the fully unrolled permutation (~50 KB of code) would thrash it. Round constants are
 // indexed by the (wave-uniform) round counter and arrive through scalar loads.
+// Round constants of the external rounds are added by the linear layer that PRECEDES the round (external_layer_fold),
+// except for round 4, which follows an internal layer.
 PW_HD void permute(uint32_t* s, const Params& P) {
-    external_layer(s);
+    external_layer_fold<true>(s, P.ext_fold[0]);
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = sbox7(bb::add(s[i], P.ext_rc[r][i]));
-        external_layer(s);
+        for (int i = 0; i < 16; ++i) s[i] = sbox7(s[i]);
+        external_layer_fold<true>(s, P.ext_fold[r + 1]);
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = sbox7(s[i]);
+    external_layer_fold<false>(s, nullptr);
 #pragma unroll 1
     for (int r = 0; r < 13; ++r) {
         s[0] = sbox7(bb::add(s[0], P.int_rc[r]));
         internal_layer(s, P.diag);
     }
-#pragma unroll 1
-    for (int r = 4; r < 8; ++r) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = sbox7(bb::add(s[i], P.ext_rc[r][i]));
-        external_layer(s);
+    for (int i = 0; i < 16; ++i) s[i] = bb::add(s[i], P.ext_rc[4][i]);
+#pragma unroll 1
+    for (int r = 4; r < 7; ++r) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = sbox7(s[i]);
+        external_layer_fold<true>(s, P.ext_fold[r + 1]);
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = sbox7(s[i]);
+    external_layer_fold<false>(s, nullptr);
 }
 
 }  // namespace p2
