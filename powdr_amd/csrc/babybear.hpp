@@ -102,12 +102,14 @@ PW_HD uint64_t wide_mul(uint32_t x, uint32_t k) {
     return (uint64_t)x * k;
 #endif
 }
-// x < 64 p  ->  x mod p.  q = floor((x >> 5) * 68 / 2^32) with 68 = floor(2^37 / p): q <= x / p and
-// x - q p < (1 - 68 / 68.27) x + p + 68 * 32 < 1.26 p.
-PW_HD uint32_t reduce_wide(uint64_t x) {
-    const uint32_t q = (uint32_t)(((x >> 5) & 0xffffffffull) * 68u >> 32);
-    return reduce_2p((uint32_t)x - q * P);
+// x < 128 p  ->  a representative of x mod p in [0, 1.03 p).  q = floor((x >> 7) * 273 / 2^32) with
+// 273 = floor(2^39 / p) = floor(273.07): q <= x / p and x - q p < (1 - 273 / 273.07) x + p + 273 * 128 < 1.03 p.
+PW_HD uint32_t reduce_wide_loose(uint64_t x) {
+    const uint32_t q = (uint32_t)(((x >> 7) & 0xffffffffull) * 273u >> 32);
+    return (uint32_t)x - q * P;
 }
+// x < 128 p  ->  x mod p
+PW_HD uint32_t reduce_wide(uint64_t x) { return reduce_2p(reduce_wide_loose(x)); }
 // x < 16 p  ->  x mod p.  q = floor(x / 2^31) <= x / p, and x - q p < x (2^27 - 1) / 2^31 + p < 2p for x < 16 p.
 PW_HD uint32_t reduce_sum(uint64_t x) {
     const uint32_t q = (uint32_t)(x >> 31);

@@ -65,6 +65,15 @@ PW_HD uint32_t sbox7(uint32_t x) {
     return bb::mul(x3, x4);
 }
 
+// x^7 left in [0, 2p), for consumers that only multiply-accumulate it (external_layer_fold); x itself may be a
+// loose representative in [0, 1.03 p) (x^2 < p 2^32 is all the first product needs)
+PW_HD uint32_t sbox7_lazy(uint32_t x) {
+    uint32_t x2 = bb::sqr(x);
+    uint32_t x3 = bb::mul_lazy(x2, x);
+    uint32_t x4 = bb::sqr(x2);
+    return bb::mul_lazy(x3, x4);
+}
+
 // [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] * (a,b,c,d)
 PW_HD void m4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
     // 11 modular additions
@@ -92,8 +101,10 @@ PW_HD void external_layer(uint32_t* s) {
 
 // The same layer followed by the addition of the next round's constants, in 64-bit accumulators: every output is
 // 2x_i + 3x_{i+1} + x_{i+2} + x_{i+3} (four multiply-adds seeded with the folded constant) plus the column sum
-// (64-bit adds), reduced once (< 40 p) — 188 instructions instead of 72 modular additions + 16 constant additions.
-template <bool FOLD>
+// (64-bit adds), reduced once — 140 instructions instead of 72 modular additions + 16 constant additions. Inputs may
+// be lazy S-box outputs in [0, 2p): an output is < 5 * (7 * 2p + p) = 75 p, inside reduce_wide's 128 p.
+// LOOSE: the outputs only feed sbox7_lazy, so the last conditional subtraction is skipped ([0, 1.03 p)).
+template <bool FOLD, bool LOOSE>
 PW_HD void external_layer_fold(uint32_t* s, const uint64_t* fold) {
     uint64_t y[16];
 #pragma unroll
@@ -111,7 +122,7 @@ PW_HD void external_layer_fold(uint32_t* s, const uint64_t* fold) {
     for (int i = 0; i < 4; ++i) {
         const uint64_t col = (y[i] + y[4 + i]) + (y[8 + i] + y[12 + i]);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) s[4 * b + i] = bb::reduce_wide(y[4 * b + i] + col);
+        for (int b = 0; b < 4; ++b) s[4 * b + i] = LOOSE ? bb::reduce_wide_loose(y[4 * b + i] + col) : bb::reduce_wide(y[4 * b + i] + col);
     }
 }
 
@@ -144,16 +155,16 @@ PW_HD void internal_layer(uint32_t* s, const uint32_t* diag) {
 // Round constants of the external rounds are added by the linear layer that PRECEDES the round (external_layer_fold),
 // except for round 4, which follows an internal layer.
 PW_HD void permute(uint32_t* s, const Params& P) {
-    external_layer_fold<true>(s, P.ext_fold[0]);
+    external_layer_fold<true, true>(s, P.ext_fold[0]);
 #pragma unroll 1
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = sbox7(s[i]);
-        external_layer_fold<true>(s, P.ext_fold[r + 1]);
+        for (int i = 0; i < 16; ++i) s[i] = sbox7_lazy(s[i]);
+        external_layer_fold<true, true>(s, P.ext_fold[r + 1]);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = sbox7(s[i]);
-    external_layer_fold<false>(s, nullptr);
+    for (int i = 0; i < 16; ++i) s[i] = sbox7_lazy(s[i]);
+    external_layer_fold<false, false>(s, nullptr);
 #pragma unroll 1
     for (int r = 0; r < 13; ++r) {
         s[0] = sbox7(bb::add(s[0], P.int_rc[r]));
@@ -164,12 +175,12 @@ PW_HD void permute(uint32_t* s, const Params& P) {
 #pragma unroll 1
     for (int r = 4; r < 7; ++r) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = sbox7(s[i]);
-        external_layer_fold<true>(s, P.ext_fold[r + 1]);
+        for (int i = 0; i < 16; ++i) s[i] = sbox7_lazy(s[i]);
+        external_layer_fold<true, true>(s, P.ext_fold[r + 1]);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = sbox7(s[i]);
-    external_layer_fold<false>(s, nullptr);
+    for (int i = 0; i < 16; ++i) s[i] = sbox7_lazy(s[i]);
+    external_layer_fold<false, false>(s, nullptr);
 }
 
 }  // namespace p2
