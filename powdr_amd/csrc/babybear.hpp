@@ -45,6 +45,9 @@ PW_HD uint32_t monty_reduce(uint64_t t) {
     return reduce_2p((uint32_t)(u >> 32));
 }
 PW_HD uint32_t mul(uint32_t a, uint32_t b) { return monty_reduce((uint64_t)a * b); }
+// a*b + c*d in one Montgomery reduction: 2 p^2 + p 2^32 < 2^64, and the result is < 2 * 0.47 p + p < 2p.
+// (Three raw products do not fit: the reduction itself adds up to p 2^32.)
+PW_HD uint32_t mul2(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return monty_reduce((uint64_t)a * b + (uint64_t)c * d); }
 PW_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
 
 // canonical u32 (< p) <-> Montgomery

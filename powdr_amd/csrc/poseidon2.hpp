@@ -5,11 +5,10 @@
 // checkout and therefore generated here by the documented splitmix64 stream —
 // one swappable table, see DESIGN.md "pw-stark v0").
 //
-// Cost per permutation: S-boxes 8*16*4 + 13*4 = 564 Montgomery products, the
-// internal diagonal adds ~8 products per internal round; the linear layers are
-// additions only (M4 = circ-like [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] needs no
-// multiplier). The MDS layer is 16x16 with entries in {1,2,3,4,6}: it is not a dense
-// contraction worth an MFMA ("MFMA for the MDS").
+// Cost per permutation: S-boxes 8*16*4 + 13*4 = 564 Montgomery products, the internal diagonal adds 7 products
+// per internal round; the linear layers are sums with coefficients <= 4, done as v_mad_u64_u32 multiply-adds into
+// 64-bit accumulators with one reduction per output (bb::wide_fma / reduce_wide). The MDS layer is not a dense
+// contraction worth an MFMA.
 #pragma once
 #include "babybear.hpp"
 
@@ -74,32 +73,9 @@ PW_HD uint32_t sbox7_lazy(uint32_t x) {
     return bb::mul_lazy(x3, x4);
 }
 
-// [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] * (a,b,c,d)
-PW_HD void m4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
-    // 11 modular additions
-    uint32_t ab = bb::add(a, b), cd = bb::add(c, d);
-    uint32_t t = bb::add(ab, cd);
-    uint32_t tb = bb::add(t, b);                            // a + 2b + c + d
-    uint32_t td = bb::add(t, d);                            // a + b + c + 2d
-    uint32_t o3 = bb::add(td, bb::double_(a));              // 3a + b + c + 2d
-    uint32_t o1 = bb::add(tb, bb::double_(c));              // a + 2b + 3c + d
-    uint32_t o0 = bb::add(tb, ab);                          // 2a + 3b + c + d
-    uint32_t o2 = bb::add(td, cd);                          // a + b + 2c + 3d
-    a = o0; b = o1; c = o2; d = o3;
-}
-
-PW_HD void external_layer(uint32_t* s) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b) m4(s[4 * b], s[4 * b + 1], s[4 * b + 2], s[4 * b + 3]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        uint32_t col = bb::add(bb::add(s[i], s[4 + i]), bb::add(s[8 + i], s[12 + i]));
-#pragma unroll
-        for (int b = 0; b < 4; ++b) s[4 * b + i] = bb::add(s[4 * b + i], col);
-    }
-}
-
-// The same layer followed by the addition of the next round's constants, in 64-bit accumulators: every output is
+// External linear layer: M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] on each block of four words, then every word
+// gets the sum of its column over the four blocks added — followed by the addition of the next round's constants.
+// All in 64-bit accumulators: every output is
 // 2x_i + 3x_{i+1} + x_{i+2} + x_{i+3} (four multiply-adds seeded with the folded constant) plus the column sum
 // (64-bit adds), reduced once — 140 instructions instead of 72 modular additions + 16 constant additions. Inputs may
 // be lazy S-box outputs in [0, 2p): an output is < 5 * (7 * 2p + p) = 75 p, inside reduce_wide's 128 p.
