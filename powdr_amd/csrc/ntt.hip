@@ -126,9 +126,12 @@ __device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t base_top)
     for (int qi = 0; qi < LOGR; ++qi) {
         const int q = DIF ? (LOGR - 1 - qi) : qi;
         // twiddles of this stage: base[q] * w_{2^(q+1)}^r, r < 2^q;  w_{2^(q+1)}^r = w16^(r << (3 - q))
-        uint32_t t[1 << (LOGR - 1)];
+        uint32_t t[1 << (LOGR - 1)], nt[1 << (LOGR - 1)];
 #pragma unroll
-        for (int r = 0; r < (1 << q); ++r) t[r] = r == 0 ? base[q] : bb::mul(base[q], roots[r << (3 - q)]);
+        for (int r = 0; r < (1 << q); ++r) {
+            t[r] = r == 0 ? base[q] : bb::mul(base[q], roots[r << (3 - q)]);
+            if (DIF) nt[r] = bb::P - t[r];  // a representative of -t in (0, p]: fine as a factor
+        }
 #pragma unroll
         for (int u = 0; u < R / 2; ++u) {
             const int lowp = u & ((1 << q) - 1);
@@ -137,7 +140,7 @@ __device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t base_top)
             const uint32_t a = v[i0], b = v[i1];
             if (DIF) {
                 v[i0] = bb::add(a, b);
-                v[i1] = bb::mul(bb::sub(a, b), t[lowp]);
+                v[i1] = bb::mul2(a, t[lowp], b, nt[lowp]);  // (a - b) t as a t + b (p - t): one reduction, no subtraction
             } else {
                 const uint32_t bt = bb::mul(b, t[lowp]);
                 v[i0] = bb::add(a, bt);
