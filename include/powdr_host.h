@@ -96,6 +96,12 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
 int powdr_xbc_eval_host(const uint32_t* postfix, uint32_t len, const uint32_t* trace, size_t r,
                         uint32_t* result, uint32_t* n_instr);
 
+/* Test hook for the small-form analysis (csrc/small_form.hpp) behind the fast bus-replay kernel: returns 0 and the
+ * value (Montgomery) when `postfix` simplifies to k0 + k1*T[a] + k2*T[b] + k3*T[a]*T[b], 1 when it does not (the
+ * interpreter handles it). `flags`: 1 uses a, 2 uses b, 4 has the product term, 8 is a plain column, 16 is a constant. */
+int powdr_small_form_eval_host(const uint32_t* postfix, uint32_t len, const uint32_t* trace, size_t r,
+                               uint32_t* result, uint32_t* flags);
+
 #ifdef __cplusplus
 }
 #endif

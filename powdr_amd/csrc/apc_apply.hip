@@ -25,6 +25,7 @@
 #include "expr_eval.hpp"
 #include "xbc.hpp"
 #include "xbc_compile.hpp"
+#include "small_form.hpp"
 #include "../../include/powdr_gpu.h"
 
 #include <cstdlib>
@@ -208,6 +209,66 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_xbc_kernel(
     }
 }
 
+// Interactions whose multiplicity and arguments are all small forms (small_form.hpp): no interpreter. All cells an
+// interaction reads are requested before the first one is used, so an interaction costs one memory round trip instead
+// of one per bytecode instruction.
+struct FastInteraction {
+    uint32_t kind;  // 0 var-range, 1 tuple2, 2 bitwise
+    uint32_t slot;  // item slot (binned mode)
+    uint32_t pad[2];
+    pw::SmallForm f[4];  // mult, arg0, arg1, selector (bitwise only)
+};
+
+template <bool BINNED>
+__global__ __launch_bounds__(kBlock) void apc_apply_bus_fast_kernel(
+    const uint32_t* __restrict__ trace, int num_calls, const FastInteraction* __restrict__ fint, uint32_t n_fint, BusParams p,
+    uint32_t per_chunk, uint32_t* __restrict__ items, size_t item_stride, size_t col_stride, size_t row0) {
+    const size_t rl = (size_t)blockIdx.x * kBlock + threadIdx.x;  // row within this launch's row window
+    const size_t r = row0 + rl;
+    const bool live = r < (size_t)num_calls;
+    if (!BINNED && !live) return;
+    if (BINNED && rl >= item_stride) return;
+    const size_t rr = live ? r : 0;  // dead rows read row 0 and discard it
+    const uint32_t i0 = blockIdx.y * per_chunk;
+    const uint32_t i1 = min(n_fint, i0 + per_chunk);
+    for (uint32_t i = i0; i < i1; ++i) {
+        const FastInteraction fi = fint[i];
+        uint32_t ta[4], tb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ta[k] = (fi.f[k].flags & pw::SmallForm::USES_A) ? trace[(size_t)fi.f[k].a * col_stride + rr] : 0u;
+            tb[k] = (fi.f[k].flags & pw::SmallForm::USES_B) ? trace[(size_t)fi.f[k].b * col_stride + rr] : 0u;
+        }
+        uint32_t bin = kItemNone;
+        const uint32_t m = live ? bb::from_monty(fi.f[0].eval(ta[0], tb[0])) : 0u;
+        uint32_t* table = fi.kind == 0 ? p.var_hist : fi.kind == 1 ? p.tuple_hist : p.bitwise_hist;
+        if (m != 0u) {
+            const uint32_t a0 = bb::from_monty(fi.f[1].eval(ta[1], tb[1]));
+            const uint32_t a1 = bb::from_monty(fi.f[2].eval(ta[2], tb[2]));
+            if (fi.kind == 0) {
+                const uint32_t idx = (a1 < 32u ? (1u << a1) : 0u) + a0 - 1u;
+                if (idx < p.var_bins) bin = idx;
+            } else if (fi.kind == 1) {
+                const uint32_t idx = a0 * p.tuple_sz1 + a1;
+                if (idx < p.tuple_sz0 * p.tuple_sz1) bin = idx;
+            } else {
+                const uint32_t sel = bb::from_monty(fi.f[3].eval(ta[3], tb[3]));
+                if (sel <= 1u && a0 < 256u && a1 < 256u) bin = bitwise_index(a0, a1, sel);
+            }
+        }
+        if (BINNED) {
+            uint32_t item = kItemNone;
+            if (bin != kItemNone) {
+                if (m < kItemMaxMult && bin < (1u << kItemBinBits)) item = bin | (m << kItemBinBits);
+                else atomicAdd(table + bin, m);
+            }
+            items[(size_t)fi.slot * item_stride + rl] = item;
+        } else if (bin != kItemNone) {
+            atomicAdd(table + bin, m);
+        }
+    }
+}
+
 constexpr uint32_t kPartBins = 32768;  // 128 KB of LDS counters
 constexpr int kHistBlock = 1024;
 
@@ -249,6 +310,10 @@ struct BusPlan {
     bool has_xbc = false;
     XInteraction* d_xint = nullptr;
     uint32_t* d_code = nullptr;
+    // the same interactions split into those that are small forms throughout (fast kernel) and the rest (interpreter)
+    FastInteraction* d_fint = nullptr;
+    XInteraction* d_xint_slow = nullptr;
+    uint32_t n_fast = 0, n_slow = 0;
 };
 std::mutex g_bus_mu;
 std::unordered_map<uint64_t, BusPlan> g_bus_plans;
@@ -345,7 +410,8 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
             BusPlan bp;
             std::vector<int32_t> slot_of(n_interactions, -1);
             std::vector<uint32_t> per_table[3];
-            std::vector<XInteraction> xints;
+            std::vector<XInteraction> xints, xints_slow;
+            std::vector<FastInteraction> fints;
             std::vector<uint32_t> code;
             xbc::Compiler cc;
             bool ok = true;
@@ -358,14 +424,22 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
                 xi.slot = bp.total_slots;
                 per_table[kind].push_back(bp.total_slots++);
                 const uint32_t which[4] = {0, 1, 2, 4};  // mult, arg0, arg1, (bitwise) selector = arg 3
+                FastInteraction fi{};
+                fi.kind = (uint32_t)kind;
+                fi.slot = xi.slot;
+                fi.f[3].flags = pw::SmallForm::IS_CONST;
+                bool fast = true;
                 for (int k = 0; k < (kind == 2 ? 4 : 3) && ok; ++k) {
                     const size_t si = (size_t)h[i].args_index_off + which[k];
                     if (si >= hs.size() || (size_t)hs[si].off + hs[si].len > hb.size()) { ok = false; break; }
                     xi.off[k] = (uint32_t)(code.size() / 2);
                     if (!cc.compile(hb.data() + hs[si].off, hs[si].len, code)) { ok = false; break; }
                     xi.len[k] = (uint32_t)(code.size() / 2) - xi.off[k];
+                    fast = fast && pw::analyze_small_form(hb.data() + hs[si].off, hs[si].len, fi.f[k]);
                 }
                 xints.push_back(xi);
+                if (fast) fints.push_back(fi);
+                else xints_slow.push_back(xi);
             }
             PW_HIP_TRY(hipMalloc(&bp.d_slot_of, (n_interactions + 1) * 4));
             PW_HIP_TRY(hipMemcpy(bp.d_slot_of, slot_of.data(), n_interactions * 4, hipMemcpyHostToDevice));
@@ -381,6 +455,13 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
                 PW_HIP_TRY(hipMalloc(&bp.d_code, (code.size() + 2) * 4));
                 if (!code.empty()) PW_HIP_TRY(hipMemcpy(bp.d_code, code.data(), code.size() * 4, hipMemcpyHostToDevice));
                 bp.has_xbc = true;
+                bp.n_fast = (uint32_t)fints.size();
+                bp.n_slow = (uint32_t)xints_slow.size();
+                PW_HIP_TRY(hipMalloc(&bp.d_fint, (fints.size() + 1) * sizeof(FastInteraction)));
+                if (!fints.empty()) PW_HIP_TRY(hipMemcpy(bp.d_fint, fints.data(), fints.size() * sizeof(FastInteraction), hipMemcpyHostToDevice));
+                PW_HIP_TRY(hipMalloc(&bp.d_xint_slow, (xints_slow.size() + 1) * sizeof(XInteraction)));
+                if (!xints_slow.empty())
+                    PW_HIP_TRY(hipMemcpy(bp.d_xint_slow, xints_slow.data(), xints_slow.size() * sizeof(XInteraction), hipMemcpyHostToDevice));
             }
             it = g_bus_plans.emplace(key, bp).first;
         }
@@ -388,18 +469,30 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
     }
     if (plan->total_slots == 0) return (int)hipGetLastError();
     const bool use_xbc = want_xbc && plan->has_xbc;
-    // chunking of the interaction list actually walked by the kernel
-    const uint32_t n_list = use_xbc ? plan->total_slots : (uint32_t)n_interactions;
-    unsigned xchunks = 1;
-    if (row_blocks < want_blocks) {
-        xchunks = (want_blocks + row_blocks - 1) / row_blocks;
-        const unsigned max_chunks = (n_list + 15) / 16;
-        if (xchunks > max_chunks) xchunks = max_chunks;
-        if (xchunks > 65535u) xchunks = 65535u;
-        if (xchunks == 0) xchunks = 1;
-    }
-    const uint32_t x_per_chunk = (n_list + xchunks - 1) / xchunks;
-    xchunks = (n_list + x_per_chunk - 1) / x_per_chunk;
+    const char* env_f = getenv("POWDR_BUS_FAST");
+    const bool use_fast = use_xbc && (env_f ? atoi(env_f) != 0 : true);
+    // chunking of an interaction list over blockIdx.y so that short traces still fill the chip
+    auto chunking = [&](uint32_t n_list, unsigned& chunks, uint32_t& per_chunk) {
+        chunks = 1;
+        if (n_list == 0) { per_chunk = 1; return; }
+        if (row_blocks < want_blocks) {
+            chunks = (want_blocks + row_blocks - 1) / row_blocks;
+            const unsigned max_chunks = (n_list + 15) / 16;
+            if (chunks > max_chunks) chunks = max_chunks;
+            if (chunks > 65535u) chunks = 65535u;
+            if (chunks == 0) chunks = 1;
+        }
+        per_chunk = (n_list + chunks - 1) / chunks;
+        chunks = (n_list + per_chunk - 1) / per_chunk;
+    };
+    unsigned xchunks, fchunks = 1;
+    uint32_t x_per_chunk, f_per_chunk = 1;
+    // the interpreter walks: all periphery interactions (xbc), only the non-small-form ones (fast mode), or the
+    // reference's full list (post-fix mode)
+    const XInteraction* x_list = use_fast ? plan->d_xint_slow : plan->d_xint;
+    const uint32_t n_x = use_fast ? plan->n_slow : plan->total_slots;
+    chunking(use_xbc ? n_x : (uint32_t)n_interactions, xchunks, x_per_chunk);
+    if (use_fast) chunking(plan->n_fast, fchunks, f_per_chunk);
 
     // ---- long traces: binned path ---------------------------------------------------------------
     if (want_binned && table_bins[0] <= (1u << kItemBinBits) && table_bins[1] <= (1u << kItemBinBits)) {
@@ -421,11 +514,16 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
                 const size_t stride = all_rows - row0 < window ? all_rows - row0 : window;
                 {
                     pw::ScopedKernelTimer t("apc_apply_bus_kernel");
-                    if (use_xbc)
-                        hipLaunchKernelGGL(apc_apply_bus_xbc_kernel<true>, dim3(pw::div_up(stride, kBlock), xchunks), dim3(kBlock), 0,
-                                           pw::stream(), d_output, num_apc_calls, plan->d_code, plan->d_xint, plan->total_slots, p,
-                                           x_per_chunk, g_items, stride, col_stride, row0);
-                    else
+                    if (use_fast && plan->n_fast)
+                        hipLaunchKernelGGL(apc_apply_bus_fast_kernel<true>, dim3(pw::div_up(stride, kBlock), fchunks), dim3(kBlock), 0,
+                                           pw::stream(), d_output, num_apc_calls, plan->d_fint, plan->n_fast, p, f_per_chunk, g_items,
+                                           stride, col_stride, row0);
+                    if (use_xbc) {
+                        if (n_x)
+                            hipLaunchKernelGGL(apc_apply_bus_xbc_kernel<true>, dim3(pw::div_up(stride, kBlock), xchunks), dim3(kBlock), 0,
+                                               pw::stream(), d_output, num_apc_calls, plan->d_code, x_list, n_x, p, x_per_chunk, g_items,
+                                               stride, col_stride, row0);
+                    } else
                         hipLaunchKernelGGL(apc_apply_bus_kernel<true>, dim3(pw::div_up(stride, kBlock), xchunks), dim3(kBlock), 0,
                                            pw::stream(), d_output, num_apc_calls, d_bytecode, d_interactions, (uint32_t)n_interactions,
                                            d_arg_spans, p, x_per_chunk, plan->d_slot_of, g_items, stride, col_stride, row0);
@@ -450,10 +548,14 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
         }
     }
     pw::ScopedKernelTimer t("apc_apply_bus_kernel");
-    if (use_xbc)
-        hipLaunchKernelGGL(apc_apply_bus_xbc_kernel<false>, dim3(row_blocks, xchunks), dim3(kBlock), 0, pw::stream(),
-                           d_output, num_apc_calls, plan->d_code, plan->d_xint, plan->total_slots, p, x_per_chunk, nullptr, 0, col_stride, 0);
-    else
+    if (use_fast && plan->n_fast)
+        hipLaunchKernelGGL(apc_apply_bus_fast_kernel<false>, dim3(row_blocks, fchunks), dim3(kBlock), 0, pw::stream(), d_output,
+                           num_apc_calls, plan->d_fint, plan->n_fast, p, f_per_chunk, nullptr, 0, col_stride, 0);
+    if (use_xbc) {
+        if (n_x)
+            hipLaunchKernelGGL(apc_apply_bus_xbc_kernel<false>, dim3(row_blocks, xchunks), dim3(kBlock), 0, pw::stream(),
+                               d_output, num_apc_calls, plan->d_code, x_list, n_x, p, x_per_chunk, nullptr, 0, col_stride, 0);
+    } else
         hipLaunchKernelGGL(apc_apply_bus_kernel<false>, dim3(row_blocks, xchunks), dim3(kBlock), 0, pw::stream(),
                            d_output, num_apc_calls, d_bytecode, d_interactions,
                            (uint32_t)n_interactions, d_arg_spans, p, x_per_chunk, nullptr, nullptr, 0, col_stride, 0);

@@ -2,6 +2,7 @@
 // post-fix expression and evaluate the resulting xbc program on the host, with exactly the
 // semantics of the device evaluator xbc::eval (xbc.hpp).
 #include "../xbc_compile.hpp"
+#include "../small_form.hpp"
 #include "../../../include/powdr_host.h"
 
 #include <vector>
@@ -40,5 +41,27 @@ extern "C" int powdr_xbc_eval_host(const uint32_t* postfix, uint32_t len, const 
         if (sp < 0 || sp > POWDR_EXPR_STACK_CAPACITY) return -3;
     }
     *result = top;
+    return 0;
+}
+
+// Test hook for the small-form analysis (small_form.hpp): 0 and the value if `postfix` is bilinear in at most two
+// columns, 1 if it is a well-formed expression of another shape (the kernels then interpret it), -1 never.
+extern "C" int powdr_small_form_eval_host(const uint32_t* postfix, uint32_t len, const uint32_t* trace, size_t r, uint32_t* result,
+                                          uint32_t* flags) {
+    pw::SmallForm f;
+    if (!pw::analyze_small_form(postfix, len, f)) return 1;
+    if (flags) *flags = f.flags;
+    const uint32_t ta = (f.flags & pw::SmallForm::USES_A) ? trace[(size_t)f.a + r] : 0u;
+    const uint32_t tb = (f.flags & pw::SmallForm::USES_B) ? trace[(size_t)f.b + r] : 0u;
+    // the device evaluator's arithmetic (SmallForm::eval), restated for the host
+    uint32_t v;
+    if (f.flags & pw::SmallForm::IS_CONST) v = f.k0;
+    else if (f.flags & pw::SmallForm::IS_COLUMN) v = ta;
+    else {
+        v = (f.flags & pw::SmallForm::USES_B) ? bb::mul2(f.k1, ta, f.k2, tb) : bb::mul(f.k1, ta);
+        if (f.flags & pw::SmallForm::HAS_PRODUCT) v = bb::add(v, bb::mul(f.k3, bb::mul(ta, tb)));
+        v = bb::add(v, f.k0);
+    }
+    *result = v;
     return 0;
 }

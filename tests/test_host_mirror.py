@@ -188,3 +188,62 @@ def test_xbc_compiler_preserves_values():
     # malformed programs are rejected (the kernels then keep the post-fix interpreter)
     for bad in ([om.OP_ADD], x + y, [Cn], [7, 0], x + [om.OP_MUL]):
         assert check(bad, 0) is None
+
+
+def test_small_form_analysis_preserves_values():
+    """The fast bus kernel evaluates multiplicities and arguments that are bilinear in at most two columns from a
+    closed form (csrc/small_form.hpp). Whatever the analysis accepts must evaluate like the expression; shapes it
+    must accept (the ones bus interactions have) and shapes it must refuse are pinned."""
+    import ctypes as C
+
+    from powdr_amd import abi
+    from tests.test_oracle_apc import _random_expr
+
+    lib = abi.lib
+    lib.powdr_small_form_eval_host.restype = C.c_int
+    rng = np.random.default_rng(11)
+    W, H = 6, 4
+    ids = list(range(W))
+    idx = {p: p for p in ids}
+    trace = rng.integers(0, om.P, size=W * H, dtype=np.uint32)
+    tm = om.to_monty(trace)
+
+    def run(bc, r):
+        bc = np.array(bc, dtype=np.uint32)
+        res, fl = C.c_uint32(), C.c_uint32()
+        rc = lib.powdr_small_form_eval_host(bc.ctypes.data_as(C.c_void_p), C.c_uint32(len(bc)), tm.ctypes.data_as(C.c_void_p),
+                                            C.c_size_t(r), C.byref(res), C.byref(fl))
+        if rc != 0:
+            return None, None
+        want = om.c_eval_expr(bc, trace, r)
+        got = int(om.from_monty(np.array([res.value], dtype=np.uint32))[0])
+        assert got == want, (bc.tolist(), r)
+        return got, fl.value
+
+    accepted = 0
+    for depth in (1, 2, 3, 4, 5):
+        for _ in range(300):
+            e = _random_expr(rng, ids[:3], depth)  # few columns: many expressions stay within two
+            bc = []
+            om.emit_expr(bc, e, idx, H)
+            if om.OP_INV_OR_ZERO in bc[::1] and run(bc, 0)[0] is None:
+                continue
+            for r in range(H):
+                accepted += run(bc, r)[0] is not None
+    assert accepted > 300
+    A, Cn, ADD, SUB, MUL, NEG = om.OP_PUSH_APC, om.OP_PUSH_CONST, om.OP_ADD, om.OP_SUB, om.OP_MUL, om.OP_NEG
+    x, y, z = [A, 1 * H], [A, 2 * H], [A, 3 * H]
+    must_accept = {
+        "column": (x, 8 | 1), "constant": ([Cn, 17], 16), "255 - byte": ([Cn, 255] + x + [SUB], 1),
+        "byte + 256 byte": (x + [Cn, 256] + y + [MUL, ADD], 1 | 2), "valid * flag": (x + y + [MUL], 1 | 2 | 4),
+        "valid * 3": (x + [Cn, 3, MUL], 1), "x - x + y": (x + x + [SUB] + y + [ADD], 8 | 1),
+        "(x + 1)(y + 2)": (x + [Cn, 1, ADD] + y + [Cn, 2, ADD, MUL], 1 | 2 | 4), "-(x) * 0 + 5": (x + [NEG, Cn, 0, MUL, Cn, 5, ADD], 16),
+    }
+    for name, (bc, flags) in must_accept.items():
+        for r in range(H):
+            v, fl = run(bc, r)
+            assert v is not None and fl == flags, (name, fl)
+    must_refuse = {"square": x + x + [MUL], "three columns": x + y + [ADD] + z + [ADD], "x y x": x + y + [MUL] + x + [MUL],
+                   "inverse": x + [om.OP_INV_OR_ZERO], "malformed": x + [ADD]}
+    for name, bc in must_refuse.items():
+        assert run(bc, 0)[0] is None, name
