@@ -67,12 +67,13 @@ struct BusParams {
     uint32_t* tuple_hist;
     uint32_t* bitwise_hist;
     uint32_t var_bins, tuple_sz0, tuple_sz1;
+    const uint32_t* slot_range;  // binned mode: per item slot, the expected partitions (in_expected_partitions)
 };
 
 // Layout of BitwiseOperationLookup<8>'s count buffer (EXTERNAL to the reference
 // checkout, assumption A3 of SURVEY.md): 2^16 range counters followed by 2^16 xor
 // counters, both indexed by x * 256 + y.
-__device__ __forceinline__ uint32_t bitwise_index(uint32_t x, uint32_t y, uint32_t selector) {
+__host__ __device__ __forceinline__ uint32_t bitwise_index(uint32_t x, uint32_t y, uint32_t selector) {
     return selector * (1u << (2 * POWDR_BITWISE_NUM_BITS)) + (x << POWDR_BITWISE_NUM_BITS) + y;
 }
 
@@ -86,6 +87,17 @@ __device__ __forceinline__ uint32_t bitwise_index(uint32_t x, uint32_t y, uint32
 constexpr uint32_t kItemNone = 0xffffffffu;
 constexpr uint32_t kItemBinBits = 20;
 constexpr uint32_t kItemMaxMult = 1u << (32 - kItemBinBits);
+constexpr uint32_t kPartBins = 32768;  // bins per histogram partition: 128 KB of LDS counters
+
+// The partitions of its table a slot's items are EXPECTED in, as (first | last << 16), decided at plan time from the
+// constant operands of the interaction (a 12-14-bit range check belongs to partition 0, a bitwise lookup with a
+// constant operation to two of four); the histogram pass of a partition skips the slots whose range excludes it. An
+// item that falls outside its slot's range (only a dishonest trace produces one) is not packed but counted directly
+// with a global atomic, so the result is exact either way.
+__device__ __forceinline__ bool in_expected_partitions(uint32_t range, uint32_t bin) {
+    const uint32_t part = bin / kPartBins;
+    return part >= (range & 0xffffu) && part <= (range >> 16);
+}
 
 template <bool BINNED>
 __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
@@ -112,6 +124,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
         else if (intr.bus_id == p.bitwise_bus) kind = 2;
         else continue;  // execution bridge / memory / pc lookup: no periphery side effect
 
+        const uint32_t range = BINNED ? p.slot_range[slot_of[i]] : 0u;
         uint32_t bin = kItemNone, m = 0u;
         uint32_t* table = kind == 0 ? p.var_hist : kind == 1 ? p.tuple_hist : p.bitwise_hist;
         if (live) {
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
         if (BINNED) {
             uint32_t item = kItemNone;
             if (bin != kItemNone) {
-                if (m < kItemMaxMult && bin < (1u << kItemBinBits)) item = bin | (m << kItemBinBits);
+                if (m < kItemMaxMult && bin < (1u << kItemBinBits) && in_expected_partitions(range, bin)) item = bin | (m << kItemBinBits);
                 else atomicAdd(table + bin, m);  // does not fit the packed item: rare, direct
             }
             items[(size_t)slot_of[i] * item_stride + rl] = item;
@@ -177,6 +190,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_xbc_kernel(
     const uint32_t i1 = min(n_xint, i0 + per_chunk);
     for (uint32_t i = i0; i < i1; ++i) {
         const XInteraction xi = xint[i];
+        const uint32_t range = BINNED ? p.slot_range[xi.slot] : 0u;
         uint32_t bin = kItemNone, m = 0u;
         uint32_t* table = xi.kind == 0 ? p.var_hist : xi.kind == 1 ? p.tuple_hist : p.bitwise_hist;
         if (live) {
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_xbc_kernel(
         if (BINNED) {
             uint32_t item = kItemNone;
             if (bin != kItemNone) {
-                if (m < kItemMaxMult && bin < (1u << kItemBinBits)) item = bin | (m << kItemBinBits);
+                if (m < kItemMaxMult && bin < (1u << kItemBinBits) && in_expected_partitions(range, bin)) item = bin | (m << kItemBinBits);
                 else atomicAdd(table + bin, m);
             }
             items[(size_t)xi.slot * item_stride + rl] = item;
@@ -233,6 +247,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_fast_kernel(
     const uint32_t i1 = min(n_fint, i0 + per_chunk);
     for (uint32_t i = i0; i < i1; ++i) {
         const FastInteraction fi = fint[i];
+        const uint32_t range = BINNED ? p.slot_range[fi.slot] : 0u;
         uint32_t ta[4], tb[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -259,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_fast_kernel(
         if (BINNED) {
             uint32_t item = kItemNone;
             if (bin != kItemNone) {
-                if (m < kItemMaxMult && bin < (1u << kItemBinBits)) item = bin | (m << kItemBinBits);
+                if (m < kItemMaxMult && bin < (1u << kItemBinBits) && in_expected_partitions(range, bin)) item = bin | (m << kItemBinBits);
                 else atomicAdd(table + bin, m);
             }
             items[(size_t)fi.slot * item_stride + rl] = item;
@@ -269,12 +284,11 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_fast_kernel(
     }
 }
 
-constexpr uint32_t kPartBins = 32768;  // 128 KB of LDS counters
 constexpr int kHistBlock = 1024;
 
 __global__ __launch_bounds__(kHistBlock) void bus_histogram_kernel(
     const uint32_t* __restrict__ items, size_t item_stride, const uint32_t* __restrict__ slots, uint32_t n_slots,
-    uint32_t* __restrict__ hist, uint32_t bins, uint32_t rows_per_chunk) {
+    uint32_t* __restrict__ hist, uint32_t bins, uint32_t rows_per_chunk, const uint32_t* __restrict__ slot_range) {
     __shared__ uint32_t lh[kPartBins];
     const uint32_t bin0 = blockIdx.x * kPartBins;
     for (uint32_t b = threadIdx.x; b < kPartBins; b += kHistBlock) lh[b] = 0u;
@@ -282,6 +296,8 @@ __global__ __launch_bounds__(kHistBlock) void bus_histogram_kernel(
     const size_t r0 = (size_t)blockIdx.y * rows_per_chunk;
     const size_t r1 = r0 + rows_per_chunk < item_stride ? r0 + rows_per_chunk : item_stride;
     for (uint32_t s = 0; s < n_slots; ++s) {
+        const uint32_t range = slot_range[slots[s]];
+        if (blockIdx.x < (range & 0xffffu) || blockIdx.x > (range >> 16)) continue;  // no item of this slot lands here
         const uint4* it = reinterpret_cast<const uint4*>(items + (size_t)slots[s] * item_stride);
         for (size_t q = (r0 >> 2) + threadIdx.x; q < (r1 >> 2); q += kHistBlock) {
             const uint4 v = it[q];
@@ -311,6 +327,7 @@ struct BusPlan {
     XInteraction* d_xint = nullptr;
     uint32_t* d_code = nullptr;
     // the same interactions split into those that are small forms throughout (fast kernel) and the rest (interpreter)
+    uint32_t* d_slot_range = nullptr;  // per item slot: expected partitions (first | last << 16)
     FastInteraction* d_fint = nullptr;
     XInteraction* d_xint_slow = nullptr;
     uint32_t n_fast = 0, n_slow = 0;
@@ -384,6 +401,7 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
     p.var_bus = var_range_bus_id; p.tuple_bus = tuple2_bus_id; p.bitwise_bus = bitwise_bus_id;
     p.var_hist = d_var_hist; p.tuple_hist = d_tuple2_hist; p.bitwise_hist = d_bitwise_hist;
     p.var_bins = (uint32_t)var_num_bins; p.tuple_sz0 = tuple2_sz0; p.tuple_sz1 = tuple2_sz1;
+    p.slot_range = nullptr;
     // ---- plan: host copy of the (small) tables, cached by content --------------------------------
     const char* env = getenv("POWDR_BUS_BINNED");
     const bool want_binned = env ? atoi(env) != 0 : num_apc_calls >= 16384;
@@ -411,6 +429,7 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
             std::vector<int32_t> slot_of(n_interactions, -1);
             std::vector<uint32_t> per_table[3];
             std::vector<XInteraction> xints, xints_slow;
+            std::vector<uint32_t> slot_range;
             std::vector<FastInteraction> fints;
             std::vector<uint32_t> code;
             xbc::Compiler cc;
@@ -440,7 +459,30 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
                 xints.push_back(xi);
                 if (fast) fints.push_back(fi);
                 else xints_slow.push_back(xi);
+                // expected partitions of this slot's items
+                uint32_t first = 0, last = (table_bins[kind] - 1) / kPartBins;
+                if (ok) {
+                    pw::SmallForm c;
+                    const auto constant_arg = [&](uint32_t arg, uint32_t& value) {
+                        const size_t si = (size_t)h[i].args_index_off + arg;
+                        if (!pw::analyze_small_form(hb.data() + hs[si].off, hs[si].len, c) || !(c.flags & pw::SmallForm::IS_CONST)) return false;
+                        value = bb::from_monty(c.k0);
+                        return true;
+                    };
+                    uint32_t v;
+                    if (kind == 0 && constant_arg(2, v) && v < 31) {  // honest values of a `v`-bit check: [2^v - 1, 2^(v+1) - 2]
+                        first = ((1u << v) - 1u) / kPartBins;
+                        last = std::min(last, ((2u << v) - 2u) / kPartBins);
+                        if (first > last) first = last;
+                    } else if (kind == 2 && constant_arg(4, v) && v <= 1) {
+                        first = bitwise_index(0, 0, v) / kPartBins;
+                        last = bitwise_index(255, 255, v) / kPartBins;
+                    }
+                }
+                slot_range.push_back(first | (last << 16));
             }
+            PW_HIP_TRY(hipMalloc(&bp.d_slot_range, (slot_range.size() + 1) * 4));
+            if (!slot_range.empty()) PW_HIP_TRY(hipMemcpy(bp.d_slot_range, slot_range.data(), slot_range.size() * 4, hipMemcpyHostToDevice));
             PW_HIP_TRY(hipMalloc(&bp.d_slot_of, (n_interactions + 1) * 4));
             PW_HIP_TRY(hipMemcpy(bp.d_slot_of, slot_of.data(), n_interactions * 4, hipMemcpyHostToDevice));
             for (int t = 0; t < 3; ++t) {
@@ -510,6 +552,7 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
         }
         if (have) {
             uint32_t* tables[3] = {d_var_hist, d_tuple2_hist, d_bitwise_hist};
+            p.slot_range = plan->d_slot_range;
             for (size_t row0 = 0; row0 < all_rows; row0 += window) {
                 const size_t stride = all_rows - row0 < window ? all_rows - row0 : window;
                 {
@@ -541,7 +584,8 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
                     n_chunks = pw::div_up(stride, rows_per_chunk);
                     pw::ScopedKernelTimer tt("bus_histogram_kernel");
                     hipLaunchKernelGGL(bus_histogram_kernel, dim3(parts, n_chunks), dim3(kHistBlock), 0,
-                                       pw::stream(), g_items, stride, plan->d_slots[t], plan->n_slots[t], tables[t], table_bins[t], rows_per_chunk);
+                                       pw::stream(), g_items, stride, plan->d_slots[t], plan->n_slots[t], tables[t], table_bins[t], rows_per_chunk,
+                                       plan->d_slot_range);
                 }
             }
             return (int)hipGetLastError();

@@ -319,6 +319,44 @@ def test_binned_path_large_multiplicity_and_hot_bins(gpu, monkeypatch):
     assert (hist_np(per.bitwise_hist) == want["bitwise"]).all()
 
 
+@pytest.mark.parametrize("fast", ["0", "1"])
+def test_binned_path_values_outside_the_expected_partition(gpu, monkeypatch, fast):
+    """The histogram pass only visits the partitions a slot's constant operands predict (a 12-bit range check: the
+    first 32 768 bins; a bitwise lookup with a constant operation: its half of the table). Values a dishonest trace
+    puts elsewhere — 17-bit values under a 12-bit check, here — are still counted exactly (direct atomics)."""
+    torch, abi, tg = gpu
+    monkeypatch.setenv("POWDR_BUS_BINNED", "1")
+    monkeypatch.setenv("POWDR_BUS_FAST", fast)
+    H, W, calls = 2048, 3, 2000
+    rng = np.random.default_rng(12)
+    trace = np.zeros(H * W, np.uint32)
+    trace[:calls] = rng.integers(0, 1 << 17, calls)            # col0: up to 17 bits
+    trace[H : H + calls] = rng.integers(0, 256, calls)         # col1: bytes
+    trace[2 * H : 2 * H + calls] = rng.integers(0, 3, calls)   # col2: selector 0, 1 and the invalid 2
+    PA, PC = om.OP_PUSH_APC, om.OP_PUSH_CONST
+    bc, spans = [], []
+
+    def span(words):
+        spans.append((len(bc), len(words)))
+        bc.extend(words)
+
+    inter = np.array([[3, 2, 0], [3, 2, 3], [6, 4, 6], [6, 4, 11]], np.uint32)
+    span([PC, 1]); span([PA, 0]); span([PC, 12])               # 12-bit check of a 17-bit column: bins up to 2^12 + 2^17
+    span([PC, 2]); span([PA, 0]); span([PC, 17])               # the honest 17-bit check of the same column
+    span([PC, 1]); span([PA, H]); span([PA, H]); span([PC, 0]); span([PC, 1])     # xor lookups: second half of the table
+    span([PC, 1]); span([PA, H]); span([PA, H]); span([PC, 0]); span([PA, 2 * H])  # selector from a column: no prediction
+    out = tg.DeviceMatrix.zeros(H, W)
+    out.buf.copy_(to_dev(torch, trace))
+    per = tg.Periphery.fresh()
+    tg.apc_apply_bus(out, calls, bc, inter, spans, per)
+    torch.cuda.synchronize()
+    want = dict(var=np.zeros(1 << 18, np.uint32), tuple=np.zeros(256 * 2048, np.uint32), bitwise=np.zeros(2 * 65536, np.uint32))
+    om.c_apc_apply_bus(trace, calls, np.array(bc, np.uint32), inter, np.array(spans, np.uint32), 3, want["var"], 7, want["tuple"], 256, 2048, 6, want["bitwise"])
+    assert want["var"][32768:].sum() > calls  # plenty of lookups beyond partition 0
+    assert (hist_np(per.var_hist) == want["var"]).all()
+    assert (hist_np(per.bitwise_hist) == want["bitwise"]).all()
+
+
 def test_column_operand_extensions_match_reference_encoding(gpu):
     """powdr_apc_apply_derived_expr_cols / powdr_apc_apply_bus_cols (PUSH_APC operand = column index, for
     traces with W*H >= 2^32) against the reference encoding (operand = col*H) on the same APC."""
