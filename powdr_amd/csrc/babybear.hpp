@@ -95,6 +95,17 @@ PW_HD uint64_t wide_fma_uniform(uint64_t c, uint32_t x, uint32_t k) {
     return c + (uint64_t)x * k;
 #endif
 }
+// acc + x * u for a wave-uniform u (a scalar register). Written as an instruction so that the compiler keeps `acc`
+// as the addend of the multiply-add (it otherwise computes x * u early and spends a second multiply-add on the sum).
+PW_HD uint64_t wide_mad_uniform(uint64_t acc, uint32_t x, uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t out;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(out) : "v"(x), "s"(u), "v"(acc) : "vcc");
+    return out;
+#else
+    return acc + (uint64_t)x * u;
+#endif
+}
 // k * x as a 64-bit value
 PW_HD uint64_t wide_mul(uint32_t x, uint32_t k) {
 #if defined(__HIP_DEVICE_COMPILE__)
