@@ -303,11 +303,12 @@ def main():
                         algorithmic_bytes_per_step=bytes_step, avg_launch_ms=ms / cnt, launches_per_step=launches_per_step,
                         algo_bytes_per_cell=abc)
             if dom == "leaf_hash_kernel":
-                # The dominant kernel is integer-VALU bound, not HBM/MFMA bound: 5330 VALU instructions per Poseidon2
+                # The dominant kernel is integer-VALU bound, not HBM/MFMA bound: 4929 VALU instructions per Poseidon2
                 # permutation (PMC SQ_INSTS_VALU / permutations, profiles/r01_pmc_leaf_hash_h18.txt; the
                 # first version needed 7089); a wave64 VALU instruction issues in 4 cycles.
                 perms = 2 * wl["H"] * ((wl["W"] + 7) // 8) + 2 * wl["H"]  # trace LDE rows + 8-col quotient LDE rows
-                wave_instr = perms * 5330 / 64
+                perms += 2 * wl["H"] * ((perm_cols + 7) // 8)            # + the permutation matrix's rows (--logup)
+                wave_instr = perms * 4929 / 64
                 peak = 1024 * 2.4e9 / 4  # SIMDs x clock / cycles per instruction
                 rate = wave_instr / (ms / args.steps * 1e-3)
                 roof["valu"] = dict(wave_instructions_per_step=wave_instr, achieved_G_wave_instr_s=rate / 1e9,
