@@ -179,11 +179,10 @@ int merkle_commit_ext_pairs(const bb::Ext* v, size_t half, uint32_t* digests) {
     return build_levels(digests, half);
 }
 
-int pow_grind(const uint32_t* d_state16, const uint32_t* d_pending, uint32_t in_len, uint32_t bits, uint32_t* witness_out) {
+int pow_grind(const uint32_t* d_state16, const uint32_t* d_pending, uint32_t in_len, uint32_t bits, uint32_t* d_best,
+              uint32_t* witness_out) {
     int rc = poseidon2_upload_params();
     if (rc) return rc;
-    uint32_t* d_best;
-    PW_HIP_TRY(hipMalloc(&d_best, 4));
     const uint32_t batch = 1u << 20;
     uint32_t best = 0xffffffffu;
     for (uint64_t base = 0; base < bb::P; base += batch) {
@@ -194,7 +193,6 @@ int pow_grind(const uint32_t* d_state16, const uint32_t* d_pending, uint32_t in_
         PW_HIP_TRY(hipStreamSynchronize(stream()));
         if (best != 0xffffffffu) break;
     }
-    (void)hipFree(d_best);
     *witness_out = best;
     return best == 0xffffffffu ? (int)hipErrorUnknown : 0;
 }

@@ -496,7 +496,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         for (size_t i = 0; i < ch.in.size(); ++i) pending[i] = ch.in[i];
         PW_HIP_TRY(hipMemcpyAsync(d_state, ch.st, 64, hipMemcpyHostToDevice, st));
         PW_HIP_TRY(hipMemcpyAsync(d_state + 16, pending, 32, hipMemcpyHostToDevice, st));
-        TRY(pow_grind(d_state, d_state + 16, (uint32_t)ch.in.size(), p->cfg.pow_bits, &witness));
+        TRY(pow_grind(d_state, d_state + 16, (uint32_t)ch.in.size(), p->cfg.pow_bits, d_state + 24, &witness));
     }
     put(witness);
     ch.observe_canonical(witness);

@@ -96,7 +96,8 @@ int deep_quotient_logup(const uint32_t* lde, uint32_t W, const uint32_t* plde, u
 
 // proof-of-work search: smallest witness w (checked in blocks) such that the transcript state,
 // after observing w, samples a value with `bits` low zero bits. state = 16 words sponge state,
-// in_len = number of pending absorbed words (they are in pending[]).
-int pow_grind(const uint32_t* state16, const uint32_t* pending, uint32_t in_len, uint32_t bits, uint32_t* witness_out);
+// in_len = number of pending absorbed words (they are in pending[]). d_best: one device word of scratch.
+int pow_grind(const uint32_t* state16, const uint32_t* pending, uint32_t in_len, uint32_t bits, uint32_t* d_best,
+              uint32_t* witness_out);
 
 }  // namespace pw
