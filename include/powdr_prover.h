@@ -141,6 +141,9 @@ int pw_verify_segment(const PwStarkConfig* cfg, const PwAirDescription* airs, si
 /* Digest over an ordered list of 8-word commitments (binary Poseidon2 tree; canonical words). */
 void pw_commitment_digest(const uint32_t* roots8, size_t n, uint32_t* digest8);
 
+/* Number of main-trace columns the prover was created for. */
+uint32_t pw_prover_width(const PwProver* p);
+
 /* Bytes of device memory the prover currently holds. */
 size_t pw_prover_device_bytes(const PwProver* p);
 

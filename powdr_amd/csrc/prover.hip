@@ -264,6 +264,8 @@ extern "C" void pw_prover_destroy(PwProver* p) {
     delete p;
 }
 
+extern "C" uint32_t pw_prover_width(const PwProver* p) { return p ? p->width : 0; }
+
 extern "C" size_t pw_prover_device_bytes(const PwProver* p) {
     return p->coef.bytes + p->lde.bytes + p->digests.bytes + p->q.bytes + p->qcoef.bytes + p->qlde.bytes +
            p->ext_arena.bytes + p->misc.bytes + p->perm.bytes + p->plde.bytes;

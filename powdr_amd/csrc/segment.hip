@@ -98,10 +98,11 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int sha
         if (!airs[i].prover || !airs[i].d_trace) return (int)hipErrorInvalidValue;
     if (n_workers == 0) n_workers = 4;
     if (n_workers > n_airs) n_workers = (unsigned)n_airs;
-    // largest first: the tail of the schedule is filled with the small proofs
+    // largest (by cells) first: the tail of the schedule is filled with the small proofs
     std::vector<size_t> order(n_airs);
     std::iota(order.begin(), order.end(), (size_t)0);
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return airs[a].log_height > airs[b].log_height; });
+    auto cells = [&](size_t i) { return (uint64_t)pw_prover_width(airs[i].prover) << airs[i].log_height; };
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cells(a) > cells(b); });
     uint32_t seed[8] = {0};
     if (shared_bus_seed) {
         // phase 1: all trace commitments (each prover keeps its LDE and tree for phase 2), then the seed binds them all
