@@ -325,6 +325,8 @@ def main():
                 base = k.split("<")[0]
                 if base == "ntt_group_kernel":  # the library times DIF (inverse) and DIT (forward) launches separately
                     base += "<dif>" if k.split("<")[1].startswith("true") else "<dit>"
+                if base.startswith("apc_apply_bus"):  # interpreter and fixed-shape kernels share one timer
+                    base = "apc_apply_bus_kernel"
                 traffic_db[base] = traffic_db.get(base, 0.0) + v["fetch_bytes_corrected"] + v["write_bytes"]
         by_kernel = {}
         for k, ms in stage_ms.items():
