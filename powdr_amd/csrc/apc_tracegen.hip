@@ -109,7 +109,27 @@ __global__ __launch_bounds__(kBlock) void apc_gather_tile_kernel(
             // (j0 != 0 happens when substitutions reach past their own block into the next call's rows)
             const uint32_t* base = src + r0 * (size_t)b + job.j0;
             const uint32_t n = (uint32_t)valid * (uint32_t)b;
-            if ((((uintptr_t)base) & 15u) == 0) {
+            if (pitch == J) {
+                // linear copy: tile[e] = base[e]
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                if ((((uintptr_t)base) & 15u) == 0) {
+                    const u32x4* base4 = reinterpret_cast<const u32x4*>(base);
+                    u32x4* tile4 = reinterpret_cast<u32x4*>(tile);
+                    const uint32_t n4 = n >> 2;
+                    uint32_t q = tid;
+                    for (; q + 3 * kBlock < n4; q += 4 * kBlock) {  // four independent 16-byte loads in flight per lane
+                        u32x4 v0 = __builtin_nontemporal_load(base4 + q);
+                        u32x4 v1 = __builtin_nontemporal_load(base4 + q + kBlock);
+                        u32x4 v2 = __builtin_nontemporal_load(base4 + q + 2 * kBlock);
+                        u32x4 v3 = __builtin_nontemporal_load(base4 + q + 3 * kBlock);
+                        tile4[q] = v0; tile4[q + kBlock] = v1; tile4[q + 2 * kBlock] = v2; tile4[q + 3 * kBlock] = v3;
+                    }
+                    for (; q < n4; q += kBlock) tile4[q] = __builtin_nontemporal_load(base4 + q);
+                    for (uint32_t e = (n4 << 2) + tid; e < n; e += kBlock) tile[e] = base[e];
+                } else {
+                    for (uint32_t e = tid; e < n; e += kBlock) tile[e] = __builtin_nontemporal_load(base + e);
+                }
+            } else if ((((uintptr_t)base) & 15u) == 0) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4* base4 = reinterpret_cast<const u32x4*>(base);
                 const uint32_t n4 = n >> 2;
@@ -279,7 +299,10 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
         auto emit = [&](size_t cb, size_t ce, int j0, int J) {
             GatherJob job;
             job.air = s0.air_index; job.col = s0.col; job.b = b; job.j0 = j0; job.J = J;
-            job.pitch = J | 1;
+            // whole-block jobs (J == b) copy their contiguous range into the tile as it is (pitch = J: 16-byte LDS stores,
+            // no per-element index arithmetic — the copy, not the transposed read-out of the few cells that are used,
+            // is where the time goes); chunked jobs keep an odd pitch for conflict-free transposed reads
+            job.pitch = J == b ? J : (J | 1);
             job.magicJ = J == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)J - 1) / (uint64_t)J);
             job.sub_begin = (uint32_t)psubs.size();
             job.sub_count = (uint32_t)(ce - cb);
