@@ -1,0 +1,40 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (small trace so that it runs in seconds)."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*extra):
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--log-height", "12", "--steps", "2", "--warmup", "1",
+                          "--cpu-log-height", "8", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_fields():
+    d = run_bench()
+    assert d["metric"].startswith("STARK cells/sec") and d["unit"] == "cells/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "u32" in d["dtype"]
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["rows"] * d["config"]["cols"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["avg_launch_ms"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "cells/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert d["stage_ms"]["leaf_hash_kernel"] > 0 and d["gauges"]["trace_gen_time_ms"] > 0
+
+
+def test_logup_and_partial_calls_modes_run():
+    d = run_bench("--logup", "--no-cpu-baseline", "--calls-fraction", "0.75")
+    assert d["cpu_baseline"] is None and "LogUp" in d["config"]["workload"] and "3072 APC calls" in d["config"]["workload"]
+    assert d["stage_ms"]["logup_perm_kernel"] > 0 and d["gauges"]["perm_trace_time_ms"] > 0
