@@ -130,6 +130,19 @@ PW_HD uint32_t reduce_sum(uint64_t x) {
     return reduce_2p((uint32_t)x - q * P);
 }
 
+// Addition and subtraction on representatives in [0, 2p) (2p < 2^32 < 4p, so the sum needs its carry). Used by the
+// forward NTT, whose butterflies then take a lazy product as they come: 3 + 4 + 3 instructions instead of 5 + 3 + 3.
+constexpr uint32_t TWO_P = 2u * P;
+PW_HD uint32_t add_2p(uint32_t a, uint32_t b) {
+    const uint32_t s = a + b;
+    const uint32_t t = s - TWO_P;
+    return s < a ? t : umin(s, t);  // carry: the true sum is s + 2^32 >= 2p, and s - 2p (mod 2^32) is it minus 2p
+}
+PW_HD uint32_t sub_2p(uint32_t a, uint32_t b) {
+    const uint32_t d = a - b;
+    return a < b ? d + TWO_P : d;
+}
+
 PW_HD uint32_t double_(uint32_t a) { return add(a, a); }
 PW_HD uint32_t halve(uint32_t a) {
     // a/2 mod p: if odd add p (p odd) then shift. a + p < 2^32.

@@ -66,6 +66,7 @@ struct GroupParams {
     int rb[4];    // window start (tile bit) per round, in execution order
     int logr[4];  // window width per round
     unsigned long long n_tiles;  // tiles per column = 2^(n-B)
+    int canonical_out;  // forward transform: the last group reduces its [0, 2p) values to [0, p) when it stores
 };
 
 __device__ __forceinline__ uint32_t lds_phys(uint32_t l) { return l + (l >> 5); }
@@ -142,9 +143,10 @@ __device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t base_top)
                 v[i0] = bb::add(a, b);
                 v[i1] = bb::mul2(a, t[lowp], b, nt[lowp]);  // (a - b) t as a t + b (p - t): one reduction, no subtraction
             } else {
-                const uint32_t bt = bb::mul(b, t[lowp]);
-                v[i0] = bb::add(a, bt);
-                v[i1] = bb::sub(a, bt);
+                // forward transform: all values are representatives in [0, 2p) between the first load and the last store
+                const uint32_t bt = bb::mul_lazy(b, t[lowp]);
+                v[i0] = bb::add_2p(a, bt);
+                v[i1] = bb::sub_2p(a, bt);
             }
         }
     }
@@ -227,6 +229,10 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
         // ---- butterflies ----
         slot_butterflies<DIF, LOGR>(x, cur_base);
         // ---- store ----
+        if (!DIF && last && gp.canonical_out) {
+#pragma unroll
+            for (int rho = 0; rho < R; ++rho) x[rho] = bb::reduce_2p(x[rho]);
+        }
         if (last) {
             if (vec_plain) {
                 bool valid;
@@ -378,6 +384,7 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
     const uint32_t* src = in;
     size_t src_stride = in_stride;
     bool expand = expand_scale_br != nullptr;
+    if (!groups.empty()) groups.back().canonical_out = 1;
     for (auto& g : groups) {
         const size_t tiles = (size_t)1 << (n - g.B);
         const size_t per_wg = (size_t)1 << (logt - g.B);
