@@ -102,6 +102,14 @@ int powdr_xbc_eval_host(const uint32_t* postfix, uint32_t len, const uint32_t* t
 int powdr_small_form_eval_host(const uint32_t* postfix, uint32_t len, const uint32_t* trace, size_t r,
                                uint32_t* result, uint32_t* flags);
 
+/* Self-test of the field arithmetic helpers the kernels are built from (Montgomery products, lazy / loose ranges,
+ * 64- and 96-bit accumulators, extension field) against plain modular arithmetic; host code, no GPU.
+ * Returns 0 or the number of the first failing check. */
+int powdr_field_selftest(uint64_t seed, uint32_t iterations);
+/* The same checks on the GPU (16 384 threads with different seeds; exercises the inline multiply-add instructions).
+ * Returns a HIP error code; *failing_check receives 0 or the number of the first failing check. */
+int powdr_field_selftest_gpu(uint64_t seed, uint32_t iterations, int* failing_check);
+
 #ifdef __cplusplus
 }
 #endif

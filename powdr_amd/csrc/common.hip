@@ -93,3 +93,28 @@ size_t powdr_gpu_timing_report(char* buf, size_t cap) {
 const char* powdr_gpu_version(void) { return "powdr_gpu-mi355x 0.1 (gfx950; Fp=BabyBear Montgomery R=2^32)"; }
 
 }  // extern "C"
+
+// ---- device run of the field self-test (field_selftest.hpp) ---------------------------------------------------
+#include "field_selftest.hpp"
+
+namespace {
+__global__ void field_selftest_kernel(uint64_t seed, uint32_t iterations, int* first_failure) {
+    const uint64_t s = seed + 0x1234567ull * (blockIdx.x * blockDim.x + threadIdx.x + 1);
+    const int rc = pw::field_selftest_checks(s, iterations);
+    if (rc) atomicCAS(first_failure, 0, rc);
+}
+}  // namespace
+
+extern "C" int powdr_field_selftest_gpu(uint64_t seed, uint32_t iterations, int* failing_check) {
+    int* d = nullptr;
+    PW_HIP_TRY(hipMalloc(&d, sizeof(int)));
+    PW_HIP_TRY(hipMemsetAsync(d, 0, sizeof(int), pw::stream()));
+    hipLaunchKernelGGL(field_selftest_kernel, dim3(64), dim3(256), 0, pw::stream(), seed, iterations, d);
+    int rc = 0;
+    hipError_t e = hipMemcpyAsync(&rc, d, sizeof(int), hipMemcpyDeviceToHost, pw::stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(pw::stream());
+    (void)hipFree(d);
+    if (e != hipSuccess) return (int)e;
+    if (failing_check) *failing_check = rc;
+    return (int)hipGetLastError();
+}

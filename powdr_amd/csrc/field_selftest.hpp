@@ -1,0 +1,65 @@
+// Self-test of the range-sensitive field helpers (babybear.hpp, ext.hpp) against plain 64-bit modular arithmetic, on
+// random values and on the edges of the ranges their comments promise. One function for host and device: on the
+// device the inline multiply-add instructions are exercised, on the host their portable fall-backs.
+#pragma once
+#include "ext.hpp"
+
+namespace pw {
+
+// returns 0 or the number of the first failing check
+PW_HD int field_selftest_checks(uint64_t seed, uint32_t iterations) {
+    using namespace bb;
+    uint64_t s = seed ? seed : 1;
+    auto rnd = [&]() { s += 0x9E3779B97F4A7C15ull; uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    auto rp = [&]() { return (uint32_t)(rnd() % P); };
+    const uint64_t edges64[] = {0, 1, P - 1, P, P + 1, 2ull * P - 1, 2ull * P, 16ull * P - 1, 75ull * P, 128ull * P - 1};
+    for (uint64_t x : edges64) {
+        if (x < 16ull * P && reduce_sum(x) != x % P) return 1;
+        const uint32_t l = reduce_wide_loose(x);
+        if (l % P != x % P || l >= (uint64_t)P + P / 32) return 2;
+        if (reduce_wide(x) != x % P) return 3;
+    }
+    const uint32_t edges[] = {0, 1, P - 1, P, P + 1, 2 * P - 1};
+    for (uint32_t a : edges)
+        for (uint32_t b : edges) {
+            const uint32_t r = add_2p(a, b), d = sub_2p(a, b);
+            if (r >= 2 * P || r % P != (uint32_t)(((uint64_t)a + b) % P)) return 4;
+            if (d >= 2 * P || d % P != (uint32_t)(((uint64_t)a + 2ull * P - b) % P)) return 5;
+        }
+    for (uint32_t it = 0; it < iterations; ++it) {
+        const uint32_t a = rp(), b = rp(), c = rp(), d = rp();
+        // Montgomery products against the definition a*b*R^-1
+        const uint32_t ab = mul(a, b);
+        if (ab >= P || (uint64_t)ab * R_MOD_P % P != (uint64_t)a * b % P) return 10;
+        const uint32_t m2 = mul2(a, b, c, d);
+        if (m2 != add(ab, mul(c, d))) return 11;
+        const uint32_t la = (uint32_t)(rnd() % (2ull * P));  // a lazy operand
+        const uint32_t ml = mul_lazy(la, b);
+        if (ml >= 2 * P || ml % P != mul(la % P, b)) return 12;
+        if (add_2p(la, (uint32_t)(rnd() % (2ull * P))) >= 2 * P) return 13;
+        const uint64_t w = rnd() % (128ull * P);
+        if (reduce_wide(w) != w % P) return 14;
+        const uint32_t loose = reduce_wide_loose(w);
+        if (loose % P != w % P || loose >= (uint64_t)P + P / 32) return 15;
+        const uint64_t w16 = rnd() % (16ull * P);
+        if (reduce_sum(w16) != w16 % P) return 16;
+        if (wide_add(w16, a) != w16 + a || wide_fma(w16, a, 3) != w16 + 3ull * a || wide_mul(a, 4) != 4ull * a) return 17;
+        // extension field: (x*y)*z == x*(y*z), x * x^-1 == 1, wide accumulation == sum of scalings
+        const Ext x{{rp(), rp(), rp(), rp()}}, y{{rp(), rp(), rp(), rp()}}, z{{rp(), rp(), rp(), rp()}};
+        if (!ext_eq(ext_mul(ext_mul(x, y), z), ext_mul(x, ext_mul(y, z)))) return 20;
+        if (!ext_eq(ext_mul(x, ext_add(y, z)), ext_add(ext_mul(x, y), ext_mul(x, z)))) return 21;
+        if ((x.c[0] | x.c[1] | x.c[2] | x.c[3]) && !ext_eq(ext_mul(x, ext_inv(x)), ext_one())) return 22;
+        ExtWideAcc acc;
+        Ext want = ext_zero();
+        for (int k = 0; k < 37; ++k) {
+            const Ext e{{rp(), rp(), rp(), rp()}};
+            const uint32_t v = rp();
+            acc.fma(e, v);
+            want = ext_add(want, ext_scale(e, v));
+        }
+        if (!ext_eq(acc.result(), want)) return 23;
+    }
+    return 0;
+}
+
+}  // namespace pw

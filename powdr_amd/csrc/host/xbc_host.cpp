@@ -3,6 +3,7 @@
 // semantics of the device evaluator xbc::eval (xbc.hpp).
 #include "../xbc_compile.hpp"
 #include "../small_form.hpp"
+#include "../field_selftest.hpp"
 #include "../../../include/powdr_host.h"
 
 #include <vector>
@@ -65,3 +66,6 @@ extern "C" int powdr_small_form_eval_host(const uint32_t* postfix, uint32_t len,
     *result = v;
     return 0;
 }
+
+// Host entry point of the field self-test (field_selftest.hpp).
+extern "C" int powdr_field_selftest(uint64_t seed, uint32_t iterations) { return pw::field_selftest_checks(seed, iterations); }

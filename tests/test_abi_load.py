@@ -33,3 +33,14 @@ def test_struct_layouts_match_reference_abi():
     assert ctypes.sizeof(abi.DerivedExprSpec) == 16 and abi.DerivedExprSpec.span.offset == 8
     assert ctypes.sizeof(abi.DevInteraction) == 12
     assert ctypes.sizeof(abi.ExprSpan) == 8
+
+
+def test_field_helpers_selftest():
+    """Range-sensitive arithmetic helpers of the kernels (lazy / loose reductions, wide accumulators, mul2, the
+    extension field) against plain modular arithmetic, including the edges of the documented ranges."""
+    from powdr_amd import abi
+
+    abi.lib.powdr_field_selftest.restype = ctypes.c_int
+    abi.lib.powdr_field_selftest.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
+    for seed in (1, 2, 0xDEADBEEF):
+        assert abi.lib.powdr_field_selftest(seed, 20000) == 0

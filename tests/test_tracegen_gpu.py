@@ -517,3 +517,16 @@ def test_expression_kernels_fuzz(gpu, seed, monkeypatch):
             assert (hist_np(per.var_hist) == hist["var"]).all(), (binned, xb)
             assert (hist_np(per.tuple_hist) == hist["tuple"]).all(), (binned, xb)
             assert (hist_np(per.bitwise_hist) == hist["bitwise"]).all(), (binned, xb)
+
+
+def test_field_helpers_selftest_on_device(gpu):
+    """The arithmetic helpers' self-test (csrc/field_selftest.hpp) on the GPU: here the 64-bit multiply-add helpers are
+    the inline v_mad_u64_u32 instructions, not their portable fall-backs."""
+    import ctypes as C
+
+    torch, abi, tg = gpu
+    abi.lib.powdr_field_selftest_gpu.restype = C.c_int
+    abi.lib.powdr_field_selftest_gpu.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_int)]
+    bad = C.c_int(-1)
+    abi.check(abi.lib.powdr_field_selftest_gpu(7, 200, C.byref(bad)), "powdr_field_selftest_gpu")
+    assert bad.value == 0
