@@ -141,6 +141,10 @@ int pw_verify_segment(const PwStarkConfig* cfg, const PwAirDescription* airs, si
 /* Digest over an ordered list of 8-word commitments (binary Poseidon2 tree; canonical words). */
 void pw_commitment_digest(const uint32_t* roots8, size_t n, uint32_t* digest8);
 
+/* Allocates every device buffer a proof of a 2^log_height-row trace needs, so that the first pw_prover_prove does not
+ * pay for the allocation (tens of gigabytes for wide traces). Buffers only grow; calling it is optional. */
+int pw_prover_reserve(PwProver* p, uint32_t log_height);
+
 /* Number of main-trace columns the prover was created for. */
 uint32_t pw_prover_width(const PwProver* p);
 

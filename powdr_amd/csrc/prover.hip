@@ -238,6 +238,38 @@ int commit_trace(PwProver* p, const CommitLayout& L, const uint32_t* d_trace, ui
     return 0;
 }
 
+
+// Every device buffer a proof of a 2^log_h-row trace needs (grown on demand; pw_prover_reserve calls this at set-up
+// time so that the first proof does not pay for tens of gigabytes of hipMalloc).
+int ensure_prove_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
+    TRY(ensure_commit_buffers(p, log_h, L));
+    const size_t H = L.H, N = L.N;
+    const int logN = (int)log_h + 1;
+    const bool lg = p->logup;
+    const uint32_t W = p->width, nc = p->n_constraints;
+    const uint32_t n_g = lg ? p->n_groups : 0;
+    const uint32_t Wp = lg ? 4 * (n_g + 1) : 0;
+    const uint32_t K = W + 2 * Wp + 8;
+    const uint32_t M = nc + (lg ? n_g + 3 : 0);
+    if (lg) {
+        TRY(p->perm.ensure((size_t)Wp * H * 4));
+        TRY(p->plde.ensure((size_t)Wp * N * 4));
+    }
+    TRY(p->q.ensure(4 * N * 4));
+    TRY(p->qcoef.ensure(8 * H * 4));
+    TRY(p->qlde.ensure(8 * N * 4));
+    // ext arena: FRI layer vectors v_0 (N) .. v_log_h (2): 2N ext; weights (H); LogUp: second weights, row sums
+    TRY(p->ext_arena.ensure((2 * N + (lg ? 3 : 1) * H + H / 4096 + 32) * sizeof(bb::Ext)));
+    const uint32_t n_chunks = div_up(H, 8192);
+    const uint32_t dot_cols = std::max({W, Wp, 8u});
+    const size_t misc_ext = (size_t)dot_cols * n_chunks + K + K + M + p->max_args + 64;
+    const uint32_t nq = p->cfg.num_queries;
+    const size_t path_records = (size_t)nq * (L.n_trees * (size_t)logN + (size_t)log_h * logN) + 16;
+    const size_t misc_bytes = misc_ext * sizeof(bb::Ext) + (size_t)nq * 4 + (size_t)nq * (W + Wp + 8) * 4 + path_records * (8 + 32) +
+                              (size_t)nq * log_h * (8 + 16) + 4096;
+    TRY(p->misc.ensure(misc_bytes));
+    return 0;
+}
 }  // namespace
 
 // Trace commitment only (LDE + Merkle root): what a segment's AIRs exchange before the bus seed can be formed.
@@ -265,6 +297,13 @@ extern "C" void pw_prover_destroy(PwProver* p) {
 }
 
 extern "C" uint32_t pw_prover_width(const PwProver* p) { return p ? p->width : 0; }
+
+extern "C" int pw_prover_reserve(PwProver* p, uint32_t log_h) {
+    if (!p || log_h < 1 || log_h > 26) return (int)hipErrorInvalidValue;
+    (void)hipGetLastError();
+    CommitLayout L;
+    return ensure_prove_buffers(p, log_h, L);
+}
 
 extern "C" size_t pw_prover_device_bytes(const PwProver* p) {
     return p->coef.bytes + p->lde.bytes + p->digests.bytes + p->q.bytes + p->qcoef.bytes + p->qlde.bytes +
@@ -294,26 +333,11 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const bool have_commitment = p->committed_trace == d_trace && p->committed_log_h == log_h;
     p->committed_trace = nullptr;  // one-shot
     CommitLayout L;
-    TRY(ensure_commit_buffers(p, log_h, L));
+    TRY(ensure_prove_buffers(p, log_h, L));
     const size_t tree_words = L.tree_words, n_trees = L.n_trees;
-    if (lg) {
-        TRY(p->perm.ensure((size_t)Wp * H * 4));
-        TRY(p->plde.ensure((size_t)Wp * N * 4));
-    }
-    TRY(p->q.ensure(4 * N * 4));
-    TRY(p->qcoef.ensure(8 * H * 4));
-    TRY(p->qlde.ensure(8 * N * 4));
-    // ext arena: FRI layer vectors v_0 (N) .. v_log_h (2): 2N ext; weights (H)
-    // ext arena: FRI layer vectors v_0 (N) .. v_log_h (2): 2N ext; weights (H); LogUp: second weights, row sums
-    TRY(p->ext_arena.ensure((2 * N + (lg ? 3 : 1) * H + H / 4096 + 32) * sizeof(bb::Ext)));
     const uint32_t n_chunks = div_up(H, 8192);
     const uint32_t dot_cols = std::max({W, Wp, 8u});  // widest matrix ext_dot_columns sees (the quotient has 8 columns)
-    const size_t misc_ext = (size_t)dot_cols * n_chunks + K + K + M + p->max_args + 64;
     const uint32_t nq = p->cfg.num_queries;
-    const size_t path_records = (size_t)nq * (n_trees * (size_t)logN + (size_t)log_h * logN) + 16;
-    size_t misc_bytes = misc_ext * sizeof(bb::Ext) + (size_t)nq * 4 + (size_t)nq * (W + Wp + 8) * 4 + path_records * (8 + 32) +
-                        (size_t)nq * log_h * (8 + 16) + 4096;
-    TRY(p->misc.ensure(misc_bytes));
 
     uint32_t* d_lde = p->lde.as<uint32_t>();
     uint32_t* d_dig = p->digests.as<uint32_t>();

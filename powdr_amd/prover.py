@@ -14,7 +14,7 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_merkle_commit", "pw_poseidon2_permute_host"]
 
 lib.pw_prover_create.restype = C.c_void_p
@@ -231,6 +231,12 @@ class Prover:
         rc = lib.pw_prover_check_constraints(self._h, d_trace_ptr, log_height, C.byref(n), C.byref(row), C.byref(c))
         abi.check(rc, "pw_prover_check_constraints")
         return (n.value, row.value, c.value) if n.value else (0, None, None)
+
+    def reserve(self, log_height: int) -> None:
+        """Allocate the device buffers of a 2^log_height-row proof now (the first prove otherwise pays for it)."""
+        lib.pw_prover_reserve.restype = C.c_int
+        lib.pw_prover_reserve.argtypes = [C.c_void_p, C.c_uint32]
+        abi.check(lib.pw_prover_reserve(self._h, log_height), "pw_prover_reserve")
 
     def device_bytes(self) -> int:
         return int(lib.pw_prover_device_bytes(self._h))

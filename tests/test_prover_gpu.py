@@ -201,6 +201,34 @@ def test_logup_large_proof_verifies(gpu):
 
 
 @pytest.mark.gpu
+def test_reserve_allocates_what_the_proof_needs(gpu):
+    """pw_prover_reserve sizes the buffers exactly like pw_prover_prove: a proof after it allocates nothing more, and
+    is the same proof."""
+    torch, abi, prover = gpu
+    s, flat, (W, H), bc, spans = _synthetic("T1", 3000, seed=5)
+    log_h = H.bit_length() - 1
+    it = None
+    for interactions in (None, "logup"):
+        if interactions:
+            from tests.test_oracle_apc import run_oracle_gpu_convention
+
+            apc, idx, _, _, _ = run_oracle_gpu_convention(synth.generate("T1", seed=5), 3000, seed=5)
+            it = sm.compile_interactions(apc, idx)
+        pr = prover.Prover(W, bc, spans, num_queries=9, interactions=it)
+        assert pr.device_bytes() == 0
+        pr.reserve(log_h)
+        reserved = pr.device_bytes()
+        assert reserved > 12 * W * H
+        d_t = to_dev(torch, flat)
+        proof = pr.prove(d_t.data_ptr(), log_h)
+        assert pr.device_bytes() == reserved
+        pr2 = prover.Prover(W, bc, spans, num_queries=9, interactions=it)
+        assert (pr2.prove(d_t.data_ptr(), log_h) == proof).all() and pr2.device_bytes() == reserved
+        pr.close()
+        pr2.close()
+
+
+@pytest.mark.gpu
 def test_large_proof_verifies(gpu):
     """2^16-row, 160-column trace: too slow to prove on the CPU oracle in a test, so the HIP
     proof is checked with the oracle's VERIFIER (accept) and a corrupted trace (reject)."""
