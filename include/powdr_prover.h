@@ -145,6 +145,12 @@ void pw_commitment_digest(const uint32_t* roots8, size_t n, uint32_t* digest8);
  * pay for the allocation (tens of gigabytes for wide traces). Buffers only grow; calling it is optional. */
 int pw_prover_reserve(PwProver* p, uint32_t log_height);
 
+/* Highest degree (in the trace columns) among the constraint programs the prover was created with; 99 if one of them
+ * is malformed or not polynomial. The blow-up-2 quotient carries degree <= 3 — the reference's bound
+ * 2 * DEFAULT_APP_LOG_BLOWUP + 1 (openvm/src/lib.rs:97-101); a prover with a higher value produces proofs that do not
+ * verify, so a key generator checks this once. */
+int pw_prover_max_constraint_degree(const PwProver* p);
+
 /* Number of main-trace columns the prover was created for. */
 uint32_t pw_prover_width(const PwProver* p);
 

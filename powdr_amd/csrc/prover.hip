@@ -78,6 +78,7 @@ struct PwProver {
     uint32_t* d_bytecode = nullptr;
     uint32_t* d_spans = nullptr;
     bool is_xbc = false;  // d_bytecode/d_spans hold plan-compiled xbc code (xbc.hpp) instead of post-fix code
+    int max_degree = 0;   // highest degree among the constraint programs (99 = a malformed / non-polynomial one)
     // LogUp extension (pw_prover_create_logup): the AIR's bus interactions as xbc programs
     bool logup = false;
     uint32_t n_inter = 0, n_groups = 0, max_args = 0;
@@ -110,6 +111,11 @@ extern "C" PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, 
     p->width = width;
     p->n_constraints = (uint32_t)n_constraints;
     p->h_spans.assign(spans, spans + 2 * n_constraints);
+    for (size_t k = 0; k < n_constraints; ++k) {
+        const uint32_t off = spans[2 * k], len = spans[2 * k + 1];
+        const int d = (size_t)off + len <= bc_len ? pw::postfix_degree(bc + off, len) : pw::kBadDegree;
+        if (d > p->max_degree) p->max_degree = d;
+    }
     // compile the post-fix constraint programs to xbc (xbc.hpp); fall back to the post-fix interpreter if
     // any program is malformed or too deep
     std::vector<uint32_t> code, xspans;
@@ -297,6 +303,7 @@ extern "C" void pw_prover_destroy(PwProver* p) {
 }
 
 extern "C" uint32_t pw_prover_width(const PwProver* p) { return p ? p->width : 0; }
+extern "C" int pw_prover_max_constraint_degree(const PwProver* p) { return p ? p->max_degree : -1; }
 
 extern "C" int pw_prover_reserve(PwProver* p, uint32_t log_h) {
     if (!p || log_h < 1 || log_h > 26) return (int)hipErrorInvalidValue;

@@ -14,7 +14,7 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_merkle_commit", "pw_poseidon2_permute_host"]
 
 lib.pw_prover_create.restype = C.c_void_p
@@ -237,6 +237,11 @@ class Prover:
         lib.pw_prover_reserve.restype = C.c_int
         lib.pw_prover_reserve.argtypes = [C.c_void_p, C.c_uint32]
         abi.check(lib.pw_prover_reserve(self._h, log_height), "pw_prover_reserve")
+
+    def max_constraint_degree(self) -> int:
+        lib.pw_prover_max_constraint_degree.restype = C.c_int
+        lib.pw_prover_max_constraint_degree.argtypes = [C.c_void_p]
+        return int(lib.pw_prover_max_constraint_degree(self._h))
 
     def device_bytes(self) -> int:
         return int(lib.pw_prover_device_bytes(self._h))

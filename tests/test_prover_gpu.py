@@ -215,6 +215,7 @@ def test_reserve_allocates_what_the_proof_needs(gpu):
             apc, idx, _, _, _ = run_oracle_gpu_convention(synth.generate("T1", seed=5), 3000, seed=5)
             it = sm.compile_interactions(apc, idx)
         pr = prover.Prover(W, bc, spans, num_queries=9, interactions=it)
+        assert 1 <= pr.max_constraint_degree() <= 3  # the degree bound of a blow-up-2 quotient
         assert pr.device_bytes() == 0
         pr.reserve(log_h)
         reserved = pr.device_bytes()
@@ -354,6 +355,7 @@ def test_proof_bytes_on_arbitrary_traces(gpu, W, log_h, n_cons, nq, pow_bits):
     spans = np.array(spans, np.uint32).reshape(-1, 2)
     want = sm.prove(flat, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits)
     pr = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits)
+    assert pr.max_constraint_degree() == (2 if n_cons else 0)
     got = pr.prove(to_dev(torch, flat).data_ptr(), log_h)
     assert len(got) == len(want) and (got == want).all()
     pr.close()
