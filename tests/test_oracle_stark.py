@@ -344,3 +344,24 @@ def test_logup_grouping_is_the_same_in_oracle_and_product():
     for rows, want in cases:
         t = table(rows)
         assert sm.group_starts(*t).tolist() == want and prover.logup_group_starts(t).tolist() == want
+
+
+def test_golden_proofs_pin_the_protocol():
+    """tests/golden/pw_stark_proofs_T0.npz (made by tests/golden/make_proof_golden.py): the oracle still produces these
+    exact words from the stored trace, and both verifiers accept them — any drift of the transcript, the hash, the
+    field conventions or the proof layout shows up here, on a machine without a GPU."""
+    from pathlib import Path
+
+    from powdr_amd import prover
+
+    z = np.load(Path(__file__).parent / "golden" / "pw_stark_proofs_T0.npz")
+    W, log_h = int(z["width"]), int(z["log_h"])
+    cons = (z["cons_bc"], z["cons_spans"])
+    it = (z["inter"], z["inter_spans"], z["inter_bc"])
+    assert (sm.prove(z["trace"], W, log_h, *cons, num_queries=4, pow_bits=5) == z["proof_v0"]).all()
+    assert (sm.prove_logup(z["trace"], W, log_h, *cons, *it, num_queries=4, pow_bits=5) == z["proof_logup"]).all()
+    assert sm.verify(z["proof_v0"], W, log_h, *cons, num_queries=4, pow_bits=5) == 0
+    assert prover.verify(z["proof_v0"], W, log_h, *cons, num_queries=4, pow_bits=5) == 0
+    assert sm.verify_logup(z["proof_logup"], W, log_h, *cons, *it, num_queries=4, pow_bits=5) == 0
+    assert prover.verify_logup(z["proof_logup"], W, log_h, *cons, it, num_queries=4, pow_bits=5)[0] == 0
+    assert z["proof_v0"][0] == 0x31535750 and z["proof_logup"][0] == 0x32535750

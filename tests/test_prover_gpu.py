@@ -201,6 +201,24 @@ def test_logup_large_proof_verifies(gpu):
 
 
 @pytest.mark.gpu
+def test_golden_proofs_from_the_device(gpu):
+    """The HIP prover reproduces the committed golden proofs (tests/golden/pw_stark_proofs_T0.npz) word for word."""
+    from pathlib import Path
+
+    torch, abi, prover = gpu
+    z = np.load(Path(__file__).parent / "golden" / "pw_stark_proofs_T0.npz")
+    W, log_h = int(z["width"]), int(z["log_h"])
+    d_t = to_dev(torch, z["trace"])
+    pr = prover.Prover(W, z["cons_bc"], z["cons_spans"], num_queries=4, pow_bits=5)
+    assert (pr.prove(d_t.data_ptr(), log_h) == z["proof_v0"]).all()
+    pr.close()
+    pr = prover.Prover(W, z["cons_bc"], z["cons_spans"], num_queries=4, pow_bits=5,
+                       interactions=(z["inter"], z["inter_spans"], z["inter_bc"]))
+    assert (pr.prove(d_t.data_ptr(), log_h) == z["proof_logup"]).all()
+    pr.close()
+
+
+@pytest.mark.gpu
 def test_reserve_allocates_what_the_proof_needs(gpu):
     """pw_prover_reserve sizes the buffers exactly like pw_prover_prove: a proof after it allocates nothing more, and
     is the same proof."""
