@@ -219,6 +219,53 @@ def test_golden_proofs_from_the_device(gpu):
 
 
 @pytest.mark.gpu
+def test_reference_keccak_constraints_proof_bytes(gpu):
+    """The reference's own pre-optimisation keccak APC (autoprecompiles/tests/keccak_apc_pre_opt.json.gz through
+    tests/golden/make_golden.py): 27 521 columns and its 28 627 real constraint programs (post-fix, deep stacks), on a
+    random trace. Byte parity of the proof does not need the constraints to hold; the mock prover counts the same
+    violations as a direct evaluation of the programs."""
+    from pathlib import Path
+
+    torch, abi, prover = gpu
+    z = np.load(Path(__file__).parent / "golden" / "keccak_apc_pre_opt.apc.npz")
+    W, log_h = len(z["poly_ids"]), 6
+    H = 1 << log_h
+    bc, spans = z["cons_bc"], z["cons_spans"]
+    rng = np.random.default_rng(3)
+    flat = rng.integers(0, 4, W * H).astype(np.uint32)  # small values: a fair share of the constraints does vanish
+    want = sm.prove(flat, W, log_h, bc, spans, num_queries=3)
+    pr = prover.Prover(W, bc, spans, num_queries=3)
+    assert pr.max_constraint_degree() <= 3
+    d_t = to_dev(torch, flat)
+    got = pr.prove(d_t.data_ptr(), log_h)
+    assert len(got) == len(want) and (got == want).all()
+    n_bad, row, cons = pr.check_constraints(d_t.data_ptr(), log_h)
+    trace = flat.reshape(W, H)
+    bad = 0
+    for k in range(0, len(spans), 97):  # a sample of the programs, evaluated directly on every row
+        off, ln = spans[k]
+        prog = bc[off:off + ln].copy()
+        pos = 0
+        while pos < len(prog):
+            if prog[pos] == om.OP_PUSH_APC:
+                prog[pos + 1] *= H
+            pos += 2 if prog[pos] <= 1 else 1
+        bad += sum(om.c_eval_expr(prog, flat, r) != 0 for r in range(H))
+    assert n_bad > 0 and bad > 0 and bad <= n_bad
+    pr.close()
+    # the same AIR with its 13 262 real bus interactions inside the proof (execution bridge, memory with 7 arguments,
+    # range checks, bitwise lookups, pc lookup): grouping, permutation trace, extended quotient
+    it = (z["bus_inter"], z["bus_spans"], z["bus_bc"])
+    groups = prover.logup_group_starts(it)
+    assert (groups == sm.group_starts(*it)).all() and len(groups) - 1 < len(it[0])
+    want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=3)
+    pr = prover.Prover(W, bc, spans, num_queries=3, interactions=it)
+    got = pr.prove(d_t.data_ptr(), log_h)
+    assert len(got) == len(want) and (got == want).all()
+    pr.close()
+
+
+@pytest.mark.gpu
 def test_reserve_allocates_what_the_proof_needs(gpu):
     """pw_prover_reserve sizes the buffers exactly like pw_prover_prove: a proof after it allocates nothing more, and
     is the same proof."""
