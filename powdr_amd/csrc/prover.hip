@@ -96,6 +96,7 @@ struct PwProver {
     uint32_t committed_root[8] = {0};  // Montgomery
     // device buffers, grown on demand
     pw::DeviceBuf coef, lde, digests, q, qcoef, qlde, ext_arena, misc;
+    pw::DeviceBuf qpart;  // partial quotient sums when the constraint list is split over workgroup rows (short traces)
     std::vector<uint32_t> proof;
 };
 
@@ -262,6 +263,10 @@ int ensure_prove_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
         TRY(p->plde.ensure((size_t)Wp * N * 4));
     }
     TRY(p->q.ensure(4 * N * 4));
+    if (!lg) {
+        const uint32_t chunks = quotient_chunks(N, nc);
+        if (chunks > 1) TRY(p->qpart.ensure((size_t)chunks * 4 * N * 4));
+    }
     TRY(p->qcoef.ensure(8 * H * 4));
     TRY(p->qlde.ensure(8 * N * 4));
     // ext arena: FRI layer vectors v_0 (N) .. v_log_h (2): 2N ext; weights (H); LogUp: second weights, row sums
@@ -295,7 +300,7 @@ extern "C" int pw_prover_trace_root(PwProver* p, const uint32_t* d_trace, uint32
 
 extern "C" void pw_prover_destroy(PwProver* p) {
     if (!p) return;
-    for (DeviceBuf* b : {&p->coef, &p->lde, &p->digests, &p->q, &p->qcoef, &p->qlde, &p->ext_arena, &p->misc, &p->perm, &p->plde}) b->release();
+    for (DeviceBuf* b : {&p->coef, &p->lde, &p->digests, &p->q, &p->qcoef, &p->qlde, &p->ext_arena, &p->misc, &p->perm, &p->plde, &p->qpart}) b->release();
     for (void* q : {(void*)p->d_inter, (void*)p->d_ixspans, (void*)p->d_icode, (void*)p->d_gstarts}) if (q) (void)hipFree(q);
     if (p->d_bytecode) (void)hipFree(p->d_bytecode);
     if (p->d_spans) (void)hipFree(p->d_spans);
@@ -314,7 +319,7 @@ extern "C" int pw_prover_reserve(PwProver* p, uint32_t log_h) {
 
 extern "C" size_t pw_prover_device_bytes(const PwProver* p) {
     return p->coef.bytes + p->lde.bytes + p->digests.bytes + p->q.bytes + p->qcoef.bytes + p->qlde.bytes +
-           p->ext_arena.bytes + p->misc.bytes + p->perm.bytes + p->plde.bytes;
+           p->ext_arena.bytes + p->misc.bytes + p->perm.bytes + p->plde.bytes + p->qpart.bytes;
 }
 
 
@@ -441,7 +446,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     if (lg)
         TRY(quotient_eval_logup(d_lde, d_plde, N, logN, prog, lp, d_apow, al, d_blpow, S, bb::sub(sH, one), bb::sub(bb::neg(sH), one), d_q));
     else
-        TRY(quotient_eval(d_lde, N, prog, d_apow, zinv_even, zinv_odd, d_q));
+        TRY(quotient_eval(d_lde, N, prog, d_apow, zinv_even, zinv_odd, d_q, p->qpart.as<uint32_t>(), quotient_chunks(N, nc)));
     TRY(intt_dif(d_q, d_q, N, N, 4, logN));
     TRY(quotient_split(d_q, H, (int)log_h, d_qcoef));
     TRY(coset_lde_from_coeffs(d_qcoef, d_qlde, H, N, 8, (int)log_h));

@@ -49,8 +49,11 @@ struct ConstraintProgram {
     bool is_xbc;
 };
 // q[k*N + j] (k < 4) = coordinate k of  sum_c alpha_pow[c] * C_c(lde row j) * zinv[j & 1]
+// Short traces with many constraints: the constraint list is split over `n_chunks` (quotient_chunks) workgroup rows,
+// partial sums go through `part` (4 * n_chunks * N words) and are added up by a second small kernel.
+uint32_t quotient_chunks(size_t N, uint32_t n_constraints);
 int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, const bb::Ext* d_alpha_pows,
-                  uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q);
+                  uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q, uint32_t* part, uint32_t n_chunks);
 // evaluate all constraints on all trace rows; d_first_and_count[0] = min(row * nc + c) over violations
 // (caller initialises to ~0), [1] = number of violations
 int check_constraints(const uint32_t* trace, size_t H, const ConstraintProgram& prog, unsigned long long* d_first_and_count);

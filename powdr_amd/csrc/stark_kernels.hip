@@ -22,13 +22,17 @@ __global__ __launch_bounds__(kBlock) void quotient_kernel(const uint32_t* __rest
                                                            const uint32_t* __restrict__ bytecode,
                                                            const uint32_t* __restrict__ spans, uint32_t n_constraints,
                                                            const bb::Ext* __restrict__ alpha_pows, uint32_t zinv_even,
-                                                           uint32_t zinv_odd, uint32_t* __restrict__ q) {
+                                                           uint32_t zinv_odd, uint32_t* __restrict__ q, uint32_t per_chunk) {
     __shared__ uint32_t stack_lds[kStackCap * kBlock];
     uint32_t* stk = stack_lds + threadIdx.x;
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= N) return;
     bb::Ext acc = bb::ext_zero();
-    for (uint32_t c = 0; c < n_constraints; ++c) {
+    // gridDim.y > 1 (short traces with many constraints): this block folds only its chunk of the constraints and
+    // leaves the partial sum in q[(4 * chunk + k) * N + j]; quotient_combine_kernel adds the chunks up
+    const uint32_t c_begin = blockIdx.y * per_chunk;
+    const uint32_t c_end = min(n_constraints, c_begin + per_chunk);
+    for (uint32_t c = c_begin; c < c_end; ++c) {
         const uint32_t off = spans[2 * c], len = spans[2 * c + 1];
         const uint32_t v = XBC ? xbc::eval<kBlock, true>(bytecode + 2 * (size_t)off, len, lde, j, stk, N)
                                : eval_expr<kBlock, true>(bytecode + off, len, lde, j, stk, N);
@@ -38,9 +42,27 @@ __global__ __launch_bounds__(kBlock) void quotient_kernel(const uint32_t* __rest
         acc.c[2] = bb::add(acc.c[2], bb::mul(a.c[2], v));
         acc.c[3] = bb::add(acc.c[3], bb::mul(a.c[3], v));
     }
+    if (gridDim.y > 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[((size_t)blockIdx.y * 4 + k) * N + j] = acc.c[k];
+        return;
+    }
     const uint32_t zi = (j & 1) ? zinv_odd : zinv_even;
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[(size_t)k * N + j] = bb::mul(acc.c[k], zi);
+}
+
+__global__ __launch_bounds__(kBlock) void quotient_combine_kernel(const uint32_t* __restrict__ part, uint32_t n_chunks, size_t N,
+                                                                   uint32_t zinv_even, uint32_t zinv_odd, uint32_t* __restrict__ q) {
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t zi = (j & 1) ? zinv_odd : zinv_even;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t a = 0u;
+        for (uint32_t c = 0; c < n_chunks; ++c) a = bb::add(a, part[((size_t)c * 4 + k) * N + j]);
+        q[(size_t)k * N + j] = bb::mul(a, zi);
+    }
 }
 
 // "mock prover": evaluate every constraint on every TRACE row; first[0] <- min over violations of row * nc + c
@@ -201,15 +223,33 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const uint32_t* __r
 
 }  // namespace
 
+uint32_t quotient_chunks(size_t N, uint32_t n_constraints) {
+    // enough workgroups for 256 CUs x 8 even when the trace is short; at least 32 constraints per chunk
+    const unsigned row_blocks = div_up(N, kBlock), want = 256u * 8u;
+    if (row_blocks >= want || n_constraints < 64) return 1;
+    uint32_t chunks = (want + row_blocks - 1) / row_blocks;
+    if (chunks > n_constraints / 32) chunks = n_constraints / 32;
+    if (chunks > 64) chunks = 64;
+    return chunks < 1 ? 1 : chunks;
+}
+
 int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, const bb::Ext* d_alpha_pows,
-                  uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q) {
+                  uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q, uint32_t* part, uint32_t n_chunks) {
     ScopedKernelTimer t("quotient_kernel");
+    if (n_chunks < 1 || !part) n_chunks = 1;
+    const uint32_t per_chunk = n_chunks > 1 ? (prog.n_constraints + n_chunks - 1) / n_chunks : (prog.n_constraints ? prog.n_constraints : 1);
+    if (n_chunks > 1) n_chunks = (prog.n_constraints + per_chunk - 1) / per_chunk;
+    uint32_t* out = n_chunks > 1 ? part : q;
+    const dim3 grid(div_up(N, kBlock), n_chunks);
     if (prog.is_xbc)
-        hipLaunchKernelGGL(quotient_kernel<true>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, N, prog.d_bytecode,
-                           prog.d_spans, prog.n_constraints, d_alpha_pows, zinv_even, zinv_odd, q);
+        hipLaunchKernelGGL(quotient_kernel<true>, grid, dim3(kBlock), 0, stream(), lde, N, prog.d_bytecode, prog.d_spans,
+                           prog.n_constraints, d_alpha_pows, zinv_even, zinv_odd, out, per_chunk);
     else
-        hipLaunchKernelGGL(quotient_kernel<false>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, N, prog.d_bytecode,
-                           prog.d_spans, prog.n_constraints, d_alpha_pows, zinv_even, zinv_odd, q);
+        hipLaunchKernelGGL(quotient_kernel<false>, grid, dim3(kBlock), 0, stream(), lde, N, prog.d_bytecode, prog.d_spans,
+                           prog.n_constraints, d_alpha_pows, zinv_even, zinv_odd, out, per_chunk);
+    if (n_chunks > 1)
+        hipLaunchKernelGGL(quotient_combine_kernel, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), part, n_chunks, N, zinv_even,
+                           zinv_odd, q);
     return (int)hipGetLastError();
 }
 
