@@ -17,39 +17,58 @@ constexpr int kBlock = 256;
 __device__ __forceinline__ bb::Ext load_ext_uniform(const bb::Ext* p) { return *p; }
 
 // ---- quotient ---------------------------------------------------------------------------
+// kQRows LDE rows per lane (rows t, t + kBlock, ... of a kQRows * kBlock-row block): the constraint interpreter is
+// bound by its scalar work, which is shared by the rows of a lane (xbc::eval_rows).
+constexpr int kQRows = 2;
 template <bool XBC>
 __global__ __launch_bounds__(kBlock) void quotient_kernel(const uint32_t* __restrict__ lde, size_t N,
                                                            const uint32_t* __restrict__ bytecode,
                                                            const uint32_t* __restrict__ spans, uint32_t n_constraints,
                                                            const bb::Ext* __restrict__ alpha_pows, uint32_t zinv_even,
                                                            uint32_t zinv_odd, uint32_t* __restrict__ q, uint32_t per_chunk) {
-    __shared__ uint32_t stack_lds[kStackCap * kBlock];
+    __shared__ uint32_t stack_lds[kStackCap * kQRows * kBlock];
     uint32_t* stk = stack_lds + threadIdx.x;
-    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= N) return;
-    bb::Ext acc = bb::ext_zero();
+    size_t rows[kQRows];
+    bool live[kQRows];
+#pragma unroll
+    for (int n = 0; n < kQRows; ++n) {
+        const size_t j = ((size_t)blockIdx.x * kQRows + n) * kBlock + threadIdx.x;
+        live[n] = j < N;
+        rows[n] = live[n] ? j : 0;  // rows past the end evaluate row 0 and are not stored
+    }
+    if (!live[0]) return;
+    bb::ExtWideAcc acc[kQRows];
     // gridDim.y > 1 (short traces with many constraints): this block folds only its chunk of the constraints and
     // leaves the partial sum in q[(4 * chunk + k) * N + j]; quotient_combine_kernel adds the chunks up
     const uint32_t c_begin = blockIdx.y * per_chunk;
     const uint32_t c_end = min(n_constraints, c_begin + per_chunk);
     for (uint32_t c = c_begin; c < c_end; ++c) {
         const uint32_t off = spans[2 * c], len = spans[2 * c + 1];
-        const uint32_t v = XBC ? xbc::eval<kBlock, true>(bytecode + 2 * (size_t)off, len, lde, j, stk, N)
-                               : eval_expr<kBlock, true>(bytecode + off, len, lde, j, stk, N);
+        uint32_t v[kQRows];
+        if (XBC) {
+            xbc::eval_rows<kBlock, true, kQRows>(bytecode + 2 * (size_t)off, len, lde, rows, stk, N, v);
+        } else {
+#pragma unroll
+            for (int n = 0; n < kQRows; ++n) v[n] = eval_expr<kBlock, true>(bytecode + off, len, lde, rows[n], stk, N);
+        }
         const bb::Ext a = alpha_pows[c];
-        acc.c[0] = bb::add(acc.c[0], bb::mul(a.c[0], v));
-        acc.c[1] = bb::add(acc.c[1], bb::mul(a.c[1], v));
-        acc.c[2] = bb::add(acc.c[2], bb::mul(a.c[2], v));
-        acc.c[3] = bb::add(acc.c[3], bb::mul(a.c[3], v));
-    }
-    if (gridDim.y > 1) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) q[((size_t)blockIdx.y * 4 + k) * N + j] = acc.c[k];
-        return;
+        for (int n = 0; n < kQRows; ++n) acc[n].fma(a, v[n]);
     }
-    const uint32_t zi = (j & 1) ? zinv_odd : zinv_even;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) q[(size_t)k * N + j] = bb::mul(acc.c[k], zi);
+    for (int n = 0; n < kQRows; ++n) {
+        if (!live[n]) continue;
+        const size_t j = rows[n];
+        const bb::Ext r = acc[n].result();
+        if (gridDim.y > 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[((size_t)blockIdx.y * 4 + k) * N + j] = r.c[k];
+        } else {
+            const uint32_t zi = (j & 1) ? zinv_odd : zinv_even;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[(size_t)k * N + j] = bb::mul(r.c[k], zi);
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void quotient_combine_kernel(const uint32_t* __restrict__ part, uint32_t n_chunks, size_t N,
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const uint32_t* __r
 
 uint32_t quotient_chunks(size_t N, uint32_t n_constraints) {
     // enough workgroups for 256 CUs x 8 even when the trace is short; at least 32 constraints per chunk
-    const unsigned row_blocks = div_up(N, kBlock), want = 256u * 8u;
+    const unsigned row_blocks = div_up(N, kBlock * kQRows), want = 256u * 8u;
     if (row_blocks >= want || n_constraints < 64) return 1;
     uint32_t chunks = (want + row_blocks - 1) / row_blocks;
     if (chunks > n_constraints / 32) chunks = n_constraints / 32;
@@ -240,7 +259,7 @@ int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, 
     const uint32_t per_chunk = n_chunks > 1 ? (prog.n_constraints + n_chunks - 1) / n_chunks : (prog.n_constraints ? prog.n_constraints : 1);
     if (n_chunks > 1) n_chunks = (prog.n_constraints + per_chunk - 1) / per_chunk;
     uint32_t* out = n_chunks > 1 ? part : q;
-    const dim3 grid(div_up(N, kBlock), n_chunks);
+    const dim3 grid(div_up(N, kBlock * kQRows), n_chunks);
     if (prog.is_xbc)
         hipLaunchKernelGGL(quotient_kernel<true>, grid, dim3(kBlock), 0, stream(), lde, N, prog.d_bytecode, prog.d_spans,
                            prog.n_constraints, d_alpha_pows, zinv_even, zinv_odd, out, per_chunk);

@@ -40,6 +40,74 @@ enum Op : uint32_t {
 };
 
 #if defined(__HIPCC__)
+// NR rows per lane: every decoded instruction is applied to NR rows, so the scalar work of the interpreter (fetch,
+// decode, dispatch — one scalar unit serves a CU's four SIMDs) is shared. Pays for long programs (the quotient's
+// constraints); for the 1-3-instruction programs of the bus replay it does not (profiles/r01_pipeline_experiments.txt).
+// `stk`: slot k of row n at stk[(k * NR + n) * STRIDE].
+template <int STRIDE, bool COLUMN_OPERANDS, int NR>
+__device__ __forceinline__ void eval_rows(const uint32_t* __restrict__ code, uint32_t n_instr, const uint32_t* __restrict__ trace,
+                                          const size_t (&r)[NR], uint32_t* __restrict__ stk, size_t col_stride, uint32_t (&top)[NR]) {
+#pragma unroll
+    for (int n = 0; n < NR; ++n) top[n] = 0u;
+    int sp = 0;
+    const uint2* ins = reinterpret_cast<const uint2*>(code);
+    for (uint32_t ip = 0; ip < n_instr; ++ip) {
+        const uint2 in = ins[ip];
+        const uint32_t op = in.x, a = in.y;
+        const uint32_t* src = COLUMN_OPERANDS ? trace + (size_t)a * col_stride : trace + (size_t)a;
+        if (op <= MUL_COL) {
+            if (op <= PUSH_CONST) {
+                if (op >= PUSH_COL) {
+#pragma unroll
+                    for (int n = 0; n < NR; ++n) stk[(sp * NR + n) * STRIDE] = top[n];
+                    ++sp;
+                }
+                if (op & 1u) {
+#pragma unroll
+                    for (int n = 0; n < NR; ++n) top[n] = a;
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NR; ++n) top[n] = src[r[n]];
+                }
+            } else {
+                uint32_t v[NR];
+#pragma unroll
+                for (int n = 0; n < NR; ++n) v[n] = src[r[n]];
+#pragma unroll
+                for (int n = 0; n < NR; ++n) {
+                    if (op == ADD_COL) top[n] = bb::add(top[n], v[n]);
+                    else if (op == SUB_COL) top[n] = bb::sub(top[n], v[n]);
+                    else if (op == RSUB_COL) top[n] = bb::sub(v[n], top[n]);
+                    else top[n] = bb::mul(top[n], v[n]);
+                }
+            }
+        } else if (op <= MUL_CONST) {
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                if (op == ADD_CONST) top[n] = bb::add(top[n], a);
+                else if (op == RSUB_CONST) top[n] = bb::sub(a, top[n]);
+                else top[n] = bb::mul(top[n], a);
+            }
+        } else if (op <= MUL) {
+            --sp;
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const uint32_t s_ = stk[(sp * NR + n) * STRIDE];
+                if (op == ADD) top[n] = bb::add(s_, top[n]);
+                else if (op == SUB) top[n] = bb::sub(s_, top[n]);
+                else if (op == RSUB) top[n] = bb::sub(top[n], s_);
+                else top[n] = bb::mul(s_, top[n]);
+            }
+        } else if (op == NEG) {
+#pragma unroll
+            for (int n = 0; n < NR; ++n) top[n] = bb::neg(top[n]);
+        } else {
+#pragma unroll
+            for (int n = 0; n < NR; ++n) top[n] = bb::inv_or_zero(top[n]);
+        }
+    }
+}
+
 // `stk` = this thread's LDS column (slot k at stk[k * STRIDE]). COLUMN_OPERANDS: operand is a column
 // index, T[a] = trace[a * col_stride + r]; otherwise an element offset, T[a] = trace[a + r].
 template <int STRIDE, bool COLUMN_OPERANDS>
