@@ -46,7 +46,14 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--pow-bits", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log-height", type=int, default=14)
+    ap.add_argument("--cpu-log-height", type=int, default=16,
+                    help="rows (log2) of the CPU-baseline sample of the same AIR (2^16 rows of C2 = 132 M cells: ~25 s on the box's host cores)")
+    ap.add_argument("--no-logup-leg", action="store_true",
+                    help="skip the second timed leg of the default run (the same step WITH the LogUp phase, reported as `logup`)")
+    ap.add_argument("--logup-steps", type=int, default=3, help="timed steps of the LogUp leg (after one warm-up step)")
+    ap.add_argument("--no-copy-ceiling", action="store_true",
+                    help="skip the 5 x 4 GiB device-to-device copies that measure the box's copy rate after the timed region "
+                         "(they show up as __amd_rocclr_copyBuffer in rocprofv3 traces: 10.7 GB/step in the round-1 PMC pass)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="host threads / HIP streams proving independent segments concurrently on each GPU "
                          "(throughput mode; default 1 = one segment at a time, which keeps per-kernel timings clean)")
@@ -159,6 +166,52 @@ def cpu_baseline(shape_name, log_h, queries, pow_bits, seed):
                 trace_gen_s=t1 - t0, prove_s=t2 - t1)
 
 
+ALGO_BYTES_PER_CELL = 48.0  # tracegen 8 + LDE 12 + Merkle 8 + quotient 8 + DEEP/openings 12 (whole pipeline, per main cell)
+
+
+def timed_leg(run_steps, steps, warmup, barrier, abi, world):
+    """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks; per-kernel event timing."""
+    run_steps(warmup)
+    barrier()
+    abi.lib.powdr_gpu_timing_enable(1)
+    t0 = time.perf_counter()
+    run_steps(steps)
+    barrier()
+    t1 = time.perf_counter()
+    timing = abi.timing_report()
+    abi.lib.powdr_gpu_timing_enable(0)
+    elapsed = t1 - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, timing
+
+
+def gauges_of(stage_ms):
+    """Kernel times grouped under the reference's gauge names (openvm/metrics-viewer/CLAUDE.md:55-116)."""
+    g = lambda *names: sum(stage_ms.get(n, 0.0) for n in names)
+    return dict(
+        trace_gen_time_ms=g("apc_gather_tile_kernel", "apc_apply_derived_expr_kernel", "apc_apply_bus_kernel", "bus_histogram_kernel"),
+        main_trace_commit_time_ms=g("ntt_group_kernel<dif>", "ntt_group_kernel<dit>", "leaf_hash_kernel", "compress_kernel", "compress_tail_kernel"),
+        perm_trace_time_ms=g("logup_perm_kernel", "logup_scan_kernels"),
+        quotient_poly_compute_time_ms=g("quotient_kernel", "quotient_logup_kernel", "quotient_split_kernel"),
+        pcs_opening_time_ms=g("barycentric_weights_kernel", "zeta_weights_kernel", "ext_dot_partial_kernel", "deep_kernel", "deep_logup_kernel",
+                              "ext_pair_leaf_kernel", "fri_fold_kernel", "gather_rows_kernel"),
+        note="main_trace_commit also contains the 8-column quotient commitment (and, with LogUp, the permutation matrix's; same kernels); "
+             "stark_prove_excluding_trace_time_ms = ms_per_step - trace_gen_time_ms")
+
+
+def load_profile_json(name):
+    f = ROOT / "profiles" / name
+    try:
+        return json.loads(f.read_text()) if f.exists() else None
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     rank, local, world = setup_distributed(args.gpus)
@@ -174,19 +227,21 @@ def main():
         torch.cuda.empty_cache()
         args.exact_source_heights = True
         wl = build_workload(args.shape, log_h, True, seed=rank, calls_fraction=args.calls_fraction)
-    inter = wl["apc"].compile_bus(1) if args.logup else None  # (interactions, spans, bytecode) with column operands
-    perm_cols = 4 * len(prover.logup_group_starts(inter)) if args.logup else 0  # 4 * (groups + 1)
+    all_inter = wl["apc"].compile_bus(1)  # (interactions, spans, bytecode) with column operands
+    lg_perm_cols = 4 * len(prover.logup_group_starts(all_inter))  # 4 * (groups + 1)
+    inter = all_inter if args.logup else None
+    perm_cols = lg_perm_cols if args.logup else 0
     pr = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits, interactions=inter)
     from powdr_amd import sharding
 
-    def run_segment(w):
+    def run_segment(w, with_logup):
         for t in (w["per"].var_hist, w["per"].tuple_hist, w["per"].bitwise_hist):
             t.zero_()
         w["apc"].generate_witness_gpu(wl["instr_air"], wl["dummy"], wl["calls"], w["out"].data_ptr(), w["per"])
         proof = w["pr"].prove(w["out"].data_ptr(), log_h, copy=False)
         if world > 1:
             # the final commitment merge: all-gather of the per-segment trace roots (32 B per segment)
-            o = 7 if args.logup else 6
+            o = 7 if with_logup else 6
             sharding.merge_commitments([rank], proof[o:o + 8].reshape(1, 8), world)
         return proof
 
@@ -210,14 +265,14 @@ def main():
         """n segments on this GPU: sequentially, or split over the pipeline's host threads/streams."""
         if args.pipeline == 1:
             for _ in range(n):
-                last["proof"] = run_segment(main_worker)
+                last["proof"] = run_segment(main_worker, args.logup)
             return
 
         def body(w, k):
             with torch.cuda.stream(w["stream"]):
                 abi.lib.powdr_gpu_set_stream(w["stream"].cuda_stream)
                 for _ in range(k):
-                    last["proof"] = run_segment(w)
+                    last["proof"] = run_segment(w, args.logup)
 
         counts = [n // len(workers) + (1 if i < n % len(workers) else 0) for i in range(len(workers))]
         th = [threading.Thread(target=body, args=(w, k)) for w, k in zip(workers, counts) if k]
@@ -231,117 +286,136 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(max(args.warmup, len(workers) if args.warmup else 0))
-    barrier()
-    abi.lib.powdr_gpu_timing_enable(1)
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    t1 = time.perf_counter()
-    timing = abi.timing_report()
-    abi.lib.powdr_gpu_timing_enable(0)
-    elapsed = t1 - t0
-    if world > 1:
-        import torch.distributed as dist
-
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, timing = timed_leg(run_steps, args.steps, max(args.warmup, len(workers) if args.warmup else 0), barrier, abi, world)
     cells_per_step = wl["W"] * wl["H"]
     total_cells = cells_per_step * args.steps * world
     value = total_cells / elapsed
+    proof_bytes = int(len(last["proof"]) * 4)
+    prover_bytes = pr.device_bytes()
 
-    proof = last["proof"]
+    # ---- second timed leg: the same step WITH the LogUp phase (the bus interactions PowdrAir::eval pushes, chip.rs:117-129,
+    # inside the proof). The headline stays constraints-only (north_star's kernel list has no permutation phase); this leg is
+    # the statement the reference's backend proves. Same inputs, same trace generation; a second prover object.
+    logup_leg = None
+    if not args.logup and not args.no_logup_leg and args.pipeline == 1:
+        pr.close()
+        torch.cuda.empty_cache()
+        try:
+            pr_lg = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits, interactions=all_inter)
+            lg_worker = dict(apc=wl["apc"], per=wl["per"], out=wl["out"], pr=pr_lg)
+            lg_last = {}
+
+            def run_lg(n):
+                for _ in range(n):
+                    lg_last["proof"] = run_segment(lg_worker, True)
+
+            lg_elapsed, lg_timing = timed_leg(run_lg, args.logup_steps, 1, barrier, abi, world)
+            rho = lg_perm_cols / wl["W"]
+            lg_bytes_per_cell = 48 + 4 + 44 * rho
+            lg_value = cells_per_step * args.logup_steps * world / lg_elapsed
+            lg_stage = {k: ms / args.logup_steps for k, (c, ms) in lg_timing.items()}
+            logup_leg = dict(
+                value=lg_value, unit="main cells/s", ms_per_step=lg_elapsed / args.logup_steps * 1e3, steps=args.logup_steps, warmup=1,
+                interaction_groups=lg_perm_cols // 4 - 1, perm_cols=lg_perm_cols, rho=rho,
+                algo_bytes_per_main_cell=lg_bytes_per_cell,
+                whole_step_hbm=dict(achieved_GBps=lg_value * lg_bytes_per_cell / 1e9, peak_GBps=HBM_PEAK_GBS,
+                                    frac=lg_value * lg_bytes_per_cell / 1e9 / HBM_PEAK_GBS),
+                proof_bytes=int(len(lg_last["proof"]) * 4), prover_device_bytes=pr_lg.device_bytes(), stage_ms=lg_stage,
+                gauges=gauges_of(lg_stage),
+                note="same segment, same trace generation, proof = pw-stark v0 + LogUp (proof magic PWS2): the AIR's bus interactions are "
+                     "inside the proof (permutation columns, running sum, extended quotient, openings at zeta and g*zeta)")
+            pr_lg.close()
+        except Exception as e:  # the extra leg must never take the headline down
+            logup_leg = dict(value=None, error=f"{type(e).__name__}: {e}")
+
     if rank == 0:
-        # dominant kernel + roofline (Merkle leaves read 4*beta = 8 B per trace cell)
         per_kernel = {k: (c, ms) for k, (c, ms) in timing.items()}
         dom = max(per_kernel, key=lambda k: per_kernel[k][1]) if per_kernel else None
+        # SURVEY.md 8d, algorithmic HBM bytes per main cell and kernel. The quotient kernel is NOT listed: it reads only the
+        # columns the constraints reference (PMC: 2.9 GB per step at C2, not 8 B x cells), so a per-cell figure does not describe it.
         algo_bytes_per_cell = {"leaf_hash_kernel": 8.0, "apc_gather_tile_kernel": 8.0, "apc_apply_bus_kernel": 4.0,
-                               "ntt_group_kernel<dif>": 8.0, "ntt_group_kernel<dit>": 16.0, "deep_kernel": 8.0,
-                               "quotient_kernel": 8.0}
+                               "ntt_group_kernel<dif>": 8.0, "ntt_group_kernel<dit>": 16.0, "deep_kernel": 8.0}
         stage_ms = {k: ms / args.steps for k, (c, ms) in per_kernel.items()}
-        # the same times grouped under the reference's gauge names (openvm/metrics-viewer/CLAUDE.md:55-116)
-        g = lambda *names: sum(stage_ms.get(n, 0.0) for n in names)
-        gauges = dict(
-            trace_gen_time_ms=g("apc_gather_tile_kernel", "apc_apply_derived_expr_kernel", "apc_apply_bus_kernel", "bus_histogram_kernel"),
-            main_trace_commit_time_ms=g("ntt_group_kernel<dif>", "ntt_group_kernel<dit>", "leaf_hash_kernel", "compress_kernel", "compress_tail_kernel"),
-            perm_trace_time_ms=g("logup_perm_kernel", "logup_scan_kernels"),
-            quotient_poly_compute_time_ms=g("quotient_kernel", "quotient_logup_kernel", "quotient_split_kernel"),
-            pcs_opening_time_ms=g("barycentric_weights_kernel", "zeta_weights_kernel", "ext_dot_partial_kernel", "deep_kernel", "deep_logup_kernel",
-                                  "ext_pair_leaf_kernel", "fri_fold_kernel", "gather_rows_kernel"),
-            note="main_trace_commit also contains the 8-column quotient commitment (and, with --logup, the permutation matrix's; same kernels); "
-                 "stark_prove_excluding_trace_time_ms = ms_per_step - trace_gen_time_ms")
-        # device-to-device copy ceiling of THIS box: 4 GiB float4-style copy
-        a_ = torch.empty(1 << 30, dtype=torch.int32, device="cuda")
-        b_ = torch.empty_like(a_)
-        b_.copy_(a_)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(4):
+        gauges = gauges_of(stage_ms)
+        copy_gbs = None
+        if not args.no_copy_ceiling:
+            # device-to-device copy ceiling of THIS box: 4 GiB copies, outside every timed region
+            a_ = torch.empty(1 << 30, dtype=torch.int32, device="cuda")
+            b_ = torch.empty_like(a_)
             b_.copy_(a_)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 4 * 2 * a_.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del a_, b_
-        roof = None
-        if dom:
-            cnt, ms = per_kernel[dom]
-            launches_per_step = cnt / args.steps
-            # bytes are summed over one step's launches of that kernel and divided by one step's time in it
-            abc = algo_bytes_per_cell.get(dom, 8.0)
-            bytes_step = abc * cells_per_step
-            achieved = bytes_step / (ms / args.steps * 1e-3) / 1e9
-            traffic = None
-            tf = ROOT / "profiles" / "r01_pmc_traffic_c2.json"
-            if tf.exists() and args.shape == "C2" and log_h == 20:
-                k = json.loads(tf.read_text())["kernels"].get(dom)
-                if k:  # HBM bytes per step from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-                    traffic = k["fetch_bytes_corrected"] + k["write_bytes"]
-            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=traffic, traffic_unit="bytes per step (PMC, profiles/r01_pmc_traffic_c2.json)",
-                        algorithmic_bytes_per_step=bytes_step, avg_launch_ms=ms / cnt, launches_per_step=launches_per_step,
-                        algo_bytes_per_cell=abc)
-            if dom == "leaf_hash_kernel":
-                # The dominant kernel is integer-VALU bound, not HBM/MFMA bound: 4929 VALU instructions per Poseidon2
-                # permutation (PMC SQ_INSTS_VALU / permutations, profiles/r01_pmc_leaf_hash_h18.txt; the
-                # first version needed 7089); a wave64 VALU instruction issues in 4 cycles.
-                perms = 2 * wl["H"] * ((wl["W"] + 7) // 8) + 2 * wl["H"]  # trace LDE rows + 8-col quotient LDE rows
-                perms += 2 * wl["H"] * ((perm_cols + 7) // 8)            # + the permutation matrix's rows (--logup)
-                wave_instr = perms * 4929 / 64
-                peak = 1024 * 2.4e9 / 4  # SIMDs x clock / cycles per instruction
-                rate = wave_instr / (ms / args.steps * 1e-3)
-                roof["valu"] = dict(wave_instructions_per_step=wave_instr, achieved_G_wave_instr_s=rate / 1e9,
-                                    peak_G_wave_instr_s=peak / 1e9, frac=rate / peak,
-                                    note="leaf_hash_kernel runs at the VALU issue ceiling (PMC: SQ_ACTIVE_INST_VALU = "
-                                         "SQ_INSTS_VALU quad-cycles = 100% of kernel time); MFMA utilisation is 0 by design "
-                                         "(the Poseidon2 MDS is additions only, DESIGN.md 3.4)")
-        # every major kernel against the HBM roofline: algorithmic bytes (SURVEY.md 8d x cells) / its time per step,
-        # and the PMC-measured HBM traffic where a profile of this exact workload is committed
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                b_.copy_(a_)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 4 * 2 * a_.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del a_, b_
+        # PMC profiles of THIS round's code (separate rocprofv3 --pmc passes of this command, tools/pmc_traffic_json.py and
+        # tools/pmc_valu_json.py): HBM traffic per kernel and step; VALU instructions per Poseidon2 permutation
+        tprof_name = "r02_pmc_traffic_c2.json"
+        tprof = load_profile_json(tprof_name) if (args.shape == "C2" and log_h == 20 and not args.logup) else None
         traffic_db = {}
-        tf = ROOT / "profiles" / "r01_pmc_traffic_c2.json"
-        if tf.exists() and args.shape == "C2" and log_h == 20:
-            for k, v in json.loads(tf.read_text())["kernels"].items():
+        if tprof:
+            for k, v in tprof["kernels"].items():
                 base = k.split("<")[0]
                 if base == "ntt_group_kernel":  # the library times DIF (inverse) and DIT (forward) launches separately
                     base += "<dif>" if k.split("<")[1].startswith("true") else "<dit>"
                 if base.startswith("apc_apply_bus"):  # interpreter and fixed-shape kernels share one timer
                     base = "apc_apply_bus_kernel"
                 traffic_db[base] = traffic_db.get(base, 0.0) + v["fetch_bytes_corrected"] + v["write_bytes"]
+        roof = None
+        if dom:
+            cnt, ms = per_kernel[dom]
+            abc = algo_bytes_per_cell.get(dom, 8.0)
+            bytes_step = abc * cells_per_step  # summed over one step's launches of that kernel
+            achieved = bytes_step / (ms / args.steps * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                        traffic=traffic_db.get(dom), traffic_unit=f"bytes per step (PMC, profiles/{tprof_name})" if tprof else None,
+                        algorithmic_bytes_per_step=bytes_step, avg_launch_ms=ms / cnt, launches_per_step=cnt / args.steps,
+                        algo_bytes_per_cell=abc)
+            # the whole step against SURVEY 8d's headline figure: 48 algorithmic bytes per main cell
+            roof["whole_step"] = dict(algo_bytes_per_cell=ALGO_BYTES_PER_CELL, achieved_GBps=value / world * ALGO_BYTES_PER_CELL / 1e9,
+                                      peak_GBps=HBM_PEAK_GBS, frac=value / world * ALGO_BYTES_PER_CELL / 1e9 / HBM_PEAK_GBS,
+                                      note="per GPU; the step is bound by integer VALU issue (Poseidon2, NTT), not by HBM")
+            if dom == "leaf_hash_kernel":
+                # The dominant kernel is integer-VALU bound. Its instruction count per permutation and the issue cost of its
+                # opcode mix are MEASURED (PMC SQ_INSTS_VALU of this round's kernel; tools/microbench_opcodes.hip) and read
+                # from profiles/ — nothing is hard-coded here; absent profile => null.
+                vm = load_profile_json("r02_valu_model.json")
+                perms = 2 * wl["H"] * ((wl["W"] + 7) // 8) + 2 * wl["H"]  # trace LDE rows + 8-col quotient LDE rows
+                perms += 2 * wl["H"] * ((perm_cols + 7) // 8)            # + the permutation matrix's rows (--logup)
+                if vm and vm.get("valu_instr_per_perm") and vm.get("cycles_per_wave_instr"):
+                    wave_instr = perms * vm["valu_instr_per_perm"] / 64
+                    peak = 1024 * 2.4e9 / vm["cycles_per_wave_instr"]  # SIMDs x clock / measured cycles per wave instruction of this mix
+                    rate = wave_instr / (ms / args.steps * 1e-3)
+                    roof["valu"] = dict(permutations_per_step=perms, valu_instr_per_perm=vm["valu_instr_per_perm"],
+                                        cycles_per_wave_instr=vm["cycles_per_wave_instr"],
+                                        achieved_G_wave_instr_s=rate / 1e9, peak_G_wave_instr_s=peak / 1e9, frac=rate / peak,
+                                        source="profiles/r02_valu_model.json: " + vm.get("source", ""),
+                                        mfma="utilisation 0 by design; measured alternative in profiles/r02_microbench_mfma_mds.txt")
+                else:
+                    roof["valu"] = None
         by_kernel = {}
         for k, ms in stage_ms.items():
             if k in algo_bytes_per_cell and ms > 0:
                 gbs = algo_bytes_per_cell[k] * cells_per_step / (ms * 1e-3) / 1e9
-                by_kernel[k] = dict(ms=ms, algorithmic_GBps=gbs, frac_of_peak=gbs / HBM_PEAK_GBS,
-                                    pmc_traffic_bytes=traffic_db.get(k, traffic_db.get(k.split("<")[0])))
+                rec = dict(ms=ms, algorithmic_GBps=gbs, frac_of_peak=gbs / HBM_PEAK_GBS)
+                tb = traffic_db.get(k, traffic_db.get(k.split("<")[0]))
+                if tb:
+                    rec["pmc_traffic_bytes"] = tb
+                    rec["pmc_GBps"] = tb / (ms * 1e-3) / 1e9
+                by_kernel[k] = rec
         cpu = None
         if not args.no_cpu_baseline:
             try:
-                cpu = cpu_baseline(args.shape, args.cpu_log_height, args.queries, args.pow_bits, seed=0)
+                cpu = cpu_baseline(args.shape, min(args.cpu_log_height, log_h), args.queries, args.pow_bits, seed=0)
             except Exception as e:  # the baseline must never take the product number down
                 cpu = dict(value=None, unit="cells/s", cores=os.cpu_count(), kind="port", sample=f"failed: {e}")
         line = dict(
-            metric="STARK cells/sec (trace rows x cols) proving guest-keccak", value=value, unit="cells/s",
+            metric="STARK cells/sec (trace rows x cols) proving guest-keccak" + ("" if args.logup else " [constraints-only proof; `logup` = with the bus argument]"),
+            value=value, unit="cells/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
             config=dict(workload=f"{args.shape} {shape.name} autoprecompile AIR: {wl['W']} cols x 2^{log_h} rows, "
@@ -349,14 +423,18 @@ def main():
                                  f"pw-stark v0 proof (blow-up 2, {args.queries} queries, {args.pow_bits} PoW bits)"
                                  + (f" WITH the LogUp phase: {perm_cols // 4 - 1} interaction groups = {perm_cols} extra committed "
                                     f"columns, rho = {perm_cols / wl['W']:.2f} (SURVEY 8d: algorithmic bytes per main cell "
-                                    f"= 48 + 4 + 44*rho = {52 + 44 * perm_cols / wl['W']:.0f})" if args.logup else "")
+                                    f"= 48 + 4 + 44*rho = {52 + 44 * perm_cols / wl['W']:.0f})" if args.logup else
+                                    "; CONSTRAINTS-ONLY proof (the bus interactions are replayed into the periphery histograms but are not "
+                                    "inside this proof — see `logup` for the same step with them)")
                                  + (f"; {wl['calls']} APC calls, the remaining rows are zero padding" if wl["calls"] != wl["H"] else "")
                                  + "; one segment per step per GPU"
                                  + ("; source heights b*calls (not padded to a power of two)" if args.exact_source_heights else ""),
                         rows=wl["H"], cols=wl["W"], parallelism=f"segments x{world}" + (f", {args.pipeline} streams per GPU" if args.pipeline > 1 else ""),
-                        source_bytes=wl["src_bytes"], proof_bytes=int(len(proof) * 4),
-                        prover_device_bytes=pr.device_bytes()),
-            roofline=roof, roofline_by_kernel=by_kernel, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges, hbm_copy_GBps_measured=copy_gbs,
+                        source_bytes=wl["src_bytes"], proof_bytes=proof_bytes, prover_device_bytes=prover_bytes,
+                        caveat="proof system pw-stark v0 is this repository's own (oracle/stark_oracle.cpp); its Poseidon2 round constants are a "
+                               "documented placeholder stream: proofs are byte-exact against the oracle, not interoperable with the reference prover"),
+            roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
+            hbm_copy_GBps_measured=copy_gbs,
         )
         print(json.dumps(line))
     if world > 1:

@@ -123,6 +123,27 @@ int powdr_apc_apply_bus_cols(const PowdrFp* d_output, size_t output_height, int 
                              uint32_t tuple2_bus_id, uint32_t* d_tuple2_hist, uint32_t tuple2_sz0,
                              uint32_t tuple2_sz1, uint32_t bitwise_bus_id, uint32_t* d_bitwise_hist);
 
+/* _apc_tracegen for a caller that still holds the tables on the host (the reference's host code builds them right
+ * before uploading them, cuda/mod.rs:272-332): `h_original_airs` / `h_subs` are host copies of what `d_original_airs`
+ * (still needed: the kernels read buffer pointers and heights from it) and the Subst table contain. The reference
+ * entry point has to copy both tables back and synchronise the stream twice to find its cached gather plan; this
+ * one only enqueues kernels. Same result. */
+int powdr_apc_tracegen_host_tables(PowdrFp* d_output, size_t output_height, const OriginalAir* d_original_airs,
+                                   const OriginalAir* h_original_airs, size_t n_airs, const Subst* h_subs,
+                                   size_t n_subs, int num_apc_calls);
+
+/* _apc_apply_bus / powdr_apc_apply_bus_cols for a caller that still holds the three tables on the host: h_* are host
+ * copies of the d_* tables. output_height = 0: PUSH_APC operands are element offsets (reference encoding); otherwise
+ * they are column indices of a trace of that height. */
+int powdr_apc_apply_bus_host_tables(const PowdrFp* d_output, size_t output_height, int num_apc_calls,
+                                    const uint32_t* d_bytecode, const uint32_t* h_bytecode, size_t bytecode_len,
+                                    const DevInteraction* d_interactions, const DevInteraction* h_interactions,
+                                    size_t n_interactions, const ExprSpan* d_arg_spans, const ExprSpan* h_arg_spans,
+                                    size_t n_arg_spans, uint32_t var_range_bus_id, uint32_t* d_var_hist,
+                                    size_t var_num_bins, uint32_t tuple2_bus_id, uint32_t* d_tuple2_hist,
+                                    uint32_t tuple2_sz0, uint32_t tuple2_sz1, uint32_t bitwise_bus_id,
+                                    uint32_t* d_bitwise_hist);
+
 /* Traces of the shared periphery chips (the RECEIVE side of the three lookup buses) from the histograms
  * _apc_apply_bus filled. The chips are EXTERNAL (openvm-circuit-primitives; instantiated in
  * openvm/src/powdr_extension/trace_generator/cuda/periphery.rs:33-85); in-repo is how a lookup becomes a histogram

@@ -77,7 +77,8 @@ int pw_prover_check_constraints(PwProver* p, const uint32_t* d_trace, uint32_t l
  * `verify_app_proof::<BabyBearPoseidon2CpuEngine>` (openvm-riscv/src/lib.rs:337-341). Constraint
  * programs as for pw_prover_create (post-fix, column-index operands, no INV_OR_ZERO).
  * Returns 0 = valid; 1 header, 2 constraint identity, 3 proof of work, 4 query index, 5 trace opening,
- * 6 quotient opening, 7 FRI layer, 8 final polynomial, 9 trailing words, 10 truncated/malformed. */
+ * 6 quotient opening, 7 FRI layer, 8 final polynomial, 9 trailing words, 10 truncated/malformed,
+ * 13 a proof word >= p (non-canonical encodings are rejected: proofs are not malleable). */
 int pw_verify(const PwStarkConfig* cfg, uint32_t width, uint32_t log_height, const uint32_t* cons_bytecode,
               size_t bytecode_len, const uint32_t* cons_spans, size_t n_constraints, const uint32_t* proof_words,
               size_t n_words);

@@ -501,6 +501,7 @@ int verify(const Config& cfg, const u32* proof, size_t len, u32 width, u32 log_h
     auto get_ext = [&]() { need(4); Ext e; memcpy(e.c, proof + pos, 16); pos += 4; return e; };
     try {
         if (get() != MAGIC || get() != log_h || get() != width || get() != prog.n || get() != cfg.num_queries || get() != cfg.pow_bits) return 1;
+        for (size_t i = 0; i < len; ++i) if (proof[i] >= P) return 13; /* non-canonical word: a second encoding of an element */
         Challenger ch;
         observe_instance(ch, log_h, width, (u32)prog.n, cfg);
         Digest t_root = get_digest();
@@ -941,6 +942,7 @@ int verify_logup(const Config& cfg, const u32* proof, size_t len, u32 width, u32
     try {
         if (get() != MAGIC2 || get() != log_h || get() != width || get() != prog.n || get() != n_int || get() != cfg.num_queries ||
             get() != cfg.pow_bits) return 1;
+        for (size_t i = 0; i < len; ++i) if (proof[i] >= P) return 13;
         Challenger ch;
         observe_instance2(ch, log_h, width, (u32)prog.n, n_int, cfg);
         Digest t_root = get_digest();

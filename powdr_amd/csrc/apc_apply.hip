@@ -29,6 +29,8 @@
 #include "../../include/powdr_gpu.h"
 
 #include <cstdlib>
+#include <cstring>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_kernel(
         if (BINNED) {
             uint32_t item = kItemNone;
             if (bin != kItemNone) {
-                if (m < kItemMaxMult && bin < (1u << kItemBinBits) && in_expected_partitions(range, bin)) item = bin | (m << kItemBinBits);
+                if (m < kItemMaxMult - 1u && bin < (1u << kItemBinBits) && in_expected_partitions(range, bin)) item = bin | (m << kItemBinBits);  // m = kItemMaxMult-1 could encode kItemNone: counted directly
                 else atomicAdd(table + bin, m);  // does not fit the packed item: rare, direct
             }
             items[(size_t)slot_of[i] * item_stride + rl] = item;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_xbc_kernel(
         if (BINNED) {
             uint32_t item = kItemNone;
             if (bin != kItemNone) {
-                if (m < kItemMaxMult && bin < (1u << kItemBinBits) && in_expected_partitions(range, bin)) item = bin | (m << kItemBinBits);
+                if (m < kItemMaxMult - 1u && bin < (1u << kItemBinBits) && in_expected_partitions(range, bin)) item = bin | (m << kItemBinBits);  // m = kItemMaxMult-1 could encode kItemNone: counted directly
                 else atomicAdd(table + bin, m);
             }
             items[(size_t)xi.slot * item_stride + rl] = item;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void apc_apply_bus_fast_kernel(
         if (BINNED) {
             uint32_t item = kItemNone;
             if (bin != kItemNone) {
-                if (m < kItemMaxMult && bin < (1u << kItemBinBits) && in_expected_partitions(range, bin)) item = bin | (m << kItemBinBits);
+                if (m < kItemMaxMult - 1u && bin < (1u << kItemBinBits) && in_expected_partitions(range, bin)) item = bin | (m << kItemBinBits);  // m = kItemMaxMult-1 could encode kItemNone: counted directly
                 else atomicAdd(table + bin, m);
             }
             items[(size_t)fi.slot * item_stride + rl] = item;
@@ -331,9 +333,26 @@ struct BusPlan {
     FastInteraction* d_fint = nullptr;
     XInteraction* d_xint_slow = nullptr;
     uint32_t n_fast = 0, n_slow = 0;
+    // what the plan was compiled from (a cache hit is confirmed by content, not by the 64-bit hash alone)
+    std::vector<DevInteraction> key_inter;
+    std::vector<ExprSpan> key_spans;
+    std::vector<uint32_t> key_bc;
+    uint32_t key_ids[3] = {0, 0, 0};
+    int device = 0;
+    uint64_t last_use = 0;
+    BusPlan() = default;
+    BusPlan(const BusPlan&) = delete;
+    BusPlan& operator=(const BusPlan&) = delete;
+    ~BusPlan() {  // hipFree waits for kernels that may still read the tables
+        for (void* q : {(void*)d_slot_of, (void*)d_slots[0], (void*)d_slots[1], (void*)d_slots[2], (void*)d_xint, (void*)d_code,
+                        (void*)d_slot_range, (void*)d_fint, (void*)d_xint_slow})
+            if (q) (void)hipFree(q);
+    }
 };
+constexpr size_t kMaxBusPlans = 64;
 std::mutex g_bus_mu;
-std::unordered_map<uint64_t, BusPlan> g_bus_plans;
+std::unordered_map<uint64_t, std::shared_ptr<BusPlan>> g_bus_plans;
+uint64_t g_bus_clock = 0;
 // item buffer of the binned path: one per host thread (= per launch stream)
 thread_local uint32_t* g_items = nullptr;
 thread_local size_t g_items_words = 0;
@@ -390,7 +409,8 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
                    uint32_t var_range_bus_id, uint32_t* d_var_hist, size_t var_num_bins,
                    uint32_t tuple2_bus_id, uint32_t* d_tuple2_hist, uint32_t tuple2_sz0,
                    uint32_t tuple2_sz1, uint32_t bitwise_bus_id,
-                   uint32_t* d_bitwise_hist, size_t col_stride) {
+                   uint32_t* d_bitwise_hist, size_t col_stride, const uint32_t* h_bytecode = nullptr,
+                   const DevInteraction* h_interactions = nullptr, const ExprSpan* h_arg_spans = nullptr) {
     if (num_apc_calls <= 0) return 0;  // apc_apply_bus.cu:146
     (void)hipGetLastError();
     if (n_interactions == 0) return (int)hipGetLastError();
@@ -411,21 +431,45 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
     std::vector<DevInteraction> h(n_interactions);
     std::vector<ExprSpan> hs(n_arg_spans);
     std::vector<uint32_t> hb(bytecode_len);
-    PW_HIP_TRY(hipMemcpyAsync(h.data(), d_interactions, n_interactions * sizeof(DevInteraction), hipMemcpyDeviceToHost, pw::stream()));
-    if (n_arg_spans) PW_HIP_TRY(hipMemcpyAsync(hs.data(), d_arg_spans, n_arg_spans * sizeof(ExprSpan), hipMemcpyDeviceToHost, pw::stream()));
-    if (bytecode_len) PW_HIP_TRY(hipMemcpyAsync(hb.data(), d_bytecode, bytecode_len * 4, hipMemcpyDeviceToHost, pw::stream()));
-    PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
+    if (h_bytecode && h_interactions && (h_arg_spans || !n_arg_spans)) {
+        // the caller still holds the tables on the host (powdr_apc_apply_bus_host_tables): no copy back, no synchronisation
+        memcpy(h.data(), h_interactions, n_interactions * sizeof(DevInteraction));
+        if (n_arg_spans) memcpy(hs.data(), h_arg_spans, n_arg_spans * sizeof(ExprSpan));
+        if (bytecode_len) memcpy(hb.data(), h_bytecode, bytecode_len * 4);
+    } else {
+        PW_HIP_TRY(hipMemcpyAsync(h.data(), d_interactions, n_interactions * sizeof(DevInteraction), hipMemcpyDeviceToHost, pw::stream()));
+        if (n_arg_spans) PW_HIP_TRY(hipMemcpyAsync(hs.data(), d_arg_spans, n_arg_spans * sizeof(ExprSpan), hipMemcpyDeviceToHost, pw::stream()));
+        if (bytecode_len) PW_HIP_TRY(hipMemcpyAsync(hb.data(), d_bytecode, bytecode_len * 4, hipMemcpyDeviceToHost, pw::stream()));
+        PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
+    }
     uint64_t key = fnv1a64(h.data(), h.size() * sizeof(DevInteraction), 1469598103934665603ull);
     key = hash_words(hs.data(), hs.size() * sizeof(ExprSpan), key);
     key = hash_words(hb.data(), hb.size() * 4, key);
     const uint32_t ids[3] = {var_range_bus_id, tuple2_bus_id, bitwise_bus_id};
     key = fnv1a64(ids, sizeof ids, key);
-    BusPlan* plan;
+    int device = 0;
+    PW_HIP_TRY(hipGetDevice(&device));
+    key = fnv1a64(&device, sizeof device, key);
+    std::shared_ptr<BusPlan> plan;
     {
         std::lock_guard<std::mutex> lk(g_bus_mu);
         auto it = g_bus_plans.find(key);
+        if (it != g_bus_plans.end()) {
+            const BusPlan& c = *it->second;
+            const bool same = c.device == device && memcmp(c.key_ids, ids, sizeof ids) == 0 && c.key_inter.size() == h.size() &&
+                              c.key_spans.size() == hs.size() && c.key_bc == hb &&
+                              (h.empty() || memcmp(c.key_inter.data(), h.data(), h.size() * sizeof(DevInteraction)) == 0) &&
+                              (hs.empty() || memcmp(c.key_spans.data(), hs.data(), hs.size() * sizeof(ExprSpan)) == 0);
+            if (!same) { g_bus_plans.erase(it); it = g_bus_plans.end(); }  // hash collision: the newer tables take the slot
+        }
         if (it == g_bus_plans.end()) {
-            BusPlan bp;
+            if (g_bus_plans.size() >= kMaxBusPlans) {
+                auto victim = g_bus_plans.begin();
+                for (auto j = g_bus_plans.begin(); j != g_bus_plans.end(); ++j) if (j->second->last_use < victim->second->last_use) victim = j;
+                g_bus_plans.erase(victim);
+            }
+            auto bpp = std::make_shared<BusPlan>();
+            BusPlan& bp = *bpp;
             std::vector<int32_t> slot_of(n_interactions, -1);
             std::vector<uint32_t> per_table[3];
             std::vector<XInteraction> xints, xints_slow;
@@ -505,9 +549,13 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
                 if (!xints_slow.empty())
                     PW_HIP_TRY(hipMemcpy(bp.d_xint_slow, xints_slow.data(), xints_slow.size() * sizeof(XInteraction), hipMemcpyHostToDevice));
             }
-            it = g_bus_plans.emplace(key, bp).first;
+            bp.key_inter = h; bp.key_spans = hs; bp.key_bc = hb;
+            memcpy(bp.key_ids, ids, sizeof ids);
+            bp.device = device;
+            it = g_bus_plans.emplace(key, std::move(bpp)).first;
         }
-        plan = &it->second;
+        plan = it->second;
+        plan->last_use = ++g_bus_clock;
     }
     if (plan->total_slots == 0) return (int)hipGetLastError();
     const bool use_xbc = want_xbc && plan->has_xbc;
@@ -631,4 +679,23 @@ extern "C" int powdr_apc_apply_bus_cols(const PowdrFp* d_output, size_t output_h
     return apply_bus_impl(d_output, num_apc_calls, d_bytecode, bytecode_len, d_interactions, n_interactions, d_arg_spans,
                           n_arg_spans, var_range_bus_id, d_var_hist, var_num_bins, tuple2_bus_id, d_tuple2_hist, tuple2_sz0,
                           tuple2_sz1, bitwise_bus_id, d_bitwise_hist, output_height);
+}
+
+// Extension: _apc_apply_bus for a caller that still holds the three tables on the host (powdr_apc_generate_witness_gpu
+// compiles them itself): h_* are host copies of the device tables. Skips the device-to-host copy of the bytecode
+// (megabytes for an un-optimised APC), its hash over the copy and the stream synchronisation of the reference entry.
+// output_height = 0: PUSH_APC operands are element offsets (reference encoding); otherwise column indices.
+extern "C" int powdr_apc_apply_bus_host_tables(const PowdrFp* d_output, size_t output_height, int num_apc_calls,
+                                               const uint32_t* d_bytecode, const uint32_t* h_bytecode, size_t bytecode_len,
+                                               const DevInteraction* d_interactions, const DevInteraction* h_interactions,
+                                               size_t n_interactions, const ExprSpan* d_arg_spans, const ExprSpan* h_arg_spans,
+                                               size_t n_arg_spans, uint32_t var_range_bus_id, uint32_t* d_var_hist,
+                                               size_t var_num_bins, uint32_t tuple2_bus_id, uint32_t* d_tuple2_hist,
+                                               uint32_t tuple2_sz0, uint32_t tuple2_sz1, uint32_t bitwise_bus_id,
+                                               uint32_t* d_bitwise_hist) {
+    if (!h_bytecode || !h_interactions || (n_arg_spans && !h_arg_spans)) return (int)hipErrorInvalidValue;
+    return apply_bus_impl(d_output, num_apc_calls, d_bytecode, bytecode_len, d_interactions, n_interactions, d_arg_spans,
+                          n_arg_spans, var_range_bus_id, d_var_hist, var_num_bins, tuple2_bus_id, d_tuple2_hist, tuple2_sz0,
+                          tuple2_sz1, bitwise_bus_id, d_bitwise_hist, output_height ? output_height : 1, h_bytecode,
+                          h_interactions, h_arg_spans);
 }

@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -70,6 +71,18 @@ struct Plan {
     PlanSub* d_subs = nullptr;
     std::vector<RClass> classes;
     size_t n_jobs = 0, n_subs = 0;
+    // what the plan was built from: a cache hit is confirmed by comparing contents, never by the hash alone
+    std::vector<Subst> key_subs;
+    std::vector<int32_t> key_bsize;
+    int device = 0;           // the device d_jobs / d_subs live on
+    uint64_t last_use = 0;    // for eviction
+    ~Plan() {
+        if (d_jobs) (void)hipFree(d_jobs);  // hipFree waits for kernels that may still read the tables
+        if (d_subs) (void)hipFree(d_subs);
+    }
+    Plan() = default;
+    Plan(const Plan&) = delete;
+    Plan& operator=(const Plan&) = delete;
 };
 
 constexpr int kBlock = 256;
@@ -214,12 +227,16 @@ uint64_t fnv1a(const void* p, size_t n, uint64_t h) {
 struct PlanKey {
     uint64_t hash;
     size_t n_subs;
-    bool operator==(const PlanKey& o) const { return hash == o.hash && n_subs == o.n_subs; }
+    int device;
+    bool operator==(const PlanKey& o) const { return hash == o.hash && n_subs == o.n_subs && device == o.device; }
 };
-struct PlanKeyHash { size_t operator()(const PlanKey& k) const { return (size_t)k.hash; } };
+struct PlanKeyHash { size_t operator()(const PlanKey& k) const { return (size_t)(k.hash ^ ((uint64_t)k.device << 56)); } };
 
+// Plans are shared_ptrs: a launch keeps its plan alive while another host thread evicts it from the (bounded) cache.
+constexpr size_t kMaxCachedPlans = 64;
 std::mutex g_plan_mu;
-std::unordered_map<PlanKey, Plan, PlanKeyHash> g_plans;
+std::unordered_map<PlanKey, std::shared_ptr<Plan>, PlanKeyHash> g_plans;
+uint64_t g_plan_clock = 0;
 
 int pick_R(int J) {
     int pitch = J | 1;
@@ -363,48 +380,43 @@ void launch_class(const RClass& c, uint32_t* out, size_t H, const OriginalAir* a
 
 }  // namespace
 
-extern "C" int _apc_tracegen(PowdrFp* d_output, size_t output_height,
-                             const OriginalAir* d_original_airs, const Subst* d_subs,
-                             size_t n_subs, int num_apc_calls) {
-    (void)hipGetLastError();  // do not report a stale error of an unrelated earlier call
-    const size_t H = output_height;
-    if ((H & (H - 1)) != 0) return (int)hipErrorInvalidValue;  // reference: assert, apc_tracegen.cu:134
-    if (H == 0 || n_subs == 0) return (int)hipGetLastError();
-    if (num_apc_calls < 0) num_apc_calls = 0;
-    if ((size_t)num_apc_calls > H) num_apc_calls = (int)H;  // rows r >= H do not exist
-
-    // D2H the (small) tables, hash, look the plan up.
-    std::vector<Subst> subs(n_subs);
-    PW_HIP_TRY(hipMemcpyAsync(subs.data(), d_subs, n_subs * sizeof(Subst), hipMemcpyDeviceToHost, pw::stream()));
-    PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
-    int max_air = -1;
-    for (auto& s : subs) {
-        if (s.air_index < 0 || s.col < 0 || s.row < 0 || s.apc_col < 0) return (int)hipErrorInvalidValue;
-        max_air = std::max(max_air, s.air_index);
-    }
-    std::vector<OriginalAir> airs((size_t)max_air + 1);
-    PW_HIP_TRY(hipMemcpyAsync(airs.data(), d_original_airs, airs.size() * sizeof(OriginalAir), hipMemcpyDeviceToHost, pw::stream()));
-    PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
-    std::vector<int32_t> bsize(airs.size());
-    for (size_t i = 0; i < airs.size(); ++i) {
-        bsize[i] = airs[i].row_block_size;
-        if (bsize[i] < 0) return (int)hipErrorInvalidValue;
-    }
+// The gather proper: `subs` / `bsize` are host copies of the Subst table and of the AIRs' row_block_size; the kernels read
+// the OriginalAir records (buffer pointers, heights) from the device table.
+static int tracegen_with_host_tables(PowdrFp* d_output, size_t H, const OriginalAir* d_original_airs,
+                                     const std::vector<Subst>& subs, const std::vector<int32_t>& bsize, int num_apc_calls) {
+    const size_t n_subs = subs.size();
     uint64_t h = fnv1a(subs.data(), n_subs * sizeof(Subst), 1469598103934665603ull);
     h = fnv1a(bsize.data(), bsize.size() * sizeof(int32_t), h);
-    PlanKey key{h, n_subs};
+    int device = 0;
+    PW_HIP_TRY(hipGetDevice(&device));
+    const PlanKey key{h, n_subs, device};
 
-    Plan* plan = nullptr;
+    std::shared_ptr<Plan> plan;
     {
         std::lock_guard<std::mutex> lk(g_plan_mu);
         auto it = g_plans.find(key);
+        if (it != g_plans.end()) {
+            const Plan& c = *it->second;
+            const bool same = c.key_subs.size() == n_subs && c.key_bsize == bsize &&
+                              (n_subs == 0 || memcmp(c.key_subs.data(), subs.data(), n_subs * sizeof(Subst)) == 0);
+            if (!same) { g_plans.erase(it); it = g_plans.end(); }  // 64-bit hash collision: the newer table takes the slot
+        }
         if (it == g_plans.end()) {
-            Plan p;
-            int rc = build_plan(subs, bsize, p);
+            if (g_plans.size() >= kMaxCachedPlans) {  // evict the least recently used plan
+                auto victim = g_plans.begin();
+                for (auto j = g_plans.begin(); j != g_plans.end(); ++j) if (j->second->last_use < victim->second->last_use) victim = j;
+                g_plans.erase(victim);
+            }
+            auto p = std::make_shared<Plan>();
+            int rc = build_plan(subs, bsize, *p);
             if (rc) return rc;
+            p->key_subs = subs;
+            p->key_bsize = bsize;
+            p->device = device;
             it = g_plans.emplace(key, std::move(p)).first;
         }
-        plan = &it->second;
+        plan = it->second;
+        plan->last_use = ++g_plan_clock;
     }
 
     pw::ScopedKernelTimer t("apc_gather_tile_kernel");
@@ -422,4 +434,66 @@ extern "C" int _apc_tracegen(PowdrFp* d_output, size_t output_height,
         }
     }
     return (int)hipGetLastError();
+}
+
+static int check_tables(const std::vector<Subst>& subs, size_t n_airs_known, int& max_air) {
+    max_air = -1;
+    for (auto& s : subs) {
+        if (s.air_index < 0 || s.col < 0 || s.row < 0 || s.apc_col < 0) return (int)hipErrorInvalidValue;
+        max_air = std::max(max_air, s.air_index);
+    }
+    if (n_airs_known && (size_t)max_air >= n_airs_known) return (int)hipErrorInvalidValue;
+    return 0;
+}
+
+extern "C" int _apc_tracegen(PowdrFp* d_output, size_t output_height,
+                             const OriginalAir* d_original_airs, const Subst* d_subs,
+                             size_t n_subs, int num_apc_calls) {
+    (void)hipGetLastError();  // do not report a stale error of an unrelated earlier call
+    const size_t H = output_height;
+    if ((H & (H - 1)) != 0) return (int)hipErrorInvalidValue;  // reference: assert, apc_tracegen.cu:134
+    if (H == 0 || n_subs == 0) return (int)hipGetLastError();
+    if (num_apc_calls < 0) num_apc_calls = 0;
+    if ((size_t)num_apc_calls > H) num_apc_calls = (int)H;  // rows r >= H do not exist
+
+    // The reference ABI hands over device tables only: D2H the (small) tables to look the plan up. Hosts that still hold
+    // the tables (powdr_apc_generate_witness_gpu does) call powdr_apc_tracegen_host_tables and skip both round trips.
+    std::vector<Subst> subs(n_subs);
+    PW_HIP_TRY(hipMemcpyAsync(subs.data(), d_subs, n_subs * sizeof(Subst), hipMemcpyDeviceToHost, pw::stream()));
+    PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
+    int max_air = -1;
+    if (int rc = check_tables(subs, 0, max_air)) return rc;
+    std::vector<OriginalAir> airs((size_t)max_air + 1);
+    PW_HIP_TRY(hipMemcpyAsync(airs.data(), d_original_airs, airs.size() * sizeof(OriginalAir), hipMemcpyDeviceToHost, pw::stream()));
+    PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
+    std::vector<int32_t> bsize(airs.size());
+    for (size_t i = 0; i < airs.size(); ++i) {
+        bsize[i] = airs[i].row_block_size;
+        if (bsize[i] < 0) return (int)hipErrorInvalidValue;
+    }
+    return tracegen_with_host_tables(d_output, H, d_original_airs, subs, bsize, num_apc_calls);
+}
+
+// Extension (not in the reference ABI): the same gather for a caller that still has the tables on the host — the
+// reference's own host code does, it builds them right before the upload (cuda/mod.rs:272-332). No device-to-host copy,
+// no stream synchronisation: the call only enqueues kernels.
+extern "C" int powdr_apc_tracegen_host_tables(PowdrFp* d_output, size_t output_height, const OriginalAir* d_original_airs,
+                                              const OriginalAir* h_original_airs, size_t n_airs, const Subst* h_subs,
+                                              size_t n_subs, int num_apc_calls) {
+    (void)hipGetLastError();
+    const size_t H = output_height;
+    if ((H & (H - 1)) != 0) return (int)hipErrorInvalidValue;
+    if (H == 0 || n_subs == 0) return (int)hipGetLastError();
+    if (!h_original_airs || !h_subs) return (int)hipErrorInvalidValue;
+    if (num_apc_calls < 0) num_apc_calls = 0;
+    if ((size_t)num_apc_calls > H) num_apc_calls = (int)H;
+    std::vector<Subst> subs(h_subs, h_subs + n_subs);
+    int max_air = -1;
+    if (int rc = check_tables(subs, n_airs, max_air)) return rc;
+    std::vector<int32_t> bsize(n_airs);
+    for (size_t i = 0; i < n_airs; ++i) {
+        bsize[i] = h_original_airs[i].row_block_size;
+        if (bsize[i] < 0) return (int)hipErrorInvalidValue;
+    }
+    return tracegen_with_host_tables(d_output, H, d_original_airs, subs, bsize, num_apc_calls);
 }

@@ -53,7 +53,7 @@ __device__ __forceinline__ uint32_t eval_expr(const uint32_t* __restrict__ bc, u
         } else if (op <= POWDR_OP_MUL) {
             // binary: a = second from top, b = top
             sp = sp > 1 ? sp - 1 : sp;
-            const uint32_t a = stk[(sp - 1) * STRIDE];
+            const uint32_t a = stk[(sp > 0 ? sp - 1 : 0) * STRIDE];  // sp == 0 (malformed code): slot 0, never below the column
             if (op == POWDR_OP_ADD) top = bb::add(a, top);
             else if (op == POWDR_OP_SUB) top = bb::sub(a, top);
             else top = bb::mul(a, top);

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -150,18 +151,30 @@ struct PowdrApc {
         uint32_t* d_dbc = nullptr; DerivedExprSpec* d_specs = nullptr; size_t n_specs = 0;
         uint32_t* d_bbc = nullptr; size_t bbc_len = 0; DevInteraction* d_inter = nullptr; size_t n_inter = 0;
         ExprSpan* d_spans = nullptr; size_t n_spans = 0;
+        // host copies of the bus tables (shared, immutable): handed to powdr_apc_apply_bus_host_tables so that the replay
+        // does not copy megabytes of bytecode back from the device to find its plan
+        std::shared_ptr<const std::vector<uint32_t>> h_bbc;
+        std::shared_ptr<const std::vector<DevInteraction>> h_inter;
+        std::shared_ptr<const std::vector<ExprSpan>> h_spans;
     };
     std::map<size_t, Compiled> compiled;
     // substitution tables keyed by the instr_air assignment hash
-    struct SubTables { std::vector<Subst> subs; std::vector<int32_t> air_ids, row_block; Subst* d_subs = nullptr; OriginalAir* d_airs = nullptr; };
+    struct SubTables { std::vector<Subst> subs; std::vector<int32_t> air_ids, row_block; Subst* d_subs = nullptr; };
     std::map<uint64_t, SubTables> sub_tables;
+    // device copies of OriginalAir tables, keyed by content (buffer pointers, heights): immutable once uploaded, so host
+    // threads on different streams can share them — a table is never rewritten under a kernel that still reads it
+    struct AirTable { std::vector<OriginalAir> h; OriginalAir* d = nullptr; uint64_t last_use = 0; };
+    std::vector<AirTable> air_tables;
+    uint64_t air_clock = 0;
+    std::mutex mu;  // guards the three caches (lookups and insertions; launches run outside it)
 
     ~PowdrApc() {
         for (auto& kv : compiled) {
             auto& c = kv.second;
             for (void* q : {(void*)c.d_dbc, (void*)c.d_specs, (void*)c.d_bbc, (void*)c.d_inter, (void*)c.d_spans}) if (q) (void)hipFree(q);
         }
-        for (auto& kv : sub_tables) { if (kv.second.d_subs) (void)hipFree(kv.second.d_subs); if (kv.second.d_airs) (void)hipFree(kv.second.d_airs); }
+        for (auto& kv : sub_tables) if (kv.second.d_subs) (void)hipFree(kv.second.d_subs);
+        for (auto& t : air_tables) if (t.d) (void)hipFree(t.d);
     }
 };
 
@@ -489,36 +502,64 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
     }
 
     // ---- OriginalAir / Subst tables (cuda/mod.rs:272-332) ----
-    uint64_t key = fnv(instr_air, apc->instructions.size() * sizeof(int32_t));
-    auto it = apc->sub_tables.find(key);
-    if (it == apc->sub_tables.end()) {
-        PowdrApc::SubTables t;
-        size_t n_airs = 0;
-        size_t n = powdr_apc_build_substitutions(apc, instr_air, nullptr, nullptr, nullptr, &n_airs);
-        t.subs.resize(n); t.air_ids.resize(n_airs); t.row_block.resize(n_airs);
-        powdr_apc_build_substitutions(apc, instr_air, t.subs.data(), t.air_ids.data(), t.row_block.data(), &n_airs);
-        int rc = upload(t.d_subs, t.subs);
-        if (rc) return rc;
-        PW_HIP_TRY(hipMalloc((void**)&t.d_airs, (n_airs ? n_airs : 1) * sizeof(OriginalAir)));
-        it = apc->sub_tables.emplace(key, std::move(t)).first;
+    int rc = 0;
+    const PowdrApc::SubTables* stb_p = nullptr;
+    const OriginalAir* d_airs = nullptr;
+    std::vector<OriginalAir> airs;
+    {
+        std::lock_guard<std::mutex> lk(apc->mu);
+        uint64_t key = fnv(instr_air, apc->instructions.size() * sizeof(int32_t));
+        auto it = apc->sub_tables.find(key);
+        if (it == apc->sub_tables.end()) {
+            PowdrApc::SubTables t;
+            size_t n_airs = 0;
+            size_t n = powdr_apc_build_substitutions(apc, instr_air, nullptr, nullptr, nullptr, &n_airs);
+            t.subs.resize(n); t.air_ids.resize(n_airs); t.row_block.resize(n_airs);
+            powdr_apc_build_substitutions(apc, instr_air, t.subs.data(), t.air_ids.data(), t.row_block.data(), &n_airs);
+            if ((rc = upload(t.d_subs, t.subs))) return rc;
+            it = apc->sub_tables.emplace(key, std::move(t)).first;
+        }
+        stb_p = &it->second;  // std::map nodes are stable; entries are never erased
+        const PowdrApc::SubTables& stb = *stb_p;
+        airs.resize(stb.air_ids.size());
+        for (size_t k = 0; k < airs.size(); ++k) {
+            int32_t id = stb.air_ids[k];
+            if (id < 0 || (size_t)id >= n_dummy) return -1;
+            memset(&airs[k], 0, sizeof(OriginalAir));  // padding bytes take part in the content compare
+            airs[k].width = dummy[id].width; airs[k].height = dummy[id].height; airs[k].buffer = dummy[id].buffer;
+            airs[k].row_block_size = stb.row_block[k];
+        }
+        // the device copy of this exact table (same buffers as last segment: no copy at all)
+        PowdrApc::AirTable* at = nullptr;
+        for (auto& t : apc->air_tables)
+            if (t.h.size() == airs.size() && (airs.empty() || memcmp(t.h.data(), airs.data(), airs.size() * sizeof(OriginalAir)) == 0)) { at = &t; break; }
+        if (!at) {
+            if (apc->air_tables.size() >= 16) {  // bounded: drop the least recently used table (hipFree waits for its readers)
+                size_t v = 0;
+                for (size_t k = 1; k < apc->air_tables.size(); ++k) if (apc->air_tables[k].last_use < apc->air_tables[v].last_use) v = k;
+                if (apc->air_tables[v].d) (void)hipFree(apc->air_tables[v].d);
+                apc->air_tables.erase(apc->air_tables.begin() + (long)v);
+            }
+            PowdrApc::AirTable t;
+            t.h = airs;
+            PW_HIP_TRY(hipMalloc((void**)&t.d, (airs.size() ? airs.size() : 1) * sizeof(OriginalAir)));
+            if (!airs.empty()) PW_HIP_TRY(hipMemcpy(t.d, airs.data(), airs.size() * sizeof(OriginalAir), hipMemcpyHostToDevice));
+            apc->air_tables.push_back(std::move(t));
+            at = &apc->air_tables.back();
+        }
+        at->last_use = ++apc->air_clock;
+        d_airs = at->d;
     }
-    PowdrApc::SubTables& stb = it->second;
-    std::vector<OriginalAir> airs(stb.air_ids.size());
-    for (size_t k = 0; k < airs.size(); ++k) {
-        int32_t id = stb.air_ids[k];
-        if (id < 0 || (size_t)id >= n_dummy) return -1;
-        airs[k].width = dummy[id].width; airs[k].height = dummy[id].height; airs[k].buffer = dummy[id].buffer;
-        airs[k].row_block_size = stb.row_block[k];
-    }
-    if (!airs.empty()) PW_HIP_TRY(hipMemcpyAsync(stb.d_airs, airs.data(), airs.size() * sizeof(OriginalAir), hipMemcpyHostToDevice, st));
-    PW_HIP_TRY(hipStreamSynchronize(st));  // `airs` is a local
-    int rc = _apc_tracegen(d_output, height, stb.d_airs, stb.d_subs, stb.subs.size(), (int)num_calls);
+    const PowdrApc::SubTables& stb = *stb_p;
+    // host copies of both tables are at hand: no device-to-host round trip to find the gather plan
+    rc = powdr_apc_tracegen_host_tables(d_output, height, d_airs, airs.data(), airs.size(), stb.subs.data(), stb.subs.size(), (int)num_calls);
     if (rc) return rc;
 
     // ---- derived columns + bus interactions, compiled once per height ----
     // Traces with width*height >= 2^32 cannot be addressed by the reference's u32 element offsets:
     // compile with column-index operands and use the *_cols entry points instead.
     const bool wide = (uint64_t)width * (uint64_t)height > 0xffffffffull;
+    std::unique_lock<std::mutex> lk(apc->mu);
     auto ct = apc->compiled.find(height);
     if (ct == apc->compiled.end()) {
         PowdrApc::Compiled c;
@@ -528,20 +569,22 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
         c.n_specs = d.specs.size(); c.bbc_len = b.bc.size(); c.n_inter = b.inter.size(); c.n_spans = b.spans.size();
         if ((rc = upload(c.d_specs, d.specs)) || (rc = upload(c.d_dbc, d.bc)) || (rc = upload(c.d_bbc, b.bc)) ||
             (rc = upload(c.d_inter, b.inter)) || (rc = upload(c.d_spans, b.spans))) return rc;
+        c.h_bbc = std::make_shared<const std::vector<uint32_t>>(std::move(b.bc));
+        c.h_inter = std::make_shared<const std::vector<DevInteraction>>(std::move(b.inter));
+        c.h_spans = std::make_shared<const std::vector<ExprSpan>>(std::move(b.spans));
         ct = apc->compiled.emplace(height, c).first;
     }
-    const PowdrApc::Compiled& c = ct->second;
+    const PowdrApc::Compiled c = ct->second;  // device tables are immutable once uploaded
+    lk.unlock();
     rc = wide ? powdr_apc_apply_derived_expr_cols(d_output, height, (int)num_calls, c.d_specs, c.n_specs, c.d_dbc)
               : _apc_apply_derived_expr(d_output, height, (int)num_calls, c.d_specs, c.n_specs, c.d_dbc);
     if (rc) return rc;
     if (per) {
-        rc = wide ? powdr_apc_apply_bus_cols(d_output, height, (int)num_calls, c.d_bbc, c.bbc_len, c.d_inter, c.n_inter, c.d_spans,
-                                             c.n_spans, per->var_range_bus_id, per->d_var_hist, per->var_num_bins,
-                                             per->tuple2_bus_id, per->d_tuple2_hist, per->tuple2_sz0, per->tuple2_sz1,
-                                             per->bitwise_bus_id, per->d_bitwise_hist)
-                  : _apc_apply_bus(d_output, (int)num_calls, c.d_bbc, c.bbc_len, c.d_inter, c.n_inter, c.d_spans, c.n_spans,
-                                   per->var_range_bus_id, per->d_var_hist, per->var_num_bins, per->tuple2_bus_id, per->d_tuple2_hist,
-                                   per->tuple2_sz0, per->tuple2_sz1, per->bitwise_bus_id, per->d_bitwise_hist);
+        rc = powdr_apc_apply_bus_host_tables(d_output, wide ? height : 0, (int)num_calls, c.d_bbc, c.h_bbc->data(), c.bbc_len, c.d_inter,
+                                             c.h_inter->data(), c.n_inter, c.d_spans, c.h_spans->data(), c.n_spans,
+                                             per->var_range_bus_id, per->d_var_hist, per->var_num_bins, per->tuple2_bus_id,
+                                             per->d_tuple2_hist, per->tuple2_sz0, per->tuple2_sz1, per->bitwise_bus_id,
+                                             per->d_bitwise_hist);
         if (rc) return rc;
     }
     return 0;

@@ -131,6 +131,9 @@ int verify_impl(const PwStarkConfig* cfg, uint32_t width, uint32_t log_h, const 
     hdr.push_back(cfg->num_queries);
     hdr.push_back(cfg->pow_bits);
     for (uint32_t h : hdr) if (get() != h) return 1;
+    // proof words are canonical field elements (indices, the witness and the header are far below p as well): a word >= p
+    // would be a second encoding of the same element, i.e. a malleable proof
+    for (size_t i = 0; i < len; ++i) if (proof[i] >= bb::P) return 13;
     Transcript ch;
     for (uint32_t h : hdr) ch.observe(bb::to_monty(h % bb::P));
 

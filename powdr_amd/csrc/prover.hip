@@ -213,7 +213,9 @@ int ensure_commit_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
     L.n_trees = p->logup ? 3 : 2;  // trace | quotient | (perm) | FRI
     // coefficients exist only per column panel (1 GB by default; larger panels = fewer, larger launches): iNTT -> panel ->
     // coset NTT into the resident LDE
-    static const int panel_log_words = [] { const char* e = getenv("POWDR_PANEL_LOG_WORDS"); int v = e ? atoi(e) : 28; return v < 20 || v > 32 ? 28 : v; }();
+    // (read per call, so that tests can force many small panels: floor 2^12 words, and never fewer than 8 columns)
+    int panel_log_words = 28;
+    if (const char* e = getenv("POWDR_PANEL_LOG_WORDS")) { const int v = atoi(e); if (v >= 12 && v <= 32) panel_log_words = v; }
     L.panel_cols = ((size_t)1 << panel_log_words) / L.H;
     if (L.panel_cols < 8) L.panel_cols = 8;
     const size_t widest = p->logup ? std::max<size_t>(p->width, 4 * ((size_t)p->n_groups + 1)) : p->width;

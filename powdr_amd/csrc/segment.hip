@@ -51,13 +51,22 @@ int for_each_air(const std::vector<size_t>& order, unsigned n_workers, F fn) {
     }
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return (int)hipGetLastError();
+    // Ordering contract (powdr_prover.h): everything the caller enqueued on ITS launch stream before this call — the
+    // trace generation kernels of _apc_tracegen / _apc_apply_* in particular — happens before any worker touches a trace.
+    // The worker streams are non-blocking (they do not synchronise with the null stream implicitly), so the dependency is
+    // an event recorded on the caller's stream that every worker stream waits for.
+    hipEvent_t ready = nullptr;
+    if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+    if (hipEventRecord(ready, pw::stream()) != hipSuccess) { (void)hipEventDestroy(ready); return (int)hipGetLastError(); }
     std::vector<std::thread> th;
     for (unsigned t = 0; t < n_workers; ++t)
         th.emplace_back([&, device] {
             hipStream_t s = nullptr;
-            if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+            if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamWaitEvent(s, ready, 0) != hipSuccess) {
                 int expected = 0;
                 first_error.compare_exchange_strong(expected, (int)hipErrorInvalidDevice);
+                if (s) (void)hipStreamDestroy(s);
                 return;
             }
             pw::set_stream(s);
@@ -67,6 +76,7 @@ int for_each_air(const std::vector<size_t>& order, unsigned n_workers, F fn) {
             (void)hipStreamDestroy(s);
         });
     for (auto& t : th) t.join();
+    (void)hipEventDestroy(ready);
     return first_error.load();
 }
 

@@ -32,6 +32,16 @@ def test_default_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "cells/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert d["stage_ms"]["leaf_hash_kernel"] > 0 and d["gauges"]["trace_gen_time_ms"] > 0
+    # the whole step against SURVEY 8d's 48 algorithmic bytes per cell
+    ws = r["whole_step"]
+    assert ws["algo_bytes_per_cell"] == 48.0 and abs(ws["achieved_GBps"] - d["value"] * 48 / 1e9) < 1e-6 * ws["achieved_GBps"]
+    # the second timed leg: the same step with the bus argument inside the proof
+    lg = d["logup"]
+    assert lg["value"] > 0 and lg["value"] < d["value"] and lg["perm_cols"] == 4 * (lg["interaction_groups"] + 1)
+    assert lg["stage_ms"]["logup_perm_kernel"] > 0 and lg["proof_bytes"] > d["config"]["proof_bytes"]
+    assert "constraints-only" in d["metric"] and "CONSTRAINTS-ONLY" in d["config"]["workload"]
+    # no per-kernel HBM fraction for the quotient kernel (it reads only the referenced columns)
+    assert "quotient_kernel" not in d["roofline_by_kernel"]
 
 
 def test_logup_and_partial_calls_modes_run():

@@ -42,7 +42,9 @@ def from_dev(t):
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_h,W", [(1, 3), (2, 2), (3, 5), (4, 1), (5, 2), (6, 4), (7, 1), (8, 2), (9, 3), (10, 2), (11, 2),
                                       (12, 1), (13, 3), (14, 2), (15, 1), (16, 2), (17, 1), (18, 1), (19, 1), (20, 1),
-                                      (21, 1), (22, 1), (23, 1)])
+                                      (21, 1), (22, 1), (23, 1),
+                                      # many columns through the multi-pass plans (blockIdx.y > 0 in every stage group)
+                                      (17, 9), (18, 5), (20, 3), (22, 3)])
 def test_lde_matches_oracle(gpu, log_h, W):
     torch, abi, prover = gpu
     rng = np.random.default_rng(log_h)
@@ -133,6 +135,129 @@ def test_logup_proof_bytes_match_oracle(gpu, shape, calls, nq, pow_bits):
     pr0 = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits)
     assert (pr0.prove(d_t.data_ptr(), log_h) == sm.prove(flat, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits)).all()
     pr0.close()
+
+
+def _prove_both_and_compare(torch, prover, flat, W, log_h, bc, spans, it, nq, pow_bits):
+    """HIP proof == oracle proof, word for word; both verifiers accept it."""
+    if it is None:
+        want = sm.prove(flat, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits)
+    else:
+        want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=nq, pow_bits=pow_bits)
+    pr = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits, interactions=it)
+    d_t = to_dev(torch, flat)
+    got = pr.prove(d_t.data_ptr(), log_h)
+    pr.close()
+    assert len(got) == len(want)
+    assert (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
+    if it is None:
+        assert prover.verify(got, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits) == 0
+        assert sm.verify(got, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits) == 0
+    else:
+        assert prover.verify_logup(got, W, log_h, bc, spans, it, num_queries=nq, pow_bits=pow_bits)[0] == 0
+        assert sm.verify_logup(got, W, log_h, bc, spans, *it, num_queries=nq, pow_bits=pow_bits) == 0
+    return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logup", [False, True])
+def test_c2_shape_proof_bytes_match_oracle(gpu, logup):
+    """BASELINE configs[1]'s AIR itself — 2 022 columns, 187 constraints, 1 734 bus interactions (867 LogUp groups,
+    3 472 permutation columns) — at 2^14 rows, the largest height the CPU oracle proves in seconds: the trace comes
+    from the oracle's trace generation, the proof bytes of the HIP prover equal the oracle's, constraints-only (the
+    bench headline) and with the LogUp phase (the bench's `logup` leg). Shape pins of the real keccak APC:
+    /root/reference/openvm-riscv/src/lib.rs:1377-1458."""
+    torch, abi, prover = gpu
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+
+    s = synth.generate("C2", seed=0)
+    calls = (1 << 14) - 5  # a few zero-padding rows
+    apc, idx, trace, _, _ = run_oracle_gpu_convention(s, calls, seed=0)
+    W, H = trace.shape
+    assert (W, H) == (2022, 1 << 14)
+    bc, spans = sm.compile_constraints(apc, idx)
+    assert len(spans) == 187
+    it = sm.compile_interactions(apc, idx) if logup else None
+    if logup:
+        assert len(it[0]) == 1734 and len(prover.logup_group_starts(it)) - 1 == 867
+    _prove_both_and_compare(torch, prover, np.ascontiguousarray(trace).reshape(-1), W, 14, bc, spans, it, nq=8, pow_bits=8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logup", [False, True])
+def test_c1_full_size_proof_bytes_match_oracle(gpu, logup):
+    """BASELINE configs[0] (sha256-shaped single segment, 2^16 rows, 1 204 columns, 377 constraints, 954 interactions)
+    at its FULL size: oracle trace generation -> oracle proof == HIP proof (tools/run_c1_oracle.py records the
+    oracle's timings of the same run under profiles/)."""
+    torch, abi, prover = gpu
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+
+    s = synth.generate("C1", seed=1)
+    calls = (1 << 16) - 3
+    apc, idx, trace, _, _ = run_oracle_gpu_convention(s, calls, seed=1)
+    W, H = trace.shape
+    assert (W, H) == (1204, 1 << 16)
+    bc, spans = sm.compile_constraints(apc, idx)
+    it = sm.compile_interactions(apc, idx) if logup else None
+    _prove_both_and_compare(torch, prover, np.ascontiguousarray(trace).reshape(-1), W, 16, bc, spans, it, nq=6, pow_bits=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,log_h,panel_log_words,logup", [(300, 16, 21, False), (300, 16, 12, False), (1204, 12, 12, True),
+                                                            (1204, 12, 19, True), (257, 17, 20, False)])
+def test_multi_panel_lde_proof_bytes_match_oracle(gpu, monkeypatch, W, log_h, panel_log_words, logup):
+    """The LDE of a wide trace runs panel by panel through a bounded coefficient buffer (1 GB panels at C2 = 8 panels,
+    C3 = 15). POWDR_PANEL_LOG_WORDS (read per call) forces many small panels here — 8 columns per panel at the floor —
+    for the main trace and, with LogUp, for the permutation matrix; the proof bytes must not depend on the panelling."""
+    torch, abi, prover = gpu
+    monkeypatch.setenv("POWDR_PANEL_LOG_WORDS", str(panel_log_words))
+    H = 1 << log_h
+    expect_panels = -(-W // max(8, (1 << panel_log_words) // H))
+    assert expect_panels >= 5
+    if logup:
+        from tests.test_oracle_apc import run_oracle_gpu_convention
+
+        s = synth.generate("C1", seed=4)
+        apc, idx, trace, _, _ = run_oracle_gpu_convention(s, H - 9, seed=4)
+        assert trace.shape == (W, H)
+        bc, spans = sm.compile_constraints(apc, idx)
+        it = sm.compile_interactions(apc, idx)
+        flat = np.ascontiguousarray(trace).reshape(-1)
+    else:
+        rng = np.random.default_rng(W + log_h + panel_log_words)
+        flat = rng.integers(0, P, W * H, dtype=np.uint32)
+        PA, PC = om.OP_PUSH_APC, om.OP_PUSH_CONST
+        bc, spans = [], []
+        for k in range(7):
+            off = len(bc)
+            a, b, c = (int(x) for x in rng.integers(0, W, 3))
+            bc += [PA, a, PA, b, om.OP_MUL, PA, c, om.OP_MUL, PC, int(rng.integers(0, P)), om.OP_ADD]
+            spans.append((off, len(bc) - off))
+        bc, spans, it = np.array(bc, np.uint32), np.array(spans, np.uint32).reshape(-1, 2), None
+    got = _prove_both_and_compare(torch, prover, flat, W, log_h, bc, spans, it, nq=5, pow_bits=0)
+    # and the default panelling gives the same bytes
+    monkeypatch.delenv("POWDR_PANEL_LOG_WORDS")
+    pr = prover.Prover(W, bc, spans, num_queries=5, interactions=it)
+    assert (pr.prove(to_dev(torch, flat).data_ptr(), log_h) == got).all()
+    pr.close()
+
+
+@pytest.mark.gpu
+def test_non_canonical_proof_words_are_rejected(gpu):
+    """A proof word w and w + p encode the same field element; both verifiers reject the second encoding (code 13),
+    so proofs are not malleable."""
+    torch, abi, prover = gpu
+    s, flat, (W, H), bc, spans = _synthetic("T0", 30, seed=2)
+    log_h = H.bit_length() - 1
+    pr = prover.Prover(W, bc, spans, num_queries=3)
+    proof = pr.prove(to_dev(torch, flat).data_ptr(), log_h)
+    pr.close()
+    assert prover.verify(proof, W, log_h, bc, spans, num_queries=3) == 0
+    for pos in (6, 20, len(proof) - 1):
+        bad = proof.copy()
+        if int(bad[pos]) + P < (1 << 32):
+            bad[pos] = int(bad[pos]) + P
+            assert prover.verify(bad, W, log_h, bc, spans, num_queries=3) == 13
+            assert sm.verify(bad, W, log_h, bc, spans, num_queries=3) == 13
 
 
 @pytest.mark.gpu
