@@ -33,6 +33,56 @@ typedef struct PowdrApc PowdrApc;
 PowdrApc* powdr_apc_from_json(const char* json, size_t len, char* err, size_t err_cap);
 void powdr_apc_free(PowdrApc* apc);
 
+/* ---- artifact readers: APCs produced on a machine with the Rust toolchain, replayed here without it ----
+ * Every reader accepts any document that CONTAINS `Apc` maps (keys block, machine, subs) and addresses them by their
+ * position in document order:
+ *   - `apc_candidate_<pcs>_<seq>[_suffix].json`: `ApcWithBusMap{#[serde(flatten)] apc, bus_map}`
+ *     (/root/reference/autoprecompiles/src/export.rs:77-93,271-276; the reference's own tests/*.json.gz fixtures are such
+ *     files): one Apc at the top level, plus the bus map (below);
+ *   - the CLI's stage caches `<artifacts-dir>/<stage>/<hash>/artifact.cbor`, written with serde_cbor
+ *     (/root/reference/cli-openvm-riscv/src/main.rs:380-407): stage `select` = Vec<ApcWithStats{apc, stats,
+ *     evaluation_result}> (autoprecompiles/src/adapter.rs:22-27, main.rs:308-336), stage `setup` = the CompiledProgram
+ *     whose PowdrExtension carries the selected APCs (main.rs:340-355). Instructions serialised as structs
+ *     ({"opcode": n, "a": ..}) instead of the export's [opcode, a..g] arrays are accepted.
+ * index >= count -> NULL with an error message. */
+PowdrApc* powdr_apc_from_json_at(const char* json, size_t len, size_t index, char* err, size_t err_cap);
+size_t powdr_apc_count_in_json(const char* json, size_t len);
+PowdrApc* powdr_apc_from_cbor(const uint8_t* bytes, size_t len, size_t index, char* err, size_t err_cap);
+size_t powdr_apc_count_in_cbor(const uint8_t* bytes, size_t len);
+
+/* The bus map of an ApcWithBusMap export (autoprecompiles/src/bus_map.rs:4-16 BusType, OpenVM's custom types
+ * openvm-bus-interaction-handler/src/bus_map.rs:17-21). 0 entries when the document had none. */
+enum {
+    POWDR_BUS_EXECUTION_BRIDGE = 0, POWDR_BUS_MEMORY = 1, POWDR_BUS_PC_LOOKUP = 2, POWDR_BUS_VARIABLE_RANGE_CHECKER = 3,
+    POWDR_BUS_BITWISE_LOOKUP = 4, POWDR_BUS_TUPLE_RANGE_CHECKER = 5, POWDR_BUS_OTHER = 6
+};
+size_t powdr_apc_bus_map_len(const PowdrApc* apc);
+/* entry i: bus id, kind (above), tuple sizes (TupleRangeChecker only), variant name. Returns 0, -1 if out of range. */
+int powdr_apc_bus_map_entry(const PowdrApc* apc, size_t i, uint64_t* bus_id, uint32_t* kind, uint32_t* sizes2, char* name,
+                            size_t name_cap);
+
+/* `apc_candidates.json` of cell PGO (/root/reference/autoprecompiles/src/pgo/cell/mod.rs:34-97, JSON_EXPORT_VERSION 4;
+ * versions 0-3 are read as far as their fields go): per candidate the execution frequency, the AIR statistics before
+ * and after optimisation (evaluation.rs:12-21,50-59), and the ranking values. The file holds no machines — it tells
+ * which candidates exist and how wide / how often; the machines are in the apc_candidate_*.json files. */
+typedef struct { uint64_t main_columns, constraints, bus_interactions; } PowdrAirStats;
+typedef struct {
+    uint64_t execution_frequency;
+    uint64_t start_pc;        /* of the first original block */
+    uint32_t n_blocks;        /* superblocks: > 1 */
+    uint32_t n_instructions;  /* over all original blocks */
+    PowdrAirStats before, after;
+    uint64_t width_before, value;
+    double cost_before, cost_after;
+} PowdrApcCandidateInfo;
+typedef struct PowdrApcCandidates PowdrApcCandidates;
+PowdrApcCandidates* powdr_apc_candidates_from_json(const char* json, size_t len, char* err, size_t err_cap);
+void powdr_apc_candidates_free(PowdrApcCandidates* c);
+uint64_t powdr_apc_candidates_version(const PowdrApcCandidates* c);
+size_t powdr_apc_candidates_count(const PowdrApcCandidates* c);
+size_t powdr_apc_candidates_num_labels(const PowdrApcCandidates* c);
+int powdr_apc_candidates_get(const PowdrApcCandidates* c, size_t i, PowdrApcCandidateInfo* out);
+
 /* machine.main_columns().count(): unique references of constraints + bus interactions */
 uint32_t powdr_apc_width(const PowdrApc* apc);
 /* ascending poly ids; column index = position (autoprecompiles/src/powdr.rs:44-57) */
@@ -79,6 +129,11 @@ typedef struct {
     uint32_t bitwise_bus_id;
     uint32_t* d_bitwise_hist;
 } PowdrPeriphery;
+
+/* Bus ids (and the tuple checker's sizes) of the three periphery buses from the APC's bus map — what the reference reads
+ * from the VM's AIR inventory at run time (openvm/src/lib.rs:337-364). Histogram pointers and var_num_bins are left
+ * untouched. Returns how many of the three were found. */
+int powdr_apc_periphery_from_bus_map(const PowdrApc* apc, PowdrPeriphery* periphery);
 
 /* try_generate_witness (cuda/mod.rs:201-401): d_output must hold
  * width * next_power_of_two_or_zero(num_apc_calls) words; it is zero-filled here

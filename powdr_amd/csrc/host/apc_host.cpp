@@ -3,6 +3,7 @@
 #include "../common.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,8 @@ struct JVal {
     bool b = false;
     bool neg = false;
     uint64_t u = 0;  // magnitude of an integer number
+    bool is_float = false;
+    double d = 0.0;  // value of a non-integer number (cost_before / cost_after of apc_candidates.json; CBOR floats)
     std::string s;
     std::vector<JPtr> arr;
     std::vector<std::pair<std::string, JPtr>> obj;
@@ -85,8 +88,15 @@ struct JParser {
             v->kind = JVal::Num;
             if (c == '-') { v->neg = true; ++p; }
             if (p >= end || *p < '0' || *p > '9') fail("bad number");
+            const char* num0 = p;
             while (p < end && *p >= '0' && *p <= '9') { v->u = v->u * 10 + (uint64_t)(*p - '0'); ++p; }
-            if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) fail("non-integer number");
+            if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) {  // a float: only statistics carry them, never field elements
+                while (p < end && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) ++p;
+                v->is_float = true;
+                v->d = strtod(std::string(num0, p).c_str(), nullptr);
+                if (v->neg) v->d = -v->d;
+                v->u = 0;
+            } else v->d = v->neg ? -(double)v->u : (double)v->u;
         } else if (!strncmp(p, "true", 4)) { v->kind = JVal::Bool; v->b = true; p += 4; }
         else if (!strncmp(p, "false", 5)) { v->kind = JVal::Bool; p += 5; }
         else if (!strncmp(p, "null", 4)) { p += 4; }
@@ -126,6 +136,116 @@ struct JParser {
     }
 };
 
+// ---------------------------------------------------------------------------------- CBOR
+// RFC 8949 subset that serde_cbor emits for the reference's artifacts (cli-openvm-riscv/src/main.rs:380-407:
+// `serde_cbor::to_writer(file, value)`): the same serde data model as the JSON export — structs are maps with text
+// keys, sequences are arrays, newtype enum variants one-entry maps, unit variants text, Option::None null, field
+// elements canonical unsigned integers — so it decodes into the same DOM and the same builders run on it.
+// Indefinite-length items, tags (skipped), byte strings (kept as Str) and half/single/double floats are handled.
+struct CborParser {
+    const uint8_t* p;
+    const uint8_t* end;
+    const uint8_t* begin;
+    int depth = 0;
+    CborParser(const uint8_t* s, size_t n) : p(s), end(s + n), begin(s) {}
+    [[noreturn]] void fail(const char* what) const {
+        throw std::runtime_error(std::string("CBOR: ") + what + " at byte " + std::to_string((size_t)(p - begin)));
+    }
+    uint8_t byte() { if (p >= end) fail("unexpected end"); return *p++; }
+    uint64_t arg(uint8_t info) {
+        if (info < 24) return info;
+        int n = info == 24 ? 1 : info == 25 ? 2 : info == 26 ? 4 : info == 27 ? 8 : 0;
+        if (!n) fail("reserved additional information");
+        uint64_t v = 0;
+        for (int i = 0; i < n; ++i) v = (v << 8) | byte();
+        return v;
+    }
+    static double half_to_double(uint16_t h) {
+        const int e = (h >> 10) & 31, m = h & 1023;
+        double v = e == 0 ? ldexp((double)m, -24) : e == 31 ? (m ? NAN : INFINITY) : ldexp((double)(m + 1024), e - 25);
+        return (h & 0x8000) ? -v : v;
+    }
+    std::string text(uint8_t info, uint8_t major) {
+        std::string out;
+        if (info == 31) {  // indefinite: chunks until break
+            for (;;) {
+                const uint8_t b = byte();
+                if (b == 0xff) break;
+                if ((b >> 5) != major) fail("bad string chunk");
+                const uint64_t n = arg(b & 31);
+                if ((uint64_t)(end - p) < n) fail("string past the end");
+                out.append((const char*)p, (size_t)n);
+                p += n;
+            }
+            return out;
+        }
+        const uint64_t n = arg(info);
+        if ((uint64_t)(end - p) < n) fail("string past the end");
+        out.assign((const char*)p, (size_t)n);
+        p += n;
+        return out;
+    }
+    JPtr parse() {
+        if (++depth > 4096) fail("nesting too deep");
+        JPtr v(new JVal());
+        uint8_t b = byte();
+        while ((b >> 5) == 6) { (void)arg(b & 31); b = byte(); }  // tags: transparent
+        const uint8_t major = b >> 5, info = b & 31;
+        switch (major) {
+            case 0: v->kind = JVal::Num; v->u = arg(info); v->d = (double)v->u; break;
+            case 1: v->kind = JVal::Num; v->u = arg(info) + 1; v->neg = true; v->d = -(double)v->u; break;  // -1 - n
+            case 2: case 3: v->kind = JVal::Str; v->s = text(info, major); break;
+            case 4:
+                v->kind = JVal::Arr;
+                if (info == 31) { while (p < end && *p != 0xff) v->arr.push_back(parse()); (void)byte(); }
+                else { const uint64_t n = arg(info); if (n > (uint64_t)(end - p)) fail("array longer than the input"); v->arr.reserve((size_t)n); for (uint64_t i = 0; i < n; ++i) v->arr.push_back(parse()); }
+                break;
+            case 5: {
+                v->kind = JVal::Obj;
+                auto entry = [&] {
+                    JPtr k = parse();
+                    std::string key = k->kind == JVal::Str ? k->s : k->kind == JVal::Num ? std::to_string(k->u) : std::string();
+                    if (k->kind != JVal::Str && k->kind != JVal::Num) fail("unsupported map key type");
+                    v->obj.emplace_back(std::move(key), parse());
+                };
+                if (info == 31) { while (p < end && *p != 0xff) entry(); (void)byte(); }
+                else { const uint64_t n = arg(info); if (n > (uint64_t)(end - p)) fail("map longer than the input"); for (uint64_t i = 0; i < n; ++i) entry(); }
+                break;
+            }
+            default:  // 7: simple values and floats
+                if (info == 20 || info == 21) { v->kind = JVal::Bool; v->b = info == 21; }
+                else if (info == 22 || info == 23) { /* null / undefined */ }
+                else if (info == 25) { v->kind = JVal::Num; v->is_float = true; v->d = half_to_double((uint16_t)arg(info)); }
+                else if (info == 26) { uint32_t w = (uint32_t)arg(info); float f; memcpy(&f, &w, 4); v->kind = JVal::Num; v->is_float = true; v->d = f; }
+                else if (info == 27) { uint64_t w = arg(info); double d; memcpy(&d, &w, 8); v->kind = JVal::Num; v->is_float = true; v->d = d; }
+                else if (info == 24) { (void)byte(); }
+                else if (info < 20) { /* unassigned simple value: null */ }
+                else fail("unexpected break / reserved simple value");
+        }
+        --depth;
+        return v;
+    }
+};
+
+// Every map of a document that looks like an `Apc` (keys block, machine, subs), in document order: the export files
+// carry one at the top level (flattened into ApcWithBusMap, autoprecompiles/src/export.rs:271-276), the CLI's `select`
+// artifact is a sequence of ApcWithStats{apc, stats, evaluation_result} (adapter.rs:22-27), the `setup` artifact nests
+// them inside the VM configuration's PowdrExtension.
+void find_apcs(const JVal& v, std::vector<const JVal*>& out) {
+    std::vector<const JVal*> st{&v};
+    while (!st.empty()) {
+        const JVal* x = st.back();
+        st.pop_back();
+        if (x->kind == JVal::Obj) {
+            const JVal* m = x->get("machine");
+            if (x->get("block") && x->get("subs") && m && m->kind == JVal::Obj && m->get("constraints")) { out.push_back(x); continue; }
+            for (auto it = x->obj.rbegin(); it != x->obj.rend(); ++it) st.push_back(it->second.get());
+        } else if (x->kind == JVal::Arr) {
+            for (auto it = x->arr.rbegin(); it != x->arr.rend(); ++it) st.push_back(it->get());
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------- model
 enum NodeKind : uint8_t { N_NUM, N_REF, N_ADD, N_SUB, N_MUL, N_NEG };
 struct Node { NodeKind kind; uint32_t a, b; };  // NUM: a = canonical value; REF: a = index into refs; NEG: a = child
@@ -145,6 +265,9 @@ struct PowdrApc {
     std::vector<std::vector<Sub>> subs;
     std::vector<uint64_t> poly_ids;                    // ascending
     std::unordered_map<uint64_t, uint32_t> id_to_index;
+    // bus_map of an ApcWithBusMap export (autoprecompiles/src/bus_map.rs: {"bus_ids": {id: type}}); empty if absent
+    struct BusMapEntry { uint64_t id; uint32_t kind; uint32_t sizes[2]; std::string name; };
+    std::vector<BusMapEntry> bus_map;
 
     // device-side caches for generate_witness_gpu, keyed by trace height
     struct Compiled {
@@ -334,82 +457,259 @@ uint64_t fnv(const void* p, size_t n) { uint64_t h = 1469598103934665603ull; aut
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-PowdrApc* powdr_apc_from_json(const char* json, size_t len, char* err, size_t err_cap) {
+// bus_map: {"bus_ids": {"<id>": "ExecutionBridge" | "Memory" | "PcLookup" | {"Other": "VariableRangeChecker" | "BitwiseLookup" |
+// {"TupleRangeChecker": [sz0, sz1]}}}} (autoprecompiles/src/bus_map.rs:4-16, openvm-bus-interaction-handler/src/bus_map.rs:17-21)
+void parse_bus_map(PowdrApc& apc, const JVal& bm) {
+    const JVal* ids = bm.get("bus_ids");
+    if (!ids || ids->kind != JVal::Obj) return;
+    for (auto& kv : ids->obj) {
+        PowdrApc::BusMapEntry e{};
+        e.id = strtoull(kv.first.c_str(), nullptr, 10);
+        const JVal* t = kv.second.get();
+        e.kind = POWDR_BUS_OTHER;
+        auto named = [&](const std::string& n) {
+            e.name = n;
+            if (n == "ExecutionBridge") e.kind = POWDR_BUS_EXECUTION_BRIDGE;
+            else if (n == "Memory") e.kind = POWDR_BUS_MEMORY;
+            else if (n == "PcLookup") e.kind = POWDR_BUS_PC_LOOKUP;
+            else if (n == "VariableRangeChecker") e.kind = POWDR_BUS_VARIABLE_RANGE_CHECKER;
+            else if (n == "BitwiseLookup") e.kind = POWDR_BUS_BITWISE_LOOKUP;
+            else if (n == "TupleRangeChecker") e.kind = POWDR_BUS_TUPLE_RANGE_CHECKER;
+        };
+        if (t->kind == JVal::Str) named(t->s);
+        else if (t->kind == JVal::Obj && t->obj.size() == 1) {
+            const JVal* o = t->obj[0].second.get();  // {"Other": ...}
+            if (t->obj[0].first != "Other") { named(t->obj[0].first); o = nullptr; }
+            if (o && o->kind == JVal::Str) named(o->s);
+            else if (o && o->kind == JVal::Obj && o->obj.size() == 1) {
+                named(o->obj[0].first);
+                const JVal* sz = o->obj[0].second.get();
+                if (sz->kind == JVal::Arr) for (size_t k = 0; k < sz->arr.size() && k < 2; ++k) e.sizes[k] = (uint32_t)sz->arr[k]->u;
+            }
+        }
+        apc.bus_map.push_back(std::move(e));
+    }
+}
+
+// One `Apc` from its DOM (JSON or CBOR): keys block, machine{constraints, bus_interactions, derived_columns}, subs [, bus_map]
+std::unique_ptr<PowdrApc> build_apc_from_dom(const JVal& root) {
     std::unique_ptr<PowdrApc> apc(new PowdrApc());
-    try {
-        JParser jp(json, len);
-        JPtr root = jp.parse();
-        const JVal* block = root->get("block");
-        const JVal* machine = root->get("machine");
-        const JVal* subs = root->get("subs");
-        if (!block || !machine || !subs) throw std::runtime_error("missing block/machine/subs");
-        const JVal* blocks = block->get("blocks");
-        if (!blocks) throw std::runtime_error("missing block.blocks");
-        for (auto& b : blocks->arr) {
-            const JVal* ins = b->get("instructions");
-            if (!ins) throw std::runtime_error("missing instructions");
-            for (auto& i : ins->arr) {
-                std::vector<uint32_t> v;
+    const JVal* block = root.get("block");
+    const JVal* machine = root.get("machine");
+    const JVal* subs = root.get("subs");
+    if (!block || !machine || !subs) throw std::runtime_error("missing block/machine/subs");
+    const JVal* blocks = block->get("blocks");
+    if (!blocks) throw std::runtime_error("missing block.blocks");
+    for (auto& b : blocks->arr) {
+        const JVal* ins = b->get("instructions");
+        if (!ins) throw std::runtime_error("missing instructions");
+        for (auto& i : ins->arr) {
+            std::vector<uint32_t> v;
+            if (i->kind == JVal::Arr) {  // export files: SimpleInstruction = [opcode, a, b, c, d, e, f, g] (export.rs:221-251)
                 for (auto& x : i->arr) v.push_back((uint32_t)x->u);
-                apc->instructions.push_back(std::move(v));
-            }
+            } else if (i->kind == JVal::Obj) {  // serde of the VM's own instruction struct: {"opcode": n, "a": .., ...}
+                const JVal* ins_obj = i.get();
+                while (ins_obj->kind == JVal::Obj && ins_obj->obj.size() == 1 && !ins_obj->get("opcode")) ins_obj = ins_obj->obj[0].second.get();  // newtype wrappers
+                const JVal* op = ins_obj->kind == JVal::Obj ? ins_obj->get("opcode") : nullptr;
+                if (!op) throw std::runtime_error("instruction without an opcode");
+                v.push_back((uint32_t)op->u);
+                for (const char* f : {"a", "b", "c", "d", "e", "f", "g"}) if (const JVal* x = ins_obj->get(f)) v.push_back(x->kind == JVal::Num ? (uint32_t)x->u : 0u);
+            } else throw std::runtime_error("cannot parse instruction");
+            apc->instructions.push_back(std::move(v));
         }
-        for (auto& row : subs->arr) {
-            std::vector<Sub> r;
-            for (auto& s : row->arr) {
-                const JVal* o = s->get("original_poly_index");
-                const JVal* a = s->get("apc_poly_id");
-                if (!o || !a) throw std::runtime_error("bad substitution");
-                r.push_back({(uint32_t)o->u, a->u});
-            }
-            apc->subs.push_back(std::move(r));
+    }
+    for (auto& row : subs->arr) {
+        std::vector<Sub> r;
+        for (auto& s : row->arr) {
+            const JVal* o = s->get("original_poly_index");
+            const JVal* a = s->get("apc_poly_id");
+            if (!o || !a) throw std::runtime_error("bad substitution");
+            r.push_back({(uint32_t)o->u, a->u});
         }
-        if (apc->subs.size() != apc->instructions.size()) throw std::runtime_error("subs / instructions length mismatch (zip_eq)");
-        const JVal* cons = machine->get("constraints");
-        const JVal* buses = machine->get("bus_interactions");
-        const JVal* derived = machine->get("derived_columns");
-        if (!cons || !buses || !derived) throw std::runtime_error("missing machine fields");
-        for (auto& c : cons->arr) apc->constraints.push_back(build_expr(*apc, *c));
-        for (auto& b : buses->arr) {
-            BusInteraction bi;
-            const JVal* id = b->get("id"); const JVal* m = b->get("mult"); const JVal* args = b->get("args");
-            if (!id || !m || !args) throw std::runtime_error("bad bus interaction");
-            bi.id = (uint32_t)id->u;
-            bi.mult = build_expr(*apc, *m);
-            for (auto& a : args->arr) bi.args.push_back(build_expr(*apc, *a));
-            apc->buses.push_back(std::move(bi));
-        }
-        for (auto& d : derived->arr) {
-            if (d->kind != JVal::Arr || d->arr.size() != 2) throw std::runtime_error("bad derived column");
-            Derived dv{};
-            dv.poly_id = parse_ref(d->arr[0]->s);
-            const JVal& method = *d->arr[1];
-            if (const JVal* c = method.get("Constant")) { dv.is_const = true; dv.constant = field_of(*c); }
-            else if (const JVal* q = method.get("QuotientOrZero")) {
-                if (q->arr.size() != 2) throw std::runtime_error("bad QuotientOrZero");
-                dv.e1 = build_expr(*apc, *q->arr[0]);
-                dv.e2 = build_expr(*apc, *q->arr[1]);
-            } else throw std::runtime_error("unknown ComputationMethod");
-            apc->derived.push_back(dv);
-        }
-        // main_columns: unique references in constraints and bus interactions, ascending id
-        std::vector<uint64_t> ids;
-        for (uint32_t c : apc->constraints) collect_refs(*apc, c, ids);
-        for (auto& b : apc->buses) { collect_refs(*apc, b.mult, ids); for (uint32_t a : b.args) collect_refs(*apc, a, ids); }
-        std::sort(ids.begin(), ids.end());
-        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-        apc->poly_ids = ids;
-        for (size_t i = 0; i < ids.size(); ++i) apc->id_to_index[ids[i]] = (uint32_t)i;
-        // every substitution / derived target must be a main column (the reference indexes the BTreeMap)
-        for (auto& row : apc->subs) for (auto& s : row) if (!apc->id_to_index.count(s.apc_poly_id)) throw std::runtime_error("substitution targets an unknown column");
-        for (auto& d : apc->derived) if (!apc->id_to_index.count(d.poly_id)) throw std::runtime_error("derived column is not a main column");
+        apc->subs.push_back(std::move(r));
+    }
+    if (apc->subs.size() != apc->instructions.size()) throw std::runtime_error("subs / instructions length mismatch (zip_eq)");
+    const JVal* cons = machine->get("constraints");
+    const JVal* buses = machine->get("bus_interactions");
+    const JVal* derived = machine->get("derived_columns");
+    if (!cons || !buses || !derived) throw std::runtime_error("missing machine fields");
+    for (auto& c : cons->arr) apc->constraints.push_back(build_expr(*apc, *c));
+    for (auto& b : buses->arr) {
+        BusInteraction bi;
+        const JVal* id = b->get("id"); const JVal* m = b->get("mult"); const JVal* args = b->get("args");
+        if (!id || !m || !args) throw std::runtime_error("bad bus interaction");
+        bi.id = (uint32_t)id->u;
+        bi.mult = build_expr(*apc, *m);
+        for (auto& a : args->arr) bi.args.push_back(build_expr(*apc, *a));
+        apc->buses.push_back(std::move(bi));
+    }
+    for (auto& d : derived->arr) {
+        if (d->kind != JVal::Arr || d->arr.size() != 2) throw std::runtime_error("bad derived column");
+        Derived dv{};
+        dv.poly_id = parse_ref(d->arr[0]->s);
+        const JVal& method = *d->arr[1];
+        if (const JVal* c = method.get("Constant")) { dv.is_const = true; dv.constant = field_of(*c); }
+        else if (const JVal* q = method.get("QuotientOrZero")) {
+            if (q->arr.size() != 2) throw std::runtime_error("bad QuotientOrZero");
+            dv.e1 = build_expr(*apc, *q->arr[0]);
+            dv.e2 = build_expr(*apc, *q->arr[1]);
+        } else throw std::runtime_error("unknown ComputationMethod");
+        apc->derived.push_back(dv);
+    }
+    // main_columns: unique references in constraints and bus interactions, ascending id
+    std::vector<uint64_t> ids;
+    for (uint32_t c : apc->constraints) collect_refs(*apc, c, ids);
+    for (auto& b : apc->buses) { collect_refs(*apc, b.mult, ids); for (uint32_t a : b.args) collect_refs(*apc, a, ids); }
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    apc->poly_ids = ids;
+    for (size_t i = 0; i < ids.size(); ++i) apc->id_to_index[ids[i]] = (uint32_t)i;
+    // every substitution / derived target must be a main column (the reference indexes the BTreeMap)
+    for (auto& row : apc->subs) for (auto& s : row) if (!apc->id_to_index.count(s.apc_poly_id)) throw std::runtime_error("substitution targets an unknown column");
+    for (auto& d : apc->derived) if (!apc->id_to_index.count(d.poly_id)) throw std::runtime_error("derived column is not a main column");
+    if (const JVal* bm = root.get("bus_map")) parse_bus_map(*apc, *bm);
+    return apc;
+}
+
+PowdrApc* apc_at(const JVal& root, size_t index, char* err, size_t err_cap) {
+    try {
+        std::vector<const JVal*> found;
+        find_apcs(root, found);
+        if (found.empty()) throw std::runtime_error("missing block/machine/subs: no Apc in the document");
+        if (index >= found.size()) throw std::runtime_error("Apc index " + std::to_string(index) + " out of range (" + std::to_string(found.size()) + " in the document)");
+        return build_apc_from_dom(*found[index]).release();
     } catch (const std::exception& e) {
         if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
         return nullptr;
     }
-    return apc.release();
+}
+
+template <class F> size_t count_apcs(F parse_root) {
+    try {
+        JPtr root = parse_root();
+        std::vector<const JVal*> found;
+        find_apcs(*root, found);
+        return found.size();
+    } catch (const std::exception&) {
+        return 0;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+PowdrApc* powdr_apc_from_json_at(const char* json, size_t len, size_t index, char* err, size_t err_cap) {
+    JPtr root;
+    try {
+        JParser jp(json, len);
+        root = jp.parse();
+    } catch (const std::exception& e) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+        return nullptr;
+    }
+    return apc_at(*root, index, err, err_cap);
+}
+PowdrApc* powdr_apc_from_json(const char* json, size_t len, char* err, size_t err_cap) { return powdr_apc_from_json_at(json, len, 0, err, err_cap); }
+size_t powdr_apc_count_in_json(const char* json, size_t len) { return count_apcs([&] { JParser jp(json, len); return jp.parse(); }); }
+
+PowdrApc* powdr_apc_from_cbor(const uint8_t* bytes, size_t len, size_t index, char* err, size_t err_cap) {
+    JPtr root;
+    try {
+        CborParser cp(bytes, len);
+        root = cp.parse();
+    } catch (const std::exception& e) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+        return nullptr;
+    }
+    return apc_at(*root, index, err, err_cap);
+}
+size_t powdr_apc_count_in_cbor(const uint8_t* bytes, size_t len) { return count_apcs([&] { CborParser cp(bytes, len); return cp.parse(); }); }
+
+size_t powdr_apc_bus_map_len(const PowdrApc* apc) { return apc->bus_map.size(); }
+int powdr_apc_bus_map_entry(const PowdrApc* apc, size_t i, uint64_t* bus_id, uint32_t* kind, uint32_t* sizes2, char* name, size_t name_cap) {
+    if (i >= apc->bus_map.size()) return -1;
+    const auto& e = apc->bus_map[i];
+    if (bus_id) *bus_id = e.id;
+    if (kind) *kind = e.kind;
+    if (sizes2) { sizes2[0] = e.sizes[0]; sizes2[1] = e.sizes[1]; }
+    if (name && name_cap) snprintf(name, name_cap, "%s", e.name.c_str());
+    return 0;
+}
+int powdr_apc_periphery_from_bus_map(const PowdrApc* apc, PowdrPeriphery* per) {
+    int found = 0;
+    for (const auto& e : apc->bus_map) {
+        if (e.kind == POWDR_BUS_VARIABLE_RANGE_CHECKER) { per->var_range_bus_id = (uint32_t)e.id; ++found; }
+        else if (e.kind == POWDR_BUS_BITWISE_LOOKUP) { per->bitwise_bus_id = (uint32_t)e.id; ++found; }
+        else if (e.kind == POWDR_BUS_TUPLE_RANGE_CHECKER) { per->tuple2_bus_id = (uint32_t)e.id; per->tuple2_sz0 = e.sizes[0]; per->tuple2_sz1 = e.sizes[1]; ++found; }
+    }
+    return found;
+}
+
+// ---- apc_candidates.json (autoprecompiles/src/pgo/cell/mod.rs:34-97) ----
+struct PowdrApcCandidates {
+    uint64_t version = 0;
+    std::vector<PowdrApcCandidateInfo> apcs;
+    size_t n_labels = 0;
+};
+
+PowdrApcCandidates* powdr_apc_candidates_from_json(const char* json, size_t len, char* err, size_t err_cap) {
+    std::unique_ptr<PowdrApcCandidates> out(new PowdrApcCandidates());
+    try {
+        JParser jp(json, len);
+        JPtr root = jp.parse();
+        const JVal* apcs = root->kind == JVal::Arr ? root.get() : root->get("apcs");  // version 0 was a bare array
+        if (const JVal* v = root->get("version")) out->version = v->u;
+        if (!apcs || apcs->kind != JVal::Arr) throw std::runtime_error("missing apcs");
+        if (const JVal* l = root->get("labels")) out->n_labels = l->obj.size();
+        auto stats = [](const JVal* s, PowdrAirStats& o) {
+            if (!s) throw std::runtime_error("missing stats");
+            const JVal* m = s->get("main_columns"); const JVal* c = s->get("constraints"); const JVal* b = s->get("bus_interactions");
+            if (!m || !c || !b) throw std::runtime_error("bad AirStats");
+            o.main_columns = m->u; o.constraints = c->u; o.bus_interactions = b->u;
+        };
+        for (auto& a : apcs->arr) {
+            PowdrApcCandidateInfo ci{};
+            const JVal* f = a->get("execution_frequency");
+            const JVal* st = a->get("stats");
+            if (!f || !st) throw std::runtime_error("bad candidate");
+            ci.execution_frequency = f->u;
+            stats(st->get("before"), ci.before);
+            stats(st->get("after"), ci.after);
+            // version >= 4: original_blocks (superblocks); 2..3: original_block; each {start_pc, instructions}
+            const JVal* blocks = a->get("original_blocks");
+            std::vector<const JVal*> bl;
+            if (blocks && blocks->kind == JVal::Arr) for (auto& b : blocks->arr) bl.push_back(b.get());
+            else if (const JVal* b1 = a->get("original_block")) bl.push_back(b1);
+            ci.n_blocks = (uint32_t)bl.size();
+            for (size_t k = 0; k < bl.size(); ++k) {
+                if (const JVal* pc = bl[k]->get("start_pc")) { if (k == 0) ci.start_pc = pc->u; }
+                const JVal* ins = bl[k]->get("instructions");
+                if (!ins) ins = bl[k]->get("statements");  // version < 2
+                if (ins) ci.n_instructions += (uint32_t)ins->arr.size();
+            }
+            if (const JVal* w = a->get("width_before")) ci.width_before = w->u;
+            if (const JVal* v = a->get("value")) ci.value = v->u;
+            if (const JVal* c = a->get("cost_before")) ci.cost_before = c->d;
+            if (const JVal* c = a->get("cost_after")) ci.cost_after = c->d;
+            out->apcs.push_back(ci);
+        }
+    } catch (const std::exception& e) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", e.what());
+        return nullptr;
+    }
+    return out.release();
+}
+void powdr_apc_candidates_free(PowdrApcCandidates* c) { delete c; }
+uint64_t powdr_apc_candidates_version(const PowdrApcCandidates* c) { return c->version; }
+size_t powdr_apc_candidates_count(const PowdrApcCandidates* c) { return c->apcs.size(); }
+size_t powdr_apc_candidates_num_labels(const PowdrApcCandidates* c) { return c->n_labels; }
+int powdr_apc_candidates_get(const PowdrApcCandidates* c, size_t i, PowdrApcCandidateInfo* out) {
+    if (i >= c->apcs.size() || !out) return -1;
+    *out = c->apcs[i];
+    return 0;
 }
 
 void powdr_apc_free(PowdrApc* apc) { delete apc; }

@@ -53,13 +53,85 @@ lib.powdr_apc_generate_witness_gpu.restype = C.c_int
 lib.powdr_apc_generate_witness_gpu.argtypes = [vp, vp, vp, sz, sz, vp, vp]
 
 
-class Apc:
-    """An autoprecompile loaded from the reference's JSON wire format."""
+lib.powdr_apc_from_json_at.restype = vp
+lib.powdr_apc_from_json_at.argtypes = [C.c_char_p, sz, sz, C.c_char_p, sz]
+lib.powdr_apc_from_cbor.restype = vp
+lib.powdr_apc_from_cbor.argtypes = [C.c_char_p, sz, sz, C.c_char_p, sz]
+lib.powdr_apc_count_in_json.restype = sz
+lib.powdr_apc_count_in_json.argtypes = [C.c_char_p, sz]
+lib.powdr_apc_count_in_cbor.restype = sz
+lib.powdr_apc_count_in_cbor.argtypes = [C.c_char_p, sz]
+lib.powdr_apc_bus_map_len.restype = sz
+lib.powdr_apc_bus_map_len.argtypes = [vp]
+lib.powdr_apc_bus_map_entry.restype = C.c_int
+lib.powdr_apc_bus_map_entry.argtypes = [vp, sz, C.POINTER(C.c_uint64), C.POINTER(u32), C.POINTER(u32 * 2), C.c_char_p, sz]
+lib.powdr_apc_periphery_from_bus_map.restype = C.c_int
+lib.powdr_apc_periphery_from_bus_map.argtypes = [vp, C.POINTER(PowdrPeriphery)]
 
-    def __init__(self, doc):
+BUS_KINDS = ["ExecutionBridge", "Memory", "PcLookup", "VariableRangeChecker", "BitwiseLookup", "TupleRangeChecker", "Other"]
+
+
+def count_apcs(data: bytes, fmt: str = "json") -> int:
+    """Number of `Apc` maps inside a JSON / CBOR document (export file, CLI stage artifact)."""
+    f = lib.powdr_apc_count_in_cbor if fmt == "cbor" else lib.powdr_apc_count_in_json
+    return int(f(data, len(data)))
+
+
+class PowdrAirStats(C.Structure):
+    _fields_ = [("main_columns", C.c_uint64), ("constraints", C.c_uint64), ("bus_interactions", C.c_uint64)]
+
+
+class PowdrApcCandidateInfo(C.Structure):
+    _fields_ = [("execution_frequency", C.c_uint64), ("start_pc", C.c_uint64), ("n_blocks", u32), ("n_instructions", u32),
+                ("before", PowdrAirStats), ("after", PowdrAirStats), ("width_before", C.c_uint64), ("value", C.c_uint64),
+                ("cost_before", C.c_double), ("cost_after", C.c_double)]
+
+
+lib.powdr_apc_candidates_from_json.restype = vp
+lib.powdr_apc_candidates_from_json.argtypes = [C.c_char_p, sz, C.c_char_p, sz]
+lib.powdr_apc_candidates_free.argtypes = [vp]
+lib.powdr_apc_candidates_version.restype = C.c_uint64
+lib.powdr_apc_candidates_version.argtypes = [vp]
+lib.powdr_apc_candidates_count.restype = sz
+lib.powdr_apc_candidates_count.argtypes = [vp]
+lib.powdr_apc_candidates_num_labels.restype = sz
+lib.powdr_apc_candidates_num_labels.argtypes = [vp]
+lib.powdr_apc_candidates_get.restype = C.c_int
+lib.powdr_apc_candidates_get.argtypes = [vp, sz, C.POINTER(PowdrApcCandidateInfo)]
+
+
+def read_apc_candidates(data: bytes):
+    """`apc_candidates.json` of cell PGO -> (version, [dict per candidate], number of labels)."""
+    err = C.create_string_buffer(512)
+    h = lib.powdr_apc_candidates_from_json(data, len(data), err, 512)
+    if not h:
+        raise ValueError(err.value.decode())
+    try:
+        out = []
+        for i in range(lib.powdr_apc_candidates_count(h)):
+            ci = PowdrApcCandidateInfo()
+            assert lib.powdr_apc_candidates_get(h, i, C.byref(ci)) == 0
+            st = lambda s: dict(main_columns=s.main_columns, constraints=s.constraints, bus_interactions=s.bus_interactions)
+            out.append(dict(execution_frequency=ci.execution_frequency, start_pc=ci.start_pc, n_blocks=ci.n_blocks,
+                            n_instructions=ci.n_instructions, before=st(ci.before), after=st(ci.after),
+                            width_before=ci.width_before, value=ci.value, cost_before=ci.cost_before, cost_after=ci.cost_after))
+        return int(lib.powdr_apc_candidates_version(h)), out, int(lib.powdr_apc_candidates_num_labels(h))
+    finally:
+        lib.powdr_apc_candidates_free(h)
+
+
+class Apc:
+    """An autoprecompile loaded from the reference's wire formats: the serde_json `Apc` / `ApcWithBusMap` export
+    (a dict or JSON bytes), or — fmt="cbor" — a serde_cbor stage artifact of the CLI; `index` picks the Apc when the
+    document holds several (the `select` artifact is a list of ApcWithStats)."""
+
+    def __init__(self, doc, fmt: str = "json", index: int = 0):
         data = doc if isinstance(doc, (bytes, bytearray)) else json.dumps(doc).encode()
         err = C.create_string_buffer(512)
-        self._h = lib.powdr_apc_from_json(data, len(data), err, 512)
+        if fmt == "cbor":
+            self._h = lib.powdr_apc_from_cbor(bytes(data), len(data), index, err, 512)
+        else:
+            self._h = lib.powdr_apc_from_json_at(bytes(data), len(data), index, err, 512)
         if not self._h:
             raise ValueError(err.value.decode())
         self.width = lib.powdr_apc_width(self._h)
@@ -76,6 +148,22 @@ class Apc:
 
     def num_subs(self):
         return [lib.powdr_apc_instruction_num_subs(self._h, i) for i in range(self.n_instructions)]
+
+    def bus_map(self):
+        """[(bus id, kind name, (sz0, sz1), variant name)] of an ApcWithBusMap export; [] if the document had none."""
+        out = []
+        for i in range(lib.powdr_apc_bus_map_len(self._h)):
+            bid, kind, sizes, name = C.c_uint64(), u32(), (u32 * 2)(), C.create_string_buffer(64)
+            assert lib.powdr_apc_bus_map_entry(self._h, i, C.byref(bid), C.byref(kind), C.byref(sizes), name, 64) == 0
+            out.append((bid.value, BUS_KINDS[kind.value], (sizes[0], sizes[1]), name.value.decode()))
+        return out
+
+    def periphery_bus_ids(self):
+        """(var-range bus, tuple bus, (sz0, sz1), bitwise bus) from the bus map; None for a bus the map does not name."""
+        per = PowdrPeriphery(0xFFFFFFFF, None, 0, 0xFFFFFFFF, None, 0, 0, 0xFFFFFFFF, None)
+        lib.powdr_apc_periphery_from_bus_map(self._h, C.byref(per))
+        f = lambda v: None if v == 0xFFFFFFFF else v
+        return f(per.var_range_bus_id), f(per.tuple2_bus_id), (per.tuple2_sz0, per.tuple2_sz1), f(per.bitwise_bus_id)
 
     def compile_bus(self, height: int):
         n_spans = sz()

@@ -137,8 +137,9 @@ def test_logup_proof_bytes_match_oracle(gpu, shape, calls, nq, pow_bits):
     pr0.close()
 
 
-def _prove_both_and_compare(torch, prover, flat, W, log_h, bc, spans, it, nq, pow_bits):
-    """HIP proof == oracle proof, word for word; both verifiers accept it."""
+def _prove_both_and_compare(torch, prover, flat, W, log_h, bc, spans, it, nq, pow_bits, satisfied=True):
+    """HIP proof == oracle proof, word for word; both verifiers accept it (satisfied=False: a random trace that does not
+    satisfy its random constraints — byte parity does not need it to — is rejected by both at the constraint identity)."""
     if it is None:
         want = sm.prove(flat, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits)
     else:
@@ -150,8 +151,8 @@ def _prove_both_and_compare(torch, prover, flat, W, log_h, bc, spans, it, nq, po
     assert len(got) == len(want)
     assert (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
     if it is None:
-        assert prover.verify(got, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits) == 0
-        assert sm.verify(got, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits) == 0
+        assert prover.verify(got, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits) == (0 if satisfied else 2)
+        assert sm.verify(got, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits) == (0 if satisfied else 2)
     else:
         assert prover.verify_logup(got, W, log_h, bc, spans, it, num_queries=nq, pow_bits=pow_bits)[0] == 0
         assert sm.verify_logup(got, W, log_h, bc, spans, *it, num_queries=nq, pow_bits=pow_bits) == 0
@@ -233,7 +234,7 @@ def test_multi_panel_lde_proof_bytes_match_oracle(gpu, monkeypatch, W, log_h, pa
             bc += [PA, a, PA, b, om.OP_MUL, PA, c, om.OP_MUL, PC, int(rng.integers(0, P)), om.OP_ADD]
             spans.append((off, len(bc) - off))
         bc, spans, it = np.array(bc, np.uint32), np.array(spans, np.uint32).reshape(-1, 2), None
-    got = _prove_both_and_compare(torch, prover, flat, W, log_h, bc, spans, it, nq=5, pow_bits=0)
+    got = _prove_both_and_compare(torch, prover, flat, W, log_h, bc, spans, it, nq=5, pow_bits=0, satisfied=logup)
     # and the default panelling gives the same bytes
     monkeypatch.delenv("POWDR_PANEL_LOG_WORDS")
     pr = prover.Prover(W, bc, spans, num_queries=5, interactions=it)

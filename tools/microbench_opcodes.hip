@@ -24,7 +24,7 @@ constexpr uint32_t P = 0x78000001u;
 enum Op {
     OP_ADD_U32, OP_SUB_U32, OP_ADD3_U32, OP_LSHL_ADD_U32, OP_XOR, OP_AND_OR, OP_LSHRREV, OP_MIN_U32, OP_CNDMASK, OP_MOV,
     OP_ADD_CO, OP_ADDC_CO, OP_BFE, OP_ALIGNBIT, OP_PERM, OP_MUL_LO, OP_MUL_HI, OP_MUL_U24, OP_MAD_U24, OP_MAD_U64_U32,
-    OP_LSHL_ADD_U64, OP_FMA_F32, OP_PK_FMA_F32, OP_FMA_F64, OP_DOT4_I32_I8, OP_MONTY5, OP_MODADD3, OP_COUNT
+    OP_LSHL_ADD_U64, OP_FMA_F32, OP_PK_FMA_F32, OP_FMA_F64, OP_DOT4_I32_I8, OP_CNDMASK_SGPR, OP_CMP_CNDMASK, OP_MAX_U32, OP_MONTY5, OP_MODADD3, OP_COUNT
 };
 
 struct OpInfo { const char* name; int instrs; };
@@ -33,7 +33,8 @@ static const OpInfo kOps[OP_COUNT] = {
     {"v_lshrrev_b32", 1}, {"v_min_u32", 1}, {"v_cndmask_b32", 1}, {"v_mov_b32", 1}, {"v_add_co_u32", 1}, {"v_addc_co_u32", 1},
     {"v_bfe_u32", 1}, {"v_alignbit_b32", 1}, {"v_perm_b32", 1}, {"v_mul_lo_u32", 1}, {"v_mul_hi_u32", 1}, {"v_mul_u32_u24", 1},
     {"v_mad_u32_u24", 1}, {"v_mad_u64_u32", 1}, {"v_lshl_add_u64", 1}, {"v_fma_f32", 1}, {"v_pk_fma_f32", 1}, {"v_fma_f64", 1},
-    {"v_dot4_i32_i8", 1}, {"montgomery product (2 mad_u64_u32, mul_lo, sub, min)", 5}, {"modular add (add, sub, min)", 3},
+    {"v_dot4_i32_i8", 1}, {"v_cndmask_b32_e64 (SGPR-pair mask)", 1}, {"v_cmp_lt_u32+v_cndmask_b32 (pair, per instruction)", 2}, {"v_max_u32", 1},
+    {"montgomery product (2 mad_u64_u32, mul_lo, sub, min)", 5}, {"modular add (add, sub, min)", 3},
 };
 
 // One loop iteration = ONE asm block of REPS x CHAINS instructions (operand %c = chain c, %8 = y, %9 = z), so that the
@@ -62,6 +63,9 @@ static const OpInfo kOps[OP_COUNT] = {
 #define T_MUL24(c) "v_mul_u32_u24 %" #c ", %" #c ", %8\n"
 #define T_MAD24(c) "v_mad_u32_u24 %" #c ", %" #c ", %8, %9\n"
 #define T_FMA(c) "v_fma_f32 %" #c ", %" #c ", %8, %9\n"
+#define T_CNDS(c) "v_cndmask_b32 %" #c ", %" #c ", %8, s[10:11]\n"
+#define T_CMPCND(c) "v_cmp_lt_u32 vcc, %" #c ", %8\nv_cndmask_b32 %" #c ", %" #c ", %9, vcc\n"
+#define T_MAX(c) "v_max_u32 %" #c ", %" #c ", %8\n"
 #define T_DOT4(c) "v_dot4_i32_i8 %" #c ", %8, %9, %" #c "\n"
 #define T_MAD64(c) "v_mad_u64_u32 %" #c ", vcc, %8, %9, %" #c "\n"
 #define T_LSHLADD64(c) "v_lshl_add_u64 %" #c ", %" #c ", 1, %10\n"
@@ -108,6 +112,9 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, unsigned long long* cycl
         else if (OP == OP_MAD_U24) ASM32(T_MAD24);
         else if (OP == OP_FMA_F32) ASM32(T_FMA);
         else if (OP == OP_DOT4_I32_I8) ASM32(T_DOT4);
+        else if (OP == OP_CNDMASK_SGPR) asm volatile("s_mov_b64 s[10:11], 0x5555\n" BODY(T_CNDS) : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) : "v"(y), "v"(z) : "s10", "s11");
+        else if (OP == OP_CMP_CNDMASK) ASM32(T_CMPCND);
+        else if (OP == OP_MAX_U32) ASM32(T_MAX);
         else if (OP == OP_MAD_U64_U32) ASM64(T_MAD64);
         else if (OP == OP_LSHL_ADD_U64) ASM64(T_LSHLADD64);
         else if (OP == OP_PK_FMA_F32) ASM64(T_PKFMA);
@@ -178,7 +185,7 @@ int main(int argc, char** argv) {
         RUN(OP_FMA_F32) RUN(OP_PK_FMA_F32) RUN(OP_FMA_F64) RUN(OP_MOV) RUN(OP_ADD_U32) RUN(OP_SUB_U32) RUN(OP_ADD3_U32) RUN(OP_LSHL_ADD_U32)
         RUN(OP_XOR) RUN(OP_AND_OR) RUN(OP_LSHRREV) RUN(OP_BFE) RUN(OP_ALIGNBIT) RUN(OP_PERM) RUN(OP_MIN_U32) RUN(OP_CNDMASK)
         RUN(OP_ADD_CO) RUN(OP_ADDC_CO) RUN(OP_LSHL_ADD_U64) RUN(OP_MUL_U24) RUN(OP_MAD_U24) RUN(OP_MUL_LO) RUN(OP_MUL_HI) RUN(OP_MAD_U64_U32)
-        RUN(OP_DOT4_I32_I8) RUN(OP_MODADD3) RUN(OP_MONTY5)
+        RUN(OP_DOT4_I32_I8) RUN(OP_CNDMASK_SGPR) RUN(OP_CMP_CNDMASK) RUN(OP_MAX_U32) RUN(OP_MODADD3) RUN(OP_MONTY5)
 #undef RUN
         if (waves_per_simd == 8) {
             printf("JSON {\"waves_per_simd\": 8");
