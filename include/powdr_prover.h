@@ -112,14 +112,26 @@ typedef struct PwSegmentAir {
     uint32_t log_height;
 } PwSegmentAir;
 
-/* Proves every AIR. `n_workers` host threads (0 = 4), each with its own HIP stream on the caller's device, take
- * the AIRs largest first (small proofs are latency bound; concurrency fills the GPU); n_workers = 1 runs inline on
- * the calling thread's stream. shared_bus_seed != 0: every prover must come from pw_prover_create_logup; phase 1
- * commits all traces, the bus seed is pw_commitment_digest over the trace roots in AIR order, phase 2 proves every
- * AIR with it (each prover reuses its phase-1 LDE and tree). proofs[i] / n_words[i] are owned by airs[i].prover and
- * valid until its next proof; bus_seed8 (may be NULL) receives the seed. Returns 0 or the first error. */
-int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int shared_bus_seed, unsigned n_workers,
-                     const uint32_t** proofs, size_t* n_words, uint32_t* bus_seed8);
+/* ONE proof for all AIRs of the segment ("pw-stark v1", proof magic PWS3; protocol: oracle/stark_segment.inc) — the
+ * shape of the reference's call: all matrices of a phase are committed in one mixed-height Poseidon2 tree, the openings of
+ * all AIRs are reduced per height and checked by one FRI over the tallest domain, one query phase answers for everything.
+ * logup != 0: every prover must come from pw_prover_create_logup (an AIR without interactions passes n_interactions = 0);
+ * the bus challenges are drawn once from the segment transcript and the proof carries every AIR's cumulative sum.
+ * Stream contract: the call runs on the calling thread's launch stream (powdr_gpu_set_stream), after everything the
+ * caller enqueued there — trace generation included. *proof_words is owned by the library (per host thread) and valid
+ * until that thread's next pw_prove_segment. Returns 0 or the first error. */
+int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int logup, const uint32_t** proof_words, size_t* n_words);
+
+/* INDEPENDENT proofs, one per AIR (v0 / v0+LogUp), proven concurrently: `n_workers` host threads (0 = 4), each with its
+ * own HIP stream on the caller's device, take the AIRs largest first; n_workers = 1 runs inline on the calling thread's
+ * stream. This is the flow AIR-level sharding over several GPUs uses (every rank proves its AIRs; powdr_amd/sharding.py).
+ * shared_bus_seed != 0: every prover must come from pw_prover_create_logup; phase 1 commits all traces, the bus seed is
+ * pw_commitment_digest over the trace roots in AIR order, phase 2 proves every AIR with it (each prover reuses its
+ * phase-1 LDE and tree). proofs[i] / n_words[i] are owned by airs[i].prover and valid until its next proof; bus_seed8
+ * (may be NULL) receives the seed. Stream contract: the worker streams wait for everything the caller enqueued on its
+ * launch stream before the call. Returns 0 or the first error. */
+int pw_prove_airs(const PwSegmentAir* airs, size_t n_airs, int shared_bus_seed, unsigned n_workers,
+                  const uint32_t** proofs, size_t* n_words, uint32_t* bus_seed8);
 
 typedef struct PwAirDescription {
     uint32_t width, log_height;
@@ -131,13 +143,22 @@ typedef struct PwAirDescription {
     const uint32_t* inter_bytecode; size_t inter_bytecode_len;
 } PwAirDescription;
 
-/* Host verification of a segment. With shared_bus_seed the seed is recomputed from the trace roots inside the
+/* Host verification (no GPU) of a pw_prove_segment proof: the counterpart of `verify_app_proof` for a whole segment.
+ * airs[i].logup is ignored (the segment's `logup` flag applies to all). Returns 0 = valid; ((air index + 1) << 8) | 2 =
+ * constraint identity of that AIR; 1 header / shape mismatch, 3 proof of work, 4 query index, 5 main opening,
+ * 6 quotient opening, 7 FRI layer, 8 final value, 9 trailing words, 10 truncated, 11 permutation opening, 13 a word >= p,
+ * 14 check_balance is set and the AIRs' cumulative bus sums do not add up to zero, 15 malformed description.
+ * total_sum4 (may be NULL) receives the sum of the cumulative sums. */
+int pw_verify_segment(const PwStarkConfig* cfg, const PwAirDescription* airs, size_t n_airs, int logup,
+                      const uint32_t* proof_words, size_t n_words, int check_balance, uint32_t* total_sum4);
+
+/* Host verification of pw_prove_airs' proofs. With shared_bus_seed the seed is recomputed from the trace roots inside the
  * proofs and every proof must have used it. Returns 0; ((air index + 1) << 8) | code of the first failing proof
  * (codes as pw_verify / pw_verify_logup); or 14 when check_balance is set and the cumulative bus sums of all AIRs
  * do not add up to zero. total_sum4 (may be NULL) receives that sum. */
-int pw_verify_segment(const PwStarkConfig* cfg, const PwAirDescription* airs, size_t n_airs,
-                      const uint32_t* const* proofs, const size_t* n_words, int shared_bus_seed, int check_balance,
-                      uint32_t* total_sum4);
+int pw_verify_airs(const PwStarkConfig* cfg, const PwAirDescription* airs, size_t n_airs,
+                   const uint32_t* const* proofs, const size_t* n_words, int shared_bus_seed, int check_balance,
+                   uint32_t* total_sum4);
 
 /* Digest over an ordered list of 8-word commitments (binary Poseidon2 tree; canonical words). */
 void pw_commitment_digest(const uint32_t* roots8, size_t n, uint32_t* digest8);

@@ -182,3 +182,54 @@ def commitment_digest(roots) -> np.ndarray:
             nxt.append(poseidon2(np.concatenate([level[i], right]))[:8])
         level = nxt
     return level[0]
+
+
+# ---- pw-stark v1: one proof per segment (oracle/stark_segment.inc) ----------------------------------------------------
+class OrSegAir(C.Structure):
+    _fields_ = [("trace", C.c_void_p), ("width", C.c_uint32), ("log_h", C.c_uint32), ("cons_bc", C.c_void_p), ("cons_spans", C.c_void_p),
+                ("n_constraints", C.c_size_t), ("inter", C.c_void_p), ("n_inter", C.c_size_t), ("ispans", C.c_void_p), ("ibc", C.c_void_p)]
+
+
+def _seg_airs(airs, with_traces=True):
+    """airs: [(trace_cm or None, width, log_h, cons_bc, cons_spans, interactions-or-None)] -> (ctypes array, keep-alive list)."""
+    keep, recs = [], (OrSegAir * max(len(airs), 1))()
+    for i, (t, w, lh, bc, sp, it) in enumerate(airs):
+        bc = np.ascontiguousarray(bc, dtype=np.uint32)
+        sp = np.ascontiguousarray(sp, dtype=np.uint32).reshape(-1, 2)
+        tt = np.ascontiguousarray(t, dtype=np.uint32) if (with_traces and t is not None) else None
+        if it is None:
+            a, b, c = np.zeros((0, 3), np.uint32), np.zeros((0, 2), np.uint32), np.zeros(0, np.uint32)
+        else:
+            a = np.ascontiguousarray(it[0], dtype=np.uint32).reshape(-1, 3)
+            b = np.ascontiguousarray(it[1], dtype=np.uint32).reshape(-1, 2)
+            c = np.ascontiguousarray(it[2], dtype=np.uint32)
+        keep += [bc, sp, tt, a, b, c]
+        recs[i] = OrSegAir(None if tt is None else tt.ctypes.data, w, lh, bc.ctypes.data, sp.ctypes.data, len(sp), a.ctypes.data, len(a),
+                           b.ctypes.data, c.ctypes.data)
+    return recs, keep
+
+
+def prove_segment(airs, num_queries=8, pow_bits=0, logup=False) -> np.ndarray:
+    """ONE proof for all AIRs of a segment. airs: [(trace_cm, width, log_h, cons_bc, cons_spans, interactions-or-None)]."""
+    lib = _lib()
+    lib.or_prove_segment.restype = C.c_size_t
+    recs, keep = _seg_airs(airs)
+    cap = 1 << 18
+    while True:
+        buf = np.zeros(cap, np.uint32)
+        n = lib.or_prove_segment(C.c_uint32(num_queries), C.c_uint32(pow_bits), C.c_int(int(logup)), recs, C.c_size_t(len(airs)), _p(buf), C.c_size_t(cap))
+        if n <= cap:
+            return buf[:n].copy()
+        cap = int(n)
+
+
+def verify_segment(proof, airs, num_queries=8, pow_bits=0, logup=False, check_balance=False):
+    """(code, sum of the AIRs' cumulative bus sums). airs as for prove_segment (traces ignored)."""
+    lib = _lib()
+    lib.or_verify_segment.restype = C.c_int
+    recs, keep = _seg_airs(airs, with_traces=False)
+    pr = np.ascontiguousarray(proof, dtype=np.uint32)
+    total = np.zeros(4, np.uint32)
+    rc = lib.or_verify_segment(C.c_uint32(num_queries), C.c_uint32(pow_bits), C.c_int(int(logup)), recs, C.c_size_t(len(airs)), _p(pr),
+                               C.c_size_t(len(pr)), C.c_int(int(check_balance)), _p(total))
+    return int(rc), total

@@ -1065,6 +1065,8 @@ int verify_logup(const Config& cfg, const u32* proof, size_t len, u32 width, u32
     return 0;
 }
 
+#include "stark_segment.inc"
+
 }  // namespace
 
 /* ---------------------------------------------------------------- C entry points for tests */
@@ -1153,6 +1155,34 @@ int or_verify_logup(uint32_t num_queries, uint32_t pow_bits, const uint32_t* pro
     Program pr{cons_bc, cons_spans, n_constraints};
     Interactions I{inter, n_inter, ispans, ibc};
     return verify_logup(cfg, proof, len, width, log_h, pr, I, expected_seed);
+}
+
+
+/* ---- pw-stark v1: one proof per segment (stark_segment.inc) ---- */
+typedef struct {
+    const uint32_t* trace; /* NULL for the verifier */
+    uint32_t width, log_h;
+    const uint32_t* cons_bc; const uint32_t* cons_spans; size_t n_constraints;
+    const uint32_t* inter; size_t n_inter; const uint32_t* ispans; const uint32_t* ibc;
+} OrSegAir;
+
+static std::vector<SegAir> seg_airs(const OrSegAir* airs, size_t n) {
+    std::vector<SegAir> v(n);
+    for (size_t i = 0; i < n; ++i)
+        v[i] = SegAir{airs[i].trace, airs[i].width, airs[i].log_h, Program{airs[i].cons_bc, airs[i].cons_spans, airs[i].n_constraints},
+                      Interactions{airs[i].inter, airs[i].n_inter, airs[i].ispans, airs[i].ibc}};
+    return v;
+}
+size_t or_prove_segment(uint32_t num_queries, uint32_t pow_bits, int logup, const OrSegAir* airs, size_t n_airs, uint32_t* proof, size_t cap) {
+    Config cfg{num_queries, pow_bits};
+    std::vector<u32> w = prove_segment(cfg, seg_airs(airs, n_airs), logup != 0);
+    if (w.size() <= cap) memcpy(proof, w.data(), w.size() * 4);
+    return w.size();
+}
+int or_verify_segment(uint32_t num_queries, uint32_t pow_bits, int logup, const OrSegAir* airs, size_t n_airs, const uint32_t* proof,
+                      size_t len, int check_balance, uint32_t* total_sum4) {
+    Config cfg{num_queries, pow_bits};
+    return verify_segment(cfg, proof, len, seg_airs(airs, n_airs), logup != 0, check_balance != 0, total_sum4);
 }
 
 }  // extern "C"

@@ -20,7 +20,7 @@ constexpr int kBlock = 256;
 __constant__ p2::Params c_params;
 p2::Params g_host_params;
 bool g_params_ready = false;
-bool g_params_uploaded = false;
+uint64_t g_params_uploaded = 0;  // bit d: the __constant__ table of device d holds the parameters (one process may drive several GPUs)
 
 __global__ __launch_bounds__(kBlock) void leaf_hash_kernel(const uint32_t* __restrict__ m, size_t height,
                                                             uint32_t width, size_t col_stride,
@@ -44,6 +44,56 @@ __global__ __launch_bounds__(kBlock) void leaf_hash_kernel(const uint32_t* __res
         p2::permute(st, c_params);
     }
     uint4* out = reinterpret_cast<uint4*>(digests + j * 8);
+    out[0] = make_uint4(st[0], st[1], st[2], st[3]);
+    out[1] = make_uint4(st[4], st[5], st[6], st[7]);
+}
+
+// The leaf hash over a COLUMN-POINTER table: the hashed row is the concatenation of row j of several matrices of one
+// height (all AIRs of that height in a segment, AIR order). The pointers are wave-uniform scalar loads; everything else
+// is the kernel above. Used by the mixed-height commitment of a segment (merkle_commit_mixed).
+__global__ __launch_bounds__(kBlock) void leaf_hash_cols_kernel(const uint32_t* const* __restrict__ cols, uint32_t n_cols,
+                                                                 size_t height, uint32_t* __restrict__ digests) {
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= height) return;
+    uint32_t st[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0u;
+    uint32_t c0 = 0;
+    for (; c0 + 8 <= n_cols; c0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st[k] = cols[c0 + k][j];
+        p2::permute(st, c_params);
+    }
+    if (c0 < n_cols) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (c0 + k < n_cols) st[k] = cols[c0 + k][j];
+        p2::permute(st, c_params);
+    }
+    uint4* out = reinterpret_cast<uint4*>(digests + j * 8);
+    out[0] = make_uint4(st[0], st[1], st[2], st[3]);
+    out[1] = make_uint4(st[4], st[5], st[6], st[7]);
+}
+
+// One level of the mixed-height tree: parent j = compress(child j, child j + n) — the sibling pairing of the FRI fold, so
+// that the ancestor of leaf q on the level of n nodes is q mod n — and, where matrices of height n exist, the digest of
+// their rows is injected: parent = compress(parent, inject[j]).
+__global__ __launch_bounds__(kBlock) void compress_strided_kernel(const uint32_t* __restrict__ children, size_t n,
+                                                                   const uint32_t* __restrict__ inject, uint32_t* __restrict__ parents) {
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const uint4* l = reinterpret_cast<const uint4*>(children + j * 8);
+    const uint4* r = reinterpret_cast<const uint4*>(children + (j + n) * 8);
+    uint4 a = l[0], b = l[1], c = r[0], d = r[1];
+    uint32_t st[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    p2::permute(st, c_params);
+    if (inject) {
+        const uint4* q = reinterpret_cast<const uint4*>(inject + j * 8);
+        c = q[0]; d = q[1];
+        st[8] = c.x; st[9] = c.y; st[10] = c.z; st[11] = c.w; st[12] = d.x; st[13] = d.y; st[14] = d.z; st[15] = d.w;
+        p2::permute(st, c_params);
+    }
+    uint4* out = reinterpret_cast<uint4*>(parents + j * 8);
     out[0] = make_uint4(st[0], st[1], st[2], st[3]);
     out[1] = make_uint4(st[4], st[5], st[6], st[7]);
 }
@@ -151,10 +201,12 @@ const p2::Params& poseidon2_params_host() {
 int poseidon2_upload_params() {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    if (g_params_uploaded) return 0;
+    int device = 0;
+    PW_HIP_TRY(hipGetDevice(&device));
+    if (device < 64 && (g_params_uploaded >> device) & 1) return 0;
     const p2::Params& p = poseidon2_params_host();
-    PW_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_params), &p, sizeof(p2::Params)));  // synchronous
-    g_params_uploaded = true;
+    PW_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_params), &p, sizeof(p2::Params)));  // synchronous; the current device's copy
+    if (device < 64) g_params_uploaded |= 1ull << device;
     return 0;
 }
 
@@ -167,6 +219,31 @@ int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_
                            col_stride, digests);
     }
     return build_levels(digests, height);
+}
+
+int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, uint32_t* d_inject) {
+    int rc = poseidon2_upload_params();
+    if (rc) return rc;
+    if (L < 0 || !by_log[L].n_cols) return (int)hipErrorInvalidValue;
+    const size_t N = (size_t)1 << L;
+    {
+        ScopedKernelTimer t("leaf_hash_kernel");
+        hipLaunchKernelGGL(leaf_hash_cols_kernel, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), by_log[L].d_cols, by_log[L].n_cols, N, digests);
+    }
+    size_t off = 0;
+    for (int lg = L - 1; lg >= 0; --lg) {
+        const size_t n = (size_t)1 << lg;
+        const uint32_t* inj = nullptr;
+        if (by_log[lg].n_cols) {
+            ScopedKernelTimer t("leaf_hash_kernel");
+            hipLaunchKernelGGL(leaf_hash_cols_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, stream(), by_log[lg].d_cols, by_log[lg].n_cols, n, d_inject);
+            inj = d_inject;
+        }
+        ScopedKernelTimer t("compress_kernel");
+        hipLaunchKernelGGL(compress_strided_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, stream(), digests + off, n, inj, digests + off + 2 * n * 8);
+        off += 2 * n * 8;
+    }
+    return (int)hipGetLastError();
 }
 
 int merkle_commit_ext_pairs(const bb::Ext* v, size_t half, uint32_t* digests) {

@@ -5,9 +5,8 @@
 // Data stays in HBM from the caller's trace to the last FRI layer; the host only sees
 // 32-byte roots, the W+8 opened values and the query answers (a few hundred KB), which is
 // what it needs to run the transcript.
-#include "prover_internal.hpp"
+#include "prover_state.hpp"
 #include "logup_groups.hpp"
-#include "../../include/powdr_prover.h"
 #include "xbc_compile.hpp"
 
 #include <cstdlib>
@@ -19,45 +18,6 @@ namespace pw {
 
 namespace {
 
-constexpr uint32_t kMagic = 0x31535750u;   // "PWS1"
-constexpr uint32_t kMagic2 = 0x32535750u;  // "PWS2": with the LogUp extension
-
-// ---- duplex-sponge challenger on Montgomery words (spec: oracle/stark_oracle.cpp Challenger) ----
-struct Challenger {
-    uint32_t st[16];
-    std::vector<uint32_t> in, out;
-    Challenger() { memset(st, 0, sizeof st); }
-    void duplex() {
-        for (size_t i = 0; i < in.size(); ++i) st[i] = in[i];
-        in.clear();
-        p2::permute(st, poseidon2_params_host());
-        out.assign(st, st + 8);
-    }
-    void observe(uint32_t m) { out.clear(); in.push_back(m); if (in.size() == 8) duplex(); }
-    void observe_canonical(uint32_t c) { observe(bb::to_monty(c)); }
-    void observe_words(const uint32_t* w, size_t n) { for (size_t i = 0; i < n; ++i) observe(w[i]); }
-    void observe_ext(const bb::Ext& e) { observe_words(e.c, 4); }
-    uint32_t sample() { if (!in.empty() || out.empty()) duplex(); uint32_t v = out.back(); out.pop_back(); return v; }
-    bb::Ext sample_ext() { bb::Ext e; for (int i = 0; i < 4; ++i) e.c[i] = sample(); return e; }
-    uint32_t sample_bits(int b) { return bb::from_monty(sample()) & ((1u << b) - 1u); }
-};
-
-struct DeviceBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t need) {
-        if (need <= bytes) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, need);
-        if (e != hipSuccess) return (int)e;
-        bytes = need;
-        return 0;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-    template <class T> T* as() { return reinterpret_cast<T*>(p); }
-};
-
 __global__ void gather_records_kernel(const uint32_t* __restrict__ arena, const uint64_t* __restrict__ offsets,
                                       uint32_t words_per_record, uint32_t n, uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,37 +28,14 @@ __global__ void gather_records_kernel(const uint32_t* __restrict__ arena, const 
 
 }  // namespace
 
-}  // namespace pw
+int gather_records(const uint32_t* arena, const uint64_t* d_offsets, uint32_t words_per_record, uint32_t n, uint32_t* out) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(gather_records_kernel, dim3(div_up((size_t)n * words_per_record, 256)), dim3(256), 0, stream(), arena, d_offsets,
+                       words_per_record, n, out);
+    return (int)hipGetLastError();
+}
 
-struct PwProver {
-    PwStarkConfig cfg;
-    uint32_t width;
-    std::vector<uint32_t> h_spans;
-    uint32_t n_constraints;
-    uint32_t* d_bytecode = nullptr;
-    uint32_t* d_spans = nullptr;
-    bool is_xbc = false;  // d_bytecode/d_spans hold plan-compiled xbc code (xbc.hpp) instead of post-fix code
-    int max_degree = 0;   // highest degree among the constraint programs (99 = a malformed / non-polynomial one)
-    // LogUp extension (pw_prover_create_logup): the AIR's bus interactions as xbc programs
-    bool logup = false;
-    uint32_t n_inter = 0, n_groups = 0, max_args = 0;
-    uint32_t* d_gstarts = nullptr;  // group boundaries (logup_groups.hpp)
-    pw::LogupInteraction* d_inter = nullptr;
-    uint32_t* d_ixspans = nullptr;
-    uint32_t* d_icode = nullptr;
-    pw::DeviceBuf perm, plde;
-    bool has_bus_seed = false;
-    uint32_t bus_seed[8] = {0};  // Montgomery
-    // pw_prover_trace_root leaves the trace's LDE and Merkle tree in `lde` / `digests`; a pw_prover_prove of the
-    // same (pointer, height) right after it starts from them instead of recomputing (one-shot)
-    const uint32_t* committed_trace = nullptr;
-    uint32_t committed_log_h = 0;
-    uint32_t committed_root[8] = {0};  // Montgomery
-    // device buffers, grown on demand
-    pw::DeviceBuf coef, lde, digests, q, qcoef, qlde, ext_arena, misc;
-    pw::DeviceBuf qpart;  // partial quotient sums when the constraint list is split over workgroup rows (short traces)
-    std::vector<uint32_t> proof;
-};
+}  // namespace pw
 
 using namespace pw;
 
@@ -197,11 +134,28 @@ extern "C" int pw_prover_set_bus_seed(PwProver* p, const uint32_t* seed8) {
     return 0;
 }
 
-namespace {
+namespace pw {
+// (read per call, so that tests can force many small panels: floor 2^12 words, and never fewer than 8 columns)
+size_t lde_panel_cols(size_t H, size_t widest) {
+    int panel_log_words = 28;
+    if (const char* e = getenv("POWDR_PANEL_LOG_WORDS")) { const int v = atoi(e); if (v >= 12 && v <= 32) panel_log_words = v; }
+    size_t cols = ((size_t)1 << panel_log_words) / H;
+    if (cols < 8) cols = 8;
+    if (cols > widest) cols = widest;
+    return cols ? cols : 1;
+}
+int lde_matrix(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_t* m, uint32_t cols, uint32_t* out) {
+    uint32_t* d_coef = p->coef.as<uint32_t>();
+    for (size_t c0 = 0; c0 < cols; c0 += L.panel_cols) {
+        const uint32_t pc = (uint32_t)(cols - c0 < L.panel_cols ? cols - c0 : L.panel_cols);
+        TRY(intt_dif(m + c0 * L.H, d_coef, L.H, L.H, pc, (int)log_h));
+        TRY(coset_lde_from_coeffs(d_coef, out + c0 * L.N, L.H, L.N, pc, (int)log_h));
+    }
+    return 0;
+}
+}  // namespace pw
 
-struct CommitLayout {
-    size_t H, N, tree_words, fri_words, n_trees, panel_cols;
-};
+namespace {
 
 // Buffers of the trace commitment, sized as pw_prover_prove needs them (so that a later prove does not reallocate)
 int ensure_commit_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
@@ -213,28 +167,14 @@ int ensure_commit_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
     L.n_trees = p->logup ? 3 : 2;  // trace | quotient | (perm) | FRI
     // coefficients exist only per column panel (1 GB by default; larger panels = fewer, larger launches): iNTT -> panel ->
     // coset NTT into the resident LDE
-    // (read per call, so that tests can force many small panels: floor 2^12 words, and never fewer than 8 columns)
-    int panel_log_words = 28;
-    if (const char* e = getenv("POWDR_PANEL_LOG_WORDS")) { const int v = atoi(e); if (v >= 12 && v <= 32) panel_log_words = v; }
-    L.panel_cols = ((size_t)1 << panel_log_words) / L.H;
-    if (L.panel_cols < 8) L.panel_cols = 8;
     const size_t widest = p->logup ? std::max<size_t>(p->width, 4 * ((size_t)p->n_groups + 1)) : p->width;
-    if (L.panel_cols > widest) L.panel_cols = widest;
+    L.panel_cols = lde_panel_cols(L.H, widest);
     TRY(p->coef.ensure(L.panel_cols * L.H * 4));
     TRY(p->lde.ensure((size_t)p->width * L.N * 4));
     TRY(p->digests.ensure((L.n_trees * L.tree_words + L.fri_words) * 4));
     return 0;
 }
 
-int lde_matrix(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_t* m, uint32_t cols, uint32_t* out) {
-    uint32_t* d_coef = p->coef.as<uint32_t>();
-    for (size_t c0 = 0; c0 < cols; c0 += L.panel_cols) {
-        const uint32_t pc = (uint32_t)(cols - c0 < L.panel_cols ? cols - c0 : L.panel_cols);
-        TRY(intt_dif(m + c0 * L.H, d_coef, L.H, L.H, pc, (int)log_h));
-        TRY(coset_lde_from_coeffs(d_coef, out + c0 * L.N, L.H, L.N, pc, (int)log_h));
-    }
-    return 0;
-}
 
 // LDE + Merkle tree of the trace into p->lde / the first tree of p->digests; root (Montgomery) to the host
 int commit_trace(PwProver* p, const CommitLayout& L, const uint32_t* d_trace, uint32_t log_h, uint32_t* root) {
@@ -582,11 +522,8 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         TRY(gather_rows(d_lde, N, W, d_idx, nq, d_trows));
         if (lg) TRY(gather_rows(d_plde, N, Wp, d_idx, nq, d_prows));
         TRY(gather_rows(d_qlde, N, 8, d_idx, nq, d_qrows));
-        hipLaunchKernelGGL(gather_records_kernel, dim3(div_up(n_dig * 8, 256)), dim3(256), 0, st, d_dig, d_dig_offs, 8u,
-                           (uint32_t)n_dig, d_dig_out);
-        if (n_ext)
-            hipLaunchKernelGGL(gather_records_kernel, dim3(div_up(n_ext * 4, 256)), dim3(256), 0, st,
-                               reinterpret_cast<const uint32_t*>(d_v), d_ext_offs, 4u, (uint32_t)n_ext, d_ext_out);
+        TRY(gather_records(d_dig, d_dig_offs, 8u, (uint32_t)n_dig, d_dig_out));
+        TRY(gather_records(reinterpret_cast<const uint32_t*>(d_v), d_ext_offs, 4u, (uint32_t)n_ext, d_ext_out));
         std::vector<uint32_t> trows((size_t)nq * W), prows((size_t)nq * Wp + 1), qrows((size_t)nq * 8), dig(n_dig * 8), ext(n_ext * 4 + 1);
         PW_HIP_TRY(hipMemcpyAsync(trows.data(), d_trows, trows.size() * 4, hipMemcpyDeviceToHost, st));
         if (lg) PW_HIP_TRY(hipMemcpyAsync(prows.data(), d_prows, (size_t)nq * Wp * 4, hipMemcpyDeviceToHost, st));

@@ -32,6 +32,13 @@ const uint32_t* shift_table(int n);  // s^k / 2^n (Montgomery), k < 2^n, device
 const p2::Params& poseidon2_params_host();
 int poseidon2_upload_params();
 int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests);
+// Mixed-height commitment of a segment (oracle/stark_segment.inc `MixedTree`): by_log[k] = the columns of all matrices of
+// height 2^k (device array of device column pointers, AIR order; n_cols = 0 if there is none), k = 0..L, by_log[L] non-empty.
+// digests: levels of 2^L, 2^(L-1), ..., 1 nodes concatenated ((2^(L+1) - 1) * 8 words), level of n nodes:
+// node j = compress(child j, child j + n) [then compress(node, H(rows j of the height-n matrices))]. d_inject: 2^(L-1) * 8 words
+// of scratch. NOTE the same scratch is reused level after level on the launch stream.
+struct MixedLevelCols { const uint32_t* const* d_cols; uint32_t n_cols; };
+int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, uint32_t* d_inject);
 // leaves = hash of the 8 words (v[i], v[i + half]) of an Ext vector of length 2*half
 int merkle_commit_ext_pairs(const bb::Ext* v, size_t half, uint32_t* digests);
 inline size_t merkle_words(size_t n_leaves) { return (2 * n_leaves - 1) * 8; }
@@ -72,6 +79,10 @@ int deep_quotient(const uint32_t* lde_a, uint32_t wa, const uint32_t* lde_b, uin
                   const bb::Ext* d_gpow, bb::Ext opened_sum, bb::Ext zeta, bb::Ext* v);
 // out[i] = (a+b)/2 + beta (a-b)/(2 x_i), a = v[i], b = v[i+half], x_i = shift * w^i
 int fri_fold(const bb::Ext* v, size_t half, int log_size, uint32_t shift, bb::Ext beta, bb::Ext* out);
+// y[i] += a * x[i] (a == nullptr: a = 1), Ext vectors of length n
+int ext_axpy(bb::Ext* y, const bb::Ext* a_or_null, const bb::Ext* x, size_t n);
+// d_out[i] = *d_ptrs[i]
+int gather_words(const uint32_t* const* d_ptrs, uint32_t n, uint32_t* d_out);
 // gather row `idx` of a column-major matrix into out[0..width)
 int gather_rows(const uint32_t* m, size_t height, uint32_t width, const uint32_t* d_indices, uint32_t n_idx, uint32_t* out);
 // ---- logup_kernels.hip (pw-stark v0 + LogUp) ----------------------------------------------------------

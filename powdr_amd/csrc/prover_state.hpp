@@ -1,0 +1,95 @@
+// State shared by the prover's translation units (prover.hip: one AIR = one proof; segment_prover.hip: one proof per
+// segment): the per-AIR prover object, the host transcript, a growable device buffer. Not part of the C ABI.
+#pragma once
+#include "prover_internal.hpp"
+#include "../../include/powdr_prover.h"
+
+#include <cstring>
+#include <vector>
+
+namespace pw {
+
+constexpr uint32_t kMagic = 0x31535750u;   // "PWS1"
+constexpr uint32_t kMagic2 = 0x32535750u;  // "PWS2": with the LogUp extension
+constexpr uint32_t kMagic3 = 0x33535750u;  // "PWS3": one proof per segment (segment_prover.hip)
+
+// ---- duplex-sponge challenger on Montgomery words (spec: oracle/stark_oracle.cpp Challenger) ----
+struct Challenger {
+    uint32_t st[16];
+    std::vector<uint32_t> in, out;
+    Challenger() { memset(st, 0, sizeof st); }
+    void duplex() {
+        for (size_t i = 0; i < in.size(); ++i) st[i] = in[i];
+        in.clear();
+        p2::permute(st, poseidon2_params_host());
+        out.assign(st, st + 8);
+    }
+    void observe(uint32_t m) { out.clear(); in.push_back(m); if (in.size() == 8) duplex(); }
+    void observe_canonical(uint32_t c) { observe(bb::to_monty(c)); }
+    void observe_words(const uint32_t* w, size_t n) { for (size_t i = 0; i < n; ++i) observe(w[i]); }
+    void observe_ext(const bb::Ext& e) { observe_words(e.c, 4); }
+    uint32_t sample() { if (!in.empty() || out.empty()) duplex(); uint32_t v = out.back(); out.pop_back(); return v; }
+    bb::Ext sample_ext() { bb::Ext e; for (int i = 0; i < 4; ++i) e.c[i] = sample(); return e; }
+    uint32_t sample_bits(int b) { return bb::from_monty(sample()) & ((1u << b) - 1u); }
+};
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) return (int)e;
+        bytes = need;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+// out[i] = arena[offsets[r] + w] for record r, word w (query answers: digests, FRI siblings)
+int gather_records(const uint32_t* arena, const uint64_t* d_offsets, uint32_t words_per_record, uint32_t n, uint32_t* out);
+
+}  // namespace pw
+
+struct PwProver {
+    PwStarkConfig cfg;
+    uint32_t width;
+    std::vector<uint32_t> h_spans;
+    uint32_t n_constraints;
+    uint32_t* d_bytecode = nullptr;
+    uint32_t* d_spans = nullptr;
+    bool is_xbc = false;  // d_bytecode/d_spans hold plan-compiled xbc code (xbc.hpp) instead of post-fix code
+    int max_degree = 0;   // highest degree among the constraint programs (99 = a malformed / non-polynomial one)
+    // LogUp extension (pw_prover_create_logup): the AIR's bus interactions as xbc programs
+    bool logup = false;
+    uint32_t n_inter = 0, n_groups = 0, max_args = 0;
+    uint32_t* d_gstarts = nullptr;  // group boundaries (logup_groups.hpp)
+    pw::LogupInteraction* d_inter = nullptr;
+    uint32_t* d_ixspans = nullptr;
+    uint32_t* d_icode = nullptr;
+    pw::DeviceBuf perm, plde;
+    bool has_bus_seed = false;
+    uint32_t bus_seed[8] = {0};  // Montgomery
+    // pw_prover_trace_root leaves the trace's LDE and Merkle tree in `lde` / `digests`; a pw_prover_prove of the
+    // same (pointer, height) right after it starts from them instead of recomputing (one-shot)
+    const uint32_t* committed_trace = nullptr;
+    uint32_t committed_log_h = 0;
+    uint32_t committed_root[8] = {0};  // Montgomery
+    // device buffers, grown on demand
+    pw::DeviceBuf coef, lde, digests, q, qcoef, qlde, ext_arena, misc;
+    pw::DeviceBuf qpart;  // partial quotient sums when the constraint list is split over workgroup rows (short traces)
+    std::vector<uint32_t> proof;
+};
+
+namespace pw {
+struct CommitLayout {
+    size_t H, N, tree_words, fri_words, n_trees, panel_cols;
+};
+// LDE of a column-major matrix (cols x 2^log_h) through the prover's coefficient panel buffer into `out` (cols x 2^(log_h+1))
+int lde_matrix(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_t* m, uint32_t cols, uint32_t* out);
+// columns per LDE panel for a 2^log_h-row matrix of `widest` columns (POWDR_PANEL_LOG_WORDS, read per call)
+size_t lde_panel_cols(size_t H, size_t widest);
+}  // namespace pw

@@ -101,7 +101,7 @@ extern "C" void pw_commitment_digest(const uint32_t* roots8, size_t n, uint32_t*
     for (int k = 0; k < 8; ++k) digest8[k] = bb::from_monty(level[0].w[k]);
 }
 
-extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int shared_bus_seed, unsigned n_workers,
+extern "C" int pw_prove_airs(const PwSegmentAir* airs, size_t n_airs, int shared_bus_seed, unsigned n_workers,
                                 const uint32_t** proofs, size_t* n_words, uint32_t* bus_seed8) {
     if (!airs || !proofs || !n_words) return (int)hipErrorInvalidValue;
     for (size_t i = 0; i < n_airs; ++i)
@@ -133,7 +133,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int sha
     });
 }
 
-extern "C" int pw_verify_segment(const PwStarkConfig* cfg, const PwAirDescription* airs, size_t n_airs, const uint32_t* const* proofs,
+extern "C" int pw_verify_airs(const PwStarkConfig* cfg, const PwAirDescription* airs, size_t n_airs, const uint32_t* const* proofs,
                                  const size_t* n_words, int shared_bus_seed, int check_balance, uint32_t* total_sum4) {
     if (!cfg || !airs || !proofs || !n_words) return 10;
     uint32_t seed[8];

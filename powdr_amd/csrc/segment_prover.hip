@@ -1,0 +1,442 @@
+// pw-stark v1 on the device: ONE proof for all AIRs of a segment (proof magic "PWS3").
+//
+// The reference makes one engine call per segment with the traces of all chips, `engine.prove(pk, ProvingContext{
+// per_trace})` (/root/reference/openvm/src/trace_generation.rs:136-139, openvm-riscv/src/lib.rs:327-332). Protocol
+// definition: oracle/stark_segment.inc (header comment); the words produced here must equal the oracle's.
+//
+//   phase 1   LDE of every main trace (per-AIR kernels of prover.hip), ONE mixed-height Poseidon2 tree over all of them:
+//             the leaf hash runs over a column-pointer table, so all AIRs of one height are hashed by one launch — a
+//             2^12-row AIR no longer gets a launch (and a quarter-empty GPU) of its own
+//   phase 2   LogUp permutation matrices (shared challenges straight from the segment transcript), one mixed tree
+//   phase 3   quotients (shared alpha), one mixed tree over the 8-column chunk matrices
+//   phase 4   openings at zeta / g_a zeta, all AIRs' values fetched with one copy
+//   phase 5   reduced openings per height; FRI over the tallest domain with the smaller heights rolled in; one query phase
+// Host round trips per segment: 3 roots + 1 (sums) + 1 (openings) + L FRI roots + queries, instead of that per AIR.
+#include "prover_state.hpp"
+#include "logup_groups.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace pw;
+
+#define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+namespace {
+
+struct SegCtx {
+    DeviceBuf dig;     // three mixed trees | FRI trees
+    DeviceBuf inject;  // row digests of the smaller heights (one level at a time)
+    DeviceBuf ext;     // FRI layers (2 N) | reduced openings of the smaller heights (N) | scratch vector (N)
+    DeviceBuf misc;    // column-pointer tables, opened values, gamma powers, query indices / answers
+    std::vector<uint32_t> proof;
+};
+thread_local SegCtx g_ctx;  // one per host thread (= per launch stream)
+
+struct Shape {
+    uint32_t W, nc, n_int, n_g, Wp, M, K, log_h;
+    size_t H, N, koff;
+    int logN;
+};
+
+// device buffers of one AIR for the segment flow (the per-AIR prover object owns them; nothing here is freed per segment)
+int ensure_air(PwProver* p, const Shape& s, bool logup, CommitLayout& Lc) {
+    Lc.H = s.H; Lc.N = s.N; Lc.tree_words = 0; Lc.fri_words = 0; Lc.n_trees = 0;
+    Lc.panel_cols = lde_panel_cols(s.H, logup ? std::max<size_t>(s.W, s.Wp) : s.W);
+    TRY(p->coef.ensure(Lc.panel_cols * s.H * 4));
+    TRY(p->lde.ensure((size_t)s.W * s.N * 4));
+    if (logup) {
+        TRY(p->perm.ensure((size_t)s.Wp * s.H * 4));
+        TRY(p->plde.ensure((size_t)s.Wp * s.N * 4));
+    }
+    TRY(p->q.ensure(4 * s.N * 4));
+    if (!logup) {
+        const uint32_t chunks = quotient_chunks(s.N, s.nc);
+        if (chunks > 1) TRY(p->qpart.ensure((size_t)chunks * 4 * s.N * 4));
+    }
+    TRY(p->qcoef.ensure(8 * s.H * 4));
+    TRY(p->qlde.ensure(8 * s.N * 4));
+    TRY(p->ext_arena.ensure((3 * s.H + s.H / 4096 + 32) * sizeof(bb::Ext)));  // weights | weights at g zeta | row sums + block totals
+    const uint32_t n_chunks = div_up(s.H, 8192);
+    const uint32_t dot_cols = std::max({s.W, s.Wp, 8u});
+    TRY(p->misc.ensure(((size_t)dot_cols * n_chunks + s.M + p->max_args + 64) * sizeof(bb::Ext) + 4096));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int logup_flag, const uint32_t** proof_words, size_t* n_words) {
+    if (!airs || !n_airs || !proof_words || !n_words) return (int)hipErrorInvalidValue;
+    const bool lg = logup_flag != 0;
+    const size_t A = n_airs;
+    for (size_t a = 0; a < A; ++a) {
+        if (!airs[a].prover || !airs[a].d_trace || airs[a].log_height < 1 || airs[a].log_height > 26) return (int)hipErrorInvalidValue;
+        if (lg && !airs[a].prover->logup) return (int)hipErrorInvalidValue;  // needs the interaction tables (pw_prover_create_logup)
+    }
+    (void)hipGetLastError();
+    hipStream_t st = stream();
+    TRY(poseidon2_upload_params());
+    SegCtx& cx = g_ctx;
+    const PwStarkConfig cfg = airs[0].prover->cfg;
+    const uint32_t nq = cfg.num_queries;
+
+    // ---- shapes -----------------------------------------------------------------------------------------------
+    std::vector<Shape> sh(A);
+    size_t K_total = 0, M_max = 0;
+    int L = 0;
+    for (size_t a = 0; a < A; ++a) {
+        const PwProver* p = airs[a].prover;
+        Shape& s = sh[a];
+        s.W = p->width; s.nc = p->n_constraints; s.log_h = airs[a].log_height;
+        s.n_int = lg ? p->n_inter : 0; s.n_g = lg ? p->n_groups : 0; s.Wp = lg ? 4 * (s.n_g + 1) : 0;
+        s.M = s.nc + (lg ? s.n_g + 3 : 0);
+        s.K = s.W + 2 * s.Wp + 8;
+        s.H = (size_t)1 << s.log_h; s.N = 2 * s.H; s.logN = (int)s.log_h + 1;
+        s.koff = K_total;
+        K_total += s.K;
+        if (s.logN > L) L = s.logN;
+        if (s.M > M_max) M_max = s.M;
+    }
+    const size_t Nmax = (size_t)1 << L;
+    const size_t tree_words = merkle_words(Nmax);
+    const int n_trees = lg ? 3 : 2;
+    const int rounds = L - 1;
+    std::vector<size_t> layer_off(rounds + 1), ftree_off(rounds);
+    size_t fri_words = 0;
+    { size_t o = 0; for (int l = 0; l <= rounds; ++l) { layer_off[l] = o; o += Nmax >> l; } }
+    for (int l = 0; l < rounds; ++l) { ftree_off[l] = fri_words; fri_words += merkle_words((Nmax >> l) / 2); }
+    // reduced-opening vectors of the smaller heights, in the ext arena after the FRI layers
+    std::vector<size_t> ro_off(L + 1, 0);
+    std::vector<char> has_height(L + 1, 0);
+    for (size_t a = 0; a < A; ++a) has_height[sh[a].logN] = 1;
+    size_t ext_words = 2 * Nmax;
+    for (int k = L - 1; k >= 2; --k) if (has_height[k]) { ro_off[k] = ext_words; ext_words += (size_t)1 << k; }
+    const size_t tmp_off = ext_words;
+    ext_words += Nmax;
+
+    // ---- buffers ----------------------------------------------------------------------------------------------
+    TRY(cx.dig.ensure((n_trees * tree_words + fri_words) * 4));
+    TRY(cx.inject.ensure((Nmax / 2 + 1) * 8 * 4));
+    TRY(cx.ext.ensure(ext_words * sizeof(bb::Ext)));
+    size_t cols_total = 0;
+    for (size_t a = 0; a < A; ++a) cols_total += std::max<size_t>({sh[a].W, sh[a].Wp, 8});
+    size_t row_words = 0;  // query answers: rows of every tree
+    for (size_t a = 0; a < A; ++a) row_words += (size_t)nq * (sh[a].W + sh[a].Wp + 8);
+    const size_t n_dig = (size_t)nq * ((size_t)n_trees * L + (size_t)rounds * L) + 16;  // upper bound of digest records
+    const size_t misc_bytes = cols_total * 8 + 4 * A * 8 + 2 * K_total * sizeof(bb::Ext) + (size_t)A * nq * 4 + row_words * 4 + n_dig * (8 + 32) +
+                              (size_t)nq * rounds * (8 + 16) + 4 * A * 4 + 8192;
+    TRY(cx.misc.ensure(misc_bytes));
+    uint32_t* d_dig = cx.dig.as<uint32_t>();
+    uint32_t* d_fdig = d_dig + n_trees * tree_words;
+    bb::Ext* d_v = cx.ext.as<bb::Ext>();
+    // misc layout (8-byte aligned pieces first)
+    uint8_t* mp = cx.misc.as<uint8_t>();
+    const uint32_t** d_cols = reinterpret_cast<const uint32_t**>(mp); mp += cols_total * 8;
+    const uint32_t** d_sptrs = reinterpret_cast<const uint32_t**>(mp); mp += 4 * A * 8;
+    uint64_t* d_offs = reinterpret_cast<uint64_t*>(mp); mp += n_dig * 8 + (size_t)nq * rounds * 8;
+    bb::Ext* d_opened = reinterpret_cast<bb::Ext*>(mp); mp += K_total * sizeof(bb::Ext);
+    bb::Ext* d_gpow = reinterpret_cast<bb::Ext*>(mp); mp += K_total * sizeof(bb::Ext);
+    uint32_t* d_idx = reinterpret_cast<uint32_t*>(mp); mp += (size_t)A * nq * 4;
+    uint32_t* d_rows = reinterpret_cast<uint32_t*>(mp); mp += row_words * 4;
+    uint32_t* d_dig_out = reinterpret_cast<uint32_t*>(mp); mp += n_dig * 32;
+    uint32_t* d_ext_out = reinterpret_cast<uint32_t*>(mp); mp += (size_t)nq * rounds * 16;
+    uint32_t* d_small = reinterpret_cast<uint32_t*>(mp);  // 4 A words (cumulative sums), PoW scratch
+
+    std::vector<CommitLayout> Lc(A);
+    for (size_t a = 0; a < A; ++a) TRY(ensure_air(airs[a].prover, sh[a], lg, Lc[a]));
+
+    std::vector<uint32_t>& pf = cx.proof;
+    pf.clear();
+    auto put = [&](uint32_t canonical) { pf.push_back(canonical); };
+    auto put_monty = [&](const uint32_t* w, size_t n) { for (size_t i = 0; i < n; ++i) pf.push_back(bb::from_monty(w[i])); };
+    Challenger ch;
+    for (uint32_t x : {kMagic3, (uint32_t)A, lg ? 1u : 0u, cfg.num_queries, cfg.pow_bits}) { ch.observe_canonical(x % bb::P); put(x); }
+    for (size_t a = 0; a < A; ++a)
+        for (uint32_t x : {sh[a].log_h, sh[a].W, sh[a].nc, sh[a].n_int}) { ch.observe_canonical(x % bb::P); put(x); }
+
+    // mixed commitment of one matrix per AIR: matrix(a) = (device pointer, width); heights are the AIRs' LDE heights
+    std::vector<const uint32_t*> h_cols;
+    auto commit_mixed = [&](auto matrix_of, int tree, uint32_t* root_monty) -> int {
+        h_cols.clear();
+        std::vector<MixedLevelCols> by_log(L + 1, MixedLevelCols{nullptr, 0});
+        for (int k = L; k >= 0; --k) {
+            const size_t first = h_cols.size();
+            for (size_t a = 0; a < A; ++a) {
+                if (sh[a].logN != k) continue;
+                const uint32_t* m; uint32_t w;
+                matrix_of(a, m, w);
+                for (uint32_t c = 0; c < w; ++c) h_cols.push_back(m + (size_t)c * sh[a].N);
+            }
+            by_log[k] = MixedLevelCols{d_cols + first, (uint32_t)(h_cols.size() - first)};
+        }
+        PW_HIP_TRY(hipMemcpyAsync(d_cols, h_cols.data(), h_cols.size() * 8, hipMemcpyHostToDevice, st));
+        uint32_t* dg = d_dig + (size_t)tree * tree_words;
+        TRY(merkle_commit_mixed(by_log.data(), L, dg, cx.inject.as<uint32_t>()));
+        PW_HIP_TRY(hipMemcpyAsync(root_monty, dg + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
+        return 0;
+    };
+
+    // ---- 1. main traces ---------------------------------------------------------------------------------------
+    uint32_t root[8];
+    for (size_t a = 0; a < A; ++a) {
+        PwProver* p = airs[a].prover;
+        p->committed_trace = nullptr;
+        TRY(lde_matrix(p, Lc[a], sh[a].log_h, airs[a].d_trace, sh[a].W, p->lde.as<uint32_t>()));
+    }
+    TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) { m = airs[a].prover->lde.as<uint32_t>(); w = sh[a].W; }, 0, root));
+    PW_HIP_TRY(hipStreamSynchronize(st));
+    put_monty(root, 8);
+    ch.observe_words(root, 8);
+
+    // per-AIR scratch pointers
+    auto weights_of = [&](size_t a) { return airs[a].prover->ext_arena.as<bb::Ext>(); };
+    auto scratch_of = [&](size_t a) { return airs[a].prover->misc.as<bb::Ext>(); };
+    auto apow_of = [&](size_t a) { return scratch_of(a) + (size_t)std::max({sh[a].W, sh[a].Wp, 8u}) * div_up(sh[a].H, 8192); };
+    auto blpow_of = [&](size_t a) { return apow_of(a) + sh[a].M + 4; };
+    auto logup_program = [&](size_t a) {
+        const PwProver* p = airs[a].prover;
+        return LogupProgram{p->d_inter, sh[a].n_int, p->d_ixspans, p->d_icode, p->d_gstarts, sh[a].n_g};
+    };
+
+    // ---- 2. LogUp ---------------------------------------------------------------------------------------------
+    bb::Ext al = bb::ext_zero(), bl = bb::ext_zero();
+    std::vector<bb::Ext> S(A, bb::ext_zero());
+    std::vector<std::vector<bb::Ext>> keep;  // host sources of asynchronous uploads, alive until the next synchronisation
+    if (lg) {
+        al = ch.sample_ext();
+        bl = ch.sample_ext();
+        std::vector<const uint32_t*> sp;
+        for (size_t a = 0; a < A; ++a) {
+            PwProver* p = airs[a].prover;
+            keep.emplace_back(p->max_args + 2);
+            { bb::Ext b = bb::ext_one(); for (auto& x : keep.back()) { x = b; b = bb::ext_mul(b, bl); } }
+            PW_HIP_TRY(hipMemcpyAsync(blpow_of(a), keep.back().data(), keep.back().size() * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
+            bb::Ext* rowsum = weights_of(a) + 2 * sh[a].H;
+            TRY(logup_perm_trace(airs[a].d_trace, sh[a].H, logup_program(a), al, blpow_of(a), p->perm.as<uint32_t>(), rowsum, rowsum + sh[a].H));
+            TRY(lde_matrix(p, Lc[a], sh[a].log_h, p->perm.as<uint32_t>(), sh[a].Wp, p->plde.as<uint32_t>()));
+            for (int k = 0; k < 4; ++k) sp.push_back(p->perm.as<uint32_t>() + ((size_t)(4 * sh[a].n_g + k) * sh[a].H + (sh[a].H - 1)));  // S = phi(last row)
+        }
+        TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) { m = airs[a].prover->plde.as<uint32_t>(); w = sh[a].Wp; }, 2, root));
+        PW_HIP_TRY(hipMemcpyAsync(d_sptrs, sp.data(), sp.size() * 8, hipMemcpyHostToDevice, st));
+        TRY(gather_words(d_sptrs, (uint32_t)sp.size(), d_small));
+        std::vector<uint32_t> sw(4 * A);
+        PW_HIP_TRY(hipMemcpyAsync(sw.data(), d_small, sw.size() * 4, hipMemcpyDeviceToHost, st));
+        PW_HIP_TRY(hipStreamSynchronize(st));
+        keep.clear();
+        put_monty(root, 8);
+        ch.observe_words(root, 8);
+        for (size_t a = 0; a < A; ++a) {
+            for (int k = 0; k < 4; ++k) S[a].c[k] = sw[4 * a + k];
+            put_monty(S[a].c, 4);
+            ch.observe_ext(S[a]);
+        }
+    }
+
+    // ---- 3. quotients -----------------------------------------------------------------------------------------
+    const bb::Ext alpha = ch.sample_ext();
+    {
+        std::vector<bb::Ext> apow_all(M_max ? M_max : 1);  // alpha^0 .. alpha^(M_max - 1)
+        { bb::Ext x = bb::ext_one(); for (auto& v : apow_all) { v = x; x = bb::ext_mul(x, alpha); } }
+        const uint32_t s_m = bb::to_monty(field::kCosetShift), one = bb::R_MOD_P;
+        for (size_t a = 0; a < A; ++a) {
+            PwProver* p = airs[a].prover;
+            const Shape& s = sh[a];
+            keep.emplace_back(s.M ? s.M : 1);
+            for (size_t j = 0; j < s.M; ++j) keep.back()[j] = apow_all[s.M - 1 - j];
+            if (s.M) PW_HIP_TRY(hipMemcpyAsync(apow_of(a), keep.back().data(), s.M * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
+            uint32_t sH = s_m;
+            for (uint32_t i = 0; i < s.log_h; ++i) sH = bb::sqr(sH);
+            const uint32_t zv_even = bb::sub(sH, one), zv_odd = bb::sub(bb::neg(sH), one);
+            ConstraintProgram prog{p->d_bytecode, p->d_spans, s.nc, p->is_xbc};
+            uint32_t* d_q = p->q.as<uint32_t>();
+            if (lg)
+                TRY(quotient_eval_logup(p->lde.as<uint32_t>(), p->plde.as<uint32_t>(), s.N, s.logN, prog, logup_program(a), apow_of(a), al,
+                                        blpow_of(a), S[a], zv_even, zv_odd, d_q));
+            else
+                TRY(quotient_eval(p->lde.as<uint32_t>(), s.N, prog, apow_of(a), bb::inv(zv_even), bb::inv(zv_odd), d_q, p->qpart.as<uint32_t>(),
+                                  quotient_chunks(s.N, s.nc)));
+            TRY(intt_dif(d_q, d_q, s.N, s.N, 4, s.logN));
+            TRY(quotient_split(d_q, s.H, (int)s.log_h, p->qcoef.as<uint32_t>()));
+            TRY(coset_lde_from_coeffs(p->qcoef.as<uint32_t>(), p->qlde.as<uint32_t>(), s.H, s.N, 8, (int)s.log_h));
+        }
+        TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) { m = airs[a].prover->qlde.as<uint32_t>(); w = 8; }, 1, root));
+        PW_HIP_TRY(hipStreamSynchronize(st));
+        keep.clear();
+    }
+    put_monty(root, 8);
+    ch.observe_words(root, 8);
+
+    // ---- 4. openings: per AIR main | perm at zeta | quotient | perm at g zeta ----------------------------------
+    const bb::Ext zeta = ch.sample_ext();
+    std::vector<bb::Ext> gzeta(A);
+    for (size_t a = 0; a < A; ++a) {
+        PwProver* p = airs[a].prover;
+        const Shape& s = sh[a];
+        bb::Ext* o = d_opened + s.koff;
+        bb::Ext* w1 = weights_of(a);
+        bb::Ext* w2 = w1 + s.H;
+        gzeta[a] = bb::ext_scale(zeta, field::root_of_unity((int)s.log_h));
+        // trace columns: barycentric evaluation straight from the caller's trace; quotient chunks from their coefficients
+        TRY(barycentric_weights(zeta, (int)s.log_h, w1));
+        TRY(ext_dot_columns(airs[a].d_trace, s.H, s.W, s.H, w1, o, scratch_of(a)));
+        if (lg) {
+            TRY(ext_dot_columns(p->perm.as<uint32_t>(), s.H, s.Wp, s.H, w1, o + s.W, scratch_of(a)));
+            TRY(barycentric_weights(gzeta[a], (int)s.log_h, w2));
+            TRY(ext_dot_columns(p->perm.as<uint32_t>(), s.H, s.Wp, s.H, w2, o + s.W + s.Wp + 8, scratch_of(a)));
+        }
+        TRY(zeta_weights(zeta, (int)s.log_h, w1));
+        TRY(ext_dot_columns(p->qcoef.as<uint32_t>(), s.H, 8, s.H, w1, o + s.W + s.Wp, scratch_of(a)));
+    }
+    std::vector<bb::Ext> opened(K_total);
+    PW_HIP_TRY(hipMemcpyAsync(opened.data(), d_opened, K_total * sizeof(bb::Ext), hipMemcpyDeviceToHost, st));
+    PW_HIP_TRY(hipStreamSynchronize(st));
+    for (const bb::Ext& e : opened) { put_monty(e.c, 4); ch.observe_ext(e); }
+
+    // ---- 5. reduced openings per height ------------------------------------------------------------------------
+    const bb::Ext gamma = ch.sample_ext();
+    std::vector<bb::Ext> gpow(K_total);
+    { bb::Ext g = bb::ext_one(); for (auto& x : gpow) { x = g; g = bb::ext_mul(g, gamma); } }
+    PW_HIP_TRY(hipMemcpyAsync(d_gpow, gpow.data(), K_total * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
+    {
+        std::vector<char> started(L + 1, 0);
+        for (size_t a = 0; a < A; ++a) {
+            PwProver* p = airs[a].prover;
+            const Shape& s = sh[a];
+            const size_t K1 = (size_t)s.W + s.Wp + 8;
+            bb::Ext sum1 = bb::ext_zero(), sum2 = bb::ext_zero();
+            for (size_t k = 0; k < K1; ++k) sum1 = bb::ext_add(sum1, bb::ext_mul(gpow[s.koff + k], opened[s.koff + k]));
+            for (size_t k = K1; k < s.K; ++k) sum2 = bb::ext_add(sum2, bb::ext_mul(gpow[s.koff + k], opened[s.koff + k]));
+            bb::Ext* target = s.logN == L ? d_v : d_v + ro_off[s.logN];
+            bb::Ext* out = started[s.logN] ? d_v + tmp_off : target;
+            if (lg)
+                TRY(deep_quotient_logup(p->lde.as<uint32_t>(), s.W, p->plde.as<uint32_t>(), s.Wp, p->qlde.as<uint32_t>(), s.N, s.logN,
+                                        d_gpow + s.koff, sum1, sum2, zeta, gzeta[a], out));
+            else
+                TRY(deep_quotient(p->lde.as<uint32_t>(), s.W, p->qlde.as<uint32_t>(), 8, s.N, s.logN, d_gpow + s.koff, sum1, zeta, out));
+            if (started[s.logN]) TRY(ext_axpy(target, nullptr, out, s.N));
+            started[s.logN] = 1;
+        }
+    }
+    PW_HIP_TRY(hipStreamSynchronize(st));  // gpow is a local
+
+    // ---- 6. FRI over the unshifted subgroups, smaller heights rolled in ------------------------------------------
+    for (int l = 0; l < rounds; ++l) {
+        const size_t half = (Nmax >> l) / 2;
+        bb::Ext* v = d_v + layer_off[l];
+        uint32_t* dg = d_fdig + ftree_off[l];
+        TRY(merkle_commit_ext_pairs(v, half, dg));
+        PW_HIP_TRY(hipMemcpyAsync(root, dg + merkle_words(half) - 8, 32, hipMemcpyDeviceToHost, st));
+        PW_HIP_TRY(hipStreamSynchronize(st));
+        put_monty(root, 8);
+        ch.observe_words(root, 8);
+        const bb::Ext beta = ch.sample_ext();
+        bb::Ext* nv = d_v + layer_off[l + 1];
+        TRY(fri_fold(v, half, L - l, bb::R_MOD_P, beta, nv));
+        const int lk = L - l - 1;
+        if (lk >= 2 && has_height[lk]) {
+            const bb::Ext beta2 = bb::ext_mul(beta, beta);
+            TRY(ext_axpy(nv, &beta2, d_v + ro_off[lk], half));
+        }
+    }
+    bb::Ext final_poly;
+    PW_HIP_TRY(hipMemcpyAsync(&final_poly, d_v + layer_off[rounds], sizeof(bb::Ext), hipMemcpyDeviceToHost, st));
+    PW_HIP_TRY(hipStreamSynchronize(st));
+    put_monty(final_poly.c, 4);
+    ch.observe_ext(final_poly);
+
+    // ---- 7. proof of work ----------------------------------------------------------------------------------------
+    uint32_t witness = 0;
+    if (cfg.pow_bits) {
+        uint32_t* d_state = d_small;
+        uint32_t pending[8] = {0};
+        for (size_t i = 0; i < ch.in.size(); ++i) pending[i] = ch.in[i];
+        PW_HIP_TRY(hipMemcpyAsync(d_state, ch.st, 64, hipMemcpyHostToDevice, st));
+        PW_HIP_TRY(hipMemcpyAsync(d_state + 16, pending, 32, hipMemcpyHostToDevice, st));
+        TRY(pow_grind(d_state, d_state + 16, (uint32_t)ch.in.size(), cfg.pow_bits, d_state + 24, &witness));
+    }
+    put(witness);
+    ch.observe_canonical(witness);
+    if (cfg.pow_bits) (void)ch.sample_bits((int)cfg.pow_bits);
+
+    // ---- 8. queries ------------------------------------------------------------------------------------------------
+    if (nq) {
+        std::vector<uint32_t> qs(nq), idx((size_t)A * nq);
+        for (auto& q : qs) q = ch.sample_bits(L);
+        for (size_t a = 0; a < A; ++a)
+            for (uint32_t i = 0; i < nq; ++i) idx[a * nq + i] = qs[i] & (uint32_t)(sh[a].N - 1);
+        PW_HIP_TRY(hipMemcpyAsync(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
+        // rows: tree by tree (proof order main, perm, quotient), AIR by AIR, nq rows each
+        const int tree_of_phase[3] = {0, 2, 1};  // digest arena order: main | quotient | perm
+        std::vector<size_t> row_off[3];
+        size_t ro = 0;
+        for (int ph = 0; ph < 3; ++ph) {
+            if (ph == 1 && !lg) continue;
+            row_off[ph].resize(A);
+            for (size_t a = 0; a < A; ++a) {
+                PwProver* p = airs[a].prover;
+                const uint32_t* m = ph == 0 ? p->lde.as<uint32_t>() : ph == 1 ? p->plde.as<uint32_t>() : p->qlde.as<uint32_t>();
+                const uint32_t w = ph == 0 ? sh[a].W : ph == 1 ? sh[a].Wp : 8u;
+                row_off[ph][a] = ro;
+                TRY(gather_rows(m, sh[a].N, w, d_idx + a * nq, nq, d_rows + ro));
+                ro += (size_t)nq * w;
+            }
+        }
+        std::vector<uint64_t> dig_offs, ext_offs;
+        for (uint32_t qi = 0; qi < nq; ++qi) {
+            const size_t q = qs[qi];
+            for (int ph = 0; ph < 3; ++ph) {
+                if (ph == 1 && !lg) continue;
+                const size_t base = (size_t)tree_of_phase[ph] * tree_words;
+                for (int l = 0; l < L; ++l) {
+                    const size_t size = Nmax >> l, p = q & (size - 1);
+                    dig_offs.push_back(base + merkle_level_offset(Nmax, l) + (((p + size / 2) & (size - 1)) * 8));
+                }
+            }
+            for (int l = 0; l < rounds; ++l) {
+                const size_t Nl = Nmax >> l, half = Nl / 2, pp = q & (Nl - 1);
+                ext_offs.push_back((layer_off[l] + (pp ^ half)) * 4);
+                const size_t leaf = pp & (half - 1);
+                for (int lv = 0; lv < L - 1 - l; ++lv)
+                    dig_offs.push_back((size_t)n_trees * tree_words + ftree_off[l] + merkle_level_offset(half, lv) + (((leaf >> lv) ^ 1) * 8));
+            }
+        }
+        const size_t nd = dig_offs.size(), ne = ext_offs.size();
+        if (nd > n_dig) return (int)hipErrorInvalidValue;
+        uint64_t* d_dig_offs = d_offs;
+        uint64_t* d_ext_offs = d_offs + nd;
+        PW_HIP_TRY(hipMemcpyAsync(d_dig_offs, dig_offs.data(), nd * 8, hipMemcpyHostToDevice, st));
+        if (ne) PW_HIP_TRY(hipMemcpyAsync(d_ext_offs, ext_offs.data(), ne * 8, hipMemcpyHostToDevice, st));
+        TRY(gather_records(d_dig, d_dig_offs, 8u, (uint32_t)nd, d_dig_out));
+        TRY(gather_records(reinterpret_cast<const uint32_t*>(d_v), d_ext_offs, 4u, (uint32_t)ne, d_ext_out));
+        std::vector<uint32_t> rows(ro + 1), dig(nd * 8 + 1), ext(ne * 4 + 1);
+        PW_HIP_TRY(hipMemcpyAsync(rows.data(), d_rows, ro * 4, hipMemcpyDeviceToHost, st));
+        PW_HIP_TRY(hipMemcpyAsync(dig.data(), d_dig_out, nd * 32, hipMemcpyDeviceToHost, st));
+        if (ne) PW_HIP_TRY(hipMemcpyAsync(ext.data(), d_ext_out, ne * 16, hipMemcpyDeviceToHost, st));
+        PW_HIP_TRY(hipStreamSynchronize(st));
+        size_t dpos = 0, epos = 0;
+        for (uint32_t qi = 0; qi < nq; ++qi) {
+            put(qs[qi]);
+            for (int ph = 0; ph < 3; ++ph) {
+                if (ph == 1 && !lg) continue;
+                for (size_t a = 0; a < A; ++a) {
+                    const uint32_t w = ph == 0 ? sh[a].W : ph == 1 ? sh[a].Wp : 8u;
+                    put_monty(&rows[row_off[ph][a] + (size_t)qi * w], w);
+                }
+                put_monty(&dig[dpos * 8], (size_t)L * 8);
+                dpos += L;
+            }
+            for (int l = 0; l < rounds; ++l) {
+                put_monty(&ext[epos * 4], 4);
+                epos += 1;
+                const size_t depth = (size_t)L - 1 - l;
+                put_monty(&dig[dpos * 8], depth * 8);
+                dpos += depth;
+            }
+        }
+    }
+    *proof_words = pf.data();
+    *n_words = pf.size();
+    return (int)hipGetLastError();
+}

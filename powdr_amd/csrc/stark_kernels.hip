@@ -233,6 +233,18 @@ __global__ __launch_bounds__(kBlock) void fri_fold_kernel(const bb::Ext* __restr
     out[i] = bb::ext_add(s, bb::ext_mul(beta, d));
 }
 
+// y[i] += a * x[i]
+__global__ __launch_bounds__(kBlock) void ext_axpy_kernel(bb::Ext* __restrict__ y, bb::Ext a, const bb::Ext* __restrict__ x, size_t n, int a_is_one) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    y[i] = bb::ext_add(y[i], a_is_one ? x[i] : bb::ext_mul(a, x[i]));
+}
+// out[i] = *ptrs[i]
+__global__ void gather_words_kernel(const uint32_t* const* __restrict__ ptrs, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = *ptrs[i];
+}
+
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const uint32_t* __restrict__ m, size_t height, uint32_t width,
                                                               const uint32_t* __restrict__ idx, uint32_t* __restrict__ out) {
     const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
@@ -336,6 +348,20 @@ int fri_fold(const bb::Ext* v, size_t half, int log_size, uint32_t shift, bb::Ex
     const uint32_t w_inv = bb::inv(field::root_of_unity(log_size));
     ScopedKernelTimer t("fri_fold_kernel");
     hipLaunchKernelGGL(fri_fold_kernel, dim3(div_up(half, kBlock)), dim3(kBlock), 0, stream(), v, half, shift_inv_half, w_inv, inv2, beta, out);
+    return (int)hipGetLastError();
+}
+
+int ext_axpy(bb::Ext* y, const bb::Ext* a_or_null, const bb::Ext* x, size_t n) {
+    if (!n) return 0;
+    ScopedKernelTimer t("ext_axpy_kernel");
+    hipLaunchKernelGGL(ext_axpy_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, stream(), y, a_or_null ? *a_or_null : bb::ext_one(), x, n,
+                       a_or_null ? 0 : 1);
+    return (int)hipGetLastError();
+}
+
+int gather_words(const uint32_t* const* d_ptrs, uint32_t n, uint32_t* d_out) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(gather_words_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream(), d_ptrs, n, d_out);
     return (int)hipGetLastError();
 }
 

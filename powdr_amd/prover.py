@@ -14,7 +14,7 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_merkle_commit", "pw_poseidon2_permute_host"]
 
 lib.pw_prover_create.restype = C.c_void_p
@@ -95,11 +95,15 @@ class PwAirDescription(C.Structure):
                 ("inter_bytecode", C.c_void_p), ("inter_bytecode_len", C.c_size_t)]
 
 
-lib.pw_prove_segment.restype = C.c_int
-lib.pw_prove_segment.argtypes = [C.POINTER(PwSegmentAir), C.c_size_t, C.c_int, C.c_uint, C.POINTER(C.POINTER(C.c_uint32)),
+lib.pw_prove_airs.restype = C.c_int
+lib.pw_prove_airs.argtypes = [C.POINTER(PwSegmentAir), C.c_size_t, C.c_int, C.c_uint, C.POINTER(C.POINTER(C.c_uint32)),
                                  C.POINTER(C.c_size_t), C.c_void_p]
+lib.pw_prove_segment.restype = C.c_int
+lib.pw_prove_segment.argtypes = [C.POINTER(PwSegmentAir), C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]
 lib.pw_verify_segment.restype = C.c_int
-lib.pw_verify_segment.argtypes = [C.POINTER(PwStarkConfig), C.POINTER(PwAirDescription), C.c_size_t, C.POINTER(C.c_void_p),
+lib.pw_verify_segment.argtypes = [C.POINTER(PwStarkConfig), C.POINTER(PwAirDescription), C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+lib.pw_verify_airs.restype = C.c_int
+lib.pw_verify_airs.argtypes = [C.POINTER(PwStarkConfig), C.POINTER(PwAirDescription), C.c_size_t, C.POINTER(C.c_void_p),
                                   C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_void_p]
 lib.pw_commitment_digest.restype = None
 lib.pw_commitment_digest.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
@@ -130,9 +134,10 @@ def commitment_digest(roots) -> np.ndarray:
     return out
 
 
-def prove_segment(airs, shared_bus_seed: bool = False, n_workers: int = 0, copy: bool = True):
+def prove_airs(airs, shared_bus_seed: bool = False, n_workers: int = 0, copy: bool = True):
     """airs: [(Prover, device trace pointer, log_height)] -> ([proof words per AIR], bus seed).
-    One call proves all AIRs of a segment on `n_workers` host threads / HIP streams (0 = 4)."""
+    INDEPENDENT proofs, one per AIR, on `n_workers` host threads / HIP streams (0 = 4) — the flow AIR-level sharding
+    over ranks uses; `prove_segment` is the one-proof-per-segment form."""
     n = len(airs)
     recs = (PwSegmentAir * max(n, 1))()
     for i, (pr, ptr, lh) in enumerate(airs):
@@ -140,8 +145,8 @@ def prove_segment(airs, shared_bus_seed: bool = False, n_workers: int = 0, copy:
     proofs = (C.POINTER(C.c_uint32) * max(n, 1))()
     lens = (C.c_size_t * max(n, 1))()
     seed = np.zeros(8, np.uint32)
-    rc = lib.pw_prove_segment(recs, n, int(shared_bus_seed), n_workers, proofs, lens, seed.ctypes.data_as(C.c_void_p))
-    abi.check(rc, "pw_prove_segment")
+    rc = lib.pw_prove_airs(recs, n, int(shared_bus_seed), n_workers, proofs, lens, seed.ctypes.data_as(C.c_void_p))
+    abi.check(rc, "pw_prove_airs")
     out = []
     for i in range(n):
         a = np.ctypeslib.as_array(proofs[i], shape=(lens[i],))
@@ -149,7 +154,53 @@ def prove_segment(airs, shared_bus_seed: bool = False, n_workers: int = 0, copy:
     return out, seed
 
 
-def verify_segment(descs, proofs, num_queries: int = 100, pow_bits: int = 0, shared_bus_seed: bool = False, check_balance: bool = False):
+def _air_descriptions(descs):
+    n = len(descs)
+    keep, recs = [], (PwAirDescription * max(n, 1))()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for i, (w, lh, bc, sp, it) in enumerate(descs):
+        bc = np.ascontiguousarray(bc, dtype=np.uint32)
+        sp = np.ascontiguousarray(sp, dtype=np.uint32).reshape(-1, 2)
+        keep += [bc, sp]
+        if it is None:
+            recs[i] = PwAirDescription(w, lh, 0, vp(bc), len(bc), vp(sp), len(sp), None, 0, None, 0, None, 0)
+        else:
+            a = np.ascontiguousarray(it[0], dtype=np.uint32).reshape(-1, 3)
+            b = np.ascontiguousarray(it[1], dtype=np.uint32).reshape(-1, 2)
+            c = np.ascontiguousarray(it[2], dtype=np.uint32)
+            keep += [a, b, c]
+            recs[i] = PwAirDescription(w, lh, 1, vp(bc), len(bc), vp(sp), len(sp), vp(a), len(a), vp(b), len(b), vp(c), len(c))
+    return recs, keep
+
+
+def prove_segment(airs, logup: bool = False, copy: bool = True) -> np.ndarray:
+    """ONE proof for all AIRs of a segment (pw-stark v1, magic PWS3): airs = [(Prover, device trace pointer, log_height)],
+    every Prover created with `interactions=` when logup. The counterpart of the reference's one engine call per segment."""
+    n = len(airs)
+    recs = (PwSegmentAir * max(n, 1))()
+    for i, (pr, ptr, lh) in enumerate(airs):
+        recs[i] = PwSegmentAir(pr._h, ptr, lh)
+    words = C.POINTER(C.c_uint32)()
+    nw = C.c_size_t()
+    abi.check(lib.pw_prove_segment(recs, n, int(logup), C.byref(words), C.byref(nw)), "pw_prove_segment")
+    a = np.ctypeslib.as_array(words, shape=(nw.value,))
+    return a.copy() if copy else a
+
+
+def verify_segment(descs, proof, num_queries: int = 100, pow_bits: int = 0, logup: bool = False, check_balance: bool = False):
+    """Host verification of a segment proof. descs: [(width, log_height, cons_bytecode, cons_spans, interactions-or-None)]
+    -> (code, sum of the AIRs' cumulative bus sums). 0 = valid; ((i+1) << 8) | 2 = constraint identity of AIR i;
+    14 = the bus sums do not cancel (check_balance)."""
+    recs, keep = _air_descriptions(descs)
+    pr = np.ascontiguousarray(proof, dtype=np.uint32)
+    cfg = PwStarkConfig(num_queries, pow_bits)
+    total = np.zeros(4, np.uint32)
+    rc = int(lib.pw_verify_segment(C.byref(cfg), recs, len(descs), int(logup), pr.ctypes.data_as(C.c_void_p), len(pr), int(check_balance),
+                                   total.ctypes.data_as(C.c_void_p)))
+    return rc, total
+
+
+def verify_airs(descs, proofs, num_queries: int = 100, pow_bits: int = 0, shared_bus_seed: bool = False, check_balance: bool = False):
     """descs: [(width, log_height, cons_bytecode, cons_spans, interactions-or-None)] -> (code, total bus sum).
     code 0 = every proof valid (and balanced if asked); ((i+1) << 8) | c = proof i failed check c; 14 = unbalanced."""
     n = len(descs)
@@ -172,7 +223,7 @@ def verify_segment(descs, proofs, num_queries: int = 100, pow_bits: int = 0, sha
     lens = (C.c_size_t * max(n, 1))(*[len(p) for p in prs])
     cfg = PwStarkConfig(num_queries, pow_bits)
     total = np.zeros(4, np.uint32)
-    rc = int(lib.pw_verify_segment(C.byref(cfg), recs, n, ptrs, lens, int(shared_bus_seed), int(check_balance), vp(total)))
+    rc = int(lib.pw_verify_airs(C.byref(cfg), recs, n, ptrs, lens, int(shared_bus_seed), int(check_balance), vp(total)))
     return rc, total
 
 

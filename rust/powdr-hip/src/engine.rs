@@ -44,22 +44,19 @@ pub struct HipEngine {
     pub config: ffi::PwStarkConfig,
     /// indexed by air_id of the `MultiStarkProvingKey`
     pub provers: Vec<HipAirProver>,
-    /// host worker threads / HIP streams of `pw_prove_segment` (0 = the library default)
-    pub n_workers: u32,
 }
 
-/// The proof of one segment: per-AIR pw-stark proofs bound by one bus seed (include/powdr_prover.h).
+/// The proof of one segment: ONE pw-stark v1 proof (magic PWS3) over all AIRs (include/powdr_prover.h).
 pub struct HipSegmentProof {
     pub air_ids: Vec<usize>,
     pub log_heights: Vec<u32>,
-    pub proofs: Vec<Vec<u32>>,
-    pub bus_seed: [u32; 8],
+    pub words: Vec<u32>,
 }
 
 impl HipEngine {
     /// keygen-side construction: `programs[air_id]` = (width, post-fix constraint bytecode, spans, interaction tables)
     /// — for APC AIRs `powdr_apc_compile_constraints` / `powdr_apc_compile_bus(apc, 1)` produce exactly these from the APC.
-    pub fn new(config: ffi::PwStarkConfig, programs: &[AirProgram], n_workers: u32) -> Self {
+    pub fn new(config: ffi::PwStarkConfig, programs: &[AirProgram]) -> Self {
         let provers = programs
             .iter()
             .map(|p| {
@@ -76,10 +73,10 @@ impl HipEngine {
                 HipAirProver { handle, width: p.width }
             })
             .collect();
-        Self { config, provers, n_workers }
+        Self { config, provers }
     }
 
-    /// `engine.prove(pk, ctx)` (trace_generation.rs:136-139): ONE call per segment with the traces of all chips.
+    /// `engine.prove(pk, ctx)` (trace_generation.rs:136-139): ONE call per segment with the traces of all chips, one proof.
     pub fn prove_segment(&self, ctx: &ProvingContext<HipBackend>) -> Result<HipSegmentProof, HipError> {
         let mut airs = vec![];
         let mut air_ids = vec![];
@@ -99,16 +96,12 @@ impl HipEngine {
             air_ids.push(*air_id);
             log_heights.push(log_h);
         }
-        let n = airs.len();
-        let mut proofs = vec![core::ptr::null::<u32>(); n];
-        let mut lens = vec![0usize; n];
-        let mut seed = [0u32; 8];
-        // shared_bus_seed = 1: every AIR of the segment draws the same LogUp challenges; the bus sums must cancel
-        HipError::from_result(unsafe {
-            ffi::pw_prove_segment(airs.as_ptr(), n, 1, self.n_workers, proofs.as_mut_ptr(), lens.as_mut_ptr(), seed.as_mut_ptr())
-        })?;
-        let proofs = proofs.iter().zip(&lens).map(|(p, l)| unsafe { std::slice::from_raw_parts(*p, *l) }.to_vec()).collect();
-        Ok(HipSegmentProof { air_ids, log_heights, proofs, bus_seed: seed })
+        let mut words: *const u32 = core::ptr::null();
+        let mut n_words = 0usize;
+        // logup = 1: the bus interactions of every AIR are inside the proof; the cumulative sums must cancel
+        HipError::from_result(unsafe { ffi::pw_prove_segment(airs.as_ptr(), airs.len(), 1, &mut words, &mut n_words) })?;
+        let words = unsafe { std::slice::from_raw_parts(words, n_words) }.to_vec();
+        Ok(HipSegmentProof { air_ids, log_heights, words })
     }
 
     /// The CPU verification step (`verify_app_proof::<BabyBearPoseidon2CpuEngine>`, openvm-riscv/src/lib.rs:337-341)
@@ -129,11 +122,9 @@ impl HipEngine {
                 }
             })
             .collect();
-        let ptrs: Vec<*const u32> = proof.proofs.iter().map(|p| p.as_ptr()).collect();
-        let lens: Vec<usize> = proof.proofs.iter().map(|p| p.len()).collect();
         let mut total = [0u32; 4];
         let rc = unsafe {
-            ffi::pw_verify_segment(&self.config, descs.as_ptr(), descs.len(), ptrs.as_ptr(), lens.as_ptr(), 1, 1, total.as_mut_ptr())
+            ffi::pw_verify_segment(&self.config, descs.as_ptr(), descs.len(), 1, proof.words.as_ptr(), proof.words.len(), 1, total.as_mut_ptr())
         };
         if rc == 0 { Ok(()) } else { Err(rc) }
     }

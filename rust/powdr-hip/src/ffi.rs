@@ -238,11 +238,15 @@ extern "C" {
     pub fn pw_logup_group_starts(interactions: *const u32, n_interactions: usize, inter_spans: *const u32,
                                  n_inter_spans: usize, inter_bytecode: *const u32, inter_bytecode_len: usize,
                                  out: *mut u32, cap: usize) -> usize;
-    pub fn pw_prove_segment(airs: *const PwSegmentAir, n_airs: usize, shared_bus_seed: c_int, n_workers: c_uint,
-                            proofs: *mut *const u32, n_words: *mut usize, bus_seed8: *mut u32) -> c_int;
-    pub fn pw_verify_segment(cfg: *const PwStarkConfig, airs: *const PwAirDescription, n_airs: usize,
-                             proofs: *const *const u32, n_words: *const usize, shared_bus_seed: c_int,
-                             check_balance: c_int, total_sum4: *mut u32) -> c_int;
+    pub fn pw_prove_segment(airs: *const PwSegmentAir, n_airs: usize, logup: c_int, proof_words: *mut *const u32,
+                            n_words: *mut usize) -> c_int;
+    pub fn pw_verify_segment(cfg: *const PwStarkConfig, airs: *const PwAirDescription, n_airs: usize, logup: c_int,
+                             proof_words: *const u32, n_words: usize, check_balance: c_int, total_sum4: *mut u32) -> c_int;
+    pub fn pw_prove_airs(airs: *const PwSegmentAir, n_airs: usize, shared_bus_seed: c_int, n_workers: c_uint,
+                         proofs: *mut *const u32, n_words: *mut usize, bus_seed8: *mut u32) -> c_int;
+    pub fn pw_verify_airs(cfg: *const PwStarkConfig, airs: *const PwAirDescription, n_airs: usize,
+                          proofs: *const *const u32, n_words: *const usize, shared_bus_seed: c_int,
+                          check_balance: c_int, total_sum4: *mut u32) -> c_int;
     pub fn pw_commitment_digest(roots8: *const u32, n: usize, digest8: *mut u32);
     pub fn pw_prover_reserve(p: *mut PwProver, log_height: u32) -> c_int;
     pub fn pw_prover_max_constraint_degree(p: *const PwProver) -> c_int;

@@ -216,6 +216,32 @@ def balanced_bus_pair(log_h, seed):
     return (t1, send), (t2, recv)
 
 
+def balanced_bus_pair_mixed(log_h_send, log_h_recv, seed):
+    """Like balanced_bus_pair with DIFFERENT heights: the sender's tuples are received by an AIR of another height —
+    the receiver aggregates duplicates into multiplicities (more rows than needed are padded with multiplicity 0),
+    or splits a tuple over several rows when it is taller."""
+    rng = np.random.default_rng(seed)
+    Hs, Hr = 1 << log_h_send, 1 << log_h_recv
+    n_distinct = min(Hs, Hr)
+    a = rng.integers(0, P, n_distinct, dtype=np.uint32)
+    b = rng.integers(0, 1 << 16, n_distinct).astype(np.uint32)
+    # sender: row r sends tuple (r mod n_distinct) with multiplicity m_s[r]
+    m_s = rng.integers(0, 4, Hs).astype(np.uint32)
+    t1 = np.stack([m_s, a[np.arange(Hs) % n_distinct], b[np.arange(Hs) % n_distinct]])
+    total = np.zeros(n_distinct, np.int64)
+    np.add.at(total, np.arange(Hs) % n_distinct, m_s)
+    # receiver: tuple k's total multiplicity is spread over the rows r = k mod n_distinct (all on the first such row)
+    m_r = np.zeros(Hr, np.uint32)
+    m_r[:n_distinct] = total.astype(np.uint32)
+    perm = rng.permutation(Hr)
+    t2 = np.stack([m_r, a[np.arange(Hr) % n_distinct], b[np.arange(Hr) % n_distinct]])[:, perm]
+    PA = om.OP_PUSH_APC
+    send = (np.array([[5, 2, 0]], np.uint32), np.array([[0, 2], [2, 2], [4, 2]], np.uint32), np.array([PA, 0, PA, 1, PA, 2], np.uint32))
+    recv = (np.array([[5, 2, 0]], np.uint32), np.array([[0, 3], [3, 2], [5, 2]], np.uint32),
+            np.array([PA, 0, om.OP_NEG, PA, 1, PA, 2], np.uint32))
+    return (t1, send), (t2, recv)
+
+
 def ext_add_canonical(x, y):
     return (x.astype(np.uint64) + y.astype(np.uint64)) % P
 
@@ -287,28 +313,28 @@ def test_verify_segment_on_oracle_proofs():
 
     descs = [(3, 4, *no_cons, send), (3, 4, *no_cons, recv)]
     proofs = proofs_for([(t1, send), (t2, recv)])
-    rc, total = prover.verify_segment(descs, proofs, num_queries=5, shared_bus_seed=True, check_balance=True)
+    rc, total = prover.verify_airs(descs, proofs, num_queries=5, shared_bus_seed=True, check_balance=True)
     assert rc == 0 and (total == 0).all()
     # the order of the AIRs is part of the seed
-    assert prover.verify_segment(descs[::-1], proofs[::-1], num_queries=5, shared_bus_seed=True)[0] == (1 << 8) | 12
+    assert prover.verify_airs(descs[::-1], proofs[::-1], num_queries=5, shared_bus_seed=True)[0] == (1 << 8) | 12
     # a tampered opening in the second proof
     bad = [proofs[0], proofs[1].copy()]
     bad[1][40] = (int(bad[1][40]) + 1) % P
-    assert prover.verify_segment(descs, bad, num_queries=5, shared_bus_seed=True)[0] >> 8 == 2
+    assert prover.verify_airs(descs, bad, num_queries=5, shared_bus_seed=True)[0] >> 8 == 2
     # an unmatched tuple: every proof is valid, the segment is not balanced
     t2b = t2.copy()
     t2b[1, int(np.argmax(t2b[0] != 0))] ^= 1
     proofs = proofs_for([(t1, send), (t2b, recv)])
-    assert prover.verify_segment(descs, proofs, num_queries=5, shared_bus_seed=True, check_balance=False)[0] == 0
-    rc, total = prover.verify_segment(descs, proofs, num_queries=5, shared_bus_seed=True, check_balance=True)
+    assert prover.verify_airs(descs, proofs, num_queries=5, shared_bus_seed=True, check_balance=False)[0] == 0
+    rc, total = prover.verify_airs(descs, proofs, num_queries=5, shared_bus_seed=True, check_balance=True)
     assert rc == 14 and total.any()
     # constraints-only proofs ("PWS1") go through the same entry point
     s, apc, idx, trace = synthetic_trace("T0", 9, seed=3)
     W, H = trace.shape
     bc, spans = sm.compile_constraints(apc, idx)
     pf = sm.prove(np.ascontiguousarray(trace).reshape(-1), W, H.bit_length() - 1, bc, spans, num_queries=5)
-    assert prover.verify_segment([(W, H.bit_length() - 1, bc, spans, None)] * 2, [pf, pf], num_queries=5)[0] == 0
-    assert prover.verify_segment([(W, H.bit_length() - 1, bc, spans, None)], [pf[:-1]], num_queries=5)[0] == (1 << 8) | 10
+    assert prover.verify_airs([(W, H.bit_length() - 1, bc, spans, None)] * 2, [pf, pf], num_queries=5)[0] == 0
+    assert prover.verify_airs([(W, H.bit_length() - 1, bc, spans, None)], [pf[:-1]], num_queries=5)[0] == (1 << 8) | 10
 
 
 def test_logup_grouping_is_the_same_in_oracle_and_product():

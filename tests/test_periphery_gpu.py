@@ -173,13 +173,13 @@ def test_prove_segment_matches_the_per_air_flow(gpu, workers):
         pr.set_bus_seed(seed)
         ref.append(pr.prove(t.data_ptr(), lh))
     # one call
-    got, seed2 = prover.prove_segment([(pr, t.data_ptr(), lh) for pr, (t, _, _, _, lh) in zip(provers, airs)], shared_bus_seed=True,
+    got, seed2 = prover.prove_airs([(pr, t.data_ptr(), lh) for pr, (t, _, _, _, lh) in zip(provers, airs)], shared_bus_seed=True,
                                       n_workers=workers)
     assert (seed2 == seed).all()
     for a, b in zip(got, ref):
         assert len(a) == len(b) and (a == b).all()
     descs = [(w, lh, *c, it) for (_, w, c, it, lh) in airs]
-    rc, total = prover.verify_segment(descs, got, num_queries=nq, shared_bus_seed=True, check_balance=True)
+    rc, total = prover.verify_airs(descs, got, num_queries=nq, shared_bus_seed=True, check_balance=True)
     assert rc == 0 and (total == 0).all()
     # the rank-sharded orchestration (here with one rank owning every AIR) gives the same bytes again
     commit, prove = sharding.gpu_segment_callables(provers, [t.data_ptr() for t, *_ in airs], [lh for *_, lh in airs])
@@ -207,7 +207,7 @@ def test_prove_segment_many_airs_of_mixed_heights(gpu):
         provers.append(prover.Prover(W, bc, spans, num_queries=6, pow_bits=3))
     ref = [pr.prove(t.data_ptr(), lh) for pr, (t, _, lh, _, _) in zip(provers, airs)]
     for workers in (4, 0, 1):
-        got, _ = prover.prove_segment([(pr, t.data_ptr(), lh) for pr, (t, _, lh, _, _) in zip(provers, airs)], n_workers=workers)
+        got, _ = prover.prove_airs([(pr, t.data_ptr(), lh) for pr, (t, _, lh, _, _) in zip(provers, airs)], n_workers=workers)
         for a, b in zip(got, ref):
             assert len(a) == len(b) and (a == b).all()
     for k in (0, 5, 13):

@@ -1,0 +1,224 @@
+"""pw-stark v1: ONE proof per segment (oracle/stark_segment.inc, csrc/segment_prover.hip, pw_verify_segment).
+
+The reference makes one engine call per segment with all chips' traces (/root/reference/openvm/src/trace_generation.rs:
+136-139, openvm-riscv/src/lib.rs:327-341). CPU tests: the oracle prover against the oracle verifier and the product's
+host verifier (independent arithmetic), failure codes, bus balance, a committed golden digest. GPU tests: the HIP segment
+prover's words equal the oracle's for mixed heights, with and without LogUp."""
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import apc_model as om
+from oracle import stark_model as sm
+from powdr_amd import synth
+
+P = om.P
+GOLDEN = Path(__file__).parent / "golden" / "pw_stark_segment_T.json"
+
+
+def synthetic_airs(spec, seed0=1):
+    """[(shape, calls)] -> oracle air tuples (trace, W, log_h, cons_bc, cons_spans, interactions)."""
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+
+    airs = []
+    for k, (shape, calls) in enumerate(spec):
+        s = synth.generate(shape, seed=seed0 + k)
+        apc, idx, trace, _, _ = run_oracle_gpu_convention(s, calls, seed=seed0 + k)
+        W, H = trace.shape
+        airs.append((np.ascontiguousarray(trace).reshape(-1), W, H.bit_length() - 1, *sm.compile_constraints(apc, idx),
+                     sm.compile_interactions(apc, idx)))
+    return airs
+
+
+def descs_of(airs):
+    return [(a[1], a[2], a[3], a[4], a[5]) for a in airs]
+
+
+SPEC = [("T0", 30), ("T1", 200), ("T0", 5), ("T1", 64), ("T0", 30)]  # LDE heights 64, 512, 16, 128, 64
+
+
+@pytest.mark.parametrize("logup", [False, True])
+def test_oracle_segment_proof_and_both_verifiers(logup):
+    from powdr_amd import prover
+
+    airs = synthetic_airs(SPEC)
+    pf = sm.prove_segment(airs, num_queries=5, pow_bits=4, logup=logup)
+    assert sm.verify_segment(pf, airs, 5, 4, logup)[0] == 0
+    rc, total = prover.verify_segment(descs_of(airs), pf, 5, 4, logup)
+    assert rc == 0 and (total == sm.verify_segment(pf, airs, 5, 4, logup)[1]).all()
+    # one FRI and one query phase for the whole segment: smaller than the independent proofs
+    separate = sum(len(sm.prove_logup(a[0], a[1], a[2], a[3], a[4], *a[5], num_queries=5, pow_bits=4)) if logup else
+                   len(sm.prove(a[0], a[1], a[2], a[3], a[4], num_queries=5, pow_bits=4)) for a in airs)
+    assert len(pf) < 0.8 * separate
+    # every tampered word is rejected, by both verifiers, with the same code
+    rng = np.random.default_rng(7)
+    codes = set()
+    for pos in list(range(0, 30)) + [int(x) for x in rng.integers(30, len(pf), 60)]:
+        bad = pf.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        c1 = sm.verify_segment(bad, airs, 5, 4, logup)[0]
+        c2 = prover.verify_segment(descs_of(airs), bad, 5, 4, logup)[0]
+        assert c1 == c2 != 0, (pos, c1, c2)
+        codes.add(c1 & 0xFF)
+    assert {1, 2, 5, 7} <= codes
+    # wrong statement: heights / order / flag
+    assert prover.verify_segment(descs_of(airs)[::-1], pf, 5, 4, logup)[0] == 1
+    assert prover.verify_segment(descs_of(airs), pf, 5, 4, not logup)[0] == 1
+    assert prover.verify_segment(descs_of(airs), pf[:-3], 5, 4, logup)[0] in (9, 10, 7)
+    big = pf.copy()
+    big[len(big) // 2] = int(big[len(big) // 2]) + P if int(big[len(big) // 2]) + P < 2 ** 32 else big[len(big) // 2]
+    if (big != pf).any():
+        assert prover.verify_segment(descs_of(airs), big, 5, 4, logup)[0] == 13 == sm.verify_segment(big, airs, 5, 4, logup)[0]
+
+
+def test_segment_with_a_violated_constraint_is_rejected():
+    from powdr_amd import prover
+
+    airs = synthetic_airs([("T0", 20), ("T1", 100)])
+    t = airs[1][0].copy()
+    s = synth.generate("T1", seed=2)
+    apc = om.load_apc(s.doc)
+    idx = apc.poly_id_to_index()
+    valid_col = idx[[q for q, k in s.kinds.items() if k[0] == "valid"][0]]
+    H = 1 << airs[1][2]
+    t[valid_col * H + 3] = 2  # is_valid = 2 breaks is_valid * (is_valid - 1)
+    bad_airs = [airs[0], (t,) + airs[1][1:]]
+    pf = sm.prove_segment(bad_airs, num_queries=4, logup=False)
+    assert sm.verify_segment(pf, bad_airs, 4, 0, False)[0] == (2 << 8) | 2
+    assert prover.verify_segment(descs_of(bad_airs), pf, 4, 0, False)[0] == (2 << 8) | 2
+
+
+@pytest.mark.parametrize("log_hs", [(4, 4), (6, 3), (3, 9)])
+def test_segment_bus_balance(log_hs):
+    """Two AIRs on one bus (sends / permuted receives) of DIFFERENT heights in one segment proof: the cumulative sums
+    cancel (check_balance passes); one changed tuple and the segment is rejected with code 14 — by both verifiers."""
+    from powdr_amd import prover
+    from tests.test_oracle_stark import balanced_bus_pair_mixed
+
+    no_cons = (np.zeros(0, np.uint32), np.zeros((0, 2), np.uint32))
+    pair = balanced_bus_pair_mixed(log_hs[0], log_hs[1], seed=sum(log_hs))
+    airs = [(t.reshape(-1), 3, lh, *no_cons, it) for (t, it), lh in zip(pair, log_hs)]
+    pf = sm.prove_segment(airs, num_queries=4, logup=True)
+    rc, total = sm.verify_segment(pf, airs, 4, 0, True, check_balance=True)
+    assert rc == 0 and (total == 0).all()
+    assert prover.verify_segment(descs_of(airs), pf, 4, 0, True, check_balance=True)[0] == 0
+    t = airs[0][0].copy()
+    t[0] = (int(t[0]) + 1) % P  # one sent tuple changes
+    off = [(t,) + airs[0][1:], airs[1]]
+    pf2 = sm.prove_segment(off, num_queries=4, logup=True)
+    assert sm.verify_segment(pf2, off, 4, 0, True, check_balance=False)[0] == 0
+    assert sm.verify_segment(pf2, off, 4, 0, True, check_balance=True)[0] == 14
+    assert prover.verify_segment(descs_of(off), pf2, 4, 0, True, check_balance=True)[0] == 14
+
+
+def test_segment_golden_digest():
+    """The oracle's segment proofs of a fixed synthetic segment are pinned by SHA-256 (tests/golden/make_segment_golden.py):
+    a change of the protocol, of the transcript or of any kernel-visible convention shows up here first."""
+    g = json.loads(GOLDEN.read_text())
+    airs = synthetic_airs([tuple(x) for x in g["spec"]], seed0=g["seed0"])
+    for key, logup in (("sha256_v1", False), ("sha256_v1_logup", True)):
+        pf = sm.prove_segment(airs, num_queries=g["num_queries"], pow_bits=g["pow_bits"], logup=logup)
+        assert hashlib.sha256(pf.astype("<u4").tobytes()).hexdigest() == g[key], key
+        assert len(pf) == g["words" + ("_logup" if logup else "")]
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from powdr_amd import abi, prover
+
+    assert torch.cuda.is_available()
+    return torch, abi, prover
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(om.to_monty(np.ascontiguousarray(a, dtype=np.uint32)).view(np.int32)).cuda()
+
+
+def hip_segment(gpu, airs, nq, pow_bits, logup):
+    torch, abi, prover = gpu
+    provers = [prover.Prover(a[1], a[3], a[4], num_queries=nq, pow_bits=pow_bits, interactions=a[5] if logup else None) for a in airs]
+    traces = [to_dev(torch, a[0]) for a in airs]
+    pf = prover.prove_segment([(pr, t.data_ptr(), a[2]) for pr, t, a in zip(provers, traces, airs)], logup=logup)
+    again = prover.prove_segment([(pr, t.data_ptr(), a[2]) for pr, t, a in zip(provers, traces, airs)], logup=logup)
+    assert (pf == again).all()  # buffer reuse
+    for pr in provers:
+        pr.close()
+    return pf
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec,nq,pow_bits", [
+    (SPEC, 5, 4),
+    ([("T0", 2)], 3, 0),                                   # one AIR of 2 rows
+    ([("T1", 100), ("T1", 100), ("T1", 100)], 4, 0),       # one height only: no roll-in
+    ([("T0", 1), ("T0", 2), ("T0", 4), ("T0", 7), ("T0", 9), ("T0", 17), ("T0", 33), ("T0", 65), ("T1", 129), ("T1", 700), ("T1", 3000)], 6, 3),
+    ([("C1", 600), ("T1", 5000), ("T0", 40), ("T1", 1000)], 8, 0),
+])
+@pytest.mark.parametrize("logup", [False, True])
+def test_hip_segment_proof_bytes_match_oracle(gpu, spec, nq, pow_bits, logup):
+    torch, abi, prover = gpu
+    airs = synthetic_airs(spec, seed0=11)
+    want = sm.prove_segment(airs, num_queries=nq, pow_bits=pow_bits, logup=logup)
+    got = hip_segment(gpu, airs, nq, pow_bits, logup)
+    assert len(got) == len(want)
+    assert (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
+    assert prover.verify_segment(descs_of(airs), got, nq, pow_bits, logup)[0] == 0
+    assert sm.verify_segment(got, airs, nq, pow_bits, logup)[0] == 0
+
+
+@pytest.mark.gpu
+def test_hip_segment_golden_and_panels(gpu, monkeypatch):
+    """The HIP prover reproduces the pinned golden segment digests, also with the LDE forced through many small panels."""
+    g = json.loads(GOLDEN.read_text())
+    airs = synthetic_airs([tuple(x) for x in g["spec"]], seed0=g["seed0"])
+    for panel in (None, "12"):
+        if panel:
+            monkeypatch.setenv("POWDR_PANEL_LOG_WORDS", panel)
+        for key, logup in (("sha256_v1", False), ("sha256_v1_logup", True)):
+            pf = hip_segment(gpu, airs, g["num_queries"], g["pow_bits"], logup)
+            assert hashlib.sha256(pf.astype("<u4").tobytes()).hexdigest() == g[key], (key, panel)
+
+
+@pytest.mark.gpu
+def test_hip_segment_balances_apc_against_periphery(gpu):
+    """One segment = {APC AIR restricted to the lookup buses, var-range AIR, tuple AIR}: trace generation filled the
+    histograms (a3), the segment proof carries the same lookups as LogUp terms (a6), pw_verify_segment(check_balance)
+    accepts — and rejects (14) once a histogram bin is off by one. Heights 2^10 / 2^18 / 2^19 in one proof."""
+    torch, abi, prover = gpu
+    from powdr_amd import periphery, tracegen as tg
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+    from tests.test_tracegen_gpu import run_gpu
+
+    no_cons = (np.zeros(0, np.uint32), np.zeros((0, 2), np.uint32))
+    s = synth.generate("T1", seed=2)
+    calls = 1000
+    apc, idx, want, hist, (bufs, dims, gt, order) = run_oracle_gpu_convention(s, calls, seed=2)
+    W, H = want.shape
+    out, per = run_gpu((torch, None, tg), W, H, calls, bufs, dims, gt.air_names, gt.row_block_size, gt.subs,
+                       om.compile_derived(apc, idx, H), om.compile_bus(apc, idx, H))
+    cons = sm.compile_constraints(apc, idx)
+    sends = periphery.select_buses(sm.compile_interactions(apc, idx), {per.var_bus, per.tuple_bus})
+
+    def run(var_hist):
+        var_t = periphery.var_range_trace(var_hist)
+        tup_t = periphery.tuple2_trace(per.tuple_hist, per.tuple_sizes)
+        airs = [(out.buf, W, H.bit_length() - 1, cons, sends),
+                (var_t, 3, var_hist.numel().bit_length() - 1, no_cons, periphery.var_range_interactions(per.var_bus)),
+                (tup_t, 3, per.tuple_hist.numel().bit_length() - 1, no_cons, periphery.tuple2_interactions(per.tuple_bus))]
+        provers = [prover.Prover(w, *c, num_queries=6, interactions=it) for (_, w, _, c, it) in airs]
+        pf = prover.prove_segment([(pr, t.data_ptr(), lh) for pr, (t, _, lh, _, _) in zip(provers, airs)], logup=True)
+        descs = [(w, lh, c[0], c[1], it) for (_, w, lh, c, it) in airs]
+        rc = prover.verify_segment(descs, pf, 6, 0, True, check_balance=True)[0]
+        for pr in provers:
+            pr.close()
+        return rc
+
+    assert run(per.var_hist) == 0
+    bin_ = int(np.argmax(hist["var"] != 0))
+    per.var_hist[bin_] -= 1
+    assert run(per.var_hist) == 14

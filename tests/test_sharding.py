@@ -127,6 +127,6 @@ def test_logup_segment_sharded_over_two_ranks_gloo(tmp_path):
     proofs = [np.load(tmp_path / f"proof_{u}.npy") for u in range(2)]
     no_cons = (np.zeros(0, np.uint32), np.zeros((0, 2), np.uint32))
     descs = [(3, 4, *no_cons, it) for _, it in balanced_bus_pair(4, seed=21)]
-    rc, total = prover.verify_segment(descs, proofs, num_queries=4, shared_bus_seed=True, check_balance=True)
+    rc, total = prover.verify_airs(descs, proofs, num_queries=4, shared_bus_seed=True, check_balance=True)
     assert rc == 0 and (total == 0).all()
     assert (proofs[0][15:23] == s0).all() and (proofs[1][15:23] == s0).all()

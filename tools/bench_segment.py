@@ -32,13 +32,13 @@ while len(airs) < n_airs:
 hist = np.bincount([a[2] for a in airs], minlength=21)[10:]
 print(f"{len(airs)} AIRs, {total/1e9:.2f} G cells, heights 2^10..2^20 counts {hist.tolist()}, widths {min(a[3] for a in airs)}..{max(a[3] for a in airs)}")
 seg = [(pr, t.data_ptr(), lh) for pr, t, lh, _ in airs]
-prover.prove_segment(seg, n_workers=4, copy=False)  # warm-up: buffers, NTT tables
+prover.prove_airs(seg, n_workers=4, copy=False)  # warm-up: buffers, NTT tables
 for workers in (1, 2, 4, 8, 16):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 3
     for _ in range(reps):
-        prover.prove_segment(seg, n_workers=workers, copy=False)
+        prover.prove_airs(seg, n_workers=workers, copy=False)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     print(f"workers={workers:2d}: {dt*1e3:8.1f} ms per segment, {total/dt/1e9:6.2f} G cells/s", flush=True)
