@@ -54,6 +54,13 @@ def parse_args():
     ap.add_argument("--no-copy-ceiling", action="store_true",
                     help="skip the 5 x 4 GiB device-to-device copies that measure the box's copy rate after the timed region "
                          "(they show up as __amd_rocclr_copyBuffer in rocprofv3 traces: 10.7 GB/step in the round-1 PMC pass)")
+    ap.add_argument("--segments", type=int, default=8,
+                    help="--shape C4 / C5 and the multi_segment leg: total number of independent segments, split over the ranks "
+                         "by cell count (STRONG scaling: the total is fixed as N grows)")
+    ap.add_argument("--segment-log-height", type=int, default=20, help="largest trace height (log2) of the C4 / C5 segment shapes")
+    ap.add_argument("--no-segment-leg", action="store_true",
+                    help="skip the multi_segment leg of the default run (C4: 10 APC AIRs + 19 system AIRs per segment, strong scaling)")
+    ap.add_argument("--segment-steps", type=int, default=2, help="timed steps of the multi_segment leg (after one warm-up)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="host threads / HIP streams proving independent segments concurrently on each GPU "
                          "(throughput mode; default 1 = one segment at a time, which keeps per-kernel timings clean)")
@@ -204,6 +211,58 @@ def gauges_of(stage_ms):
              "stark_prove_excluding_trace_time_ms = ms_per_step - trace_gen_time_ms")
 
 
+def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, queries, pow_bits, rank, world, abi, barrier):
+    """Multi-AIR segments, STRONG scaling: a fixed number of independent segments is placed on the
+    ranks by cell count; every rank proves its segments one after the other — ONE pw-stark v1 proof per segment
+    (pw_prove_segment: all AIRs of a phase in one mixed-height commitment, one FRI) — and the main commitments are
+    all-gathered (32 B per segment) inside the timed region. Traces are resident random matrices of the segment's
+    shapes (trace generation is measured on the single-AIR configs; a proof's cost does not depend on the values);
+    all segments of a rank share one set of device buffers. Returns the record (rank 0) or None."""
+    from powdr_amd import prover, sharding, synth
+
+    shapes = synth.segment_shape(kind, seed=0, max_log_height=max_log_height)
+    cells_seg = sum(w << lh for _, w, lh, _, _ in shapes)
+    provers, traces = [], []
+    for k, (name, w, lh, nc, ni) in enumerate(shapes):
+        bc, sp, it = synth.random_air_programs(w, nc, ni, seed=k)
+        provers.append(prover.Prover(w, bc, sp, num_queries=queries, pow_bits=pow_bits, interactions=it if logup else None))
+        t = torch.empty(w << lh, dtype=torch.int32, device="cuda")
+        t.random_(0, P)
+        traces.append(t)
+    seg = [(pr, t.data_ptr(), lh) for pr, t, (_, _, lh, _, _) in zip(provers, traces, shapes)]
+    hdr = 5 + 4 * len(shapes)  # proof words before the main commitment
+    last = {}
+
+    def prove_one(u):
+        pf = prover.prove_segment(seg, logup=logup, copy=False)
+        last["words"] = len(pf)
+        return pf[hdr:hdr + 8].copy()
+
+    def run_steps(n):
+        for _ in range(n):
+            mine, merged = sharding.prove_segments_sharded([cells_seg] * n_segments, prove_one, rank, world)
+            last["mine"], last["merged"] = mine, merged
+
+    elapsed, timing = timed_leg(run_steps, steps, warmup, barrier, abi, world)
+    assert (last["merged"] != 0).any(axis=1).all(), "a segment's commitment is missing from the merge"
+    total_cells = cells_seg * n_segments * steps
+    stage = {k: ms / steps for k, (c, ms) in timing.items()}
+    rec = dict(shape=kind, scaling="strong", n_segments=n_segments, segments_on_rank0=len(last["mine"]), airs_per_segment=len(shapes),
+               cells_per_segment=cells_seg, value=total_cells / elapsed, unit="cells/s", ms_per_step=elapsed / steps * 1e3, steps=steps,
+               warmup=warmup, logup=bool(logup), proof_bytes_per_segment=int(last["words"]) * 4,
+               widths=f"{min(s[1] for s in shapes)}..{max(s[1] for s in shapes)} (sum {sum(s[1] for s in shapes)})",
+               log_heights=f"{min(s[2] for s in shapes)}..{max(s[2] for s in shapes)}",
+               constraints=sum(s[3] for s in shapes), interactions=sum(s[4] for s in shapes),
+               prover_device_bytes=sum(pr.device_bytes() for pr in provers), stage_ms_rank0=stage,
+               note="one pw-stark v1 proof per segment (pw_prove_segment); proof only, traces resident; value = all segments of all ranks / "
+                    "max-over-ranks time; the 19 system AIRs have the reference's pinned totals (819 columns, 643 constraints, 253 interactions)")
+    for pr in provers:
+        pr.close()
+    del traces
+    torch.cuda.empty_cache()
+    return rec if rank == 0 else None
+
+
 def load_profile_json(name):
     f = ROOT / "profiles" / name
     try:
@@ -216,6 +275,37 @@ def main():
     args = parse_args()
     rank, local, world = setup_distributed(args.gpus)
     from powdr_amd import abi, prover, synth
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.shape in ("C4", "C5"):
+        # BASELINE configs[3] / configs[4]: multi-AIR segments sharded over the GPUs of the node, strong scaling
+        rec = segment_bench(args.shape, args.segments, args.segment_log_height, args.steps, args.warmup, args.logup, args.queries,
+                            args.pow_bits, rank, world, abi, barrier)
+        if rank == 0:
+            whole = rec["value"] / world * ALGO_BYTES_PER_CELL / 1e9
+            line = dict(metric="STARK cells/sec (trace rows x cols), multi-segment " + ("guest-pairing-shaped" if args.shape == "C4" else "reth-shaped")
+                               + (" [with the bus argument]" if args.logup else " [constraints-only proofs]"),
+                        value=rec["value"], unit="cells/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=rec["ms_per_step"],
+                        higher_is_better=True, scaling="strong", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
+                        config=dict(workload=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs ({rec['cells_per_segment']} cells each, "
+                                             f"heights 2^{rec['log_heights']}, widths {rec['widths']}), one proof per segment, segments sharded over "
+                                             f"{world} GPU(s) by cells, main commitments all-gathered",
+                                    parallelism=f"segments over {world} ranks (strong)", proof_bytes=rec["proof_bytes_per_segment"]),
+                        roofline=dict(bound="hbm", kernel="whole step", achieved=whole, peak=HBM_PEAK_GBS, unit="GB/s", frac=whole / HBM_PEAK_GBS,
+                                      traffic=None, algo_bytes_per_cell=ALGO_BYTES_PER_CELL, note="per GPU, 48 B per cell (proof stages only use 40 of them)"),
+                        cpu_baseline=None, multi_segment=rec)
+            print(json.dumps(line))
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
+        return
 
     shape = synth.SHAPES[args.shape]
     log_h = args.log_height or shape.log_height
@@ -279,13 +369,6 @@ def main():
         [t.start() for t in th]
         [t.join() for t in th]
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-
-            dist.barrier()
-        torch.cuda.synchronize()
-
     elapsed, timing = timed_leg(run_steps, args.steps, max(args.warmup, len(workers) if args.warmup else 0), barrier, abi, world)
     cells_per_step = wl["W"] * wl["H"]
     total_cells = cells_per_step * args.steps * world
@@ -325,8 +408,28 @@ def main():
                 note="same segment, same trace generation, proof = pw-stark v0 + LogUp (proof magic PWS2): the AIR's bus interactions are "
                      "inside the proof (permutation columns, running sum, extended quotient, openings at zeta and g*zeta)")
             pr_lg.close()
+            lg_worker.clear()
         except Exception as e:  # the extra leg must never take the headline down
             logup_leg = dict(value=None, error=f"{type(e).__name__}: {e}")
+
+    # ---- third leg: multi-AIR segments, strong scaling (BASELINE configs[3]: sharded multi-segment guest-pairing). Every rank takes
+    # part; the single-AIR workload's 180 GB are released first.
+    segment_leg = None
+    if not args.no_segment_leg and args.pipeline == 1 and not args.logup:
+        try:
+            pr.close()
+            for k in ("tensors", "dummy", "out"):
+                wl.pop(k, None)
+            main_worker.clear()
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
+            seg_log = min(args.segment_log_height, log_h)
+            segment_leg = segment_bench("C4", args.segments, seg_log, args.segment_steps, 1, False, args.queries, args.pow_bits, rank, world,
+                                        abi, barrier)
+        except Exception as e:  # must never take the headline down
+            segment_leg = dict(value=None, error=f"{type(e).__name__}: {e}")
 
     if rank == 0:
         per_kernel = {k: (c, ms) for k, (c, ms) in timing.items()}
@@ -433,7 +536,7 @@ def main():
                         source_bytes=wl["src_bytes"], proof_bytes=proof_bytes, prover_device_bytes=prover_bytes,
                         caveat="proof system pw-stark v0 is this repository's own (oracle/stark_oracle.cpp); its Poseidon2 round constants are a "
                                "documented placeholder stream: proofs are byte-exact against the oracle, not interoperable with the reference prover"),
-            roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
+            roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, multi_segment=segment_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
             hbm_copy_GBps_measured=copy_gbs,
         )
         print(json.dumps(line))

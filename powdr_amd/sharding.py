@@ -76,7 +76,8 @@ def allreduce_histograms(histograms, group=None):
 
 def prove_segment_sharded(my_units, n_units: int, commit, prove, group=None):
     """AIR-level sharding of ONE segment whose AIRs share buses (SURVEY.md 8e level 2; the single-process form is
-    `pw_prove_segment(shared_bus_seed=1)`). Every rank owns the AIRs `my_units` (see `assign_units`).
+    `pw_prove_airs(shared_bus_seed=1)`; independent per-AIR proofs — the one-proof-per-segment form `pw_prove_segment`
+    needs all matrices on one device). Every rank owns the AIRs `my_units` (see `assign_units`).
 
       phase 1  commit(u) -> 8-word trace root of AIR u           (rank-local: LDE + Merkle tree stay on the GPU)
       exchange all-gather of the roots, 32 bytes per AIR          (the only collective on this path)
@@ -85,7 +86,7 @@ def prove_segment_sharded(my_units, n_units: int, commit, prove, group=None):
 
     Returns (seed, {u: proof}). `commit` / `prove` are callables so that the same orchestration drives the GPU
     provers (`gpu_segment_callables`) and, in the CPU tests, a stand-in prover. The verifier needs nothing from this
-    exchange: `pw_verify_segment` recomputes the seed from the trace roots inside the proofs."""
+    exchange: `pw_verify_airs` recomputes the seed from the trace roots inside the proofs."""
     roots = np.array([commit(u) for u in my_units], dtype=np.uint32).reshape(-1, 8)
     merged = merge_commitments(my_units, roots, n_units, group=group)
     seed = commitment_digest(merged)
@@ -103,3 +104,14 @@ def gpu_segment_callables(provers, trace_ptrs, log_heights):
         return provers[u].prove(trace_ptrs[u], log_heights[u])
 
     return commit, prove
+
+
+def prove_segments_sharded(cells_per_segment, prove_segment, rank: int, world_size: int, group=None):
+    """STRONG scaling over a fixed list of independent segments (SURVEY.md 8e level 1; the reference proves them one
+    after the other on one device, /root/reference/openvm/src/trace_generation.rs:111-141): the segments are placed on
+    the ranks by cell count, largest first (`assign_units`, identical on every rank), rank r proves its own with
+    `prove_segment(u) -> 8-word main commitment of segment u`, and the only exchange is the final all-gather of those
+    commitments (32 bytes per segment). Returns (the segments this rank proved, uint32 [n_segments, 8] on every rank)."""
+    mine = assign_units(list(cells_per_segment), world_size)[rank]
+    roots = np.array([prove_segment(u) for u in mine], dtype=np.uint32).reshape(-1, 8)
+    return mine, merge_commitments(mine, roots, len(cells_per_segment), group=group)

@@ -378,3 +378,92 @@ def fill_dummy_traces_numpy(s: SynthApc, num_calls: int, seed: int = 0, pow2: bo
         view = bufs[idx[name]][col * h + row : col * h + row + b * num_calls : b]
         view[:] = rng.integers(0, bound, size=len(view), dtype=np.uint32)
     return bufs, dims
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Multi-AIR segments: shapes only — widths, heights, constraint and interaction counts. The proofs'
+# cost does not depend on the values, so the bench proves random traces against programs of the right size and form.
+SYSTEM_AIR_WIDTHS = [2, 4, 5, 7, 8, 10, 12, 17, 19, 20, 21, 26, 31, 36, 41, 53, 98, 139, 270]  # 19 AIRs, sum 819
+SYSTEM_AIR_LOG_HEIGHTS = [10, 12, 14, 13, 16, 15, 17, 18, 16, 19, 17, 20, 18, 19, 20, 18, 15, 14, 16]
+# /root/reference/openvm-riscv/src/lib.rs:1114-1122: 19 non-powdr machines, main width 819, 643 constraints, 253 interactions
+SYSTEM_CONSTRAINTS, SYSTEM_INTERACTIONS = 643, 253
+assert sum(SYSTEM_AIR_WIDTHS) == 819 and len(SYSTEM_AIR_WIDTHS) == len(SYSTEM_AIR_LOG_HEIGHTS) == 19
+C4_APC_WIDTHS = [520, 440, 380, 330, 290, 260, 230, 210, 180, 160]  # 10 APC AIRs of a pairing-shaped segment, sum 3000
+
+
+def _split(total, weights):
+    """integers proportional to `weights` that add up to `total`"""
+    w = np.asarray(weights, dtype=np.float64)
+    x = np.floor(total * w / w.sum()).astype(int)
+    for i in np.argsort(-(total * w / w.sum() - x))[: total - int(x.sum())]:
+        x[i] += 1
+    return [int(v) for v in x]
+
+
+def segment_shape(kind: str, seed: int = 0, max_log_height: int = 20):
+    """[(name, width, log_height, n_constraints, n_interactions)] of one segment.
+    C4: 10 APC AIRs (sum W = 3 000) at 2^max_log_height rows + the 19 system AIRs (sum W = 819).
+    C5: reth-shaped, ~57 APC AIRs with log-uniform heights 2^10..2^max and widths 30..4 000 (about 3 G cells) + the system AIRs.
+    APC AIRs carry constraints / interactions at the keccak APC's densities (187 and 1 734 per 2 022 columns)."""
+    shrink = 20 - max_log_height
+    airs = []
+    sc, si = _split(SYSTEM_CONSTRAINTS, SYSTEM_AIR_WIDTHS), _split(SYSTEM_INTERACTIONS, SYSTEM_AIR_WIDTHS)
+    system = [(f"sys{k}", w, max(2, lh - shrink), sc[k], si[k]) for k, (w, lh) in enumerate(zip(SYSTEM_AIR_WIDTHS, SYSTEM_AIR_LOG_HEIGHTS))]
+    apc = lambda name, w, lh: (name, w, lh, max(1, round(w * 187 / 2022)), max(1, round(w * 1734 / 2022)))
+    if kind == "C4":
+        airs = [apc(f"apc{k}", w, max_log_height) for k, w in enumerate(C4_APC_WIDTHS)]
+    elif kind == "C5":
+        rng = np.random.default_rng(1000 + seed)
+        budget, total = 3.0e9 / (1 << (2 * shrink)) if shrink else 3.0e9, 0
+        while len(airs) < 57:
+            lh = int(rng.integers(10, 21)) - shrink
+            w = int(np.exp(rng.uniform(np.log(30), np.log(4000))))
+            if lh < 2 or total + (w << lh) > budget:
+                if all((30 << max(2, h - shrink)) + total > budget for h in range(10, 21)):
+                    break
+                continue
+            total += w << lh
+            airs.append(apc(f"apc{len(airs)}", w, lh))
+    else:
+        raise ValueError(kind)
+    return airs + system
+
+
+def random_air_programs(width: int, n_constraints: int, n_interactions: int, seed: int):
+    """Constraint programs (post-fix, column operands) of the forms an optimised APC has — a*b - c, a*(a - 1), a*b*c - d,
+    a + k*b - c — and bus interactions with a column multiplicity and 2-4 degree-1 arguments (column, k - column,
+    column + 256*column). Returns (cons_bc, cons_spans[n,2], (inter[n,3], ispans[m,2], ibc))."""
+    rng = np.random.default_rng(seed)
+    PA, PC, ADD, SUB, MUL = 0, 1, 2, 3, 4
+    col = lambda: int(rng.integers(0, width))
+    bc, spans = [], []
+    for k in range(n_constraints):
+        off, form = len(bc), k % 4
+        if form == 0:
+            bc += [PA, col(), PA, col(), MUL, PA, col(), SUB]
+        elif form == 1:
+            a = col()
+            bc += [PA, a, PA, a, PC, 1, SUB, MUL]
+        elif form == 2:
+            bc += [PA, col(), PA, col(), MUL, PA, col(), MUL, PA, col(), SUB]
+        else:
+            bc += [PA, col(), PC, int(rng.integers(1, 1 << 16)), PA, col(), MUL, ADD, PA, col(), SUB]
+        spans.append((off, len(bc) - off))
+    ibc, ispans, inter = [], [], []
+    for k in range(n_interactions):
+        n_args = int(rng.integers(2, 5))
+        inter.append((int(rng.choice([1, 3, 6, 7])), n_args, len(ispans)))
+        off = len(ibc)
+        ibc += [PA, col()]  # multiplicity: a column
+        ispans.append((off, len(ibc) - off))
+        for j in range(n_args):
+            off, form = len(ibc), (k + j) % 3
+            if form == 0:
+                ibc += [PA, col()]
+            elif form == 1:
+                ibc += [PC, 255, PA, col(), SUB]
+            else:
+                ibc += [PA, col(), PC, 256, PA, col(), MUL, ADD]
+            ispans.append((off, len(ibc) - off))
+    return (np.array(bc, np.uint32), np.array(spans, np.uint32).reshape(-1, 2),
+            (np.array(inter, np.uint32).reshape(-1, 3), np.array(ispans, np.uint32).reshape(-1, 2), np.array(ibc, np.uint32)))

@@ -40,6 +40,10 @@ def test_default_line_has_the_contract_fields():
     assert lg["value"] > 0 and lg["value"] < d["value"] and lg["perm_cols"] == 4 * (lg["interaction_groups"] + 1)
     assert lg["stage_ms"]["logup_perm_kernel"] > 0 and lg["proof_bytes"] > d["config"]["proof_bytes"]
     assert "constraints-only" in d["metric"] and "CONSTRAINTS-ONLY" in d["config"]["workload"]
+    # the third leg: multi-AIR segments (C4 shape), one proof per segment, strong scaling over a fixed number of segments
+    ms = d["multi_segment"]
+    assert ms["shape"] == "C4" and ms["scaling"] == "strong" and ms["n_segments"] == 8 and ms["airs_per_segment"] == 29
+    assert ms["value"] > 0 and ms["proof_bytes_per_segment"] > 0 and ms["segments_on_rank0"] == 8
     # no per-kernel HBM fraction for the quotient kernel (it reads only the referenced columns)
     assert "quotient_kernel" not in d["roofline_by_kernel"]
 
@@ -48,3 +52,11 @@ def test_logup_and_partial_calls_modes_run():
     d = run_bench("--logup", "--no-cpu-baseline", "--calls-fraction", "0.75")
     assert d["cpu_baseline"] is None and "LogUp" in d["config"]["workload"] and "3072 APC calls" in d["config"]["workload"]
     assert d["stage_ms"]["logup_perm_kernel"] > 0 and d["gauges"]["perm_trace_time_ms"] > 0
+
+
+def test_segment_shapes_run_as_the_main_workload():
+    d = run_bench("--shape", "C4", "--segments", "3", "--segment-log-height", "11", "--no-cpu-baseline")
+    assert d["scaling"] == "strong" and "multi-segment" in d["metric"] and d["multi_segment"]["n_segments"] == 3
+    assert d["value"] > 0 and abs(d["value"] - 3 * d["multi_segment"]["cells_per_segment"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    d = run_bench("--shape", "C5", "--segments", "2", "--segment-log-height", "12", "--logup")
+    assert d["multi_segment"]["logup"] is True and d["multi_segment"]["airs_per_segment"] > 30

@@ -130,3 +130,49 @@ def test_logup_segment_sharded_over_two_ranks_gloo(tmp_path):
     rc, total = prover.verify_airs(descs, proofs, num_queries=4, shared_bus_seed=True, check_balance=True)
     assert rc == 0 and (total == 0).all()
     assert (proofs[0][15:23] == s0).all() and (proofs[1][15:23] == s0).all()
+
+
+def _strong_scaling_worker(rank, world, port, out_dir):
+    """The bench's C4 / C5 path (bench.py segment_bench) on CPU: a fixed list of segments, each proven as ONE segment proof
+    (the oracle stands in for pw_prove_segment), placed by cells, main commitments all-gathered."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import stark_model as sm
+    from tests.test_segment_proof import synthetic_airs
+
+    segments = [synthetic_airs([("T0", 10 + u), ("T1", 40 * (u + 1))], seed0=50 + u) for u in range(5)]
+    cells = [sum(a[1] << a[2] for a in seg) for seg in segments]
+    proofs = {}
+
+    def prove_one(u):
+        pf = sm.prove_segment(segments[u], num_queries=3, logup=False)
+        proofs[u] = pf
+        hdr = 5 + 4 * len(segments[u])
+        return pf[hdr:hdr + 8]
+
+    mine, merged = sharding.prove_segments_sharded(cells, prove_one, rank, world)
+    np.save(os.path.join(out_dir, f"merged_{rank}.npy"), merged)
+    np.save(os.path.join(out_dir, f"mine_{rank}.npy"), np.array(mine))
+    for u, pf in proofs.items():
+        np.save(os.path.join(out_dir, f"seg_{u}.npy"), pf)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_over_segments_world_size_2_gloo(tmp_path):
+    from powdr_amd import prover
+    from tests.test_segment_proof import descs_of, synthetic_airs
+
+    port = _free_port()
+    mp.spawn(_strong_scaling_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    m0, m1 = np.load(tmp_path / "merged_0.npy"), np.load(tmp_path / "merged_1.npy")
+    assert m0.shape == (5, 8) and (m0 == m1).all() and m0.any(axis=1).all()
+    mine = [set(np.load(tmp_path / f"mine_{r}.npy").tolist()) for r in range(2)]
+    assert mine[0] | mine[1] == set(range(5)) and not (mine[0] & mine[1]) and all(mine)
+    # balance by cells: neither rank carries more than the other plus the largest segment
+    for u in range(5):
+        seg = synthetic_airs([("T0", 10 + u), ("T1", 40 * (u + 1))], seed0=50 + u)
+        pf = np.load(tmp_path / f"seg_{u}.npy")
+        assert prover.verify_segment(descs_of(seg), pf, 3, 0, False)[0] == 0  # the product's host verifier accepts every segment
+        assert (pf[5 + 4 * 2:5 + 4 * 2 + 8] == m0[u]).all()  # the merged row IS that segment's main commitment
