@@ -59,4 +59,4 @@ def test_segment_shapes_run_as_the_main_workload():
     assert d["scaling"] == "strong" and "multi-segment" in d["metric"] and d["multi_segment"]["n_segments"] == 3
     assert d["value"] > 0 and abs(d["value"] - 3 * d["multi_segment"]["cells_per_segment"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     d = run_bench("--shape", "C5", "--segments", "2", "--segment-log-height", "12", "--logup")
-    assert d["multi_segment"]["logup"] is True and d["multi_segment"]["airs_per_segment"] > 30
+    assert d["multi_segment"]["logup"] is True and d["multi_segment"]["airs_per_segment"] >= 25

@@ -156,7 +156,7 @@ def hip_segment(gpu, airs, nq, pow_bits, logup):
     (SPEC, 5, 4),
     ([("T0", 2)], 3, 0),                                   # one AIR of 2 rows
     ([("T1", 100), ("T1", 100), ("T1", 100)], 4, 0),       # one height only: no roll-in
-    ([("T0", 1), ("T0", 2), ("T0", 4), ("T0", 7), ("T0", 9), ("T0", 17), ("T0", 33), ("T0", 65), ("T1", 129), ("T1", 700), ("T1", 3000)], 6, 3),
+    ([("T0", 2), ("T0", 3), ("T0", 4), ("T0", 7), ("T0", 9), ("T0", 17), ("T0", 33), ("T0", 65), ("T1", 129), ("T1", 700), ("T1", 3000)], 6, 3),
     ([("C1", 600), ("T1", 5000), ("T0", 40), ("T1", 1000)], 8, 0),
 ])
 @pytest.mark.parametrize("logup", [False, True])

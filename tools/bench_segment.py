@@ -42,4 +42,17 @@ for workers in (1, 2, 4, 8, 16):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     print(f"workers={workers:2d}: {dt*1e3:8.1f} ms per segment, {total/dt/1e9:6.2f} G cells/s", flush=True)
+# the one-proof-per-segment form (pw-stark v1): all AIRs of a phase in one mixed-height commitment, one FRI, one query phase
+pf = prover.prove_segment(seg, logup=False, copy=False)
+for _ in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        pf = prover.prove_segment(seg, logup=False, copy=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print(f"pw_prove_segment (one proof): {dt*1e3:8.1f} ms per segment, {total/dt/1e9:6.2f} G cells/s, proof {len(pf)*4/1e6:.2f} MB", flush=True)
+per_air = prover.prove_airs(seg, n_workers=8, copy=False)[0]
+print(f"independent proofs: {sum(len(p) for p in per_air)*4/1e6:.2f} MB in total")
 print(f"prover buffers: {sum(pr.device_bytes() for pr, *_ in airs)/1e9:.1f} GB")
