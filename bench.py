@@ -50,6 +50,8 @@ def parse_args():
                     help="rows (log2) of the CPU-baseline sample of the same AIR (2^16 rows of C2 = 132 M cells: ~25 s on the box's host cores)")
     ap.add_argument("--no-logup-leg", action="store_true",
                     help="skip the second timed leg of the default run (the same step WITH the LogUp phase, reported as `logup`)")
+    ap.add_argument("--no-callmajor-leg", action="store_true",
+                    help="skip the measurement of the gather from call-major compacted sources (reported as `tracegen_callmajor`)")
     ap.add_argument("--logup-steps", type=int, default=3, help="timed steps of the LogUp leg (after one warm-up step)")
     ap.add_argument("--no-copy-ceiling", action="store_true",
                     help="skip the 5 x 4 GiB device-to-device copies that measure the box's copy rate after the timed region "
@@ -202,7 +204,7 @@ def gauges_of(stage_ms):
     g = lambda *names: sum(stage_ms.get(n, 0.0) for n in names)
     return dict(
         trace_gen_time_ms=g("apc_gather_tile_kernel", "apc_apply_derived_expr_kernel", "apc_apply_bus_kernel", "bus_histogram_kernel"),
-        main_trace_commit_time_ms=g("ntt_group_kernel<dif>", "ntt_group_kernel<dit>", "leaf_hash_kernel", "compress_kernel", "compress_tail_kernel"),
+        main_trace_commit_time_ms=g("ntt_group_kernel<dif>", "lde_fused_kernel", "ntt_group_kernel<dit>", "leaf_hash_kernel", "compress_kernel", "compress_tail_kernel"),
         perm_trace_time_ms=g("logup_perm_kernel", "logup_scan_kernels"),
         quotient_poly_compute_time_ms=g("quotient_kernel", "quotient_logup_kernel", "quotient_split_kernel"),
         pcs_opening_time_ms=g("barycentric_weights_kernel", "zeta_weights_kernel", "ext_dot_partial_kernel", "deep_kernel", "deep_logup_kernel",
@@ -376,6 +378,59 @@ def main():
     proof_bytes = int(len(last["proof"]) * 4)
     prover_bytes = pr.device_bytes()
 
+    # ---- trace generation from CALL-MAJOR COMPACTED sources (layout half; powdr_apc_tracegen_callmajor):
+    # the same APC trace gathered from buffers that hold, per call, only the cells the APC uses. Not part of `value`: the
+    # reference hands over full column-major dummy traces (cuda/mod.rs:228-253) and the timed step above consumes those.
+    callmajor_leg = None
+    if not args.no_callmajor_leg and args.pipeline == 1:
+        try:
+            from powdr_amd import tracegen as tg
+
+            subs, air_ids, rbs = wl["apc"].build_substitutions(wl["instr_air"])
+            calls = wl["calls"]
+            slots = [dict() for _ in air_ids]
+            subs_cm = np.zeros((len(subs), 3), np.int32)
+            for i, (a, col, row, apc_col) in enumerate(subs):
+                d = slots[a]
+                subs_cm[i] = (a, d.setdefault((int(row), int(col)), len(d)), apc_col)
+            cm_airs, cm_bytes = [], 0
+            for k, d in enumerate(slots):
+                ptr, w, h = wl["dummy"][int(air_ids[k])]
+                t = next(tt for tt, ww, hh, bb in wl["tensors"].values() if tt.data_ptr() == ptr)
+                U, b = len(d), int(rbs[k])
+                base = torch.tensor([col * h + row for (row, col) in d], dtype=torch.int64, device="cuda")
+                buf = torch.empty(calls * U, dtype=torch.int32, device="cuda")
+                view = buf.view(calls, U)
+                for r0 in range(0, calls, 1 << 15):  # chunks keep the index tensor small
+                    r = torch.arange(r0, min(calls, r0 + (1 << 15)), device="cuda", dtype=torch.int64)
+                    view[r0:r0 + len(r)] = t[base[None, :] + (r * b)[:, None]]
+                cm_airs.append((buf, U))
+                cm_bytes += buf.numel() * 4
+            out2 = tg.DeviceMatrix(torch.empty_like(wl["out"]), wl["H"], wl["W"])
+            tg.apc_tracegen_callmajor(out2, cm_airs, subs_cm, calls)  # warm-up + plan
+            torch.cuda.synchronize()
+            abi.lib.powdr_gpu_timing_enable(1)
+            for _ in range(3):
+                tg.apc_tracegen_callmajor(out2, cm_airs, subs_cm, calls)
+            torch.cuda.synchronize()
+            cm_ms = abi.timing_report()["apc_gather_callmajor_kernel"][1] / 3
+            abi.lib.powdr_gpu_timing_enable(0)
+            # same cells as the reference-layout gather wrote (derived columns aside: compare the substituted columns)
+            cols = sorted(set(int(c) for c in subs_cm[:, 2]))
+            same = all(torch.equal(out2.buf[c * wl["H"]:(c + 1) * wl["H"]], wl["out"][c * wl["H"]:(c + 1) * wl["H"]]) for c in cols[:: max(1, len(cols) // 64)])
+            moved = cm_bytes + len(cols) * wl["H"] * 4
+            callmajor_leg = dict(gather_ms=cm_ms, source_bytes=cm_bytes, cells_per_call=int(sum(len(d) for d in slots)),
+                                 moved_GBps=moved / (cm_ms * 1e-3) / 1e9, frac_of_hbm_peak=moved / (cm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 equals_reference_layout_gather=bool(same),
+                                 reference_layout_gather_ms=timing.get("apc_gather_tile_kernel", (0, 0.0))[1] / args.steps,
+                                 reference_layout_source_bytes=wl["src_bytes"],
+                                 note="powdr_apc_tracegen_callmajor: sources = per call only the cells the APC uses, contiguous; what the original "
+                                      "chips would have to write for the gather to move 8 B per APC cell (SURVEY 8d) instead of the whole dummy traces")
+            del out2, cm_airs
+            torch.cuda.empty_cache()
+        except Exception as e:
+            callmajor_leg = dict(gather_ms=None, error=f"{type(e).__name__}: {e}")
+
     # ---- second timed leg: the same step WITH the LogUp phase (the bus interactions PowdrAir::eval pushes, chip.rs:117-129,
     # inside the proof). The headline stays constraints-only (north_star's kernel list has no permutation phase); this leg is
     # the statement the reference's backend proves. Same inputs, same trace generation; a second prover object.
@@ -437,7 +492,7 @@ def main():
         # SURVEY.md 8d, algorithmic HBM bytes per main cell and kernel. The quotient kernel is NOT listed: it reads only the
         # columns the constraints reference (PMC: 2.9 GB per step at C2, not 8 B x cells), so a per-cell figure does not describe it.
         algo_bytes_per_cell = {"leaf_hash_kernel": 8.0, "apc_gather_tile_kernel": 8.0, "apc_apply_bus_kernel": 4.0,
-                               "ntt_group_kernel<dif>": 8.0, "ntt_group_kernel<dit>": 16.0, "deep_kernel": 8.0}
+                               "ntt_group_kernel<dif>": 8.0, "lde_fused_kernel": 12.0, "ntt_group_kernel<dit>": 16.0, "deep_kernel": 8.0}
         stage_ms = {k: ms / args.steps for k, (c, ms) in per_kernel.items()}
         gauges = gauges_of(stage_ms)
         copy_gbs = None
@@ -536,7 +591,7 @@ def main():
                         source_bytes=wl["src_bytes"], proof_bytes=proof_bytes, prover_device_bytes=prover_bytes,
                         caveat="proof system pw-stark v0 is this repository's own (oracle/stark_oracle.cpp); its Poseidon2 round constants are a "
                                "documented placeholder stream: proofs are byte-exact against the oracle, not interoperable with the reference prover"),
-            roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, multi_segment=segment_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
+            roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, multi_segment=segment_leg, tracegen_callmajor=callmajor_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
             hbm_copy_GBps_measured=copy_gbs,
         )
         print(json.dumps(line))

@@ -144,6 +144,24 @@ int powdr_apc_apply_bus_host_tables(const PowdrFp* d_output, size_t output_heigh
                                     uint32_t tuple2_sz0, uint32_t tuple2_sz1, uint32_t bitwise_bus_id,
                                     uint32_t* d_bitwise_hist);
 
+/* SURVEY.md §8 row (f)-1, the layout half: the gather for sources that arrive CALL-MAJOR AND COMPACTED — per original AIR
+ * a buffer holding, for every APC call r, only the cells the APC uses, contiguous: buffer[r * cells_per_call + slot].
+ * out[apc_col * H + r] = r < num_apc_calls ? air[air_index].buffer[r * cells_per_call + slot] : 0; duplicate apc_col:
+ * the last SubstCM wins. An original chip would produce this layout by writing, per record, only the cells named by the
+ * APC's (row, column) -> slot map instead of its full rows (the reference materialises full column-major traces,
+ * cuda/mod.rs:228-253, of which an optimised APC keeps a few percent). Tables are HOST arrays (buffers inside are device
+ * pointers); at most 16 AIRs. The reference layout stays served by _apc_tracegen. */
+typedef struct {
+    const PowdrFp* buffer;  /* device: num_apc_calls x cells_per_call, Montgomery */
+    int32_t cells_per_call;
+    int32_t reserved;
+} PowdrCallMajorAir;
+typedef struct {
+    int32_t air_index, slot, apc_col;
+} PowdrSubstCM;
+int powdr_apc_tracegen_callmajor(PowdrFp* d_output, size_t output_height, const PowdrCallMajorAir* h_airs, size_t n_airs,
+                                 const PowdrSubstCM* h_subs, size_t n_subs, int num_apc_calls);
+
 /* Traces of the shared periphery chips (the RECEIVE side of the three lookup buses) from the histograms
  * _apc_apply_bus filled. The chips are EXTERNAL (openvm-circuit-primitives; instantiated in
  * openvm/src/powdr_extension/trace_generator/cuda/periphery.rs:33-85); in-repo is how a lookup becomes a histogram

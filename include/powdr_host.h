@@ -37,7 +37,7 @@ void powdr_apc_free(PowdrApc* apc);
  * Every reader accepts any document that CONTAINS `Apc` maps (keys block, machine, subs) and addresses them by their
  * position in document order:
  *   - `apc_candidate_<pcs>_<seq>[_suffix].json`: `ApcWithBusMap{#[serde(flatten)] apc, bus_map}`
- *     (/root/reference/autoprecompiles/src/export.rs:77-93,271-276; the reference's own tests/*.json.gz fixtures are such
+ *     (/root/reference/autoprecompiles/src/export.rs:77-93,271-276; the reference's own tests/NAME.json.gz fixtures are such
  *     files): one Apc at the top level, plus the bus map (below);
  *   - the CLI's stage caches `<artifacts-dir>/<stage>/<hash>/artifact.cbor`, written with serde_cbor
  *     (/root/reference/cli-openvm-riscv/src/main.rs:380-407): stage `select` = Vec<ApcWithStats{apc, stats,

@@ -185,6 +185,11 @@ size_t pw_prover_device_bytes(const PwProver* p);
  * receives natural-order evaluations on the coset 31 * <g_{n+1}>. */
 int pw_lde_batch(const uint32_t* d_trace, uint32_t width, uint32_t log_height, uint32_t* d_coeffs, uint32_t* d_lde);
 
+/* The same LDE the way the provers run it: three passes over HBM instead of four — the contiguous stage groups of the
+ * inverse and of the forward transform share one kernel, the coefficient array is never written (d_tmp: width x H words of
+ * scratch for the strided stages of traces taller than 2^12 rows; its contents are unspecified afterwards). */
+int pw_lde_fused(const uint32_t* d_trace, uint32_t width, uint32_t log_height, uint32_t* d_tmp, uint32_t* d_lde);
+
 /* Poseidon2 Merkle tree of a column-major matrix; d_digests gets (2*height - 1) * 8 words,
  * leaves first, root last. */
 int pw_merkle_commit(const uint32_t* d_matrix, size_t height, uint32_t width, uint32_t* d_digests);

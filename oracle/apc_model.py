@@ -429,6 +429,40 @@ def c_apc_tracegen(H, width, airs_buf, airs_height, airs_rbs, subs, num_calls, o
     return out
 
 
+def compact_call_major(airs_buf, airs_height, airs_rbs, subs, num_calls):
+    """Reference-layout gather inputs -> the call-major compacted form of powdr_apc_tracegen_callmajor: per AIR the
+    used (row, col) cells get slots in order of first appearance; buffer[r * U + slot] = dense[col * h + row + r * b].
+    Returns (list of uint32 arrays [num_calls * U], cells_per_call, subs_cm int32 [n, 3])."""
+    subs = np.ascontiguousarray(subs, dtype=np.int32).reshape(-1, 4)
+    slots = [dict() for _ in airs_buf]
+    subs_cm = np.zeros((len(subs), 3), np.int32)
+    for i, (a, col, row, apc_col) in enumerate(subs):
+        d = slots[a]
+        subs_cm[i] = (a, d.setdefault((int(row), int(col)), len(d)), apc_col)
+    bufs, cells = [], []
+    r = np.arange(num_calls, dtype=np.int64)
+    for a, d in enumerate(slots):
+        U = len(d)
+        buf = np.zeros(max(num_calls * U, 1), np.uint32)
+        if U and num_calls:
+            view = buf[:num_calls * U].reshape(num_calls, U)
+            for (row, col), slot in d.items():
+                view[:, slot] = airs_buf[a][col * int(airs_height[a]) + row + r * int(airs_rbs[a])]
+        bufs.append(buf)
+        cells.append(U)
+    return bufs, np.array(cells, np.int32), subs_cm
+
+
+def c_apc_tracegen_callmajor(H, width, bufs, cells, subs_cm, num_calls):
+    lib = c_oracle()
+    out = np.zeros(H * width, dtype=np.uint32)
+    ptrs = (ctypes.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+    c = np.ascontiguousarray(cells, dtype=np.int32)
+    s = np.ascontiguousarray(subs_cm, dtype=np.int32)
+    lib.or_apc_tracegen_callmajor(_p(out), ctypes.c_size_t(H), ptrs, _p(c), _p(s), ctypes.c_size_t(len(s)), ctypes.c_int(num_calls))
+    return out
+
+
 def c_apc_apply_derived(out, H, num_calls, col_base, offs, lens, bc):
     lib = c_oracle()
     col_base = np.ascontiguousarray(col_base, dtype=np.uint64)

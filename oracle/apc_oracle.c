@@ -93,6 +93,21 @@ void or_apc_tracegen(uint32_t* out, size_t H, const uint32_t* const* airs_buf, c
     }
 }
 
+/* Extension (include/powdr_gpu.h powdr_apc_tracegen_callmajor): the same gather from call-major compacted sources,
+ * airs_buf[a][r * cells_per_call[a] + slot]; subs = n x {air, slot, apc_col}; sequential like the reference loop
+ * (a later substitution to the same column overwrites an earlier one). */
+void or_apc_tracegen_callmajor(uint32_t* out, size_t H, const uint32_t* const* airs_buf, const int32_t* cells_per_call,
+                               const int32_t* subs, size_t n_subs, int num_calls) {
+    for (size_t r = 0; r < H; ++r) {
+        int in_range = r < (size_t)(num_calls < 0 ? 0 : num_calls);
+        for (size_t i = 0; i < n_subs; ++i) {
+            const int32_t* s = subs + 3 * i;
+            size_t a = (size_t)s[0];
+            out[(size_t)s[2] * H + r] = in_range ? airs_buf[a][r * (size_t)cells_per_call[a] + (size_t)s[1]] : 0;
+        }
+    }
+}
+
 /* apc_tracegen.cu:72-100. specs = n_cols x {col_base(u64 as 2 x u32 lo,hi), off, len}. */
 int or_apc_apply_derived(uint32_t* out, size_t H, int num_calls, const uint64_t* col_base,
                          const uint32_t* span_off, const uint32_t* span_len, size_t n_cols,

@@ -497,3 +497,138 @@ extern "C" int powdr_apc_tracegen_host_tables(PowdrFp* d_output, size_t output_h
     }
     return tracegen_with_host_tables(d_output, H, d_original_airs, subs, bsize, num_apc_calls);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row (f)-1 of SURVEY.md §8, as far as it can go without the original chips: the gather when the sources arrive CALL-MAJOR
+// AND COMPACTED — for every APC call the cells the APC actually uses, contiguous (`buffer[r * cells_per_call + slot]`) —
+// instead of as full column-major dummy traces of which the optimised APC keeps ~7 % (C2: 27 521 source cells per call,
+// 2 021 used). That layout is what an original chip's trace generation would write if it were handed the (row, column) ->
+// slot map of the APC (it computes every cell of its rows from one record anyway, /root/reference/openvm/src/
+// powdr_extension/trace_generator/cuda/mod.rs:228-253 calls `chip.generate_proving_ctx(record_arena)` per original AIR).
+// The gather then is a plain tiled transpose [calls x slots] -> [columns x rows]: 4 bytes read + 4 written per APC cell,
+// which is SURVEY 8d's algorithmic figure for this stage.
+namespace {
+
+constexpr int kCmMaxAirs = 16;
+struct CMAirs {
+    const uint32_t* buf[kCmMaxAirs];
+    int32_t cells[kCmMaxAirs];
+};
+struct CMJob { int32_t air, slot0, col_off, n_slots; };
+
+__global__ __launch_bounds__(256) void apc_gather_callmajor_kernel(uint32_t* __restrict__ out, size_t H, CMAirs airs,
+                                                                    const CMJob* __restrict__ jobs, const int32_t* __restrict__ col_of,
+                                                                    int num_calls) {
+    __shared__ uint32_t tile[64][65];
+    const CMJob job = jobs[blockIdx.y];
+    const size_t r0 = (size_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const uint32_t* __restrict__ src = airs.buf[job.air];
+    const size_t U = (size_t)airs.cells[job.air];
+    const bool slot_ok = tx < job.n_slots;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = ty + 4 * i;
+        uint32_t v = 0u;
+        if (slot_ok && r0 + r < (size_t)num_calls) v = __builtin_nontemporal_load(src + (r0 + r) * U + job.slot0 + tx);
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    if (r0 + tx >= H) return;
+    for (int s = ty; s < job.n_slots; s += 4) {
+        const int32_t col = col_of[job.col_off + job.slot0 + s];
+        if (col >= 0) __builtin_nontemporal_store(tile[tx][s], out + (size_t)col * H + r0 + tx);
+    }
+}
+
+struct CMPlan {
+    CMJob* d_jobs = nullptr;
+    int32_t* d_col_of = nullptr;
+    size_t n_jobs = 0;
+    std::vector<PowdrSubstCM> key_subs;
+    std::vector<int32_t> key_cells;
+    int device = 0;
+    uint64_t last_use = 0;
+    ~CMPlan() { if (d_jobs) (void)hipFree(d_jobs); if (d_col_of) (void)hipFree(d_col_of); }
+};
+std::mutex g_cm_mu;
+std::unordered_map<uint64_t, std::shared_ptr<CMPlan>> g_cm_plans;
+uint64_t g_cm_clock = 0;
+
+}  // namespace
+
+extern "C" int powdr_apc_tracegen_callmajor(PowdrFp* d_output, size_t output_height, const PowdrCallMajorAir* h_airs, size_t n_airs,
+                                            const PowdrSubstCM* h_subs, size_t n_subs, int num_apc_calls) {
+    (void)hipGetLastError();
+    const size_t H = output_height;
+    if ((H & (H - 1)) != 0 || n_airs > (size_t)kCmMaxAirs || (n_subs && (!h_airs || !h_subs))) return (int)hipErrorInvalidValue;
+    if (H == 0 || n_subs == 0) return (int)hipGetLastError();
+    if (num_apc_calls < 0) num_apc_calls = 0;
+    if ((size_t)num_apc_calls > H) num_apc_calls = (int)H;
+    std::vector<int32_t> cells(n_airs);
+    CMAirs airs{};
+    for (size_t a = 0; a < n_airs; ++a) {
+        if (h_airs[a].cells_per_call < 0) return (int)hipErrorInvalidValue;
+        cells[a] = h_airs[a].cells_per_call;
+        airs.buf[a] = h_airs[a].buffer;
+        airs.cells[a] = cells[a];
+    }
+    for (size_t i = 0; i < n_subs; ++i)
+        if (h_subs[i].air_index < 0 || (size_t)h_subs[i].air_index >= n_airs || h_subs[i].slot < 0 ||
+            h_subs[i].slot >= cells[h_subs[i].air_index] || h_subs[i].apc_col < 0)
+            return (int)hipErrorInvalidValue;
+    uint64_t key = fnv1a(h_subs, n_subs * sizeof(PowdrSubstCM), 1469598103934665603ull);
+    key = fnv1a(cells.data(), cells.size() * 4, key);
+    int device = 0;
+    PW_HIP_TRY(hipGetDevice(&device));
+    key = fnv1a(&device, sizeof device, key);
+    std::shared_ptr<CMPlan> plan;
+    {
+        std::lock_guard<std::mutex> lk(g_cm_mu);
+        auto it = g_cm_plans.find(key);
+        if (it != g_cm_plans.end()) {
+            const CMPlan& c = *it->second;
+            if (c.device != device || c.key_cells != cells || c.key_subs.size() != n_subs ||
+                memcmp(c.key_subs.data(), h_subs, n_subs * sizeof(PowdrSubstCM)) != 0) { g_cm_plans.erase(it); it = g_cm_plans.end(); }
+        }
+        if (it == g_cm_plans.end()) {
+            if (g_cm_plans.size() >= kMaxCachedPlans) {
+                auto victim = g_cm_plans.begin();
+                for (auto j = g_cm_plans.begin(); j != g_cm_plans.end(); ++j) if (j->second->last_use < victim->second->last_use) victim = j;
+                g_cm_plans.erase(victim);
+            }
+            auto p = std::make_shared<CMPlan>();
+            // slot -> APC column per AIR (duplicate destinations resolve like the sequential reference loop: the last Subst wins)
+            std::vector<size_t> off(n_airs + 1, 0);
+            for (size_t a = 0; a < n_airs; ++a) off[a + 1] = off[a] + (size_t)cells[a];
+            std::vector<int32_t> col_of(off[n_airs] ? off[n_airs] : 1, -1);
+            std::unordered_map<int32_t, size_t> last;
+            for (size_t i = 0; i < n_subs; ++i) last[h_subs[i].apc_col] = i;
+            for (size_t i = 0; i < n_subs; ++i)
+                if (last[h_subs[i].apc_col] == i) col_of[off[h_subs[i].air_index] + h_subs[i].slot] = h_subs[i].apc_col;
+            std::vector<CMJob> jobs;
+            for (size_t a = 0; a < n_airs; ++a)
+                for (int32_t s0 = 0; s0 < cells[a]; s0 += 64)
+                    jobs.push_back({(int32_t)a, s0, (int32_t)off[a], std::min<int32_t>(64, cells[a] - s0)});
+            p->n_jobs = jobs.size();
+            PW_HIP_TRY(hipMalloc(&p->d_jobs, (jobs.size() + 1) * sizeof(CMJob)));
+            PW_HIP_TRY(hipMalloc(&p->d_col_of, col_of.size() * 4));
+            if (!jobs.empty()) PW_HIP_TRY(hipMemcpy(p->d_jobs, jobs.data(), jobs.size() * sizeof(CMJob), hipMemcpyHostToDevice));
+            PW_HIP_TRY(hipMemcpy(p->d_col_of, col_of.data(), col_of.size() * 4, hipMemcpyHostToDevice));
+            p->key_subs.assign(h_subs, h_subs + n_subs);
+            p->key_cells = cells;
+            p->device = device;
+            it = g_cm_plans.emplace(key, std::move(p)).first;
+        }
+        plan = it->second;
+        plan->last_use = ++g_cm_clock;
+    }
+    pw::ScopedKernelTimer t("apc_gather_callmajor_kernel");
+    const unsigned row_tiles = pw::div_up(H, 64);
+    for (size_t j = 0; j < plan->n_jobs; j += 65535) {
+        const unsigned cnt = (unsigned)std::min<size_t>(65535, plan->n_jobs - j);
+        hipLaunchKernelGGL(apc_gather_callmajor_kernel, dim3(row_tiles, cnt), dim3(256), 0, pw::stream(), d_output, H, airs, plan->d_jobs + j,
+                           plan->d_col_of, num_apc_calls);
+    }
+    return (int)hipGetLastError();
+}

@@ -163,9 +163,12 @@ template <bool DIF, int LOGR, int EPT, bool EXPAND>
 __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, const GroupParams& gp, int round,
                                           const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                           const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid,
-                                          uint32_t& tw_base) {
+                                          uint32_t& tw_base, bool io_first = true, bool io_last = true) {
     const int rb = gp.rb[round];
-    const bool first = round == 0, last = round == gp.n_rounds - 1;
+    // io_first / io_last = false: the group's first round reads / its last round writes the LDS tile instead of HBM
+    // (the fused LDE kernel chains two groups through LDS)
+    const bool last_round = round == gp.n_rounds - 1;
+    const bool first = round == 0 && io_first, last = last_round && io_last;
     constexpr int R = 1 << LOGR;
     constexpr int SLOTS = EPT / R;
     const bool vec_plain = rb == 0 && gp.c == 0 && LOGR >= 2;   // the slot's elements are contiguous in HBM
@@ -185,7 +188,7 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
         // fetch the next slot's (or the next round's first) twiddle base while this slot computes
         const uint32_t cur_base = tw_base;
         if (m + 1 < SLOTS) tw_base = load_twiddle_base<DIF>(im, gp, round, m + 1, tid, tw);
-        else if (!last) tw_base = load_twiddle_base<DIF>(im, gp, round + 1, 0, tid, tw);
+        else if (!last_round) tw_base = load_twiddle_base<DIF>(im, gp, round + 1, 0, tid, tw);
         // ---- load ----
         if (first) {
             if (EXPAND ? vec_expand : vec_plain) {
@@ -285,6 +288,69 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     }
 }
 
+// all rounds of one stage group on the workgroup's tile(s)
+template <bool DIF, int EPT>
+__device__ __forceinline__ void run_group(uint32_t* tile, const IndexMap& im, const GroupParams& gp, const uint32_t* __restrict__ src,
+                                          uint32_t* __restrict__ dst, const uint32_t* __restrict__ tw, int tid, bool io_first, bool io_last) {
+    uint32_t tw_base = load_twiddle_base<DIF>(im, gp, 0, 0, tid, tw);
+    for (int r = 0; r < gp.n_rounds; ++r) {
+        switch (gp.logr[r]) {
+            case 1: run_round<DIF, 1, EPT, false>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            case 2: run_round<DIF, 2, EPT, false>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            case 3: run_round<DIF, 3, EPT, false>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            default: run_round<DIF, 4, EPT, false>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+        }
+        if (r + 1 < gp.n_rounds) __syncthreads();
+    }
+}
+
+// The middle of the LDE in ONE pass over HBM: the last (contiguous) stage group of the inverse transform, the coset
+// scaling s^k / H, the zero-padding to 2H (a duplication in bit-reversed order) and the first (contiguous) stage group of
+// the forward transform all act on the same 2^ka bit-reversed coefficients, so a workgroup loads them once, runs the DIF
+// rounds, expands through LDS and runs the DIT rounds on the 2^(ka+1) results: the H-sized coefficient array is neither
+// written nor re-read (8 of the 44 bytes the unfused schedule moves per trace cell). For H <= 2^12 the whole LDE of a
+// column is this one launch.
+__global__ __launch_bounds__(kBlock) void lde_fused_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t in_stride,
+                                                           size_t out_stride, GroupParams ga, GroupParams gd,
+                                                           const uint32_t* __restrict__ tw_inv, const uint32_t* __restrict__ tw_fwd,
+                                                           const uint32_t* __restrict__ scale_br) {
+    constexpr int LOGA = 12, LOGD = 13;
+    __shared__ uint32_t tile[(1 << LOGD) + ((1 << LOGD) >> 5)];
+    const int tid = threadIdx.x;
+    const uint32_t* src = in + (size_t)blockIdx.y * in_stride;
+    uint32_t* dst = out + (size_t)blockIdx.y * out_stride;
+    IndexMap ia;
+    ia.B = ga.B; ia.c = ga.c; ia.lowbits = ga.lowbits; ia.k = ga.k;
+    ia.cmask = (1u << ga.c) - 1u;
+    ia.tile0 = (size_t)blockIdx.x << (LOGA - ga.B);
+    ia.n_tiles = (size_t)ga.n_tiles;
+    run_group<true, (1 << LOGA) / kBlock>(tile, ia, ga, src, nullptr, tw_inv, tid, true, false);
+    __syncthreads();
+    // scale and duplicate: element l of the coefficient tile becomes elements 2l, 2l + 1 of the forward tile
+    uint32_t v[(1 << LOGA) / kBlock];
+#pragma unroll
+    for (int m = 0; m < (1 << LOGA) / kBlock; ++m) {
+        const uint32_t l = (uint32_t)tid + 256u * m;
+        bool valid;
+        const size_t q = ia.global(l, valid);
+        v[m] = valid ? bb::mul(tile[lds_phys(l)], scale_br[q]) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < (1 << LOGA) / kBlock; ++m) {
+        const uint32_t l = (uint32_t)tid + 256u * m;
+        tile[lds_phys(2 * l)] = v[m];
+        tile[lds_phys(2 * l + 1)] = v[m];
+    }
+    __syncthreads();
+    IndexMap id;
+    id.B = gd.B; id.c = gd.c; id.lowbits = gd.lowbits; id.k = gd.k;
+    id.cmask = (1u << gd.c) - 1u;
+    id.tile0 = (size_t)blockIdx.x << (LOGD - gd.B);
+    id.n_tiles = (size_t)gd.n_tiles;
+    run_group<false, (1 << LOGD) / kBlock>(tile, id, gd, nullptr, dst, tw_fwd, tid, false, true);
+}
+
 struct Tables {
     uint32_t* tw_fwd = nullptr;    // g_n^j, j < 2^(n-1)
     uint32_t* tw_inv = nullptr;    // g_n^-j
@@ -331,28 +397,36 @@ const Tables* tables(int n) {
 }
 
 // Split stages [first, n) into groups of at most `LOGT - c` stages and each group into rounds.
-std::vector<GroupParams> plan_groups(bool dif, int n, int first, int& logt_out) {
+// `end` < n: only the stages [first, end) (the fused LDE kernel takes the rest); `balance`: the groups get nearly equal numbers
+// of stages instead of greedy-full groups followed by a short one.
+std::vector<GroupParams> plan_groups(bool dif, int n, int first, int& logt_out, int end = -1, bool balance = false) {
     std::vector<GroupParams> out;
     if (const char* e = getenv("POWDR_NTT_C")) { int v = atoi(e); if (v >= 0 && v <= 6) kStridedC = v; }
-    const int total = n - first;
+    if (end < 0) end = n;
+    const int total = end - first;
     // tile size: 2^13 when it saves a pass or the transform is large, else 2^12
     int logt = 12;
+    int n_groups = 0;
     {
         auto passes = [&](int lt) {
             int s = first, p = 0;
-            while (s < n) {
-                int rem = n - s, k = rem < lt ? rem : lt;
+            while (s < end) {
+                int rem = end - s, k = rem < lt ? rem : lt;
                 for (; k >= 1; --k) { int lb = dif ? n - s - k : s; int c = lb < kStridedC ? lb : kStridedC; if (k + c <= lt) break; }
                 s += k; ++p;
             }
             return p;
         };
         if (total > 0 && passes(13) < passes(12)) logt = 13;
+        n_groups = total > 0 ? passes(logt) : 0;
     }
     logt_out = logt;
     int s = first;
-    while (s < n) {
-        int rem = n - s, k = rem < logt ? rem : logt;
+    int groups_left = n_groups;
+    while (s < end) {
+        int rem = end - s, k = rem < logt ? rem : logt;
+        if (balance && groups_left > 0) { const int target = (rem + groups_left - 1) / groups_left; if (k > target) k = target; }
+        --groups_left;
         int c = 0;
         for (; k >= 1; --k) { int lb = dif ? n - s - k : s; c = lb < kStridedC ? lb : kStridedC; if (k + c <= logt) break; }
         GroupParams g{};
@@ -423,7 +497,88 @@ __global__ void expand_small_kernel(const uint32_t* in, uint32_t* out, size_t in
     out[(size_t)blockIdx.y * out_stride + 2 * q + 1] = v;
 }
 
+template <bool DIF>
+void launch_groups(std::vector<GroupParams>& groups, int logt, const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_stride,
+                   uint32_t cols, int n, const uint32_t* tw, const char* name) {
+    const uint32_t* src = in;
+    size_t src_stride = in_stride;
+    for (auto& g : groups) {
+        const size_t tiles = (size_t)1 << (n - g.B);
+        const size_t per_wg = (size_t)1 << (logt - g.B);
+        const unsigned wgs = (unsigned)((tiles + per_wg - 1) / per_wg);
+        for (uint32_t c0 = 0; c0 < cols; c0 += 65535u) {
+            const uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;
+            ScopedKernelTimer t(name);
+            const uint32_t* s_ = src + (size_t)c0 * src_stride;
+            uint32_t* d_ = out + (size_t)c0 * out_stride;
+            dim3 grid(wgs, cc), block(kBlock);
+            if (logt == 13) hipLaunchKernelGGL((ntt_group_kernel<DIF, 13, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, (const uint32_t*)nullptr);
+            else hipLaunchKernelGGL((ntt_group_kernel<DIF, 12, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, (const uint32_t*)nullptr);
+        }
+        src = out;
+        src_stride = out_stride;
+    }
+}
+
+GroupParams contiguous_group(bool dif, int n, int s0, int k, int c) {
+    GroupParams g{};
+    g.n = n; g.s0 = s0; g.k = k; g.c = c; g.lowbits = dif ? n - s0 - k : s0; g.B = k + c;
+    g.n_tiles = 1ull << (n - g.B);
+    const int nr = (k + 3) / 4;
+    g.n_rounds = nr;
+    int widths[4];
+    for (int r = 0; r < nr; ++r) widths[r] = k / nr + (r < k % nr ? 1 : 0);
+    if (dif) { int top = c + k; for (int r = 0; r < nr; ++r) { top -= widths[r]; g.rb[r] = top; g.logr[r] = widths[r]; } }
+    else { int bot = c; for (int r = 0; r < nr; ++r) { g.rb[r] = bot; g.logr[r] = widths[r]; bot += widths[r]; } }
+    return g;
+}
+
 }  // namespace
+
+// The whole LDE of `cols` columns: natural-order evaluations on <g_n> (in) -> natural-order evaluations on the coset
+// s <g_(n+1)> (out), through the fused middle kernel: strided DIF groups (stages 0 .. n-13, into `tmp`, which needs
+// cols x 2^n words and is untouched when n <= 12), lde_fused_kernel (the 12 contiguous DIF stages, scaling, duplication,
+// 12 contiguous DIT stages), strided DIT groups in place on `out`. Same values as intt_dif + coset_lde_from_coeffs.
+int lde_fused(const uint32_t* in, uint32_t* tmp, uint32_t* out, size_t in_stride, size_t tmp_stride, size_t out_stride, uint32_t cols, int n) {
+    if (n == 0) {
+        int rc = intt_dif(in, tmp, in_stride, tmp_stride, cols, n);
+        return rc ? rc : coset_lde_from_coeffs(tmp, out, tmp_stride, out_stride, cols, n);
+    }
+    const Tables* tn = tables(n);
+    const Tables* t1 = tables(n + 1);
+    if (!tn || !t1) return (int)hipErrorOutOfMemory;
+    const int ka = n < 12 ? n : 12;
+    const uint32_t* src = in;
+    size_t src_stride = in_stride;
+    if (n > ka) {
+        int logt = 12;
+        auto groups = plan_groups(true, n, 0, logt, n - ka, true);
+        launch_groups<true>(groups, logt, in, tmp, in_stride, tmp_stride, cols, n, tn->tw_inv, "ntt_group_kernel<dif>");
+        src = tmp;
+        src_stride = tmp_stride;
+    }
+    GroupParams ga = contiguous_group(true, n, n - ka, ka, 0);
+    GroupParams gd = contiguous_group(false, n + 1, 1, ka, 1);
+    gd.canonical_out = ka == n ? 1 : 0;
+    {
+        const size_t tiles = (size_t)1 << (n - ka);
+        const size_t per_wg = (size_t)1 << (12 - ka);
+        const unsigned wgs = (unsigned)((tiles + per_wg - 1) / per_wg);
+        for (uint32_t c0 = 0; c0 < cols; c0 += 65535u) {
+            const uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;
+            ScopedKernelTimer t("lde_fused_kernel");
+            hipLaunchKernelGGL(lde_fused_kernel, dim3(wgs, cc), dim3(kBlock), 0, stream(), src + (size_t)c0 * src_stride,
+                               out + (size_t)c0 * out_stride, src_stride, out_stride, ga, gd, tn->tw_inv, t1->tw_fwd, tn->shift_br);
+        }
+    }
+    if (n > ka) {
+        int logt = 12;
+        auto groups = plan_groups(false, n + 1, ka + 1, logt, n + 1, true);
+        if (!groups.empty()) groups.back().canonical_out = 1;
+        launch_groups<false>(groups, logt, out, out, out_stride, out_stride, cols, n + 1, t1->tw_fwd, "ntt_group_kernel<dit>");
+    }
+    return (int)hipGetLastError();
+}
 
 // Unscaled inverse NTT: natural-order evaluations on <g_n> -> bit-reversed coefficient order,
 // out[q] = 2^n * coefficient[bitrev(q)].

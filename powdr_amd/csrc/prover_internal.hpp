@@ -24,6 +24,9 @@ inline uint32_t root_of_unity(int n) {
 // ---- ntt.hip ---------------------------------------------------------------------------
 int intt_dif(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n);
 int coset_lde_from_coeffs(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n);
+// intt_dif + coset_lde_from_coeffs in three (instead of four) passes over HBM: the contiguous stage groups of both transforms
+// run in one kernel (ntt.hip lde_fused_kernel). tmp: cols x 2^n words of scratch (unused for n <= 12).
+int lde_fused(const uint32_t* in, uint32_t* tmp, uint32_t* out, size_t in_stride, size_t tmp_stride, size_t out_stride, uint32_t cols, int n);
 const uint32_t* shift_table(int n);  // s^k / 2^n (Montgomery), k < 2^n, device
 
 // ---- merkle.hip ------------------------------------------------------------------------

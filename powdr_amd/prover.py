@@ -15,7 +15,7 @@ class PwStarkConfig(C.Structure):
 
 
 PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
-                  "pw_lde_batch", "pw_merkle_commit", "pw_poseidon2_permute_host"]
+                  "pw_lde_batch", "pw_lde_fused", "pw_merkle_commit", "pw_poseidon2_permute_host"]
 
 lib.pw_prover_create.restype = C.c_void_p
 lib.pw_prover_create.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -32,6 +32,8 @@ lib.pw_prover_device_bytes.restype = C.c_size_t
 lib.pw_prover_device_bytes.argtypes = [C.c_void_p]
 lib.pw_lde_batch.restype = C.c_int
 lib.pw_lde_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+lib.pw_lde_fused.restype = C.c_int
+lib.pw_lde_fused.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
 lib.pw_merkle_commit.restype = C.c_int
 lib.pw_merkle_commit.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
 lib.pw_poseidon2_permute_host.argtypes = [C.c_void_p]

@@ -99,3 +99,20 @@ def apc_apply_bus(output: DeviceMatrix, num_calls: int, bytecode, interactions, 
         p.bitwise_bus, p.bitwise_hist.data_ptr())
     abi.check(rc, "_apc_apply_bus")
     return d_bc, d_int, d_sp
+
+
+class PowdrCallMajorAir(C.Structure):
+    _fields_ = [("buffer", C.c_void_p), ("cells_per_call", C.c_int32), ("reserved", C.c_int32)]
+
+
+def apc_tracegen_callmajor(output: DeviceMatrix, airs: list, subs_cm: np.ndarray, num_calls: int):
+    """Extension (layout half): airs = [(device int32 tensor [num_calls * cells_per_call], cells_per_call)],
+    subs_cm int32 [n, 3] = {air, slot, apc_col}. out[apc_col * H + r] = air.buffer[r * cells_per_call + slot]."""
+    abi.lib.powdr_apc_tracegen_callmajor.restype = C.c_int
+    abi.lib.powdr_apc_tracegen_callmajor.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    recs = (PowdrCallMajorAir * max(len(airs), 1))()
+    for i, (t, u) in enumerate(airs):
+        recs[i] = PowdrCallMajorAir(t.data_ptr(), int(u), 0)
+    s = np.ascontiguousarray(subs_cm, dtype=np.int32).reshape(-1, 3)
+    rc = abi.lib.powdr_apc_tracegen_callmajor(output.ptr(), output.height, recs, len(airs), s.ctypes.data, len(s), num_calls)
+    abi.check(rc, "powdr_apc_tracegen_callmajor")

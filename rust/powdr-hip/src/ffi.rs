@@ -46,6 +46,21 @@ pub struct DevInteraction {
     pub args_index_off: u32,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct PowdrCallMajorAir {
+    pub buffer: *const PowdrFp,
+    pub cells_per_call: i32,
+    pub reserved: i32,
+}
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct PowdrSubstCM {
+    pub air_index: i32,
+    pub slot: i32,
+    pub apc_col: i32,
+}
+
 extern "C" {
     // ---- the reference ABI, openvm/src/cuda_abi.rs:8-64 ----
     pub fn _apc_tracegen(d_output: *mut PowdrFp, output_height: usize, d_original_airs: *const OriginalAir,
@@ -77,6 +92,8 @@ extern "C" {
                                            var_num_bins: usize, tuple2_bus_id: u32, d_tuple2_hist: *mut u32,
                                            tuple2_sz0: u32, tuple2_sz1: u32, bitwise_bus_id: u32,
                                            d_bitwise_hist: *mut u32) -> i32;
+    pub fn powdr_apc_tracegen_callmajor(d_output: *mut PowdrFp, output_height: usize, h_airs: *const PowdrCallMajorAir, n_airs: usize,
+                                        h_subs: *const PowdrSubstCM, n_subs: usize, num_apc_calls: i32) -> i32;
     pub fn powdr_periphery_var_range_trace(d_var_hist: *const u32, var_num_bins: usize, d_out: *mut PowdrFp) -> i32;
     pub fn powdr_periphery_tuple2_trace(d_tuple2_hist: *const u32, tuple2_sz0: u32, tuple2_sz1: u32, d_out: *mut PowdrFp) -> i32;
     pub fn powdr_periphery_bitwise_trace(d_bitwise_hist: *const u32, d_out: *mut PowdrFp) -> i32;
@@ -253,6 +270,7 @@ extern "C" {
     pub fn pw_prover_width(p: *const PwProver) -> u32;
     pub fn pw_prover_device_bytes(p: *const PwProver) -> usize;
     pub fn pw_lde_batch(d_trace: *const u32, width: u32, log_height: u32, d_coeffs: *mut u32, d_lde: *mut u32) -> c_int;
+    pub fn pw_lde_fused(d_trace: *const u32, width: u32, log_height: u32, d_tmp: *mut u32, d_lde: *mut u32) -> c_int;
     pub fn pw_merkle_commit(d_matrix: *const u32, height: usize, width: u32, d_digests: *mut u32) -> c_int;
     pub fn pw_poseidon2_permute_host(state16: *mut u32);
 }

@@ -57,6 +57,12 @@ def test_lde_matches_oracle(gpu, log_h, W):
     abi.check(prover.lib.pw_lde_batch(d_t.data_ptr(), W, log_h, d_c.data_ptr(), d_l.data_ptr()), "pw_lde_batch")
     torch.cuda.synchronize()
     assert (from_dev(d_l) == want).all()
+    # the fused schedule the provers use (contiguous DIF + DIT stage groups in one kernel): same LDE
+    d_l2 = torch.empty(W * 2 * H, dtype=torch.int32, device="cuda")
+    d_tmp = torch.empty(W * H, dtype=torch.int32, device="cuda")
+    abi.check(prover.lib.pw_lde_fused(d_t.data_ptr(), W, log_h, d_tmp.data_ptr(), d_l2.data_ptr()), "pw_lde_fused")
+    torch.cuda.synchronize()
+    assert torch.equal(d_l2, d_l)
     # the coefficient buffer: H * coefficient[bitrev(q)]
     coef = sm.dft(t[:H], inverse=True)
     got = from_dev(d_c)[:H]

@@ -530,3 +530,63 @@ def test_field_helpers_selftest_on_device(gpu):
     bad = C.c_int(-1)
     abi.check(abi.lib.powdr_field_selftest_gpu(7, 200, C.byref(bad)), "powdr_field_selftest_gpu")
     assert bad.value == 0
+
+
+@pytest.mark.parametrize("shape,num_calls,seed", [("T0", 1, 0), ("T0", 5, 1), ("T0", 64, 2), ("T1", 37, 3), ("T1", 1000, 4),
+                                                   ("T1", 4097, 5), ("C1", 300, 6), ("C1", 5000, 7)])
+def test_callmajor_sources_give_the_same_trace(gpu, shape, num_calls, seed):
+    """SURVEY.md §8 row (f)-1, layout half: sources handed over call-major and compacted (only the cells the APC uses,
+    contiguous per call — what an original chip would write given the APC's (row, column) -> slot map) produce the SAME
+    APC trace as the reference's column-major dummy traces: oracle (A) on the reference layout == oracle on the compacted
+    layout == powdr_apc_tracegen_callmajor on the device; derived columns and the bus replay on top are unchanged."""
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+
+    torch, abi, tg = gpu
+    s = synth.generate(shape, seed=seed)
+    apc, idx, want, hist, (bufs, dims, gt, order) = run_oracle_gpu_convention(s, num_calls, seed=seed)
+    W, H = want.shape
+    name_to = {n: i for i, (n, _, _, _) in enumerate(dims)}
+    dense = [bufs[name_to[n]] for n in gt.air_names]
+    heights = [dims[name_to[n]][2] for n in gt.air_names]
+    cm_bufs, cells, subs_cm = om.compact_call_major(dense, heights, gt.row_block_size, gt.subs, num_calls)
+    assert int(cells.sum()) <= len(gt.subs)  # nothing but used cells
+    # the gather alone, against the reference-layout oracle
+    ref_gather = om.c_apc_tracegen(H, W, dense, heights, gt.row_block_size, gt.subs, num_calls)
+    assert (om.c_apc_tracegen_callmajor(H, W, cm_bufs, cells, subs_cm, num_calls) == ref_gather).all()
+    out = tg.DeviceMatrix.zeros(H, W)
+    keep = [to_dev(torch, b) for b in cm_bufs]
+    tg.apc_tracegen_callmajor(out, list(zip(keep, cells)), subs_cm, num_calls)
+    torch.cuda.synchronize()
+    assert (from_dev(out.buf) == ref_gather).all()
+    # a second call hits the cached plan; then the rest of trace generation gives the full oracle trace
+    out.buf.zero_()
+    tg.apc_tracegen_callmajor(out, list(zip(keep, cells)), subs_cm, num_calls)
+    k2 = tg.apc_apply_derived_expr(out, num_calls, *om.compile_derived(apc, idx, H))
+    per = tg.Periphery.fresh()
+    inter, spans, bc = om.compile_bus(apc, idx, H)
+    k3 = tg.apc_apply_bus(out, num_calls, bc, inter, spans, per)
+    torch.cuda.synchronize()
+    assert (from_dev(out.buf).reshape(W, H) == want).all()
+    assert (hist_np(per.var_hist) == hist["var"]).all()
+    del k2, k3
+
+
+def test_callmajor_edge_cases(gpu):
+    torch, abi, tg = gpu
+    rng = np.random.default_rng(1)
+    # duplicate destination: the last substitution wins; slots that nobody reads; rows beyond the calls are zero
+    calls, H, U = 70, 128, 5
+    buf = rng.integers(0, om.P, calls * U, dtype=np.uint32)
+    subs_cm = np.array([[0, 0, 2], [0, 3, 0], [0, 1, 2], [0, 4, 1]], np.int32)  # column 2 written twice
+    want = om.c_apc_tracegen_callmajor(H, 3, [buf], np.array([U], np.int32), subs_cm, calls).reshape(3, H)
+    assert (want[2, :calls] == buf.reshape(calls, U)[:, 1]).all() and (want[:, calls:] == 0).all()
+    out = tg.DeviceMatrix.zeros(H, 3)
+    out.buf.fill_(7)
+    t = to_dev(torch, buf)
+    tg.apc_tracegen_callmajor(out, [(t, U)], subs_cm, calls)
+    torch.cuda.synchronize()
+    assert (from_dev(out.buf).reshape(3, H) == want).all()
+    with pytest.raises(abi.HipError):
+        tg.apc_tracegen_callmajor(out, [(t, U)], np.array([[0, 5, 0]], np.int32), calls)  # slot out of range
+    with pytest.raises(abi.HipError):
+        tg.apc_tracegen_callmajor(tg.DeviceMatrix.zeros(96, 3), [(t, U)], subs_cm, calls)  # height not a power of two
