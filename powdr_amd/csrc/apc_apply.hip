@@ -356,6 +356,7 @@ uint64_t g_bus_clock = 0;
 // item buffer of the binned path: one per host thread (= per launch stream)
 thread_local uint32_t* g_items = nullptr;
 thread_local size_t g_items_words = 0;
+thread_local int g_items_device = -1;  // the device the buffer lives on (a host thread may move to another GPU)
 
 // 8 bytes per step (the bytecode of an un-optimised APC is megabytes)
 uint64_t hash_words(const void* p, size_t n, uint64_t h) {
@@ -592,7 +593,8 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
         const size_t window = all_rows < ((size_t)1 << 20) ? all_rows : ((size_t)1 << 20);
         const size_t need = (size_t)plan->total_slots * window;
         bool have = true;
-        if (need > g_items_words) {
+        if (need > g_items_words || g_items_device != device) {
+            g_items_device = device;
             if (g_items) (void)hipFree(g_items);
             g_items = nullptr; g_items_words = 0;
             if (hipMalloc(&g_items, need * 4) == hipSuccess) g_items_words = need;

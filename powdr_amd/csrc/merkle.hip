@@ -10,6 +10,7 @@
 // work — see DESIGN.md §kernels.
 #include "prover_internal.hpp"
 
+#include <algorithm>
 #include <mutex>
 
 namespace pw {
@@ -48,29 +49,45 @@ __global__ __launch_bounds__(kBlock) void leaf_hash_kernel(const uint32_t* __res
     out[1] = make_uint4(st[4], st[5], st[6], st[7]);
 }
 
-// The leaf hash over a COLUMN-POINTER table: the hashed row is the concatenation of row j of several matrices of one
-// height (all AIRs of that height in a segment, AIR order). The pointers are wave-uniform scalar loads; everything else
-// is the kernel above. Used by the mixed-height commitment of a segment (merkle_commit_mixed).
-__global__ __launch_bounds__(kBlock) void leaf_hash_cols_kernel(const uint32_t* const* __restrict__ cols, uint32_t n_cols,
-                                                                 size_t height, uint32_t* __restrict__ digests) {
-    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j >= height) return;
+// The leaf hash of a mixed-height commitment runs over COLUMN-POINTER tables: the hashed row is the concatenation of row j of
+// several matrices of one height (all AIRs of that height in a segment, AIR order); the pointers are wave-uniform scalar loads.
+// All heights of a mixed-height commitment in ONE launch: a workgroup belongs to one level (first_block table, scalar scan);
+// the levels are ordered widest first, so the threads that run the most permutations start first. A segment with eleven
+// different heights otherwise pays eleven launches of which the short ones are latency bound — 64 waves hashing 2 400
+// columns take as long as 300 dependent permutations take, however few rows there are.
+struct LeafLevel {
+    const uint32_t* const* cols;
+    uint32_t n_cols;
+    uint32_t first_block;  // blocks [first_block, next level's first_block) hash this level's rows
+    uint64_t height;
+    uint32_t* out;
+};
+struct LeafLevels {  // passed by value in the kernel arguments (28 x 32 bytes): no table upload, nothing to keep alive
+    LeafLevel lv[28];
+    int n;
+};
+__global__ __launch_bounds__(kBlock) void leaf_hash_levels_kernel(const LeafLevels levels) {
+    int k = 0;
+    while (k + 1 < levels.n && blockIdx.x >= levels.lv[k + 1].first_block) ++k;
+    const LeafLevel lv = levels.lv[k];
+    const size_t j = (size_t)(blockIdx.x - lv.first_block) * kBlock + threadIdx.x;
+    if (j >= lv.height) return;
     uint32_t st[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) st[i] = 0u;
     uint32_t c0 = 0;
-    for (; c0 + 8 <= n_cols; c0 += 8) {
+    for (; c0 + 8 <= lv.n_cols; c0 += 8) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) st[k] = cols[c0 + k][j];
+        for (int q = 0; q < 8; ++q) st[q] = lv.cols[c0 + q][j];
         p2::permute(st, c_params);
     }
-    if (c0 < n_cols) {
+    if (c0 < lv.n_cols) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (c0 + k < n_cols) st[k] = cols[c0 + k][j];
+        for (int q = 0; q < 8; ++q)
+            if (c0 + q < lv.n_cols) st[q] = lv.cols[c0 + q][j];
         p2::permute(st, c_params);
     }
-    uint4* out = reinterpret_cast<uint4*>(digests + j * 8);
+    uint4* out = reinterpret_cast<uint4*>(lv.out + j * 8);
     out[0] = make_uint4(st[0], st[1], st[2], st[3]);
     out[1] = make_uint4(st[4], st[5], st[6], st[7]);
 }
@@ -224,25 +241,34 @@ int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_
 int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, uint32_t* d_inject) {
     int rc = poseidon2_upload_params();
     if (rc) return rc;
-    if (L < 0 || !by_log[L].n_cols) return (int)hipErrorInvalidValue;
+    if (L < 0 || L > 27 || !by_log[L].n_cols) return (int)hipErrorInvalidValue;
     const size_t N = (size_t)1 << L;
+    // row digests of every height in one launch: level L into the tree's leaves, smaller heights into their slice of
+    // d_inject (offset 2^lg * 8 words: the slices of all heights below L fit in 2^L * 8 words)
+    LeafLevels levels{};
+    LeafLevel* h_levels = levels.lv;
+    int n_levels = 0;
+    for (int lg = L; lg >= 0; --lg)
+        if (by_log[lg].n_cols)
+            h_levels[n_levels++] = LeafLevel{by_log[lg].d_cols, by_log[lg].n_cols, 0u, (uint64_t)1 << lg,
+                                             lg == L ? digests : d_inject + ((size_t)1 << lg) * 8};
+    std::stable_sort(h_levels, h_levels + n_levels, [](const LeafLevel& a, const LeafLevel& b) { return a.n_cols > b.n_cols; });
+    uint32_t blocks = 0;
+    for (int k = 0; k < n_levels; ++k) { h_levels[k].first_block = blocks; blocks += div_up((size_t)h_levels[k].height, kBlock); }
+    levels.n = n_levels;
     {
         ScopedKernelTimer t("leaf_hash_kernel");
-        hipLaunchKernelGGL(leaf_hash_cols_kernel, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), by_log[L].d_cols, by_log[L].n_cols, N, digests);
+        hipLaunchKernelGGL(leaf_hash_levels_kernel, dim3(blocks), dim3(kBlock), 0, stream(), levels);
     }
     size_t off = 0;
     for (int lg = L - 1; lg >= 0; --lg) {
         const size_t n = (size_t)1 << lg;
-        const uint32_t* inj = nullptr;
-        if (by_log[lg].n_cols) {
-            ScopedKernelTimer t("leaf_hash_kernel");
-            hipLaunchKernelGGL(leaf_hash_cols_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, stream(), by_log[lg].d_cols, by_log[lg].n_cols, n, d_inject);
-            inj = d_inject;
-        }
+        const uint32_t* inj = by_log[lg].n_cols ? d_inject + n * 8 : nullptr;
         ScopedKernelTimer t("compress_kernel");
         hipLaunchKernelGGL(compress_strided_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, stream(), digests + off, n, inj, digests + off + 2 * n * 8);
         off += 2 * n * 8;
     }
+    (void)N;
     return (int)hipGetLastError();
 }
 

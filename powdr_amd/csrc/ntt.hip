@@ -358,24 +358,29 @@ struct Tables {
     uint32_t* shift_br = nullptr;  // shift[bitrev_n(q)]
 };
 std::mutex g_mu;
-std::map<int, Tables> g_tables;
-bool g_roots_uploaded = false;
+std::map<std::pair<int, int>, Tables> g_tables;  // (device, n): twiddle tables live on the device that was current when they were built
+uint64_t g_roots_uploaded = 0;                   // bit d: device d's __constant__ copy of the 16th roots is initialised
 
 int upload_roots() {
-    if (g_roots_uploaded) return 0;
+    int device = 0;
+    PW_HIP_TRY(hipGetDevice(&device));
+    if (device < 64 && (g_roots_uploaded >> device) & 1) return 0;
     uint32_t h[2][8];
     const uint32_t w16 = field::root_of_unity(4), w16i = bb::inv(w16);
     uint32_t a = bb::R_MOD_P, b = bb::R_MOD_P;
     for (int r = 0; r < 8; ++r) { h[0][r] = a; h[1][r] = b; a = bb::mul(a, w16); b = bb::mul(b, w16i); }
     PW_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_roots16), h, sizeof h));
-    g_roots_uploaded = true;
+    if (device < 64) g_roots_uploaded |= 1ull << device;
     return 0;
 }
 
 const Tables* tables(int n) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (upload_roots()) return nullptr;
-    auto it = g_tables.find(n);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    const std::pair<int, int> key{device, n};
+    auto it = g_tables.find(key);
     if (it != g_tables.end()) return &it->second;
     Tables t;
     size_t half = n ? (size_t)1 << (n - 1) : 1, full = (size_t)1 << n;
@@ -393,7 +398,7 @@ const Tables* tables(int n) {
     hipLaunchKernelGGL(bitrev_copy_kernel, dim3(div_up(full, 256)), dim3(256), 0, stream(), t.shift, t.shift_br, n);
     // other host threads (other streams) may use the tables as soon as they are published
     if (hipStreamSynchronize(stream()) != hipSuccess) return nullptr;
-    return &g_tables.emplace(n, t).first->second;
+    return &g_tables.emplace(key, t).first->second;
 }
 
 // Split stages [first, n) into groups of at most `LOGT - c` stages and each group into rounds.

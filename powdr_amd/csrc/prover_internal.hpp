@@ -41,6 +41,8 @@ int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_
 // node j = compress(child j, child j + n) [then compress(node, H(rows j of the height-n matrices))]. d_inject: 2^(L-1) * 8 words
 // of scratch. NOTE the same scratch is reused level after level on the launch stream.
 struct MixedLevelCols { const uint32_t* const* d_cols; uint32_t n_cols; };
+// d_inject: 2^L * 8 words (row digests of the smaller heights, the slice of height 2^k at offset 2^k * 8). All heights are hashed
+// by ONE launch (widest level first); L <= 27.
 int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, uint32_t* d_inject);
 // leaves = hash of the 8 words (v[i], v[i + half]) of an Ext vector of length 2*half
 int merkle_commit_ext_pairs(const bb::Ext* v, size_t half, uint32_t* digests);

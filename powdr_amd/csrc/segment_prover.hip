@@ -118,7 +118,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
 
     // ---- buffers ----------------------------------------------------------------------------------------------
     TRY(cx.dig.ensure((n_trees * tree_words + fri_words) * 4));
-    TRY(cx.inject.ensure((Nmax / 2 + 1) * 8 * 4));
+    TRY(cx.inject.ensure((Nmax + 1) * 8 * 4));  // row digests of the heights below N: the slice of height n starts at n * 8 words
     TRY(cx.ext.ensure(ext_words * sizeof(bb::Ext)));
     size_t cols_total = 0;
     for (size_t a = 0; a < A; ++a) cols_total += std::max<size_t>({sh[a].W, sh[a].Wp, 8});

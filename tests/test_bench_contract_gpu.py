@@ -60,3 +60,28 @@ def test_segment_shapes_run_as_the_main_workload():
     assert d["value"] > 0 and abs(d["value"] - 3 * d["multi_segment"]["cells_per_segment"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     d = run_bench("--shape", "C5", "--segments", "2", "--segment-log-height", "12", "--logup")
     assert d["multi_segment"]["logup"] is True and d["multi_segment"]["airs_per_segment"] >= 25
+
+
+def test_two_ranks_on_one_gpu_weak_and_strong_legs():
+    """The N > 1 code path of bench.py as the driver launches it (torch.distributed.run, one process per rank), with both
+    ranks on GPU 0 over gloo (POWDR_DIST_BACKEND): weak scaling of the single-AIR step in `value`, strong scaling of the
+    multi-segment leg (8 segments -> 4 per rank), commitments all-gathered inside the timed regions."""
+    import os
+    import socket
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, POWDR_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--log-height", "12", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * d["config"]["rows"] * d["config"]["cols"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    ms = d["multi_segment"]
+    assert ms["scaling"] == "strong" and ms["n_segments"] == 8 and ms["segments_on_rank0"] == 4 and ms["value"] > 0
+    assert d["logup"]["value"] > 0
