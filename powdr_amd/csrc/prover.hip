@@ -533,6 +533,10 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         TRY(gather_rows(d_qlde, N, 8, d_idx, nq, d_qrows));
         TRY(gather_records(d_dig, d_dig_offs, 8u, (uint32_t)n_dig, d_dig_out));
         TRY(gather_records(reinterpret_cast<const uint32_t*>(d_v), d_ext_offs, 4u, (uint32_t)n_ext, d_ext_out));
+        // the answers leave the device as canonical words (d_trows .. d_qrows are contiguous)
+        TRY(canonicalize_words(d_trows, (size_t)nq * (W + Wp + 8)));
+        TRY(canonicalize_words(d_dig_out, n_dig * 8));
+        TRY(canonicalize_words(d_ext_out, n_ext * 4));
         std::vector<uint32_t> trows((size_t)nq * W), prows((size_t)nq * Wp + 1), qrows((size_t)nq * 8), dig(n_dig * 8), ext(n_ext * 4 + 1);
         PW_HIP_TRY(hipMemcpyAsync(trows.data(), d_trows, trows.size() * 4, hipMemcpyDeviceToHost, st));
         if (lg) PW_HIP_TRY(hipMemcpyAsync(prows.data(), d_prows, (size_t)nq * Wp * 4, hipMemcpyDeviceToHost, st));
@@ -540,21 +544,23 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         PW_HIP_TRY(hipMemcpyAsync(dig.data(), d_dig_out, n_dig * 32, hipMemcpyDeviceToHost, st));
         if (n_ext) PW_HIP_TRY(hipMemcpyAsync(ext.data(), d_ext_out, n_ext * 16, hipMemcpyDeviceToHost, st));
         PW_HIP_TRY(hipStreamSynchronize(st));
+        auto put_raw = [&](const uint32_t* w, size_t n) { pf.insert(pf.end(), w, w + n); };
+        pf.reserve(pf.size() + nq + trows.size() + prows.size() + qrows.size() + dig.size() + ext.size());
         size_t dpos = 0, epos = 0;
         for (uint32_t qi = 0; qi < nq; ++qi) {
             put(idx[qi]);
-            put_monty(&trows[(size_t)qi * W], W);
-            put_monty(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
+            put_raw(&trows[(size_t)qi * W], W);
+            put_raw(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
             if (lg) {
-                put_monty(&prows[(size_t)qi * Wp], Wp);
-                put_monty(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
+                put_raw(&prows[(size_t)qi * Wp], Wp);
+                put_raw(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
             }
-            put_monty(&qrows[(size_t)qi * 8], 8);
-            put_monty(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
+            put_raw(&qrows[(size_t)qi * 8], 8);
+            put_raw(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
             for (uint32_t l = 0; l < log_h; ++l) {
-                put_monty(&ext[epos * 4], 4); epos += 1;
+                put_raw(&ext[epos * 4], 4); epos += 1;
                 const size_t depth = (size_t)logN - 1 - l;
-                put_monty(&dig[dpos * 8], depth * 8); dpos += depth;
+                put_raw(&dig[dpos * 8], depth * 8); dpos += depth;
             }
         }
     }

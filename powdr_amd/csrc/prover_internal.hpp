@@ -86,6 +86,8 @@ int deep_quotient(const uint32_t* lde_a, uint32_t wa, const uint32_t* lde_b, uin
 int fri_fold(const bb::Ext* v, size_t half, int log_size, uint32_t shift, bb::Ext beta, bb::Ext* out);
 // y[i] += a * x[i] (a == nullptr: a = 1), Ext vectors of length n
 int ext_axpy(bb::Ext* y, const bb::Ext* a_or_null, const bb::Ext* x, size_t n);
+// Montgomery -> canonical, in place (proof words leave the device canonical)
+int canonicalize_words(uint32_t* d_words, size_t n);
 // d_out[i] = *d_ptrs[i]
 int gather_words(const uint32_t* const* d_ptrs, uint32_t n, uint32_t* d_out);
 // gather row `idx` of a column-major matrix into out[0..width)

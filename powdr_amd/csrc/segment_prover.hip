@@ -410,11 +410,17 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         if (ne) PW_HIP_TRY(hipMemcpyAsync(d_ext_offs, ext_offs.data(), ne * 8, hipMemcpyHostToDevice, st));
         TRY(gather_records(d_dig, d_dig_offs, 8u, (uint32_t)nd, d_dig_out));
         TRY(gather_records(reinterpret_cast<const uint32_t*>(d_v), d_ext_offs, 4u, (uint32_t)ne, d_ext_out));
+        // the answers leave the device as canonical words
+        TRY(canonicalize_words(d_rows, ro));
+        TRY(canonicalize_words(d_dig_out, nd * 8));
+        TRY(canonicalize_words(d_ext_out, ne * 4));
         std::vector<uint32_t> rows(ro + 1), dig(nd * 8 + 1), ext(ne * 4 + 1);
         PW_HIP_TRY(hipMemcpyAsync(rows.data(), d_rows, ro * 4, hipMemcpyDeviceToHost, st));
         PW_HIP_TRY(hipMemcpyAsync(dig.data(), d_dig_out, nd * 32, hipMemcpyDeviceToHost, st));
         if (ne) PW_HIP_TRY(hipMemcpyAsync(ext.data(), d_ext_out, ne * 16, hipMemcpyDeviceToHost, st));
         PW_HIP_TRY(hipStreamSynchronize(st));
+        auto put_raw = [&](const uint32_t* w, size_t n) { pf.insert(pf.end(), w, w + n); };
+        pf.reserve(pf.size() + nq + ro + nd * 8 + ne * 4);
         size_t dpos = 0, epos = 0;
         for (uint32_t qi = 0; qi < nq; ++qi) {
             put(qs[qi]);
@@ -422,16 +428,16 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
                 if (ph == 1 && !lg) continue;
                 for (size_t a = 0; a < A; ++a) {
                     const uint32_t w = ph == 0 ? sh[a].W : ph == 1 ? sh[a].Wp : 8u;
-                    put_monty(&rows[row_off[ph][a] + (size_t)qi * w], w);
+                    put_raw(&rows[row_off[ph][a] + (size_t)qi * w], w);
                 }
-                put_monty(&dig[dpos * 8], (size_t)L * 8);
+                put_raw(&dig[dpos * 8], (size_t)L * 8);
                 dpos += L;
             }
             for (int l = 0; l < rounds; ++l) {
-                put_monty(&ext[epos * 4], 4);
+                put_raw(&ext[epos * 4], 4);
                 epos += 1;
                 const size_t depth = (size_t)L - 1 - l;
-                put_monty(&dig[dpos * 8], depth * 8);
+                put_raw(&dig[dpos * 8], depth * 8);
                 dpos += depth;
             }
         }

@@ -233,6 +233,13 @@ __global__ __launch_bounds__(kBlock) void fri_fold_kernel(const bb::Ext* __restr
     out[i] = bb::ext_add(s, bb::ext_mul(beta, d));
 }
 
+// w[i] <- canonical representative of the Montgomery word w[i] (query answers are converted on the device: the host would
+// spend ~7 ns per proof word on it, 21 ms for the 3 M words of a reth-shaped segment's proof)
+__global__ __launch_bounds__(kBlock) void canonicalize_kernel(uint32_t* __restrict__ w, size_t n) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) w[i] = bb::from_monty(w[i]);
+}
+
 // y[i] += a * x[i]
 __global__ __launch_bounds__(kBlock) void ext_axpy_kernel(bb::Ext* __restrict__ y, bb::Ext a, const bb::Ext* __restrict__ x, size_t n, int a_is_one) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -356,6 +363,12 @@ int ext_axpy(bb::Ext* y, const bb::Ext* a_or_null, const bb::Ext* x, size_t n) {
     ScopedKernelTimer t("ext_axpy_kernel");
     hipLaunchKernelGGL(ext_axpy_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, stream(), y, a_or_null ? *a_or_null : bb::ext_one(), x, n,
                        a_or_null ? 0 : 1);
+    return (int)hipGetLastError();
+}
+
+int canonicalize_words(uint32_t* d_words, size_t n) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(canonicalize_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, stream(), d_words, n);
     return (int)hipGetLastError();
 }
 
