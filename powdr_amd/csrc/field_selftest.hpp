@@ -3,6 +3,7 @@
 // device the inline multiply-add instructions are exercised, on the host their portable fall-backs.
 #pragma once
 #include "ext.hpp"
+#include "poseidon2.hpp"
 
 namespace pw {
 
@@ -26,8 +27,26 @@ PW_HD int field_selftest_checks(uint64_t seed, uint32_t iterations) {
             if (r >= 2 * P || r % P != (uint32_t)(((uint64_t)a + b) % P)) return 4;
             if (d >= 2 * P || d % P != (uint32_t)(((uint64_t)a + 2ull * P - b) % P)) return 5;
         }
+    // the lazy S-box on the edges of its input range [0, 1.032 p): value and output range
+    {
+        const uint32_t hi = (uint32_t)((uint64_t)P + P / 32);
+        const uint32_t xs[] = {0, 1, 2, P - 1, P, P + 1, hi - 1, hi};
+        for (uint32_t x : xs) {
+            uint32_t want = R_MOD_P;
+            for (int k = 0; k < 7; ++k) want = mul(want, x % P);
+            const uint32_t l = p2::sbox7_lazy(x);
+            if (l % P != want || l >= (uint64_t)P + (uint64_t)P * 852 / 1000) return 6;
+            if (p2::sbox7(x) != want) return 7;
+        }
+    }
     for (uint32_t it = 0; it < iterations; ++it) {
         const uint32_t a = rp(), b = rp(), c = rp(), d = rp();
+        {
+            const uint32_t x = (uint32_t)(rnd() % ((uint64_t)P + P / 32));
+            uint32_t want = R_MOD_P;
+            for (int k = 0; k < 7; ++k) want = mul(want, x % P);
+            if (p2::sbox7_lazy(x) % P != want || p2::sbox7(x) != want) return 8;
+        }
         // Montgomery products against the definition a*b*R^-1
         const uint32_t ab = mul(a, b);
         if (ab >= P || (uint64_t)ab * R_MOD_P % P != (uint64_t)a * b % P) return 10;

@@ -11,6 +11,7 @@
 #include "prover_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 namespace pw {
@@ -23,7 +24,10 @@ p2::Params g_host_params;
 bool g_params_ready = false;
 uint64_t g_params_uploaded = 0;  // bit d: the __constant__ table of device d holds the parameters (one process may drive several GPUs)
 
-__global__ __launch_bounds__(kBlock) void leaf_hash_kernel(const uint32_t* __restrict__ m, size_t height,
+// MINW = minimum waves per SIMD the compiler must leave room for: 8 caps the kernel at 64 VGPRs (less interleaving of the
+// independent S-box chains), 1 lets it take what it wants (79 VGPRs = 6 waves per SIMD). POWDR_HASH_WAVES picks at run time.
+template <int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void leaf_hash_kernel(const uint32_t* __restrict__ m, size_t height,
                                                             uint32_t width, size_t col_stride,
                                                             uint32_t* __restrict__ digests) {
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -66,7 +70,8 @@ struct LeafLevels {  // passed by value in the kernel arguments (28 x 32 bytes):
     LeafLevel lv[28];
     int n;
 };
-__global__ __launch_bounds__(kBlock) void leaf_hash_levels_kernel(const LeafLevels levels) {
+template <int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void leaf_hash_levels_kernel(const LeafLevels levels) {
     int k = 0;
     while (k + 1 < levels.n && blockIdx.x >= levels.lv[k + 1].first_block) ++k;
     const LeafLevel lv = levels.lv[k];
@@ -190,6 +195,11 @@ __global__ __launch_bounds__(1024) void compress_tail_kernel(uint32_t* __restric
     }
 }
 
+int hash_min_waves() {
+    const char* e = getenv("POWDR_HASH_WAVES");
+    return e ? atoi(e) : 1;
+}
+
 int build_levels(uint32_t* digests, size_t n_leaves) {
     size_t off = 0;
     size_t n = n_leaves;
@@ -232,8 +242,10 @@ int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_
     if (rc) return rc;
     {
         ScopedKernelTimer t("leaf_hash_kernel");
-        hipLaunchKernelGGL(leaf_hash_kernel, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width,
-                           col_stride, digests);
+        if (hash_min_waves() >= 8)
+            hipLaunchKernelGGL(leaf_hash_kernel<8>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width, col_stride, digests);
+        else
+            hipLaunchKernelGGL(leaf_hash_kernel<1>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width, col_stride, digests);
     }
     return build_levels(digests, height);
 }
@@ -258,7 +270,8 @@ int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, 
     levels.n = n_levels;
     {
         ScopedKernelTimer t("leaf_hash_kernel");
-        hipLaunchKernelGGL(leaf_hash_levels_kernel, dim3(blocks), dim3(kBlock), 0, stream(), levels);
+        if (hash_min_waves() >= 8) hipLaunchKernelGGL(leaf_hash_levels_kernel<8>, dim3(blocks), dim3(kBlock), 0, stream(), levels);
+        else hipLaunchKernelGGL(leaf_hash_levels_kernel<1>, dim3(blocks), dim3(kBlock), 0, stream(), levels);
     }
     size_t off = 0;
     for (int lg = L - 1; lg >= 0; --lg) {
