@@ -44,6 +44,14 @@ PW_HD uint32_t monty_reduce(uint64_t t) {
     uint64_t u = t + (uint64_t)m * P;
     return reduce_2p((uint32_t)(u >> 32));
 }
+// the same without the conditional subtraction: t < 2^64 - 2^32 p (= 2.418 p^2)  ->  a representative in [0, t / 2^32 + p)
+PW_HD uint32_t monty_reduce_lazy(uint64_t t) {
+    uint32_t m = (uint32_t)t * NEG_PINV;
+    uint64_t u = t + (uint64_t)m * P;
+    return (uint32_t)(u >> 32);
+}
+// a in [0, 1.032 p) (reduce_wide_loose's range), b in [0, p)  ->  a representative of a + b in [0, 1.032 p)
+PW_HD uint32_t add_loose(uint32_t a, uint32_t b) { return reduce_2p(a + b); }
 PW_HD uint32_t mul(uint32_t a, uint32_t b) { return monty_reduce((uint64_t)a * b); }
 // a*b + c*d in one Montgomery reduction: 2 p^2 + p 2^32 < 2^64, and the result is < 2 * 0.47 p + p < 2p.
 // (Three raw products do not fit: the reduction itself adds up to p 2^32.)

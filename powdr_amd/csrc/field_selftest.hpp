@@ -39,6 +39,25 @@ PW_HD int field_selftest_checks(uint64_t seed, uint32_t iterations) {
             if (p2::sbox7(x) != want) return 7;
         }
     }
+    // the lazy internal layer at the top of its ranges (s_0 < 1.86 p, the others < 2.004 p, factors up to p - 1) and on
+    // random lazy states: values mod p and the ranges it promises for the next round
+    for (uint32_t it = 0; it < 4 + iterations / 16; ++it) {
+        const uint32_t top0 = (uint32_t)((uint64_t)P + (uint64_t)P * 86 / 100), top = (uint32_t)(2ull * P + (uint64_t)P * 4 / 1000);
+        uint32_t st[16], diag[16], want[16];
+        uint64_t sum = 0;
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t hi = i ? top : top0;
+            st[i] = it == 0 ? hi - 1 : it == 1 ? (hi - 1) * (uint32_t)(i & 1) : (uint32_t)(rnd() % hi);
+            diag[i] = it < 2 ? P - 1 : it == 2 ? 1u : rp();
+            sum += st[i] % P;
+        }
+        const uint32_t next = it < 2 ? P - 1 : rp();
+        for (int i = 0; i < 16; ++i) want[i] = (uint32_t)((sum % P + (uint64_t)mul(st[i] % P, diag[i]) + (i ? 0u : next)) % P);
+        p2::internal_layer(st, diag, (uint64_t)next * R_MOD_P);
+        if (st[0] != want[0]) return 9;
+        for (int i = 1; i < 16; ++i)
+            if (st[i] % P != want[i] || st[i] >= top) return 9;
+    }
     for (uint32_t it = 0; it < iterations; ++it) {
         const uint32_t a = rp(), b = rp(), c = rp(), d = rp();
         {

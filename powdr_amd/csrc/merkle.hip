@@ -25,7 +25,7 @@ bool g_params_ready = false;
 uint64_t g_params_uploaded = 0;  // bit d: the __constant__ table of device d holds the parameters (one process may drive several GPUs)
 
 // MINW = minimum waves per SIMD the compiler must leave room for: 8 caps the kernel at 64 VGPRs (less interleaving of the
-// independent S-box chains), 1 lets it take what it wants (79 VGPRs = 6 waves per SIMD). POWDR_HASH_WAVES picks at run time.
+// independent S-box chains), 6 allows 80 (what the unconstrained kernel wants, give or take two). POWDR_HASH_WAVES picks at run time.
 template <int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void leaf_hash_kernel(const uint32_t* __restrict__ m, size_t height,
                                                             uint32_t width, size_t col_stride,
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024) void compress_tail_kernel(uint32_t* __restric
 
 int hash_min_waves() {
     const char* e = getenv("POWDR_HASH_WAVES");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 6;
 }
 
 int build_levels(uint32_t* digests, size_t n_leaves) {
@@ -245,7 +245,7 @@ int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_
         if (hash_min_waves() >= 8)
             hipLaunchKernelGGL(leaf_hash_kernel<8>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width, col_stride, digests);
         else
-            hipLaunchKernelGGL(leaf_hash_kernel<1>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width, col_stride, digests);
+            hipLaunchKernelGGL(leaf_hash_kernel<6>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width, col_stride, digests);
     }
     return build_levels(digests, height);
 }
@@ -271,7 +271,7 @@ int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, 
     {
         ScopedKernelTimer t("leaf_hash_kernel");
         if (hash_min_waves() >= 8) hipLaunchKernelGGL(leaf_hash_levels_kernel<8>, dim3(blocks), dim3(kBlock), 0, stream(), levels);
-        else hipLaunchKernelGGL(leaf_hash_levels_kernel<1>, dim3(blocks), dim3(kBlock), 0, stream(), levels);
+        else hipLaunchKernelGGL(leaf_hash_levels_kernel<6>, dim3(blocks), dim3(kBlock), 0, stream(), levels);
     }
     size_t off = 0;
     for (int lg = L - 1; lg >= 0; --lg) {

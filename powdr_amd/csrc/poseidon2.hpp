@@ -18,10 +18,16 @@ struct Params {
     uint32_t ext_rc[8][16];
     uint32_t int_rc[13];
     uint32_t diag[16];
-    // ext_rc[r] folded into the external linear layer that precedes round r (external_layer_fold): the layer adds
-    // to every output the sum of its column over the four blocks, so the constant that enters block q, column i is
-    // c[q][i] - (sum_q' c[q'][i]) / 5; 64-bit words because they seed 64-bit accumulators from a scalar register pair
+    // ext_rc[r] folded into the external linear layer that precedes round r (external_layer_fold). The layer adds to every
+    // output the sum of its column over the four blocks, so block q, column i must carry f[q][i] = c[q][i] - (sum_q' c[q'][i]) / 5
+    // before the column sums. The M4 network shares its partial sums, so a block takes its constants as two seeds
+    // (a into x0 + x1, b into x2 + x3: outputs get 2a + b, a + b, a + 2b, a + b) and two corrections:
+    // ext_fold[r][4q + {0,1,2,3}] = {a, b, f[q][1] - a - b, f[q][3] - a - b} with a = (2 f0 - f2) / 3, b = (2 f2 - f0) / 3;
+    // 64-bit words because they enter 64-bit accumulators from a scalar register pair
     uint64_t ext_fold[8][16];
+    // the constant s_0 meets next, as a raw product c * (R mod p) that joins s_0's multiply-add of partial round r
+    // (internal_layer): int_rc[r + 1] for r < 12, ext_rc[4][0] for the last one
+    uint64_t int_fold[13];
 };
 
 // host-side generation (Montgomery form)
@@ -55,6 +61,19 @@ inline void generate_params(Params& p) {
             const uint32_t t = bb::mul(col, inv5);
             for (int q = 0; q < 4; ++q) p.ext_fold[r][4 * q + i] = bb::sub(p.ext_rc[r][4 * q + i], t);
         }
+    const uint32_t inv3 = bb::inv(m(3));
+    for (int r = 0; r < 8; ++r)
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t f0 = (uint32_t)p.ext_fold[r][4 * q], f1 = (uint32_t)p.ext_fold[r][4 * q + 1], f2 = (uint32_t)p.ext_fold[r][4 * q + 2],
+                           f3 = (uint32_t)p.ext_fold[r][4 * q + 3];
+            const uint32_t a = bb::mul(bb::sub(bb::double_(f0), f2), inv3), b = bb::mul(bb::sub(bb::double_(f2), f0), inv3);
+            const uint32_t ab = bb::add(a, b);
+            p.ext_fold[r][4 * q] = a;
+            p.ext_fold[r][4 * q + 1] = b;
+            p.ext_fold[r][4 * q + 2] = bb::sub(f1, ab);
+            p.ext_fold[r][4 * q + 3] = bb::sub(f3, ab);
+        }
+    for (int r = 0; r < 13; ++r) p.int_fold[r] = (uint64_t)(r < 12 ? p.int_rc[r + 1] : p.ext_rc[4][0]) * bb::R_MOD_P;
 }
 
 // x^7 with every product lazy (bb::mul_lazy: (a b + m p) >> 32 < a b / 2^32 + p, valid while a b < 2^64 - 2^32 p = 2.418 p^2)
@@ -62,7 +81,8 @@ inline void generate_params(Params& p) {
 // of the round constants deliver (exact bounds: tools/poseidon2_bounds.py):
 //   x2 = x*x   < 1.499 p      x3 = x2*x  < 1.725 p      x4 = x2*x2 < 2.053 p (< 2^32 = 2.133 p), after the subtraction < 1.053 p
 //   x3*x4 < 1.82 p^2: the last product is valid; lazy it is < 1.851 p, reduced it is canonical.
-// 14 instructions (sbox7_lazy) / 16 (sbox7) instead of 16 / 18 with two fully reduced squarings.
+// 14 instructions (sbox7_lazy) / 16 (sbox7) instead of 16 / 18 with two fully reduced squarings. The input may be as
+// large as 1.088 p before x4 leaves 32 bits.
 PW_HD uint32_t sbox7(uint32_t x) {
     const uint32_t x2 = bb::mul_lazy(x, x);
     const uint32_t x3 = bb::mul_lazy(x2, x);
@@ -80,24 +100,27 @@ PW_HD uint32_t sbox7_lazy(uint32_t x) {
 
 // External linear layer: M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] on each block of four words, then every word
 // gets the sum of its column over the four blocks added — followed by the addition of the next round's constants.
-// All in 64-bit accumulators: every output is
-// 2x_i + 3x_{i+1} + x_{i+2} + x_{i+3} (four multiply-adds seeded with the folded constant) plus the column sum
-// (64-bit adds), reduced once — 140 instructions instead of 72 modular additions + 16 constant additions. Inputs may
-// be lazy S-box outputs in [0, 2p): an output is < 5 * (7 * 2p + p) = 75 p, inside reduce_wide's 128 p.
-// LOOSE: the outputs only feed sbox7_lazy, so the last conditional subtraction is skipped ([0, 1.03 p)).
+// All in 64-bit accumulators (one instruction per 32+64-bit or 64+64-bit addition, per small-constant multiply-add),
+// with M4's shared partial sums: t01 = x0 + x1, t23 = x2 + x3, t = t01 + t23, ta = t + x1, tb = t + x3,
+// y0 = ta + t01, y1 = ta + 2 x2, y2 = tb + t23, y3 = tb + 2 x0 — 11 instructions per block, 13 with the constants
+// (Params::ext_fold) — then the column sums (12) and one reduction per output: 124 + 16 reductions where separate
+// multiply-add chains took 140 and modular additions 72 * 3 + 16 * 3.
+// Inputs may be lazy S-box outputs in [0, 1.86 p): an output is < 5 * (7 * 1.86 p + 4 p) = 85 p, inside reduce_wide's 128 p.
+// LOOSE: the outputs only feed an S-box or the partial rounds, so the last conditional subtraction is skipped ([0, 1.032 p)).
 template <bool FOLD, bool LOOSE>
 PW_HD void external_layer_fold(uint32_t* s, const uint64_t* fold) {
     uint64_t y[16];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t x0 = s[4 * b + i], x1 = s[4 * b + ((i + 1) & 3)], x2 = s[4 * b + ((i + 2) & 3)], x3 = s[4 * b + ((i + 3) & 3)];
-            uint64_t a = FOLD ? bb::wide_fma_uniform(fold[4 * b + i], x0, 2) : bb::wide_mul(x0, 2);
-            a = bb::wide_fma(a, x1, 3);
-            a = bb::wide_add(a, x2);
-            y[4 * b + i] = bb::wide_add(a, x3);
-        }
+        const uint32_t x0 = s[4 * b], x1 = s[4 * b + 1], x2 = s[4 * b + 2], x3 = s[4 * b + 3];
+        const uint64_t t01 = bb::wide_add(FOLD ? bb::wide_fma_uniform(fold[4 * b], x0, 1) : bb::wide_mul(x0, 1), x1);
+        const uint64_t t23 = bb::wide_add(FOLD ? bb::wide_fma_uniform(fold[4 * b + 1], x2, 1) : bb::wide_mul(x2, 1), x3);
+        const uint64_t t = t01 + t23;
+        const uint64_t ta = bb::wide_add(t, x1), tb = bb::wide_add(t, x3);
+        y[4 * b] = ta + t01;
+        y[4 * b + 1] = bb::wide_fma(ta, x2, 2) + (FOLD ? fold[4 * b + 2] : 0ull);
+        y[4 * b + 2] = tb + t23;
+        y[4 * b + 3] = bb::wide_fma(tb, x0, 2) + (FOLD ? fold[4 * b + 3] : 0ull);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -109,18 +132,24 @@ PW_HD void external_layer_fold(uint32_t* s, const uint64_t* fold) {
 
 // s_i <- sum + mu_i * s_i with mu = [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/4, 1/8, 2^-27, -2^-8, -1/16, -2^-27]
 // (diag[i] = mu_i in Montgomery form). Each output is ONE Montgomery reduction of sum * R + mu_i * s_i: the raw
-// product sum * (R mod p) is shared, every element adds its own product to it with a single multiply-add and pays
-// one reduction — 5 instructions per element where a Montgomery product plus a modular addition took 8.
-PW_HD void internal_layer(uint32_t* s, const uint32_t* diag) {
-    uint64_t wide = s[0];  // 16 terms < p: one reduction at the end instead of 15
+// product sum * (R mod p) is shared and every element adds its own product to it with a single multiply-add.
+// Between partial rounds only s_0 has to be small (it enters the S-box), so the other fifteen words stay LAZY: their
+// reduction drops the conditional subtraction (3 instructions per word instead of 5, s_1 included: mu_1 = 1 is a
+// product like the others), and the 16-term sum is reduced with reduce_wide_loose (4 instructions instead of 5).
+// Ranges (exact: tools/poseidon2_bounds.py): sum < 1.032 p, sum * R < 0.138 p^2; a word below B p gives
+// (0.138 + B) p^2 / 2^32 + p, whose fixed point is B = 2.0037 (< 2^32 / p = 2.133; the product stays below the
+// reduction's 2.418 p^2); the 16-term sum is below 1.86 p + 15 * 2.0037 p < 32 p, inside reduce_wide_loose's 128 p.
+// s_0 arrives as a lazy S-box output (< 1.86 p) and leaves canonical, with the constant it meets next already added
+// (`next_c` = that constant times R mod p, < 0.134 p^2: the product stays below 2.13 p^2).
+PW_HD void internal_layer(uint32_t* s, const uint32_t* diag, uint64_t next_c) {
+    uint64_t wide = s[0];
 #pragma unroll
     for (int i = 1; i < 16; ++i) wide = bb::wide_add(wide, s[i]);
-    const uint32_t sum = bb::reduce_sum(wide);
-    const uint64_t sum_r = (uint64_t)sum * bb::R_MOD_P;  // < p^2; + mu_i * s_i < 2 p^2 stays reducible
-    s[0] = bb::monty_reduce(bb::wide_mad_uniform(sum_r, s[0], diag[0]));
-    s[1] = bb::add(sum, s[1]);
+    const uint32_t sum = bb::reduce_wide_loose(wide);
+    const uint64_t sum_r = (uint64_t)sum * bb::R_MOD_P;
+    s[0] = bb::monty_reduce(bb::wide_mad_uniform(sum_r + next_c, s[0], diag[0]));
 #pragma unroll
-    for (int i = 2; i < 16; ++i) s[i] = bb::monty_reduce(bb::wide_mad_uniform(sum_r, s[i], diag[i]));
+    for (int i = 1; i < 16; ++i) s[i] = bb::monty_reduce_lazy(bb::wide_mad_uniform(sum_r, s[i], diag[i]));
 }
 
 // The round loops are deliberately NOT unrolled: one full round + one partial round is
@@ -139,14 +168,16 @@ PW_HD void permute(uint32_t* s, const Params& P) {
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = sbox7_lazy(s[i]);
-    external_layer_fold<false, false>(s, nullptr);
+    external_layer_fold<false, true>(s, nullptr);  // [0, 1.032 p): what the partial rounds take
+    s[0] = bb::add_loose(s[0], P.int_rc[0]);
 #pragma unroll 1
     for (int r = 0; r < 13; ++r) {
-        s[0] = sbox7(bb::add(s[0], P.int_rc[r]));
-        internal_layer(s, P.diag);
+        s[0] = sbox7_lazy(s[0]);
+        internal_layer(s, P.diag, P.int_fold[r]);
     }
+    // the partial rounds leave s_0 canonical (constant of the next round included) and the others in [0, 2.004 p)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = bb::add(s[i], P.ext_rc[4][i]);
+    for (int i = 1; i < 16; ++i) s[i] = bb::add(bb::reduce_2p(s[i]), P.ext_rc[4][i]);
 #pragma unroll 1
     for (int r = 4; r < 7; ++r) {
 #pragma unroll
