@@ -126,9 +126,17 @@ PW_HD uint64_t wide_mul(uint32_t x, uint32_t k) {
 }
 // x < 128 p  ->  a representative of x mod p in [0, 1.03 p).  q = floor((x >> 7) * 273 / 2^32) with
 // 273 = floor(2^39 / p) = floor(273.07): q <= x / p and x - q p < (1 - 273 / 273.07) x + p + 273 * 128 < 1.03 p.
+// Three instructions: a funnel shift, a mul_hi and ONE multiply-add — x + q (2^32 - p), of which only the low word is
+// kept (the ISA has no 32-bit multiply-subtract; the 64-bit multiply-add does it when its high half is ignored).
 PW_HD uint32_t reduce_wide_loose(uint64_t x) {
     const uint32_t q = (uint32_t)(((x >> 7) & 0xffffffffull) * 273u >> 32);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PW_NO_REDUCE_MAD)
+    uint64_t out;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(out) : "v"(q), "s"(0u - P), "v"(x) : "vcc");
+    return (uint32_t)out;
+#else
     return (uint32_t)x - q * P;
+#endif
 }
 // x < 128 p  ->  x mod p
 PW_HD uint32_t reduce_wide(uint64_t x) { return reduce_2p(reduce_wide_loose(x)); }

@@ -36,18 +36,18 @@ __global__ __launch_bounds__(kBlock, MINW) void leaf_hash_kernel(const uint32_t*
 #pragma unroll
     for (int i = 0; i < 16; ++i) st[i] = 0u;
     const uint32_t* col = m + j;
-    uint32_t c0 = 0;
-    for (; c0 + 8 <= width; c0 += 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) st[k] = col[(size_t)(c0 + k) * col_stride];
-        p2::permute(st, c_params);
-    }
-    if (c0 < width) {
+    // one copy of the permutation in the kernel: the short last chunk keeps the words it does not overwrite (scalar tests);
+    // between permutations nothing reads the state, so they skip the final conditional subtractions (permute<true>) and
+    // the digest is reduced once
+#pragma unroll 1
+    for (uint32_t c0 = 0; c0 < width; c0 += 8) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if (c0 + k < width) st[k] = col[(size_t)(c0 + k) * col_stride];
-        p2::permute(st, c_params);
+        p2::permute<true>(st, c_params);
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st[k] = bb::reduce_2p(st[k]);
     uint4* out = reinterpret_cast<uint4*>(digests + j * 8);
     out[0] = make_uint4(st[0], st[1], st[2], st[3]);
     out[1] = make_uint4(st[4], st[5], st[6], st[7]);
@@ -80,18 +80,15 @@ __global__ __launch_bounds__(kBlock, MINW) void leaf_hash_levels_kernel(const Le
     uint32_t st[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) st[i] = 0u;
-    uint32_t c0 = 0;
-    for (; c0 + 8 <= lv.n_cols; c0 += 8) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) st[q] = lv.cols[c0 + q][j];
-        p2::permute(st, c_params);
-    }
-    if (c0 < lv.n_cols) {
+#pragma unroll 1
+    for (uint32_t c0 = 0; c0 < lv.n_cols; c0 += 8) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (c0 + q < lv.n_cols) st[q] = lv.cols[c0 + q][j];
-        p2::permute(st, c_params);
+        p2::permute<true>(st, c_params);
     }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) st[q] = bb::reduce_2p(st[q]);
     uint4* out = reinterpret_cast<uint4*>(lv.out + j * 8);
     out[0] = make_uint4(st[0], st[1], st[2], st[3]);
     out[1] = make_uint4(st[4], st[5], st[6], st[7]);

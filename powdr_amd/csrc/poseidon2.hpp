@@ -12,6 +12,17 @@
 #pragma once
 #include "babybear.hpp"
 
+#ifndef PW_P2_UNROLL
+#define PW_P2_UNROLL 1
+#endif
+#define PW_P2_STR2(x) #x
+#define PW_P2_STR(x) PW_P2_STR2(x)
+#define PW_P2_ROUND_LOOP _Pragma(PW_P2_STR(unroll PW_P2_UNROLL))
+#ifndef PW_P2_UNROLL_PARTIAL
+#define PW_P2_UNROLL_PARTIAL 1
+#endif
+#define PW_P2_PARTIAL_LOOP _Pragma(PW_P2_STR(unroll PW_P2_UNROLL_PARTIAL))
+
 namespace p2 {
 
 struct Params {
@@ -158,9 +169,12 @@ PW_HD void internal_layer(uint32_t* s, const uint32_t* diag, uint64_t next_c) {
 // indexed by the (wave-uniform) round counter and arrive through scalar loads.
 // Round constants of the external rounds are added by the linear layer that PRECEDES the round (external_layer_fold),
 // except for round 4, which follows an internal layer.
+// SPONGE: the permutation of an absorbing sponge whose output is not read — the rate words are overwritten and the
+// capacity words only enter the next permutation's first linear layer, so the last layer leaves them in [0, 1.032 p).
+template <bool SPONGE = false>
 PW_HD void permute(uint32_t* s, const Params& P) {
     external_layer_fold<true, true>(s, P.ext_fold[0]);
-#pragma unroll 1
+PW_P2_ROUND_LOOP
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = sbox7_lazy(s[i]);
@@ -170,7 +184,7 @@ PW_HD void permute(uint32_t* s, const Params& P) {
     for (int i = 0; i < 16; ++i) s[i] = sbox7_lazy(s[i]);
     external_layer_fold<false, true>(s, nullptr);  // [0, 1.032 p): what the partial rounds take
     s[0] = bb::add_loose(s[0], P.int_rc[0]);
-#pragma unroll 1
+PW_P2_PARTIAL_LOOP
     for (int r = 0; r < 13; ++r) {
         s[0] = sbox7_lazy(s[0]);
         internal_layer(s, P.diag, P.int_fold[r]);
@@ -178,7 +192,7 @@ PW_HD void permute(uint32_t* s, const Params& P) {
     // the partial rounds leave s_0 canonical (constant of the next round included) and the others in [0, 2.004 p)
 #pragma unroll
     for (int i = 1; i < 16; ++i) s[i] = bb::add(bb::reduce_2p(s[i]), P.ext_rc[4][i]);
-#pragma unroll 1
+PW_P2_ROUND_LOOP
     for (int r = 4; r < 7; ++r) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = sbox7_lazy(s[i]);
@@ -186,7 +200,7 @@ PW_HD void permute(uint32_t* s, const Params& P) {
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = sbox7_lazy(s[i]);
-    external_layer_fold<false, false>(s, nullptr);
+    external_layer_fold<false, SPONGE>(s, nullptr);
 }
 
 }  // namespace p2
