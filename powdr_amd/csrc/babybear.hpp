@@ -146,6 +146,110 @@ PW_HD uint32_t reduce_sum(uint64_t x) {
     return reduce_2p((uint32_t)x - q * P);
 }
 
+// ---- signed representatives --------------------------------------------------------------------------------------------
+// The Poseidon2 permutation (poseidon2.hpp) keeps its state as SIGNED 32-bit representatives: with a signed Montgomery
+// factor m in [-2^31, 2^31) the reduction (t + m p) / 2^32 lands in (t / 2^32 - p / 2, t / 2^32 + p / 2), so a product of
+// two words below 1.04 p is again below p in magnitude WITHOUT any conditional subtraction — x^7 is four products of three
+// instructions each — and sums go through signed 64-bit multiply-adds (v_mad_i64_i32) exactly like the unsigned ones.
+// t must satisfy |t| + 2^31 p < 2^63, i.e. |t| < 1.209 p^2.
+PW_HD int64_t smul(int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t out;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(out) : "v"(a), "v"(b) : "vcc");
+    return out;
+#else
+    return (int64_t)a * b;
+#endif
+}
+PW_HD int64_t smul_uniform(int32_t a, int32_t u) {  // u wave-uniform
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t out;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(out) : "v"(a), "s"(u) : "vcc");
+    return out;
+#else
+    return (int64_t)a * u;
+#endif
+}
+PW_HD int32_t smont(int64_t t) {
+    const int32_t m = (int32_t)((uint32_t)t * NEG_PINV);
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t u;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(u) : "v"(m), "s"((int32_t)P), "v"(t) : "vcc");
+    return (int32_t)(u >> 32);
+#else
+    return (int32_t)((t + (int64_t)m * (int64_t)P) >> 32);
+#endif
+}
+// acc + x, acc + k x (k a small constant), c + k x for a wave-uniform c, acc + x u for a wave-uniform u, k x
+PW_HD int64_t swide_add(int64_t acc, int32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t out;
+    asm("v_mad_i64_i32 %0, vcc, %1, 1, %2" : "=v"(out) : "v"(x), "v"(acc) : "vcc");
+    return out;
+#else
+    return acc + x;
+#endif
+}
+PW_HD int64_t swide_fma(int64_t acc, int32_t x, int32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t out;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(out) : "v"(x), "n"(k), "v"(acc) : "vcc");
+    return out;
+#else
+    return acc + (int64_t)x * k;
+#endif
+}
+PW_HD int64_t swide_fma_uniform(int64_t c, int32_t x, int32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t out;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(out) : "v"(x), "n"(k), "s"(c) : "vcc");
+    return out;
+#else
+    return c + (int64_t)x * k;
+#endif
+}
+PW_HD int64_t swide_mad_uniform(int64_t acc, int32_t x, int32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t out;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(out) : "v"(x), "s"(u), "v"(acc) : "vcc");
+    return out;
+#else
+    return acc + (int64_t)x * u;
+#endif
+}
+PW_HD int64_t swide_mul(int32_t x, int32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t out;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(out) : "v"(x), "n"(k) : "vcc");
+    return out;
+#else
+    return (int64_t)x * k;
+#endif
+}
+// |y| < 64 p  ->  a representative of y mod p in (-0.017 p, 1.017 p) (for the |y| < 43 p of Poseidon2: (-0.011 p, 1.011 p)):  q = floor(floor(y / 2^7) * 273 / 2^32) with
+// 273 = floor(2^39 / p); y - q p = y (1 - 273 p / 2^39) + (rounding of the two floors, in [0, p + 273 p / 2^32)), and
+// 1 - 273 p / 2^39 = 0.000256. Three instructions: a funnel shift, a signed mul_hi and one multiply-add y + q (-p) of
+// which only the low word is kept.
+PW_HD int32_t sreduce_wide_loose(int64_t y) {
+    const int32_t a = (int32_t)(y >> 7);
+    const int32_t q = (int32_t)(((int64_t)a * 273) >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t out;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(out) : "v"(q), "s"(-(int32_t)P), "v"(y) : "vcc");
+    return (int32_t)out;
+#else
+    return (int32_t)((uint32_t)y - (uint32_t)q * P);
+#endif
+}
+// the centred representative (-p/2, p/2) of a canonical word
+PW_HD int32_t centred(uint32_t canonical) { return canonical > P / 2 ? (int32_t)(canonical - P) : (int32_t)canonical; }
+// a signed representative in (-p, 1.13 p) -> canonical (u + p must not wrap for the non-negative ones)
+PW_HD uint32_t canonical_of(int32_t x) {
+    uint32_t u = (uint32_t)x;
+    u = umin(u, u + P);      // negative (huge as unsigned) -> + p
+    return umin(u, u - P);   // [p, 2p) -> - p
+}
+
 // Addition and subtraction on representatives in [0, 2p) (2p < 2^32 < 4p, so the sum needs its carry). Used by the
 // forward NTT, whose butterflies then take a lazy product as they come: 3 + 4 + 3 instructions instead of 5 + 3 + 3.
 constexpr uint32_t TWO_P = 2u * P;

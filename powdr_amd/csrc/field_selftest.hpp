@@ -27,44 +27,59 @@ PW_HD int field_selftest_checks(uint64_t seed, uint32_t iterations) {
             if (r >= 2 * P || r % P != (uint32_t)(((uint64_t)a + b) % P)) return 4;
             if (d >= 2 * P || d % P != (uint32_t)(((uint64_t)a + 2ull * P - b) % P)) return 5;
         }
-    // the lazy S-box on the edges of its input range [0, 1.032 p): value and output range
+    // signed representatives: reduction of wide sums, the S-box and the internal layer at the edges of their ranges
+    auto smodp = [](int64_t v) { const int64_t r = v % (int64_t)P; return (uint32_t)(r < 0 ? r + P : r); };
     {
-        const uint32_t hi = (uint32_t)((uint64_t)P + P / 32);
-        const uint32_t xs[] = {0, 1, 2, P - 1, P, P + 1, hi - 1, hi};
-        for (uint32_t x : xs) {
+        const int64_t ys[] = {0, 1, -1, (int64_t)P, -(int64_t)P, 64ll * P - 1, -64ll * P + 1, 43ll * P, -43ll * P, 12345678901ll, -12345678901ll};
+        for (int64_t y : ys) {
+            const int32_t r = sreduce_wide_loose(y);
+            if (smodp(r) != smodp(y) || r <= -(int32_t)(P / 50) || r >= (int32_t)(P + P / 50)) return 6;
+            if (r > -(int32_t)P && canonical_of(r) != smodp(y)) return 6;
+        }
+        const int32_t hi = (int32_t)((uint64_t)P + (uint64_t)P * 45 / 1000);  // 1.045 p
+        const int32_t xs[] = {0, 1, -1, (int32_t)P - 1, (int32_t)P, -(int32_t)P, hi - 1, -(hi - 1), (int32_t)(P / 2), -(int32_t)(P / 2)};
+        for (int32_t x : xs) {
             uint32_t want = R_MOD_P;
-            for (int k = 0; k < 7; ++k) want = mul(want, x % P);
-            const uint32_t l = p2::sbox7_lazy(x);
-            if (l % P != want || l >= (uint64_t)P + (uint64_t)P * 852 / 1000) return 6;
-            if (p2::sbox7(x) != want) return 7;
+            for (int k = 0; k < 7; ++k) want = mul(want, smodp(x));
+            const int32_t l = p2::sbox7(x);
+            if (smodp(l) != want || l <= -(int32_t)P || l >= (int32_t)P) return 7;
         }
     }
-    // the lazy internal layer at the top of its ranges (s_0 < 1.86 p, the others < 2.004 p, factors up to p - 1) and on
-    // random lazy states: values mod p and the ranges it promises for the next round
     for (uint32_t it = 0; it < 4 + iterations / 16; ++it) {
-        const uint32_t top0 = (uint32_t)((uint64_t)P + (uint64_t)P * 86 / 100), top = (uint32_t)(2ull * P + (uint64_t)P * 4 / 1000);
-        uint32_t st[16], diag[16], want[16];
-        uint64_t sum = 0;
+        const int32_t top0 = (int32_t)((uint64_t)P * 97 / 100), top = (int32_t)((uint64_t)P * 75 / 100);  // |s_0| < 0.97 p, others < 0.75 p
+        int32_t st[16], diag[16];
+        uint32_t want[16];
+        int64_t sum = 0;
         for (int i = 0; i < 16; ++i) {
-            const uint32_t hi = i ? top : top0;
-            st[i] = it == 0 ? hi - 1 : it == 1 ? (hi - 1) * (uint32_t)(i & 1) : (uint32_t)(rnd() % hi);
-            diag[i] = it < 2 ? P - 1 : it == 2 ? 1u : rp();
-            sum += st[i] % P;
+            const int32_t hi = i ? top : top0;
+            const int32_t mag = it < 3 ? hi - 1 : (int32_t)(rnd() % (uint64_t)hi);
+            st[i] = it == 0 ? mag : it == 1 ? -mag : it == 2 ? ((i & 1) ? mag : -mag) : ((rnd() & 1) ? mag : -mag);
+            diag[i] = it < 3 ? ((i & 2) ? (int32_t)(P / 2) : -(int32_t)(P / 2)) : centred(rp());
+            sum += smodp(st[i]);
         }
-        const uint32_t next = it < 2 ? P - 1 : rp();
-        for (int i = 0; i < 16; ++i) want[i] = (uint32_t)((sum % P + (uint64_t)mul(st[i] % P, diag[i]) + (i ? 0u : next)) % P);
-        p2::internal_layer(st, diag, (uint64_t)next * R_MOD_P);
-        if (st[0] != want[0]) return 9;
-        for (int i = 1; i < 16; ++i)
-            if (st[i] % P != want[i] || st[i] >= top) return 9;
+        const uint32_t next = it < 3 ? P - 1 : rp(), ex = it < 3 ? (P + 1) / 2 : rp();
+        int64_t exit_c[16];
+        for (int i = 0; i < 16; ++i) exit_c[i] = (int64_t)centred(ex) * (int64_t)R_MOD_P;
+        const bool last = it & 1;
+        for (int i = 0; i < 16; ++i)
+            want[i] = (uint32_t)(((uint64_t)sum % P + (uint64_t)mul(smodp(st[i]), smodp(diag[i])) + (i ? (last ? ex : 0u) : next)) % P);
+        if (last) p2::internal_layer<true>(st, diag, (int64_t)centred(next) * (int64_t)R_MOD_P, exit_c);
+        else p2::internal_layer<false>(st, diag, (int64_t)centred(next) * (int64_t)R_MOD_P, exit_c);
+        for (int i = 0; i < 16; ++i)
+            if (smodp(st[i]) != want[i]) return 9;
+        const int32_t lim = last ? (int32_t)((uint64_t)P * 78 / 100) : top;  // with the exit constants: 0.78 p, still an S-box input
+        for (int i = 0; i < 16; ++i)
+            if (st[i] <= -(i ? lim : top0) || st[i] >= (i ? lim : top0)) return 9;
     }
     for (uint32_t it = 0; it < iterations; ++it) {
         const uint32_t a = rp(), b = rp(), c = rp(), d = rp();
         {
-            const uint32_t x = (uint32_t)(rnd() % ((uint64_t)P + P / 32));
+            const int32_t x = (int32_t)(rnd() % (2ull * P + P / 11)) - (int32_t)(P + P / 22);  // (-1.045 p, 1.045 p)
             uint32_t want = R_MOD_P;
-            for (int k = 0; k < 7; ++k) want = mul(want, x % P);
-            if (p2::sbox7_lazy(x) % P != want || p2::sbox7(x) != want) return 8;
+            for (int k = 0; k < 7; ++k) want = mul(want, smodp(x));
+            if (smodp(p2::sbox7(x)) != want) return 8;
+            const int64_t y = (int64_t)(rnd() % (128ull * P)) - 64ll * P;
+            if (smodp(sreduce_wide_loose(y)) != smodp(y)) return 8;
         }
         // Montgomery products against the definition a*b*R^-1
         const uint32_t ab = mul(a, b);

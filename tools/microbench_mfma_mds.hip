@@ -3,7 +3,7 @@
 // The layer is  out = M s  (mod p) with M = circ(2 M4, M4, M4, M4), entries in {1,2,3,4,6}, row sums 35; s = 16 BabyBear
 // words per row. Two implementations on the same states, both returning canonical words, compared word for word:
 //
-//  (A) the production form (powdr_amd/csrc/poseidon2.hpp external_layer_fold): lane = row, 64-bit multiply-add
+//  (A) the production form at the time of the measurement (external_layer_valu below): lane = row, 64-bit multiply-add
 //      accumulators, one reduce_wide per output — integer VALU only.
 //  (B) v_mfma_i32_16x16x64_i8 on byte planes. Out^T = M S^T per tile of 16 rows: A = M (out index x word index), B = the
 //      bytes of S^T. The i8 inputs force the 31-bit words into 4 byte planes; the planes cannot share one MFMA because
@@ -32,13 +32,37 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kBlock = 256;
 
 // ---- (A) production form ------------------------------------------------------------------------------------------
+// The VALU form this experiment was measured against (round 2, before the permutation moved to signed representatives and
+// shared M4 partial sums — powdr_amd/csrc/poseidon2.hpp has the current one): four multiply-add chains per block in unsigned
+// 64-bit accumulators, the column sums, one reduce_wide per output. 140 instructions.
+__device__ __forceinline__ void external_layer_valu(uint32_t* s) {
+    uint64_t y[16];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t x0 = s[4 * b + i], x1 = s[4 * b + ((i + 1) & 3)], x2 = s[4 * b + ((i + 2) & 3)], x3 = s[4 * b + ((i + 3) & 3)];
+            uint64_t a = bb::wide_mul(x0, 2);
+            a = bb::wide_fma(a, x1, 3);
+            a = bb::wide_add(a, x2);
+            y[4 * b + i] = bb::wide_add(a, x3);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t col = (y[i] + y[4 + i]) + (y[8 + i] + y[12 + i]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s[4 * b + i] = bb::reduce_wide(y[4 * b + i] + col);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void mds_valu_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, int layers) {
     const size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
     uint32_t s[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = in[row * 16 + i];
 #pragma unroll 1
-    for (int l = 0; l < layers; ++l) p2::external_layer_fold<false, false>(s, nullptr);
+    for (int l = 0; l < layers; ++l) external_layer_valu(s);
 #pragma unroll
     for (int i = 0; i < 16; ++i) out[row * 16 + i] = s[i];
 }
