@@ -24,7 +24,7 @@ constexpr uint32_t P = 0x78000001u;
 enum Op {
     OP_ADD_U32, OP_SUB_U32, OP_ADD3_U32, OP_LSHL_ADD_U32, OP_XOR, OP_AND_OR, OP_LSHRREV, OP_MIN_U32, OP_CNDMASK, OP_MOV,
     OP_ADD_CO, OP_ADDC_CO, OP_BFE, OP_ALIGNBIT, OP_PERM, OP_MUL_LO, OP_MUL_HI, OP_MUL_U24, OP_MAD_U24, OP_MAD_U64_U32,
-    OP_LSHL_ADD_U64, OP_FMA_F32, OP_PK_FMA_F32, OP_FMA_F64, OP_DOT4_I32_I8, OP_CNDMASK_SGPR, OP_CMP_CNDMASK, OP_MAX_U32, OP_MONTY5, OP_MODADD3, OP_COUNT
+    OP_LSHL_ADD_U64, OP_FMA_F32, OP_PK_FMA_F32, OP_FMA_F64, OP_DOT4_I32_I8, OP_CNDMASK_SGPR, OP_CMP_CNDMASK, OP_MAX_U32, OP_MONTY5, OP_MODADD3, OP_MAD_I64_I32, OP_MUL_HI_I32, OP_SMONTY3, OP_COUNT
 };
 
 struct OpInfo { const char* name; int instrs; };
@@ -35,6 +35,7 @@ static const OpInfo kOps[OP_COUNT] = {
     {"v_mad_u32_u24", 1}, {"v_mad_u64_u32", 1}, {"v_lshl_add_u64", 1}, {"v_fma_f32", 1}, {"v_pk_fma_f32", 1}, {"v_fma_f64", 1},
     {"v_dot4_i32_i8", 1}, {"v_cndmask_b32_e64 (SGPR-pair mask)", 1}, {"v_cmp_lt_u32+v_cndmask_b32 (pair, per instruction)", 2}, {"v_max_u32", 1},
     {"montgomery product (2 mad_u64_u32, mul_lo, sub, min)", 5}, {"modular add (add, sub, min)", 3},
+    {"v_mad_i64_i32", 1}, {"v_mul_hi_i32", 1}, {"signed_montgomery product (2 mad_i64_i32, mul_lo)", 3},
 };
 
 // One loop iteration = ONE asm block of REPS x CHAINS instructions (operand %c = chain c, %8 = y, %9 = z), so that the
@@ -68,6 +69,8 @@ static const OpInfo kOps[OP_COUNT] = {
 #define T_MAX(c) "v_max_u32 %" #c ", %" #c ", %8\n"
 #define T_DOT4(c) "v_dot4_i32_i8 %" #c ", %8, %9, %" #c "\n"
 #define T_MAD64(c) "v_mad_u64_u32 %" #c ", vcc, %8, %9, %" #c "\n"
+#define T_MADI64(c) "v_mad_i64_i32 %" #c ", vcc, %8, %9, %" #c "\n"
+#define T_MULHII(c) "v_mul_hi_i32 %" #c ", %" #c ", %8\n"
 #define T_LSHLADD64(c) "v_lshl_add_u64 %" #c ", %" #c ", 1, %10\n"
 #define T_PKFMA(c) "v_pk_fma_f32 %" #c ", %" #c ", %10, %10\n"
 #define T_FMA64(c) "v_fma_f64 %" #c ", %" #c ", %10, %10\n"
@@ -78,6 +81,12 @@ __device__ __forceinline__ uint32_t monty_mul(uint32_t a, uint32_t b) {  // as b
     const uint64_t u = t + (uint64_t)m * P;
     const uint32_t r = (uint32_t)(u >> 32);
     return min(r, r - P);
+}
+
+__device__ __forceinline__ int32_t smonty_mul(int32_t a, int32_t b) {  // as bb::smont(bb::smul(a, b)): no conditional subtraction
+    const int64_t t = (int64_t)a * b;
+    const int32_t m = (int32_t)((uint32_t)t * 0x77ffffffu);
+    return (int32_t)((t + (int64_t)m * (int64_t)P) >> 32);
 }
 
 template <int OP>
@@ -119,7 +128,14 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, unsigned long long* cycl
         else if (OP == OP_LSHL_ADD_U64) ASM64(T_LSHLADD64);
         else if (OP == OP_PK_FMA_F32) ASM64(T_PKFMA);
         else if (OP == OP_FMA_F64) ASM64(T_FMA64);
-        else if (OP == OP_MONTY5) {
+        else if (OP == OP_MAD_I64_I32) ASM64(T_MADI64);
+        else if (OP == OP_MUL_HI_I32) ASM32(T_MULHII);
+        else if (OP == OP_SMONTY3) {
+#pragma unroll
+            for (int r = 0; r < REPS; ++r)
+#pragma unroll
+                for (int c = 0; c < CHAINS; ++c) x[c] = (uint32_t)smonty_mul((int32_t)x[c], (int32_t)(y >> 1));
+        } else if (OP == OP_MONTY5) {
 #pragma unroll
             for (int r = 0; r < REPS; ++r)
 #pragma unroll
@@ -185,7 +201,7 @@ int main(int argc, char** argv) {
         RUN(OP_FMA_F32) RUN(OP_PK_FMA_F32) RUN(OP_FMA_F64) RUN(OP_MOV) RUN(OP_ADD_U32) RUN(OP_SUB_U32) RUN(OP_ADD3_U32) RUN(OP_LSHL_ADD_U32)
         RUN(OP_XOR) RUN(OP_AND_OR) RUN(OP_LSHRREV) RUN(OP_BFE) RUN(OP_ALIGNBIT) RUN(OP_PERM) RUN(OP_MIN_U32) RUN(OP_CNDMASK)
         RUN(OP_ADD_CO) RUN(OP_ADDC_CO) RUN(OP_LSHL_ADD_U64) RUN(OP_MUL_U24) RUN(OP_MAD_U24) RUN(OP_MUL_LO) RUN(OP_MUL_HI) RUN(OP_MAD_U64_U32)
-        RUN(OP_DOT4_I32_I8) RUN(OP_CNDMASK_SGPR) RUN(OP_CMP_CNDMASK) RUN(OP_MAX_U32) RUN(OP_MODADD3) RUN(OP_MONTY5)
+        RUN(OP_DOT4_I32_I8) RUN(OP_CNDMASK_SGPR) RUN(OP_CMP_CNDMASK) RUN(OP_MAX_U32) RUN(OP_MAD_I64_I32) RUN(OP_MUL_HI_I32) RUN(OP_MODADD3) RUN(OP_MONTY5) RUN(OP_SMONTY3)
 #undef RUN
         if (waves_per_simd == 8) {
             printf("JSON {\"waves_per_simd\": 8");

@@ -19,6 +19,7 @@ def sums(d, counter):
             k = k.replace("pw::(anonymous namespace)::", "").replace("(anonymous namespace)::", "")
             k = re.sub(r"^void ", "", k)
             k = re.sub(r"\(.*$", "", k)
+            k = re.sub(r"<\d+>$", "", k)
             agg[k] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
     return agg, disp

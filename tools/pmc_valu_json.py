@@ -14,6 +14,7 @@ agg, disp = defaultdict(lambda: defaultdict(float)), defaultdict(set)
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = re.sub(r"\(.*$", "", re.sub(r"^void ", "", r["Kernel_Name"].replace("pw::(anonymous namespace)::", "")))
+        k = re.sub(r"<\d+>$", "", k)  # leaf_hash_kernel<6> (the VGPR-cap variants) -> leaf_hash_kernel
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
 lh = agg.get("leaf_hash_kernel") or agg.get("leaf_hash_cols_kernel")
@@ -22,9 +23,9 @@ perms = n_proofs * (2 * H * ((width + 7) // 8) + 2 * H)  # trace LDE rows x ceil
 instr = lh["SQ_INSTS_VALU"]  # wave instructions summed over waves; x 64 lanes / 64 lanes per wave-permutation
 per_perm = instr / (perms / 64)
 mix = json.loads([l for l in open(opc) if l.startswith("JSON ")][0][5:])
-out = dict(valu_instr_per_perm=per_perm, cycles_per_wave_instr=mix["montgomery"],
+out = dict(valu_instr_per_perm=per_perm, cycles_per_wave_instr=mix["signed_montgomery"],
            source=f"SQ_INSTS_VALU {instr:.4g} over {len(disp['leaf_hash_kernel'])} leaf-hash dispatches = {perms} permutations "
-                  f"(C2 AIR at 2^{log_h} rows, {n_proofs} proofs); issue cost = measured cycles per wave instruction of the Montgomery-product "
-                  f"mix at 8 waves/SIMD, nominal 2.4 GHz (profiles/r02_microbench_opcodes.txt)",
+                  f"(C2 AIR at 2^{log_h} rows, {n_proofs} proofs); issue cost = measured cycles per wave instruction of the signed Montgomery product "
+                  f"(2 v_mad_i64_i32 + v_mul_lo_u32, what 97 % of the kernel's instruction stream looks like) at 8 waves/SIMD, nominal 2.4 GHz (profiles/r02_microbench_opcodes.txt)",
            counters={k: v for k, v in lh.items()}, opcode_cycles=mix)
 print(json.dumps(out, indent=1))
