@@ -36,13 +36,18 @@ struct Challenger {
 struct DeviceBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    int device = -1;  // the device the buffer lives on: a host thread (thread_local contexts) may have moved to another GPU
     int ensure(size_t need) {
-        if (need <= bytes) return 0;
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        if (p && dev == device && need <= bytes) return 0;
         if (p) (void)hipFree(p);
         p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, need);
+        e = hipMalloc(&p, need);
         if (e != hipSuccess) return (int)e;
         bytes = need;
+        device = dev;
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }

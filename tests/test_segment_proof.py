@@ -4,6 +4,7 @@ The reference makes one engine call per segment with all chips' traces (/root/re
 136-139, openvm-riscv/src/lib.rs:327-341). CPU tests: the oracle prover against the oracle verifier and the product's
 host verifier (independent arithmetic), failure codes, bus balance, a committed golden digest. GPU tests: the HIP segment
 prover's words equal the oracle's for mixed heights, with and without LogUp."""
+import ctypes
 import hashlib
 import json
 from pathlib import Path
@@ -222,3 +223,51 @@ def test_hip_segment_balances_apc_against_periphery(gpu):
     bin_ = int(np.argmax(hist["var"] != 0))
     per.var_hist[bin_] -= 1
     assert run(per.var_hist) == 14
+
+
+@pytest.mark.gpu
+def test_two_host_threads_prove_different_segments_concurrently(gpu):
+    """One process, two host threads, each with its own launch stream (powdr_gpu_set_stream is per thread) and its own prover
+    objects: the segment provers share no mutable state (per-thread contexts, per-device tables behind mutexes), so the
+    proofs equal the ones made one after the other — what a thread-per-GPU host relies on (robustness)."""
+    import threading
+
+    torch, abi, prover = gpu
+    specs = [[("T0", 30), ("T1", 200), ("T0", 5)], [("T1", 700), ("T0", 9), ("T1", 64), ("T0", 33)]]
+    jobs = []
+    for k, spec in enumerate(specs):
+        airs = synthetic_airs(spec, seed0=40 + 10 * k)
+        jobs.append((airs, hip_segment(gpu, airs, 5, 2, True)))  # sequential reference (checked against the oracle elsewhere)
+    results = [None, None]
+    errors = []
+
+    def work(k):
+        try:
+            airs = jobs[k][0]
+            st = torch.cuda.Stream()
+            abi.lib.powdr_gpu_set_stream(ctypes.c_void_p(st.cuda_stream))
+            with torch.cuda.stream(st):
+                provers = [prover.Prover(a[1], a[3], a[4], num_queries=5, pow_bits=2, interactions=a[5]) for a in airs]
+                traces = [to_dev(torch, a[0]) for a in airs]
+                st.synchronize()
+                out = None
+                for _ in range(6):  # several rounds so the two threads really overlap
+                    pf = prover.prove_segment([(pr, t.data_ptr(), a[2]) for pr, t, a in zip(provers, traces, airs)], logup=True)
+                    assert out is None or (pf == out).all()
+                    out = pf
+                for pr in provers:
+                    pr.close()
+            results[k] = out
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(e)))
+        finally:
+            abi.lib.powdr_gpu_set_stream(None)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        assert (results[k] == jobs[k][1]).all()
