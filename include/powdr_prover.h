@@ -59,6 +59,11 @@ PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t width, const
  * default) an AIR uses its own trace root. Canonical words. */
 int pw_prover_trace_root(PwProver* p, const uint32_t* d_trace, uint32_t log_height, uint32_t* root8);
 int pw_prover_set_bus_seed(PwProver* p, const uint32_t* seed8);
+/* How the LogUp kernels evaluate this AIR's multiplicities and arguments: 0 = no LogUp extension, 1 = the bytecode
+ * interpreter, 2 = "small forms" (k0 + k1 A + k2 B + k3 A B over at most two columns — fixed code; what the interactions of
+ * optimised APCs look like; the few wider expressions of such an AIR still go through the interpreter). Chosen when at least
+ * half of the expressions are small forms; POWDR_LOGUP_INTERPRET=1 at creation forces 1 (tests). */
+int pw_prover_logup_path(const PwProver* p);
 void pw_prover_destroy(PwProver* p);
 
 /* Prove one trace (column-major, width x 2^log_height, Montgomery words, device).

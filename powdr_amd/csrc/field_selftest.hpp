@@ -111,6 +111,19 @@ PW_HD int field_selftest_checks(uint64_t seed, uint32_t iterations) {
             want = ext_add(want, ext_scale(e, v));
         }
         if (!ext_eq(acc.result(), want)) return 23;
+        ExtProductAcc pacc;
+        Ext pwant = ext_zero();
+        for (int k = 0; k < 29; ++k) {
+            const bool edge = k < 2;  // all coordinates p - 1: the largest raw sums
+            const Ext e{{edge ? P - 1 : rp(), edge ? P - 1 : rp(), edge ? P - 1 : rp(), edge ? P - 1 : rp()}};
+            const Ext f{{edge ? P - 1 : rp(), edge ? P - 1 : rp(), edge ? P - 1 : rp(), edge ? P - 1 : rp()}};
+            pacc.fma(e, f);
+            pwant = ext_add(pwant, ext_mul(e, f));
+            const uint32_t v = k == 2 ? P - 1 : rp();
+            pacc.fma_base(f, v);
+            pwant = ext_add(pwant, ext_scale(f, v));
+        }
+        if (!ext_eq(pacc.result(), pwant)) return 24;
     }
     return 0;
 }

@@ -12,34 +12,80 @@ namespace {
 constexpr int kBlock = 256;
 using bb::Ext;
 
-// d_i = al + bus_i + sum_j bl^(j+1) a_ij on row r of matrix `m` (column stride `stride`)
-__device__ __forceinline__ Ext interaction_denominator(const LogupInteraction& it, const uint32_t* __restrict__ xspans,
-                                                       const uint32_t* __restrict__ code, const uint32_t* __restrict__ m,
-                                                       size_t stride, size_t r, uint32_t* stk, const Ext& al,
+// d_i = al + bus_i + sum_j bl^(j+1) a_ij on row r of matrix `m` (column stride `stride`).
+// Every coordinate is a sum of products accumulated RAW in a signed 64-bit register (one v_mad_i64_i32 per term) and reduced
+// by signed Montgomery reductions (bb::smont, no conditional subtraction): the challenge powers are wave-uniform, so their
+// centred representatives (|b| <= p/2) come from the scalar unit for free, an argument a is a canonical word, a product is
+// below p^2 / 2 and two of them fit the reduction's domain (1.209 p^2) on top of what is already there (<= 0.134 p^2);
+// after two products the accumulator is reduced and re-enters as r * (R mod p). Per coordinate and argument ~3.5
+// instructions where a Montgomery product and a modular addition took 8.
+// One multiplicity / argument on row r. FAST: the span's small form (k0 + k1 A + k2 B + k3 A B, fixed code, both loads issued at
+// once, ~10 scalar instructions); else the xbc interpreter (a scalar decode of ~15 instructions per xbc instruction on the
+// CU's one scalar unit, which is what bounds these kernels when it runs: PMC profiles/r02_pmc_logup_kernels.txt).
+template <bool FAST>
+__device__ __forceinline__ uint32_t eval_span(const LogupProgram& lp, uint32_t span, const uint32_t* __restrict__ m, size_t stride,
+                                              size_t r, uint32_t* stk) {
+    if (FAST && !(lp.d_forms[span].flags & SmallForm::NOT_SMALL)) {
+        const SmallForm f = lp.d_forms[span];
+        const uint32_t ta = (f.flags & SmallForm::USES_A) ? m[(size_t)f.a * stride + r] : 0u;
+        const uint32_t tb = (f.flags & SmallForm::USES_B) ? m[(size_t)f.b * stride + r] : 0u;
+        return f.eval(ta, tb);
+    }
+    const uint32_t off = lp.d_xspans[2 * span], len = lp.d_xspans[2 * span + 1];
+    return xbc::eval<kBlock, true>(lp.d_code + 2 * (size_t)off, len, m, r, stk, stride);
+}
+
+struct DenominatorSeeds {
+    int64_t s[4];   // centred(al_k) * (R mod p): the value al_k in the accumulators' domain (k = 0: without the bus)
+    uint32_t al0;
+};
+__device__ __forceinline__ DenominatorSeeds denominator_seeds(const Ext& al) {
+    DenominatorSeeds sd;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sd.s[k] = (int64_t)bb::centred(al.c[k]) * (int64_t)bb::R_MOD_P;
+    sd.al0 = al.c[0];
+    return sd;
+}
+template <bool FAST>
+__device__ __forceinline__ Ext interaction_denominator(const LogupInteraction& it, const LogupProgram& lp, const uint32_t* __restrict__ m,
+                                                       size_t stride, size_t r, uint32_t* stk, const DenominatorSeeds& sd,
                                                        const Ext* __restrict__ blpow) {
-    Ext d = al;
-    d.c[0] = bb::add(d.c[0], it.bus_monty);
+    int64_t T[4] = {(int64_t)bb::centred(bb::add(sd.al0, it.bus_monty)) * (int64_t)bb::R_MOD_P, sd.s[1], sd.s[2], sd.s[3]};
+    uint32_t pending = 0;
     for (uint32_t j = 0; j < it.n_args; ++j) {
-        const uint32_t off = xspans[2 * (it.first_span + 1 + j)], len = xspans[2 * (it.first_span + 1 + j) + 1];
-        const uint32_t a = xbc::eval<kBlock, true>(code + 2 * (size_t)off, len, m, r, stk, stride);
+        const int32_t a = (int32_t)eval_span<FAST>(lp, it.first_span + 1 + j, m, stride, r, stk);
+        if (pending == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) T[k] = bb::smul_uniform(bb::smont(T[k]), (int32_t)bb::R_MOD_P);
+            pending = 0;
+        }
         const Ext b = blpow[j + 1];
-        d.c[0] = bb::add(d.c[0], bb::mul(b.c[0], a));
-        d.c[1] = bb::add(d.c[1], bb::mul(b.c[1], a));
-        d.c[2] = bb::add(d.c[2], bb::mul(b.c[2], a));
-        d.c[3] = bb::add(d.c[3], bb::mul(b.c[3], a));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) T[k] = bb::swide_mad_uniform(T[k], a, bb::centred(b.c[k]));
+        ++pending;
+    }
+    if (pending == 2) {  // keep the last reduction's result inside (-p, p)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) T[k] = bb::smul_uniform(bb::smont(T[k]), (int32_t)bb::R_MOD_P);
+    }
+    Ext d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t x = (uint32_t)bb::smont(T[k]);  // in (-0.8 p, 0.8 p)
+        d.c[k] = bb::umin(x, x + bb::P);
     }
     return d;
 }
-__device__ __forceinline__ uint32_t interaction_mult(const LogupInteraction& it, const uint32_t* __restrict__ xspans,
-                                                     const uint32_t* __restrict__ code, const uint32_t* __restrict__ m,
+template <bool FAST>
+__device__ __forceinline__ uint32_t interaction_mult(const LogupInteraction& it, const LogupProgram& lp, const uint32_t* __restrict__ m,
                                                      size_t stride, size_t r, uint32_t* stk) {
-    const uint32_t off = xspans[2 * it.first_span], len = xspans[2 * it.first_span + 1];
-    return xbc::eval<kBlock, true>(code + 2 * (size_t)off, len, m, r, stk, stride);
+    return eval_span<FAST>(lp, it.first_span, m, stride, r, stk);
 }
 
 // perm[(4g+k)*H + r] = coordinate k of q_g(r) = sum_{i in g} m_i(r) / d_i(r);  rowsum[r] = sum_g q_g(r).
 // Only interactions with a non-zero multiplicity on the row contribute (padding rows cost no inversion at all); the
 // active ones of a group share one inversion: q = num / den, (num, den) <- (num d_i + m_i den, den d_i).
+template <bool FAST>
 __global__ __launch_bounds__(kBlock) void logup_perm_kernel(const uint32_t* __restrict__ trace, size_t H, LogupProgram lp, Ext al,
                                                              const Ext* __restrict__ blpow, uint32_t* __restrict__ perm,
                                                              Ext* __restrict__ rowsum) {
@@ -47,15 +93,16 @@ __global__ __launch_bounds__(kBlock) void logup_perm_kernel(const uint32_t* __re
     uint32_t* stk = stack_lds + threadIdx.x;
     const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= H) return;
+    const DenominatorSeeds sd = denominator_seeds(al);
     Ext acc = bb::ext_zero();
     for (uint32_t g = 0; g < lp.n_groups; ++g) {
         Ext num = bb::ext_zero(), den = bb::ext_one();
         bool any = false;
         for (uint32_t i = lp.d_gstarts[g]; i < lp.d_gstarts[g + 1]; ++i) {
             const LogupInteraction it = lp.d_inter[i];
-            const uint32_t m = interaction_mult(it, lp.d_xspans, lp.d_code, trace, H, r, stk);
+            const uint32_t m = interaction_mult<FAST>(it, lp, trace, H, r, stk);
             if (m == 0u) continue;
-            const Ext d = interaction_denominator(it, lp.d_xspans, lp.d_code, trace, H, r, stk, al, blpow);
+            const Ext d = interaction_denominator<FAST>(it, lp, trace, H, r, stk, sd, blpow);
             if (any) {
                 num = bb::ext_add(bb::ext_mul(num, d), bb::ext_scale(den, m));
                 den = bb::ext_mul(den, d);
@@ -133,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void scan_write_kernel(const Ext* __restric
 // acc = sum_k apow[k] C_k + sum_g apow[nc+g] (q_g den_g - num_g) + apow[nc+G] is_first (phi - sum q)
 //       + apow[nc+G+1] is_trans (phi' - phi - sum q') + apow[nc+G+2] is_last (phi - S);  q = acc / Z_H
 // with den_g = prod_{i in g} d_i, num_g = sum_{i in g} m_i prod_{j != i} d_j, G = number of groups
-template <bool XBC>
+template <bool XBC, bool FAST>
 __global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* __restrict__ lde, const uint32_t* __restrict__ plde,
                                                                  size_t N, const uint32_t* __restrict__ bytecode,
                                                                  const uint32_t* __restrict__ spans, uint32_t nc, LogupProgram lp,
@@ -145,12 +192,14 @@ __global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* 
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= N) return;
     const size_t jn = (j + 2) & (N - 1);
-    Ext acc = bb::ext_zero();
+    const DenominatorSeeds sd = denominator_seeds(al);
+    // sum_k apow[k] * (constraint or group value): raw products in 96-bit accumulators, reduced once per row
+    bb::ExtProductAcc wide;
     for (uint32_t c = 0; c < nc; ++c) {
         const uint32_t off = spans[2 * c], len = spans[2 * c + 1];
         const uint32_t v = XBC ? xbc::eval<kBlock, true>(bytecode + 2 * (size_t)off, len, lde, j, stk, N)
                                : eval_expr<kBlock, true>(bytecode + off, len, lde, j, stk, N);
-        acc = bb::ext_add(acc, bb::ext_scale(apow[c], v));
+        wide.fma_base(apow[c], v);
     }
     Ext sumq = bb::ext_zero(), sumq_next = bb::ext_zero();
     for (uint32_t g = 0; g < lp.n_groups; ++g) {
@@ -163,8 +212,8 @@ __global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* 
         Ext num, den;
         for (uint32_t i = i0; i < i1; ++i) {
             const LogupInteraction it = lp.d_inter[i];
-            const Ext d = interaction_denominator(it, lp.d_xspans, lp.d_code, lde, N, j, stk, al, blpow);
-            const uint32_t m = interaction_mult(it, lp.d_xspans, lp.d_code, lde, N, j, stk);
+            const Ext d = interaction_denominator<FAST>(it, lp, lde, N, j, stk, sd, blpow);
+            const uint32_t m = interaction_mult<FAST>(it, lp, lde, N, j, stk);
             if (i == i0) {
                 num = bb::ext_from_base(m);
                 den = d;
@@ -173,9 +222,9 @@ __global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* 
                 den = bb::ext_mul(den, d);
             }
         }
-        const Ext c = bb::ext_sub(bb::ext_mul(qi, den), num);
-        acc = bb::ext_add(acc, bb::ext_mul(apow[nc + g], c));
+        wide.fma(apow[nc + g], bb::ext_sub(bb::ext_mul(qi, den), num));
     }
+    Ext acc = wide.result();
     const uint32_t* pp = plde + (size_t)(4 * lp.n_groups) * N;
     const Ext phi = {{pp[j], pp[N + j], pp[2 * N + j], pp[3 * N + j]}};
     const Ext phin = {{pp[jn], pp[N + jn], pp[2 * N + jn], pp[3 * N + jn]}};
@@ -224,7 +273,8 @@ int logup_perm_trace(const uint32_t* trace, size_t H, const LogupProgram& lp, bb
                      bb::Ext* d_rowsum, bb::Ext* d_block_totals) {
     {
         ScopedKernelTimer t("logup_perm_kernel");
-        hipLaunchKernelGGL(logup_perm_kernel, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), trace, H, lp, al, d_blpow, perm, d_rowsum);
+        if (lp.d_forms) hipLaunchKernelGGL(logup_perm_kernel<true>, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), trace, H, lp, al, d_blpow, perm, d_rowsum);
+        else hipLaunchKernelGGL(logup_perm_kernel<false>, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), trace, H, lp, al, d_blpow, perm, d_rowsum);
     }
     const uint32_t blocks = div_up(H, kScanChunk);
     ScopedKernelTimer t("logup_scan_kernels");
@@ -241,12 +291,11 @@ int quotient_eval_logup(const uint32_t* lde, const uint32_t* plde, size_t N, int
     const uint32_t shift = bb::to_monty(field::kCosetShift), wN = field::root_of_unity(logN);
     const uint32_t ginv = bb::inv(field::root_of_unity(logN - 1));
     ScopedKernelTimer t("quotient_logup_kernel");
-    if (prog.is_xbc)
-        hipLaunchKernelGGL(quotient_logup_kernel<true>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, plde, N, prog.d_bytecode,
-                           prog.d_spans, prog.n_constraints, lp, d_apow, al, d_blpow, S, zval_even, zval_odd, shift, wN, ginv, q);
-    else
-        hipLaunchKernelGGL(quotient_logup_kernel<false>, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, plde, N, prog.d_bytecode,
-                           prog.d_spans, prog.n_constraints, lp, d_apow, al, d_blpow, S, zval_even, zval_odd, shift, wN, ginv, q);
+#define PW_LAUNCH_QL(X, F) hipLaunchKernelGGL((quotient_logup_kernel<X, F>), dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, plde, N, \
+                                            prog.d_bytecode, prog.d_spans, prog.n_constraints, lp, d_apow, al, d_blpow, S, zval_even, zval_odd, shift, wN, ginv, q)
+    if (prog.is_xbc) { if (lp.d_forms) PW_LAUNCH_QL(true, true); else PW_LAUNCH_QL(true, false); }
+    else { if (lp.d_forms) PW_LAUNCH_QL(false, true); else PW_LAUNCH_QL(false, false); }
+#undef PW_LAUNCH_QL
     return (int)hipGetLastError();
 }
 

@@ -91,6 +91,8 @@ extern "C" PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t w
     // interactions: {bus, n_args, first span}; spans [mult, arg0, ...] into ibc (post-fix, column operands)
     std::vector<pw::LogupInteraction> li(n_inter);
     std::vector<uint32_t> xspans, code;
+    std::vector<pw::SmallForm> forms;  // one per span; the few that are no small forms (sums of many flags, ...) stay with the interpreter
+    size_t not_small = 0;
     xbc::Compiler cc;
     bool ok = true;
     for (size_t i = 0; i < n_inter && ok; ++i) {
@@ -103,6 +105,9 @@ extern "C" PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t w
             if ((size_t)off + len > ibc_len) { ok = false; break; }
             const uint32_t o = (uint32_t)(code.size() / 2);
             if (!cc.compile(ibc + off, len, code)) { ok = false; break; }
+            pw::SmallForm f{};
+            if (!pw::analyze_small_form(ibc + off, len, f)) { f = pw::SmallForm{}; f.flags = pw::SmallForm::NOT_SMALL; ++not_small; }
+            forms.push_back(f);
             xspans.push_back(o);
             xspans.push_back((uint32_t)(code.size() / 2) - o);
         }
@@ -115,7 +120,9 @@ extern "C" PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t w
     if (ok) gstarts = pw::logup_group_starts(inter, n_inter, ispans, ibc);
     if (!ok || !up((void**)&p->d_gstarts, gstarts.data(), gstarts.size() * 4) ||
         !up((void**)&p->d_inter, li.data(), li.size() * sizeof(pw::LogupInteraction)) ||
-        !up((void**)&p->d_ixspans, xspans.data(), xspans.size() * 4) || !up((void**)&p->d_icode, code.data(), code.size() * 4)) {
+        !up((void**)&p->d_ixspans, xspans.data(), xspans.size() * 4) || !up((void**)&p->d_icode, code.data(), code.size() * 4) ||
+        (2 * not_small <= forms.size() && !getenv("POWDR_LOGUP_INTERPRET") &&
+         !up((void**)&p->d_iforms, forms.data(), forms.size() * sizeof(pw::SmallForm)))) {
         pw_prover_destroy(p);
         return nullptr;
     }
@@ -126,6 +133,8 @@ extern "C" PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t w
 }
 
 #define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+extern "C" int pw_prover_logup_path(const PwProver* p) { return !p || !p->logup ? 0 : p->d_iforms ? 2 : 1; }
 
 extern "C" int pw_prover_set_bus_seed(PwProver* p, const uint32_t* seed8) {
     if (!p || !p->logup) return (int)hipErrorInvalidValue;
@@ -252,7 +261,7 @@ extern "C" int pw_prover_trace_root(PwProver* p, const uint32_t* d_trace, uint32
 extern "C" void pw_prover_destroy(PwProver* p) {
     if (!p) return;
     for (DeviceBuf* b : {&p->coef, &p->lde, &p->digests, &p->q, &p->qcoef, &p->qlde, &p->ext_arena, &p->misc, &p->perm, &p->plde, &p->qpart}) b->release();
-    for (void* q : {(void*)p->d_inter, (void*)p->d_ixspans, (void*)p->d_icode, (void*)p->d_gstarts}) if (q) (void)hipFree(q);
+    for (void* q : {(void*)p->d_inter, (void*)p->d_ixspans, (void*)p->d_icode, (void*)p->d_gstarts, (void*)p->d_iforms}) if (q) (void)hipFree(q);
     if (p->d_bytecode) (void)hipFree(p->d_bytecode);
     if (p->d_spans) (void)hipFree(p->d_spans);
     delete p;
@@ -346,7 +355,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
 
     // ---- 1b. LogUp: permutation trace, its LDE and commitment ---------------------------------------
     bb::Ext al = bb::ext_zero(), S = bb::ext_zero();
-    LogupProgram lp{p->d_inter, n_int, p->d_ixspans, p->d_icode, p->d_gstarts, n_g};
+    LogupProgram lp{p->d_inter, n_int, p->d_ixspans, p->d_icode, p->d_gstarts, n_g, p->d_iforms};
     if (lg) {
         // the bus challenges come from a transcript that saw only the bus seed (shared by all AIRs of a segment;
         // a lone AIR uses its own trace root), see oracle/stark_oracle.cpp bus_challenges

@@ -2,6 +2,7 @@
 #pragma once
 #include "babybear.hpp"
 #include "ext.hpp"
+#include "small_form.hpp"
 #include "poseidon2.hpp"
 #include "common.hpp"
 
@@ -105,6 +106,7 @@ struct LogupProgram {
     const uint32_t* d_code;    // xbc code, column-index operands
     const uint32_t* d_gstarts; // n_groups + 1 interaction indices (logup_groups.hpp)
     uint32_t n_groups;
+    const SmallForm* d_forms;  // one per span, or nullptr: every multiplicity / argument as a small form (small_form.hpp)
 };
 // perm (4(n_groups+1) columns x H): q_g coordinates then phi; d_rowsum: H Ext scratch; d_block_totals: H/4096+1 Ext scratch
 int logup_perm_trace(const uint32_t* trace, size_t H, const LogupProgram& lp, bb::Ext al, const bb::Ext* d_blpow, uint32_t* perm,

@@ -75,6 +75,7 @@ struct PwProver {
     pw::LogupInteraction* d_inter = nullptr;
     uint32_t* d_ixspans = nullptr;
     uint32_t* d_icode = nullptr;
+    pw::SmallForm* d_iforms = nullptr;  // all spans as small forms, when every one of them is one (else nullptr)
     pw::DeviceBuf perm, plde;
     bool has_bus_seed = false;
     uint32_t bus_seed[8] = {0};  // Montgomery

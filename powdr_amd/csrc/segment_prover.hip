@@ -197,7 +197,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     auto blpow_of = [&](size_t a) { return apow_of(a) + sh[a].M + 4; };
     auto logup_program = [&](size_t a) {
         const PwProver* p = airs[a].prover;
-        return LogupProgram{p->d_inter, sh[a].n_int, p->d_ixspans, p->d_icode, p->d_gstarts, sh[a].n_g};
+        return LogupProgram{p->d_inter, sh[a].n_int, p->d_ixspans, p->d_icode, p->d_gstarts, sh[a].n_g, p->d_iforms};
     };
 
     // ---- 2. LogUp ---------------------------------------------------------------------------------------------

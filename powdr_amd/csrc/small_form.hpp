@@ -18,7 +18,8 @@ struct SmallForm {
     uint32_t k0, k1, k2, k3;  // Montgomery
     uint32_t flags;
     uint32_t pad;
-    enum : uint32_t { USES_A = 1, USES_B = 2, HAS_PRODUCT = 4, IS_COLUMN = 8, IS_CONST = 16 };
+    enum : uint32_t { USES_A = 1, USES_B = 2, HAS_PRODUCT = 4, IS_COLUMN = 8, IS_CONST = 16,
+                      NOT_SMALL = 32 };  // set by users that keep a table entry for every expression: evaluate it some other way
 #if defined(__HIPCC__)
     // ta / tb: the loaded cells (only read where the flags say so); flags are wave-uniform
     __device__ __forceinline__ uint32_t eval(uint32_t ta, uint32_t tb) const {

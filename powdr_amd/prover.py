@@ -14,7 +14,7 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_logup_path", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_lde_fused", "pw_merkle_commit", "pw_poseidon2_permute_host"]
 
 lib.pw_prover_create.restype = C.c_void_p
@@ -60,6 +60,8 @@ lib.pw_verify_logup.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_uint32
                                 C.c_void_p, C.c_void_p]
 lib.pw_prover_trace_root.restype = C.c_int
 lib.pw_prover_trace_root.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+lib.pw_prover_logup_path.restype = C.c_int
+lib.pw_prover_logup_path.argtypes = [C.c_void_p]
 lib.pw_prover_set_bus_seed.restype = C.c_int
 lib.pw_prover_set_bus_seed.argtypes = [C.c_void_p, C.c_void_p]
 
@@ -298,6 +300,10 @@ class Prover:
 
     def device_bytes(self) -> int:
         return int(lib.pw_prover_device_bytes(self._h))
+
+    def logup_path(self) -> int:
+        """0 = no LogUp extension, 1 = interpreter, 2 = small forms (pw_prover_logup_path)."""
+        return int(lib.pw_prover_logup_path(self._h))
 
     def close(self):
         if self._h:

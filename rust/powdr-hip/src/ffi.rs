@@ -240,6 +240,7 @@ extern "C" {
                                   inter_bytecode: *const u32, inter_bytecode_len: usize) -> *mut PwProver;
     pub fn pw_prover_trace_root(p: *mut PwProver, d_trace: *const u32, log_height: u32, root8: *mut u32) -> c_int;
     pub fn pw_prover_set_bus_seed(p: *mut PwProver, seed8: *const u32) -> c_int;
+    pub fn pw_prover_logup_path(p: *const PwProver) -> c_int;
     pub fn pw_prover_destroy(p: *mut PwProver);
     pub fn pw_prover_prove(p: *mut PwProver, d_trace: *const u32, log_height: u32, proof_words: *mut *const u32,
                            n_words: *mut usize) -> c_int;

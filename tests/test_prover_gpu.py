@@ -115,7 +115,7 @@ def test_proof_bytes_match_oracle(gpu, shape, calls, nq, pow_bits):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,calls,nq,pow_bits", [("T0", 2, 3, 0), ("T0", 7, 4, 0), ("T0", 64, 5, 5), ("T1", 100, 6, 0), ("T1", 1000, 8, 0),
                                                       ("T1", 5000, 10, 0)])
-def test_logup_proof_bytes_match_oracle(gpu, shape, calls, nq, pow_bits):
+def test_logup_proof_bytes_match_oracle(gpu, monkeypatch, shape, calls, nq, pow_bits):
     """pw-stark v0 + LogUp: the HIP proof (permutation columns, prefix scan, extended quotient, openings at
     zeta and g*zeta, third Merkle tree) equals the oracle's byte for byte, and the oracle's verifier accepts it."""
     torch, abi, prover = gpu
@@ -136,7 +136,15 @@ def test_logup_proof_bytes_match_oracle(gpu, shape, calls, nq, pow_bits):
     assert len(got) == len(want)
     assert (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
     assert (pr.prove(d_t.data_ptr(), log_h) == want).all()
+    assert pr.logup_path() == 2  # the synthetic APCs' multiplicities and arguments are small forms, like the real ones
     pr.close()
+    # the interpreter path (what an interaction with a wider expression falls back to) gives the same words
+    monkeypatch.setenv("POWDR_LOGUP_INTERPRET", "1")
+    pri = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits, interactions=(inter, ispans, ibc))
+    monkeypatch.delenv("POWDR_LOGUP_INTERPRET")
+    assert pri.logup_path() == 1
+    assert (pri.prove(d_t.data_ptr(), log_h) == want).all()
+    pri.close()
     # the constraints-only prover is unaffected
     pr0 = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits)
     assert (pr0.prove(d_t.data_ptr(), log_h) == sm.prove(flat, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits)).all()
