@@ -256,6 +256,8 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
                log_heights=f"{min(s[2] for s in shapes)}..{max(s[2] for s in shapes)}",
                constraints=sum(s[3] for s in shapes), interactions=sum(s[4] for s in shapes),
                prover_device_bytes=sum(pr.device_bytes() for pr in provers), stage_ms_rank0=stage,
+               stage_ms_note="per-kernel elapsed times; the per-AIR stages of a segment run on side streams (POWDR_SEGMENT_STREAMS, default 4) and "
+                             "overlap, so the sum exceeds the wall time of the step",
                note="one pw-stark v1 proof per segment (pw_prove_segment); proof only, traces resident; value = all segments of all ranks / "
                     "max-over-ranks time; the 19 system AIRs have the reference's pinned totals (819 columns, 643 constraints, 253 interactions)")
     for pr in provers:

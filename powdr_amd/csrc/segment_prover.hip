@@ -26,12 +26,28 @@ using namespace pw;
 
 namespace {
 
+constexpr int kMaxSide = 8;
 struct SegCtx {
     DeviceBuf dig;     // three mixed trees | FRI trees
     DeviceBuf inject;  // row digests of the smaller heights (one level at a time)
     DeviceBuf ext;     // FRI layers (2 N) | reduced openings of the smaller heights (N) | scratch vector (N)
     DeviceBuf misc;    // column-pointer tables, opened values, gamma powers, query indices / answers
     std::vector<uint32_t> proof;
+    // side streams for the per-AIR stages of a segment with many AIRs (fork from / join into the caller's stream by events)
+    hipStream_t side[kMaxSide] = {};
+    hipEvent_t fork_ev = nullptr, done_ev[kMaxSide] = {};
+    int n_side = 0, side_device = -1;
+    int ensure_side(int want) {
+        int dev = 0;
+        PW_HIP_TRY(hipGetDevice(&dev));
+        if (dev != side_device) { n_side = 0; fork_ev = nullptr; side_device = dev; }  // handles of another device are simply dropped
+        if (!fork_ev) PW_HIP_TRY(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        for (; n_side < want; ++n_side) {
+            PW_HIP_TRY(hipStreamCreateWithFlags(&side[n_side], hipStreamNonBlocking));
+            PW_HIP_TRY(hipEventCreateWithFlags(&done_ev[n_side], hipEventDisableTiming));
+        }
+        return 0;
+    }
 };
 thread_local SegCtx g_ctx;  // one per host thread (= per launch stream)
 
@@ -79,6 +95,33 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     hipStream_t st = stream();
     TRY(poseidon2_upload_params());
     SegCtx& cx = g_ctx;
+    // The per-AIR stages (LDE, permutation trace, quotient, openings, query rows) of different AIRs are independent chains of
+    // small launches; on one stream a segment of 60 AIRs pays ~10 us of dispatch latency between 1 400 dependent kernels
+    // (profiles/r02_segment_gaps.txt: 15 of 176 ms). With K side streams the chains of different AIRs overlap:
+    // fork = the side streams wait for what the caller's stream has done, AIR a runs on side[a % K], join = the caller's stream
+    // waits for all of them. POWDR_SEGMENT_STREAMS=0 keeps everything on the caller's stream.
+    int K = 4;
+    if (const char* e = getenv("POWDR_SEGMENT_STREAMS")) K = atoi(e);
+    if (K > kMaxSide) K = kMaxSide;
+    if (K < 2 || A < 4) K = 0;
+    if (K) TRY(cx.ensure_side(K));
+    struct StreamRestore { hipStream_t s; ~StreamRestore() { set_stream(s); } } restore{st};
+    auto fork = [&]() -> int {
+        if (!K) return 0;
+        PW_HIP_TRY(hipEventRecord(cx.fork_ev, st));
+        for (int k = 0; k < K; ++k) PW_HIP_TRY(hipStreamWaitEvent(cx.side[k], cx.fork_ev, 0));
+        return 0;
+    };
+    auto on_air = [&](size_t a) { if (K) set_stream(cx.side[a % (size_t)K]); };
+    auto join = [&]() -> int {
+        if (!K) return 0;
+        set_stream(st);
+        for (int k = 0; k < K; ++k) {
+            PW_HIP_TRY(hipEventRecord(cx.done_ev[k], cx.side[k]));
+            PW_HIP_TRY(hipStreamWaitEvent(st, cx.done_ev[k], 0));
+        }
+        return 0;
+    };
     const PwStarkConfig cfg = airs[0].prover->cfg;
     const uint32_t nq = cfg.num_queries;
 
@@ -180,11 +223,14 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
 
     // ---- 1. main traces ---------------------------------------------------------------------------------------
     uint32_t root[8];
+    TRY(fork());
     for (size_t a = 0; a < A; ++a) {
         PwProver* p = airs[a].prover;
         p->committed_trace = nullptr;
+        on_air(a);
         TRY(lde_matrix(p, Lc[a], sh[a].log_h, airs[a].d_trace, sh[a].W, p->lde.as<uint32_t>()));
     }
+    TRY(join());
     TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) { m = airs[a].prover->lde.as<uint32_t>(); w = sh[a].W; }, 0, root));
     PW_HIP_TRY(hipStreamSynchronize(st));
     put_monty(root, 8);
@@ -208,16 +254,19 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         al = ch.sample_ext();
         bl = ch.sample_ext();
         std::vector<const uint32_t*> sp;
+        TRY(fork());
         for (size_t a = 0; a < A; ++a) {
             PwProver* p = airs[a].prover;
             keep.emplace_back(p->max_args + 2);
             { bb::Ext b = bb::ext_one(); for (auto& x : keep.back()) { x = b; b = bb::ext_mul(b, bl); } }
-            PW_HIP_TRY(hipMemcpyAsync(blpow_of(a), keep.back().data(), keep.back().size() * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
+            on_air(a);
+            PW_HIP_TRY(hipMemcpyAsync(blpow_of(a), keep.back().data(), keep.back().size() * sizeof(bb::Ext), hipMemcpyHostToDevice, stream()));
             bb::Ext* rowsum = weights_of(a) + 2 * sh[a].H;
             TRY(logup_perm_trace(airs[a].d_trace, sh[a].H, logup_program(a), al, blpow_of(a), p->perm.as<uint32_t>(), rowsum, rowsum + sh[a].H));
             TRY(lde_matrix(p, Lc[a], sh[a].log_h, p->perm.as<uint32_t>(), sh[a].Wp, p->plde.as<uint32_t>()));
             for (int k = 0; k < 4; ++k) sp.push_back(p->perm.as<uint32_t>() + ((size_t)(4 * sh[a].n_g + k) * sh[a].H + (sh[a].H - 1)));  // S = phi(last row)
         }
+        TRY(join());
         TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) { m = airs[a].prover->plde.as<uint32_t>(); w = sh[a].Wp; }, 2, root));
         PW_HIP_TRY(hipMemcpyAsync(d_sptrs, sp.data(), sp.size() * 8, hipMemcpyHostToDevice, st));
         TRY(gather_words(d_sptrs, (uint32_t)sp.size(), d_small));
@@ -240,12 +289,14 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         std::vector<bb::Ext> apow_all(M_max ? M_max : 1);  // alpha^0 .. alpha^(M_max - 1)
         { bb::Ext x = bb::ext_one(); for (auto& v : apow_all) { v = x; x = bb::ext_mul(x, alpha); } }
         const uint32_t s_m = bb::to_monty(field::kCosetShift), one = bb::R_MOD_P;
+        TRY(fork());
         for (size_t a = 0; a < A; ++a) {
             PwProver* p = airs[a].prover;
             const Shape& s = sh[a];
             keep.emplace_back(s.M ? s.M : 1);
             for (size_t j = 0; j < s.M; ++j) keep.back()[j] = apow_all[s.M - 1 - j];
-            if (s.M) PW_HIP_TRY(hipMemcpyAsync(apow_of(a), keep.back().data(), s.M * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
+            on_air(a);
+            if (s.M) PW_HIP_TRY(hipMemcpyAsync(apow_of(a), keep.back().data(), s.M * sizeof(bb::Ext), hipMemcpyHostToDevice, stream()));
             uint32_t sH = s_m;
             for (uint32_t i = 0; i < s.log_h; ++i) sH = bb::sqr(sH);
             const uint32_t zv_even = bb::sub(sH, one), zv_odd = bb::sub(bb::neg(sH), one);
@@ -261,6 +312,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             TRY(quotient_split(d_q, s.H, (int)s.log_h, p->qcoef.as<uint32_t>()));
             TRY(coset_lde_from_coeffs(p->qcoef.as<uint32_t>(), p->qlde.as<uint32_t>(), s.H, s.N, 8, (int)s.log_h));
         }
+        TRY(join());
         TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) { m = airs[a].prover->qlde.as<uint32_t>(); w = 8; }, 1, root));
         PW_HIP_TRY(hipStreamSynchronize(st));
         keep.clear();
@@ -271,9 +323,11 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     // ---- 4. openings: per AIR main | perm at zeta | quotient | perm at g zeta ----------------------------------
     const bb::Ext zeta = ch.sample_ext();
     std::vector<bb::Ext> gzeta(A);
+    TRY(fork());
     for (size_t a = 0; a < A; ++a) {
         PwProver* p = airs[a].prover;
         const Shape& s = sh[a];
+        on_air(a);
         bb::Ext* o = d_opened + s.koff;
         bb::Ext* w1 = weights_of(a);
         bb::Ext* w2 = w1 + s.H;
@@ -289,6 +343,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         TRY(zeta_weights(zeta, (int)s.log_h, w1));
         TRY(ext_dot_columns(p->qcoef.as<uint32_t>(), s.H, 8, s.H, w1, o + s.W + s.Wp, scratch_of(a)));
     }
+    TRY(join());
     std::vector<bb::Ext> opened(K_total);
     PW_HIP_TRY(hipMemcpyAsync(opened.data(), d_opened, K_total * sizeof(bb::Ext), hipMemcpyDeviceToHost, st));
     PW_HIP_TRY(hipStreamSynchronize(st));
@@ -371,6 +426,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         const int tree_of_phase[3] = {0, 2, 1};  // digest arena order: main | quotient | perm
         std::vector<size_t> row_off[3];
         size_t ro = 0;
+        TRY(fork());  // after the index upload
         for (int ph = 0; ph < 3; ++ph) {
             if (ph == 1 && !lg) continue;
             row_off[ph].resize(A);
@@ -379,10 +435,12 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
                 const uint32_t* m = ph == 0 ? p->lde.as<uint32_t>() : ph == 1 ? p->plde.as<uint32_t>() : p->qlde.as<uint32_t>();
                 const uint32_t w = ph == 0 ? sh[a].W : ph == 1 ? sh[a].Wp : 8u;
                 row_off[ph][a] = ro;
+                on_air(a);
                 TRY(gather_rows(m, sh[a].N, w, d_idx + a * nq, nq, d_rows + ro));
                 ro += (size_t)nq * w;
             }
         }
+        TRY(join());
         std::vector<uint64_t> dig_offs, ext_offs;
         for (uint32_t qi = 0; qi < nq; ++qi) {
             const size_t q = qs[qi];
