@@ -433,6 +433,53 @@ def main():
         except Exception as e:
             callmajor_leg = dict(gather_ms=None, error=f"{type(e).__name__}: {e}")
 
+    # ---- the reference-layout gather on COLUMN-STRUCTURED substitutions: same dummy traces, same _apc_tracegen, but the
+    # surviving cells are few columns of each original AIR present in most instructions — the structure of the reference's own
+    # optimised-APC snapshots (synth.column_structured_substitutions cites them) — instead of cells scattered uniformly over the
+    # block (the timed step's workload: every sector of every source column is touched). Not part of `value`.
+    colstruct_leg = None
+    if not args.no_callmajor_leg and args.pipeline == 1:
+        try:
+            from powdr_amd import synth as _synth, tracegen as tg
+
+            subs0, air_ids, rbs = wl["apc"].build_substitutions(wl["instr_air"])
+            calls = wl["calls"]
+            dims, airs_cs = [], []
+            for k in range(len(air_ids)):
+                ptr, w, h = wl["dummy"][int(air_ids[k])]
+                t = next(tt for tt, ww, hh, bb in wl["tensors"].values() if tt.data_ptr() == ptr)
+                dims.append((w, int(rbs[k])))
+                airs_cs.append((t, w, h, int(rbs[k])))
+            subs_cs = _synth.column_structured_substitutions(dims, len(subs0), seed=1)
+            out2 = tg.DeviceMatrix(torch.zeros_like(wl["out"]), wl["H"], wl["W"])
+            keep = tg.apc_tracegen(out2, airs_cs, subs_cs, calls)  # warm-up + plan
+            torch.cuda.synchronize()
+            abi.lib.powdr_gpu_timing_enable(1)
+            for _ in range(3):
+                keep = tg.apc_tracegen(out2, airs_cs, subs_cs, calls)
+            torch.cuda.synchronize()
+            cs_ms = abi.timing_report()["apc_gather_tile_kernel"][1] / 3
+            abi.lib.powdr_gpu_timing_enable(0)
+            ok = True
+            r = torch.arange(0, calls, device="cuda", dtype=torch.int64)
+            for a, col, row, apc_col in subs_cs[:: max(1, len(subs_cs) // 48)].tolist():
+                t, w, h, b = airs_cs[a]
+                ok = ok and torch.equal(out2.buf[apc_col * wl["H"]: apc_col * wl["H"] + calls], t[col * h + row + r * b])
+            used_cols = len(set((int(a), int(c)) for a, c, _, _ in subs_cs))
+            src_touched = sum(airs_cs[a][2] * 4 for a, c in set((int(a), int(c)) for a, c, _, _ in subs_cs))
+            colstruct_leg = dict(gather_ms=cs_ms, substitutions=int(len(subs_cs)), source_columns_used=used_cols,
+                                 source_columns_total=int(sum(w for w, _ in dims)), source_bytes_touched=int(src_touched),
+                                 matches_direct_indexing=bool(ok),
+                                 scattered_gather_ms=timing.get("apc_gather_tile_kernel", (0, 0.0))[1] / args.steps,
+                                 step_ms_with_this_gather=elapsed / args.steps * 1e3 - timing.get("apc_gather_tile_kernel", (0, 0.0))[1] / args.steps + cs_ms,
+                                 note="_apc_tracegen on the reference's source layout with column-structured substitutions (few columns of every "
+                                      "original AIR, present in ~65 % of its instructions: what optimised APCs look like in the reference's snapshots); "
+                                      "the timed step uses uniformly scattered cells, the worst case for the gather")
+            del out2, keep
+            torch.cuda.empty_cache()
+        except Exception as e:
+            colstruct_leg = dict(gather_ms=None, error=f"{type(e).__name__}: {e}")
+
     # ---- second timed leg: the same step WITH the LogUp phase (the bus interactions PowdrAir::eval pushes, chip.rs:117-129,
     # inside the proof). The headline stays constraints-only (north_star's kernel list has no permutation phase); this leg is
     # the statement the reference's backend proves. Same inputs, same trace generation; a second prover object.
@@ -593,7 +640,7 @@ def main():
                         source_bytes=wl["src_bytes"], proof_bytes=proof_bytes, prover_device_bytes=prover_bytes,
                         caveat="proof system pw-stark v0 is this repository's own (oracle/stark_oracle.cpp); its Poseidon2 round constants are a "
                                "documented placeholder stream: proofs are byte-exact against the oracle, not interoperable with the reference prover"),
-            roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, multi_segment=segment_leg, tracegen_callmajor=callmajor_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
+            roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, multi_segment=segment_leg, tracegen_callmajor=callmajor_leg, tracegen_column_structured=colstruct_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
             hbm_copy_GBps_measured=copy_gbs,
         )
         print(json.dumps(line))

@@ -467,3 +467,41 @@ def random_air_programs(width: int, n_constraints: int, n_interactions: int, see
             ispans.append((off, len(ibc) - off))
     return (np.array(bc, np.uint32), np.array(spans, np.uint32).reshape(-1, 2),
             (np.array(inter, np.uint32).reshape(-1, 3), np.array(ispans, np.uint32).reshape(-1, 2), np.array(ibc, np.uint32)))
+
+
+def column_structured_substitutions(air_dims, n_sub: int, seed: int = 0, coverage: float = 0.65) -> np.ndarray:
+    """Substitutions (air_index, col, row, apc_col) with the structure optimised APCs show in the reference's own snapshots:
+    the surviving cells are FEW COLUMNS of an original AIR, each present in most of the block's instructions, not cells
+    scattered over the whole block. Evidence: /root/reference/sp1-benchmarks/tests/apc_snapshots/complex/
+    keccak_permutation.txt (13 693 -> 2 940 columns over 263 instructions, but only 73 distinct column names: the bitwise
+    chip keeps b_low_bytes / c_low_bytes / result, 16 columns, in 100-155 of its 184 instructions) and
+    /root/reference/openvm-riscv/tests/apc_snapshots/complex/aligned_memcpy.txt (the same 14 LoadStore columns —
+    mem_ptr_limbs, prev_data, timestamps — survive in every LOADW / STOREW). `generate` scatters the cells uniformly over
+    the block instead, which is the worst case for the gather: every 64-byte sector of every source column holds a used cell.
+    air_dims: [(width, row_block_size)]; every AIR gets u_k ~ width-proportional used columns so that
+    sum_k u_k * b_k * coverage ~ n_sub, rows are dropped at random down to exactly n_sub cells."""
+    rng = np.random.default_rng(seed ^ 0xC01)
+    dims = [(int(w), int(b)) for w, b in air_dims]
+    total_w = sum(w for w, _ in dims)
+    target = n_sub / coverage
+    frac = target / sum(w * b for w, b in dims)
+    cells = []
+    for k, (w, b) in enumerate(dims):
+        u = min(w, max(1, int(round(frac * w + 0.5))))
+        for c in rng.choice(w, size=u, replace=False):
+            for r in range(b):
+                cells.append((k, int(c), r))
+    while len(cells) < n_sub:  # tiny shapes: top up with unused cells
+        k = int(rng.integers(len(dims)))
+        cand = (k, int(rng.integers(dims[k][0])), int(rng.integers(dims[k][1])))
+        if cand not in cells:
+            cells.append(cand)
+    keep = rng.choice(len(cells), size=n_sub, replace=False)
+    keep.sort()
+    out = np.zeros((n_sub, 4), np.int32)
+    apc_cols = rng.permutation(n_sub)
+    for i, j in enumerate(keep.tolist()):
+        k, c, r = cells[j]
+        out[i] = (k, c, r, int(apc_cols[i]))
+    assert total_w > 0
+    return out

@@ -590,3 +590,31 @@ def test_callmajor_edge_cases(gpu):
         tg.apc_tracegen_callmajor(out, [(t, U)], np.array([[0, 5, 0]], np.int32), calls)  # slot out of range
     with pytest.raises(abi.HipError):
         tg.apc_tracegen_callmajor(tg.DeviceMatrix.zeros(96, 3), [(t, U)], subs_cm, calls)  # height not a power of two
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("calls,seed", [(1, 0), (37, 1), (1000, 2), (5000, 3)])
+def test_column_structured_substitutions_parity(gpu, calls, seed):
+    """The gather on the substitution structure of optimised APCs (few columns of every original AIR, present in most of its
+    instructions: synth.column_structured_substitutions, calibrated on the reference's snapshots) — what bench.py's
+    `tracegen_column_structured` record times — equals the oracle's restatement of apc_tracegen.cu:35-66."""
+    torch, abi, tg = gpu
+    rng = np.random.default_rng(seed)
+    dims = [(36, 318), (53, 116), (41, 241), (26, 1), (18, 1)]  # the C2 keccak sources (SURVEY.md 8a)
+    n_sub = 400
+    subs = synth.column_structured_substitutions(dims, n_sub, seed=seed)
+    assert len(set(map(tuple, subs[:, :3].tolist()))) == n_sub and sorted(subs[:, 3].tolist()) == list(range(n_sub))
+    used = len(set(map(tuple, subs[:, :2].tolist())))
+    assert used <= 0.2 * sum(w for w, _ in dims)  # few source columns
+    H = max(synth.next_pow2_or_zero(calls), 2)
+    bufs, hs, airs = [], [], []
+    for w, b in dims:
+        h = max(synth.next_pow2_or_zero(b * calls), 4)
+        src = rng.integers(0, om.P, size=w * h, dtype=np.uint32)
+        bufs.append(src); hs.append(h)
+        airs.append((to_dev(torch, src), w, h, b))
+    want = om.c_apc_tracegen(H, n_sub, bufs, hs, [b for _, b in dims], subs, calls)
+    out = tg.DeviceMatrix.zeros(H, n_sub)
+    tg.apc_tracegen(out, airs, subs, calls)
+    torch.cuda.synchronize()
+    assert (from_dev(out.buf) == want).all()
