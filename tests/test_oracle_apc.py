@@ -191,3 +191,33 @@ def test_committed_golden_summary_matches_pins():
     k = summ["keccak_apc_pre_opt"]
     assert (k["main_columns"], k["bus_interactions"], k["constraints"]) == (27521, 13262, 28627)
     assert k["airs"] == {"BaseAlu": [36, 318], "Shift": [53, 116], "LoadStore": [41, 241], "BranchEqual": [26, 1], "JalLui": [18, 1]}
+
+
+def test_column_structured_substitutions_shape_and_oracle_gather():
+    """synth.column_structured_substitutions: distinct source cells, a permutation of the APC columns, few source columns with
+    most of their rows — and the oracle's gather (apc_tracegen.cu:35-66 restated) places exactly those cells."""
+    dims = [(36, 318), (53, 116), (41, 241), (26, 1), (18, 1)]
+    n_sub, calls = 2017, 3
+    subs = synth.column_structured_substitutions(dims, n_sub, seed=5)
+    assert subs.shape == (n_sub, 4)
+    assert len(set(map(tuple, subs[:, :3].tolist()))) == n_sub
+    assert sorted(subs[:, 3].tolist()) == list(range(n_sub))
+    for a, col, row, _ in subs.tolist():
+        assert 0 <= col < dims[a][0] and 0 <= row < dims[a][1]
+    used = {}
+    for a, col, row, _ in subs.tolist():
+        used.setdefault((a, col), set()).add(row)
+    assert len(used) <= 0.15 * sum(w for w, _ in dims)
+    big = [len(rows) / dims[a][1] for (a, _), rows in used.items() if dims[a][1] > 1]
+    assert min(big) > 0.4 and sum(big) / len(big) > 0.55
+    rng = np.random.default_rng(1)
+    H = 4
+    bufs, hs = [], []
+    for w, b in dims:
+        h = max(synth.next_pow2_or_zero(b * calls), 4)
+        bufs.append(rng.integers(0, om.P, size=w * h, dtype=np.uint32)); hs.append(h)
+    got = om.c_apc_tracegen(H, n_sub, bufs, hs, [b for _, b in dims], subs, calls).reshape(n_sub, H)
+    for a, col, row, apc_col in subs[::37].tolist():
+        for r in range(H):
+            want = bufs[a][col * hs[a] + row + r * dims[a][1]] if r < calls else 0
+            assert got[apc_col, r] == want
