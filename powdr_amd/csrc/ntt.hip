@@ -67,6 +67,7 @@ struct GroupParams {
     int logr[4];  // window width per round
     unsigned long long n_tiles;  // tiles per column = 2^(n-B)
     int canonical_out;  // forward transform: the last group reduces its [0, 2p) values to [0, p) when it stores
+    unsigned twt_off[4];  // per round: offset of its twiddle table (contiguous groups of the fused LDE kernel, see FusedTwiddles)
 };
 
 __device__ __forceinline__ uint32_t lds_phys(uint32_t l) { return l + (l >> 5); }
@@ -114,15 +115,19 @@ __device__ __forceinline__ uint32_t load_twiddle_base(const IndexMap& im, const 
     return tw[g << sh_top];
 }
 
-template <bool DIF, int LOGR>
-__device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t base_top) {
+// `tt` (TWT): the slot's 2^LOGR - 1 twiddles, stage q at [2^q - 1, 2^(q+1) - 1), loaded from a table instead of being derived
+// from `base_top` by LOGR - 1 squarings and 2^LOGR - 1 - LOGR products (70 of a radix-16 slot's 390 instructions).
+template <bool DIF, int LOGR, bool TWT = false>
+__device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t base_top, const uint32_t* tt = nullptr) {
     constexpr int R = 1 << LOGR;
     const uint32_t* roots = c_roots16[DIF ? 1 : 0];
     // base[q] = w^(g << shift_q); the smallest shift belongs to q = LOGR-1 and base[q-1] = base[q]^2
     uint32_t base[LOGR];
-    base[LOGR - 1] = base_top;
+    if (!TWT) {
+        base[LOGR - 1] = base_top;
 #pragma unroll
-    for (int q = LOGR - 2; q >= 0; --q) base[q] = bb::sqr(base[q + 1]);
+        for (int q = LOGR - 2; q >= 0; --q) base[q] = bb::sqr(base[q + 1]);
+    }
 #pragma unroll
     for (int qi = 0; qi < LOGR; ++qi) {
         const int q = DIF ? (LOGR - 1 - qi) : qi;
@@ -130,7 +135,8 @@ __device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t base_top)
         uint32_t t[1 << (LOGR - 1)], nt[1 << (LOGR - 1)];
 #pragma unroll
         for (int r = 0; r < (1 << q); ++r) {
-            t[r] = r == 0 ? base[q] : bb::mul(base[q], roots[r << (3 - q)]);
+            if (TWT) t[r] = tt[(1 << q) - 1 + r];
+            else t[r] = r == 0 ? base[q] : bb::mul(base[q], roots[r << (3 - q)]);
             if (DIF) nt[r] = bb::P - t[r];  // a representative of -t in (0, p]: fine as a factor
         }
 #pragma unroll
@@ -159,7 +165,7 @@ __device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t base_top)
 // EXPAND: `src` is the H-sized bit-reversed coefficient array (n = log2(2H)); element g of the
 // 2H-sized vector is src[g >> 1] * scale_br[g >> 1].
 // `tw_base` enters as the twiddle base of this round's slot 0 and leaves as the one of the next round's slot 0.
-template <bool DIF, int LOGR, int EPT, bool EXPAND>
+template <bool DIF, int LOGR, int EPT, bool EXPAND, bool TWT = false>
 __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, const GroupParams& gp, int round,
                                           const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                           const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid,
@@ -187,8 +193,15 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
         const uint32_t p0 = lds_phys(l0);
         // fetch the next slot's (or the next round's first) twiddle base while this slot computes
         const uint32_t cur_base = tw_base;
-        if (m + 1 < SLOTS) tw_base = load_twiddle_base<DIF>(im, gp, round, m + 1, tid, tw);
-        else if (!last_round) tw_base = load_twiddle_base<DIF>(im, gp, round + 1, 0, tid, tw);
+        uint32_t tt[R];  // TWT: the slot's twiddles from the group's table (`tw`), [stage-major index][g], g = the index bits below the window
+        if (TWT) {
+            const uint32_t* tab = tw + gp.twt_off[round] + (l0 & ((1u << rb) - 1u));
+#pragma unroll
+            for (int j = 0; j < R - 1; ++j) tt[j] = tab[(uint32_t)j << rb];
+        } else {
+            if (m + 1 < SLOTS) tw_base = load_twiddle_base<DIF>(im, gp, round, m + 1, tid, tw);
+            else if (!last_round) tw_base = load_twiddle_base<DIF>(im, gp, round + 1, 0, tid, tw);
+        }
         // ---- load ----
         if (first) {
             if (EXPAND ? vec_expand : vec_plain) {
@@ -230,7 +243,7 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
             for (int rho = 0; rho < R; ++rho) x[rho] = tile[p0 + lds_off(rho)];
         }
         // ---- butterflies ----
-        slot_butterflies<DIF, LOGR>(x, cur_base);
+        slot_butterflies<DIF, LOGR, TWT>(x, cur_base, tt);
         // ---- store ----
         if (!DIF && last && gp.canonical_out) {
 #pragma unroll
@@ -288,17 +301,17 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     }
 }
 
-// all rounds of one stage group on the workgroup's tile(s)
-template <bool DIF, int EPT>
+// all rounds of one stage group on the workgroup's tile(s). TWT: `tw` is the group's twiddle TABLE (FusedTwiddles).
+template <bool DIF, int EPT, bool TWT = false>
 __device__ __forceinline__ void run_group(uint32_t* tile, const IndexMap& im, const GroupParams& gp, const uint32_t* __restrict__ src,
                                           uint32_t* __restrict__ dst, const uint32_t* __restrict__ tw, int tid, bool io_first, bool io_last) {
-    uint32_t tw_base = load_twiddle_base<DIF>(im, gp, 0, 0, tid, tw);
+    uint32_t tw_base = TWT ? 0u : load_twiddle_base<DIF>(im, gp, 0, 0, tid, tw);
     for (int r = 0; r < gp.n_rounds; ++r) {
         switch (gp.logr[r]) {
-            case 1: run_round<DIF, 1, EPT, false>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
-            case 2: run_round<DIF, 2, EPT, false>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
-            case 3: run_round<DIF, 3, EPT, false>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
-            default: run_round<DIF, 4, EPT, false>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            case 1: run_round<DIF, 1, EPT, false, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            case 2: run_round<DIF, 2, EPT, false, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            case 3: run_round<DIF, 3, EPT, false, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            default: run_round<DIF, 4, EPT, false, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
         }
         if (r + 1 < gp.n_rounds) __syncthreads();
     }
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void lde_fused_kernel(const uint32_t* __res
     ia.cmask = (1u << ga.c) - 1u;
     ia.tile0 = (size_t)blockIdx.x << (LOGA - ga.B);
     ia.n_tiles = (size_t)ga.n_tiles;
-    run_group<true, (1 << LOGA) / kBlock>(tile, ia, ga, src, nullptr, tw_inv, tid, true, false);
+    run_group<true, (1 << LOGA) / kBlock, true>(tile, ia, ga, src, nullptr, tw_inv, tid, true, false);
     __syncthreads();
     // scale and duplicate: element l of the coefficient tile becomes elements 2l, 2l + 1 of the forward tile
     uint32_t v[(1 << LOGA) / kBlock];
@@ -348,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void lde_fused_kernel(const uint32_t* __res
     id.cmask = (1u << gd.c) - 1u;
     id.tile0 = (size_t)blockIdx.x << (LOGD - gd.B);
     id.n_tiles = (size_t)gd.n_tiles;
-    run_group<false, (1 << LOGD) / kBlock>(tile, id, gd, nullptr, dst, tw_fwd, tid, false, true);
+    run_group<false, (1 << LOGD) / kBlock, true>(tile, id, gd, nullptr, dst, tw_fwd, tid, false, true);
 }
 
 struct Tables {
@@ -540,6 +553,59 @@ GroupParams contiguous_group(bool dif, int n, int s0, int k, int c) {
 
 }  // namespace
 
+// Twiddle tables of the fused kernel's two contiguous groups. In a contiguous group the twiddle of a butterfly depends on
+// the tile-local index only — the stages are the last ones of the inverse / the first ones of the forward transform, their
+// factors are the roots of order 2^(rb + logr) of a round with window [rb, rb + logr) whatever the transform size — so a
+// table per round, [stage-major twiddle index j < 2^logr - 1][g < 2^rb], serves every tile, column and size: <= 46 KB for
+// ka = 12, L2-resident, each of a slot's 15 loads one coalesced 256-byte read per wave. Replaces 3 squarings + 11 products
+// per radix-16 slot (70 of its 390 instructions).
+struct FusedTwiddles {
+    uint32_t* d = nullptr;
+    unsigned dif_off[4] = {0, 0, 0, 0}, dit_off[4] = {0, 0, 0, 0};  // relative to d / to d + dit_base
+    size_t dit_base = 0;
+};
+std::map<std::pair<int, int>, FusedTwiddles> g_fused_tw;  // (device, ka)
+
+const FusedTwiddles* fused_twiddles(int ka, const GroupParams& ga, const GroupParams& gd) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    auto it = g_fused_tw.find({device, ka});
+    if (it != g_fused_tw.end()) return &it->second;
+    FusedTwiddles ft;
+    std::vector<uint32_t> h;
+    auto build = [&](const GroupParams& gp, bool dif, unsigned* offs, size_t base) {
+        const uint32_t w16 = field::root_of_unity(4), w16i = bb::inv(w16);
+        uint32_t roots[8];
+        { uint32_t a = bb::R_MOD_P; for (int r = 0; r < 8; ++r) { roots[r] = a; a = bb::mul(a, dif ? w16i : w16); } }
+        for (int r = 0; r < gp.n_rounds; ++r) {
+            const int rb = gp.rb[r], logr = gp.logr[r];
+            offs[r] = (unsigned)(h.size() - base);
+            const size_t G = (size_t)1 << rb, J = ((size_t)1 << logr) - 1;
+            h.resize(h.size() + J * G);
+            uint32_t* tab = h.data() + base + offs[r];
+            uint32_t om = field::root_of_unity(rb + logr);
+            if (dif) om = bb::inv(om);
+            uint32_t bt = bb::R_MOD_P;  // om^g
+            for (size_t g = 0; g < G; ++g) {
+                uint32_t bq[4];
+                bq[logr - 1] = bt;
+                for (int q = logr - 2; q >= 0; --q) bq[q] = bb::sqr(bq[q + 1]);
+                for (int q = 0; q < logr; ++q)
+                    for (int rr = 0; rr < (1 << q); ++rr)
+                        tab[(((size_t)1 << q) - 1 + rr) * G + g] = rr == 0 ? bq[q] : bb::mul(bq[q], roots[rr << (3 - q)]);
+                bt = bb::mul(bt, om);
+            }
+        }
+    };
+    build(ga, true, ft.dif_off, 0);
+    ft.dit_base = h.size();
+    build(gd, false, ft.dit_off, ft.dit_base);
+    if (hipMalloc(&ft.d, h.size() * 4) != hipSuccess) return nullptr;
+    if (hipMemcpy(ft.d, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;  // synchronous: published complete
+    return &g_fused_tw.emplace(std::make_pair(device, ka), ft).first->second;
+}
+
 // The whole LDE of `cols` columns: natural-order evaluations on <g_n> (in) -> natural-order evaluations on the coset
 // s <g_(n+1)> (out), through the fused middle kernel: strided DIF groups (stages 0 .. n-13, into `tmp`, which needs
 // cols x 2^n words and is untouched when n <= 12), lde_fused_kernel (the 12 contiguous DIF stages, scaling, duplication,
@@ -565,6 +631,9 @@ int lde_fused(const uint32_t* in, uint32_t* tmp, uint32_t* out, size_t in_stride
     GroupParams ga = contiguous_group(true, n, n - ka, ka, 0);
     GroupParams gd = contiguous_group(false, n + 1, 1, ka, 1);
     gd.canonical_out = ka == n ? 1 : 0;
+    const FusedTwiddles* ft = fused_twiddles(ka, ga, gd);
+    if (!ft) return (int)hipErrorOutOfMemory;
+    for (int r = 0; r < 4; ++r) { ga.twt_off[r] = ft->dif_off[r]; gd.twt_off[r] = ft->dit_off[r]; }
     {
         const size_t tiles = (size_t)1 << (n - ka);
         const size_t per_wg = (size_t)1 << (12 - ka);
@@ -573,7 +642,7 @@ int lde_fused(const uint32_t* in, uint32_t* tmp, uint32_t* out, size_t in_stride
             const uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;
             ScopedKernelTimer t("lde_fused_kernel");
             hipLaunchKernelGGL(lde_fused_kernel, dim3(wgs, cc), dim3(kBlock), 0, stream(), src + (size_t)c0 * src_stride,
-                               out + (size_t)c0 * out_stride, src_stride, out_stride, ga, gd, tn->tw_inv, t1->tw_fwd, tn->shift_br);
+                               out + (size_t)c0 * out_stride, src_stride, out_stride, ga, gd, ft->d, ft->d + ft->dit_base, tn->shift_br);
         }
     }
     if (n > ka) {
