@@ -46,30 +46,38 @@ PW_HD int field_selftest_checks(uint64_t seed, uint32_t iterations) {
         }
     }
     for (uint32_t it = 0; it < 4 + iterations / 16; ++it) {
-        const int32_t top0 = (int32_t)((uint64_t)P * 97 / 100), top = (int32_t)((uint64_t)P * 75 / 100);  // |s_0| < 0.97 p, others < 0.75 p
-        int32_t st[16], diag[16];
+        // internal_layer with arbitrary (centred) constants: out_i = (kappa s_0 + sum_{i>=1} s_i) / R * rho / R + s_i m_i / R (+ constants)
+        const int32_t top0 = (int32_t)((uint64_t)P * 97 / 100), top = (int32_t)((uint64_t)P * 92 / 100);  // |s_0| < 0.97 p, others < 0.92 p
+        int32_t st[16], m[16];
         uint32_t want[16];
-        int64_t sum = 0;
         for (int i = 0; i < 16; ++i) {
             const int32_t hi = i ? top : top0;
             const int32_t mag = it < 3 ? hi - 1 : (int32_t)(rnd() % (uint64_t)hi);
             st[i] = it == 0 ? mag : it == 1 ? -mag : it == 2 ? ((i & 1) ? mag : -mag) : ((rnd() & 1) ? mag : -mag);
-            diag[i] = it < 3 ? ((i & 2) ? (int32_t)(P / 2) : -(int32_t)(P / 2)) : centred(rp());
-            sum += smodp(st[i]);
+            m[i] = it < 3 ? ((i & 2) ? (int32_t)(P / 2) : -(int32_t)(P / 2)) : centred(rp());
         }
+        const int32_t kappa = it < 3 ? ((it & 1) ? (int32_t)(P / 2) : -(int32_t)(P / 2)) : centred(rp());
+        const int32_t rho = it < 3 ? ((it & 2) ? (int32_t)(P / 2) : -(int32_t)(P / 2)) : centred(rp());
         const uint32_t next = it < 3 ? P - 1 : rp(), ex = it < 3 ? (P + 1) / 2 : rp();
         int64_t exit_c[16];
         for (int i = 0; i < 16; ++i) exit_c[i] = (int64_t)centred(ex) * (int64_t)R_MOD_P;
         const bool last = it & 1;
-        for (int i = 0; i < 16; ++i)
-            want[i] = (uint32_t)(((uint64_t)sum % P + (uint64_t)mul(smodp(st[i]), smodp(diag[i])) + (i ? (last ? ex : 0u) : next)) % P);
-        if (last) p2::internal_layer<true>(st, diag, (int64_t)centred(next) * (int64_t)R_MOD_P, exit_c);
-        else p2::internal_layer<false>(st, diag, (int64_t)centred(next) * (int64_t)R_MOD_P, exit_c);
+        // reference with canonical Montgomery arithmetic: x / R = mul(x, 1)
+        uint32_t wide = mul(mul(smodp(st[0]), smodp(kappa)), R2_MOD_P);  // s_0 kappa (exact product, as a residue)
+        for (int i = 1; i < 16; ++i) wide = add(wide, smodp(st[i]));
+        const uint32_t sum = mul(wide, 1u);
+        const uint32_t sum_r = mul(mul(sum, smodp(rho)), R2_MOD_P);      // sum * rho as a residue
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t prod = mul(mul(smodp(st[i]), smodp(m[i])), R2_MOD_P);
+            const uint32_t c = i ? (last ? mul(mul(smodp(centred(ex)), R_MOD_P), R2_MOD_P) : 0u) : mul(mul(smodp(centred(next)), R_MOD_P), R2_MOD_P);
+            want[i] = mul(add(add(sum_r, prod), c), 1u);
+        }
+        if (last) p2::internal_layer<true>(st, m, kappa, rho, (int64_t)centred(next) * (int64_t)R_MOD_P, exit_c);
+        else p2::internal_layer<false>(st, m, kappa, rho, (int64_t)centred(next) * (int64_t)R_MOD_P, exit_c);
         for (int i = 0; i < 16; ++i)
             if (smodp(st[i]) != want[i]) return 9;
-        const int32_t lim = last ? (int32_t)((uint64_t)P * 78 / 100) : top;  // with the exit constants: 0.78 p, still an S-box input
         for (int i = 0; i < 16; ++i)
-            if (st[i] <= -(i ? lim : top0) || st[i] >= (i ? lim : top0)) return 9;
+            if (st[i] <= -(int32_t)P || st[i] >= (int32_t)P) return 9;
     }
     for (uint32_t it = 0; it < iterations; ++it) {
         const uint32_t a = rp(), b = rp(), c = rp(), d = rp();

@@ -1,13 +1,13 @@
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r02_microbench_hash.txt
+OUT=$R/gpurun_out/r02_microbench_hash2.txt
 : > $OUT
-for v in unsigned unsigned_part13 signed signed_w8 signed_part4 signed_part12 signed_part12_w8 signed_full; do
+for v in unsigned signed scaled scaled_w8 signed scaled; do
   echo "== $v" >> $OUT
   timeout 120 $R/tools/_hb/$v 19 512 5 >> $OUT 2>&1
 done
 cd /tmp && export TMPDIR=/tmp
-for v in unsigned signed signed_part12; do
+for v in signed scaled; do
   rm -rf /tmp/pmc_$v
   timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVE_CYCLES --output-format csv -d /tmp/pmc_$v -- $R/tools/_hb/$v 19 512 1 > /dev/null 2>&1
   echo "== pmc $v" >> $OUT

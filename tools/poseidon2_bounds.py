@@ -18,7 +18,7 @@ def smont(tmax):
 def sreduce(ymax):
     """|y| <= ymax -> (lowest, highest) value of y - q p, q = floor(floor(y / 128) * 273 / 2^32); exact extremes are hard,
     so use the analytic envelope: y (1 - 273 p / 2^39) + [0, p + 273 p / 2^32 + 1)"""
-    assert ymax < 64 * p
+    assert ymax < 128 * p  # floor(y / 128) must fit an int32
     eps = 1 - 273 * p / 2 ** 39
     lo = -int(ymax * eps) - 1
     hi = int(ymax * eps) + p + (273 * p >> 32) + 2
@@ -45,41 +45,45 @@ for cand in range(p, int(1.2 * p), p // 1000):
         break
 print(f"S-box input may be as large as {lo_ok / p:.3f} p")
 
-# external layer: inputs |x| < X, constants centred (|a|, |b|, |d| <= p/2): block outputs < 7 X + 1.5 p, column sums x 5
-def ext_out(X, consts=True):
-    y = 5 * (7 * X + (3 * HALF if consts else 0))
-    return sreduce(y), y
+# external layer: inputs |x| < X, constants centred (|a|, |b|, |d| <= p/2): block outputs < 7 X + 1.5 p, column sums x 5.
+# Every layer but the last reduces with a signed Montgomery reduction (|out| < |y| / 2^32 + p / 2); the last one (bias 4 p seeds,
+# Barrett-style sreduce_wide_loose) is checked at the end.
+def ext_y(X, consts=True):
+    return 5 * (7 * X + (3 * HALF if consts else 0))
 
-# closure of "permutation input -> layer -> S-box -> layer ...": inputs are canonical words or sponge outputs
-sb_in = p
+# closure of "permutation input -> layer -> S-box -> layer ...": inputs are canonical words or sponge outputs ([0, 1.011 p))
+lo_last, hi_last = sreduce(35 * p + 60 * p)  # the last layer's outputs (bias included, non-negative): what a sponge hands to the next permutation
+sb_in = hi_last
 for _ in range(8):
-    (lo, hi), y0 = ext_out(sb_in)                 # a layer fed by permutation inputs / previous outputs
+    y0 = ext_y(sb_in)                       # a layer fed by permutation inputs
     x7 = smont(smont(smont(sb_in * sb_in) * sb_in) * smont(smont(sb_in * sb_in) ** 2))
-    (lo2, hi2), y1 = ext_out(x7)                  # a layer fed by S-box outputs
-    nxt = max(sb_in, -lo, hi, -lo2, hi2)
+    y1 = ext_y(x7)                          # a layer fed by S-box outputs
+    nxt = max(sb_in, smont(y0), smont(y1))
     if nxt == sb_in:
         break
     sb_in = nxt
-x7 = sbox(sb_in, "external rounds")
-print(f"external layer: |y| < {max(y0, y1) / p:.1f} p (sreduce_wide_loose takes 64 p), outputs in ({min(lo, lo2) / p:.4f} p, {max(hi, hi2) / p:.4f} p)")
+assert max(y0, y1) < 1 << 62
+x7 = sbox(sb_in, "external rounds (inputs: permutation input / Montgomery-reduced layer outputs)")
+mid = max(smont(y0), smont(y1))
+x7m = sbox(mid, "external rounds after the first layer")
+print(f"external layer: |y| < {max(y0, y1) / p:.1f} p, Montgomery-reduced to |x| < {mid / p:.4f} p")
 assert sb_in <= lo_ok
 
-# entry of the partial rounds: s_0 + int_rc[0] through min(x, x - p) as unsigned
-(lo3, hi3), _ = ext_out(x7, consts=False)
-assert hi3 + p - 1 < R  # the unsigned sum does not wrap
-s0_in = max(hi3, p - lo3)  # [0, hi3) or (-p + lo3, -p)
+# entry of the partial rounds: s_0 + entry_c (centred)
+y3 = ext_y(x7m, consts=False)
+B0 = smont(y3)
+s0_in = B0 + HALF
 assert s0_in <= lo_ok
-s0 = sbox(max(s0_in, sb_in), "partial rounds, s_0")
+s0 = sbox(s0_in, "partial rounds, s_0 on entry")
 
-# partial rounds: words |s_i| < B_r in round r (B_0 = what the layer before delivers), s_0 an S-box output
-Bs = [max(-lo3, hi3)]
-s0_max, S_max, wide_max, t_max = s0, 0, 0, 0
+# partial rounds: |kappa|, |rho|, |m_i| <= p/2
+Bs = [B0]
+s0_max, S_max, t_max = s0, 0, 0
 for r in range(13):
     B = Bs[-1]
-    wide = s0_max + 15 * B
-    slo, shi = sreduce(wide)
-    S = max(-slo, shi)
-    sum_r = S * R_MOD_P
+    wide = s0_max * HALF + 15 * B
+    S = smont(wide)
+    sum_r = S * HALF
     last = r == 12
     t_i = sum_r + (HALF * R_MOD_P if last else 0) + B * HALF
     t_0 = sum_r + HALF * R_MOD_P + s0_max * HALF
@@ -87,12 +91,16 @@ for r in range(13):
     s0_in_next = smont(t_0)
     assert s0_in_next <= lo_ok
     s0_max = max(s0_max, smont(smont(smont(s0_in_next ** 2) * s0_in_next) * smont(smont(s0_in_next ** 2) ** 2)))
-    S_max, wide_max, t_max = max(S_max, S), max(wide_max, wide), max(t_max, t_i, t_0)
-print(f"partial rounds: |s_i| < {Bs[0] / p:.4f} p on entry, {Bs[1] / p:.4f} p after one round, {Bs[12] / p:.4f} p after twelve, "
-      f"{Bs[13] / p:.4f} p after the last (exit constants added); |sum| < {S_max / p:.4f} p, 16-term sum < {wide_max / p:.2f} p, "
-      f"s_0 leaves below {s0_in_next / p:.4f} p, products < {t_max / p / p:.3f} p^2 (domain 1.209 p^2)")
-assert Bs[13] <= sb_in and s0_in_next <= sb_in, "the words leaving the partial rounds must be S-box inputs of the external rounds"
+    S_max, t_max = max(S_max, S), max(t_max, t_i, t_0)
+print(f"partial rounds: |s_i| < {Bs[0] / p:.4f} p on entry, {Bs[1] / p:.4f} p after one round, {max(Bs) / p:.4f} p at most, "
+      f"{Bs[13] / p:.4f} p after the last (exit constants added); |sum| < {S_max / p:.4f} p, s_0 leaves below {s0_in_next / p:.4f} p, "
+      f"products < {t_max / p / p:.3f} p^2 (domain 1.209 p^2)")
+assert max(Bs) <= lo_ok and s0_in_next <= lo_ok, "the words leaving the partial rounds must be S-box inputs of the external rounds"
+x7e = sbox(max(Bs[13], s0_in_next), "external round 4 (inputs from the partial rounds)")
+assert ext_y(x7e) < 1 << 62
 
 # last layer: bias seeds 4 p -> 40 p or 60 p on an output; the sum itself is within 35 x^7
-assert 35 * x7 < 40 * p and 35 * x7 + 60 * p < 128 * p
-print(f"last layer: |sum| < {35 * x7 / p:.1f} p, biased into [{(40 * p - 35 * x7) / p:.1f} p, {(60 * p + 35 * x7) / p:.1f} p)")
+x7l = x7m
+assert 35 * x7l < 40 * p and 35 * x7l + 60 * p < 128 * p
+lo_f, hi_f = sreduce(35 * x7l + 60 * p)
+print(f"last layer: |sum| < {35 * x7l / p:.1f} p, biased into [{(40 * p - 35 * x7l) / p:.1f} p, {(60 * p + 35 * x7l) / p:.1f} p): outputs in [0, {hi_f / p:.4f} p)")
