@@ -52,6 +52,8 @@ struct GatherJob {
     uint32_t magicJ;    // ceil(2^32 / J) for e / J
     uint32_t sub_begin; // into plan subs
     uint32_t sub_count;
+    int32_t sparse;     // 1: only the used rows are fetched, cell by cell (J = their number, tile row c = [row s of call c])
+    int32_t pad;
 };
 
 struct PlanSub {
@@ -117,7 +119,23 @@ __global__ __launch_bounds__(kBlock) void apc_gather_tile_kernel(
         const uint32_t* __restrict__ src =
             air.buffer + (size_t)job.col * (size_t)(uint32_t)air.height;
         const int J = job.J, b = job.b, pitch = job.pitch;
-        if (J == b) {
+        if (job.sparse) {
+            // Scattered survivors: fetch ONLY the used cells. Lane e -> (call e / J, used row e % J): the lanes of one call run
+            // through its used rows in ascending order, so cells that share a 64-byte sector are fetched by one request and
+            // the sectors that hold no used cell are never read (at 7 % density ~30 % of them). The rows come from the job's
+            // substitution list, staged in LDS behind the tile.
+            uint32_t* rows_lds = tile + (size_t)R * pitch;
+            const PlanSub* __restrict__ js0 = subs + job.sub_begin;
+            for (uint32_t s = tid; s < (uint32_t)J; s += kBlock) rows_lds[s] = (uint32_t)js0[s].j;
+            __syncthreads();
+            const uint32_t* base = src + r0 * (size_t)b;
+            const uint32_t n = (uint32_t)valid * (uint32_t)J;
+            for (uint32_t e = tid; e < n; e += kBlock) {
+                const uint32_t i = fast_div(e, job.magicJ, J);
+                const uint32_t sidx = e - i * (uint32_t)J;
+                tile[i * pitch + sidx] = __builtin_nontemporal_load(base + (size_t)i * b + rows_lds[sidx]);
+            }
+        } else if (J == b) {
             // J == b: the per-call segments [j0, j0+b) abut, so the tile is one contiguous range of the column
             // (j0 != 0 happens when substitutions reach past their own block into the next call's rows)
             const uint32_t* base = src + r0 * (size_t)b + job.j0;
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void apc_gather_tile_kernel(
     for (uint32_t s = slot; s < job.sub_count; s += kSubsPerPass) {
         const PlanSub ps = js[s];
         uint32_t* __restrict__ dst = out + (size_t)ps.apc_col * H + r0;
-        const int j = ps.j - job.j0;
+        const int j = job.sparse ? (int)s : ps.j - job.j0;
 #pragma unroll
         for (int i = lane_i; i < R; i += kLanes) {
             if (i < rows) {
@@ -238,6 +256,9 @@ std::mutex g_plan_mu;
 std::unordered_map<PlanKey, std::shared_ptr<Plan>, PlanKeyHash> g_plans;
 uint64_t g_plan_clock = 0;
 
+bool g_sparse_jobs = true;  // POWDR_GATHER_SPARSE=0: never use the cell-by-cell form
+int g_sparse_pct = 100;     // ... which must move at most this share of the streaming forms' bytes (POWDR_GATHER_SPARSE_PCT)
+
 int pick_R(int J) {
     int pitch = J | 1;
     int R = kMaxR;
@@ -250,6 +271,8 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
         int v = atoi(e);
         if (v >= 2048 && v <= 16384) kMaxTileWords = v;
     }
+    if (const char* e = getenv("POWDR_GATHER_SPARSE")) g_sparse_jobs = atoi(e) != 0;
+    if (const char* e = getenv("POWDR_GATHER_SPARSE_PCT")) { int v = atoi(e); if (v >= 10 && v <= 200) g_sparse_pct = v; }
     if (const char* e = getenv("POWDR_GATHER_MIN_R")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) kMinR = v; }
     kMaxChunkJ = kMaxTileWords / kMinR - 1;
     const size_t n = subs_in.size();
@@ -313,8 +336,16 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
         const int max_row = subs_in[idx[ge - 1]].row;
         const bool whole_ok = b >= 1 && b <= kMaxChunkJ && max_row < b;
         const size_t cost_whole = (size_t)b * 4;
-        auto emit = [&](size_t cb, size_t ce, int j0, int J) {
+        // candidate C: fetch the used cells one by one — bytes per call = 64-byte sectors that hold a used row (+ one for the
+        // alignment of a call's block, which shifts from call to call)
+        const size_t U = ge - g;
+        size_t cost_sparse = 64;
+        for (size_t k = g; k < ge; ++k)
+            if (k == g || subs_in[idx[k]].row / 16 != subs_in[idx[k - 1]].row / 16) cost_sparse += 64;
+        const bool sparse_ok = g_sparse_jobs && U <= (size_t)kMaxChunkJ && U >= 1;
+        auto emit = [&](size_t cb, size_t ce, int j0, int J, bool sparse = false) {
             GatherJob job;
+            job.sparse = sparse ? 1 : 0; job.pad = 0;
             job.air = s0.air_index; job.col = s0.col; job.b = b; job.j0 = j0; job.J = J;
             // whole-block jobs (J == b) copy their contiguous range into the tile as it is (pitch = J: 16-byte LDS stores,
             // no per-element index arithmetic — the copy, not the transposed read-out of the few cells that are used,
@@ -328,7 +359,10 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
             jobs.push_back(job);
             jobR.push_back(pick_R(J));
         };
-        if (whole_ok && cost_whole <= cost_chunks) {
+        // the sparse form pays a request per cell instead of 16-byte streaming loads: it has to save a share of the bytes
+        if (sparse_ok && cost_sparse * 100 <= std::min(whole_ok ? cost_whole : (size_t)-1, cost_chunks) * (size_t)g_sparse_pct) {
+            emit(g, ge, 0, (int)U, true);
+        } else if (whole_ok && cost_whole <= cost_chunks) {
             emit(g, ge, 0, b);
         } else {
             for (auto& ch : chunks) {
@@ -348,7 +382,7 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
     for (size_t i = 0; i < jorder.size(); ++i) {
         sorted[i] = jobs[jorder[i]];
         int R = jobR[jorder[i]];
-        size_t lds = (size_t)R * sorted[i].pitch * 4;
+        size_t lds = (size_t)R * sorted[i].pitch * 4 + (sorted[i].sparse ? (size_t)sorted[i].J * 4 : 0);
         if (plan.classes.empty() || plan.classes.back().R != R)
             plan.classes.push_back({R, (uint32_t)i, 0, 0});
         plan.classes.back().job_count++;
