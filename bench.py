@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--no-callmajor-leg", action="store_true",
                     help="skip the measurement of the gather from call-major compacted sources (reported as `tracegen_callmajor`)")
     ap.add_argument("--logup-steps", type=int, default=3, help="timed steps of the LogUp leg (after one warm-up step)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="skip the two short rocprofv3 --pmc passes that measure the dominant kernel's HBM bytes and VALU instructions in this run")
     ap.add_argument("--no-copy-ceiling", action="store_true",
                     help="skip the 5 x 4 GiB device-to-device copies that measure the box's copy rate after the timed region "
                          "(they show up as __amd_rocclr_copyBuffer in rocprofv3 traces: 10.7 GB/step in the round-1 PMC pass)")
@@ -265,6 +267,45 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
     del traces
     torch.cuda.empty_cache()
     return rec if rank == 0 else None
+
+
+def live_pmc_leaf_hash(width: int, log_n: int):
+    """The dominant kernel's PMC counters measured IN THIS RUN: two short rocprofv3 --pmc passes (FETCH_SIZE; SQ_INSTS_VALU — one
+    counter set per pass, MI355X_MICROARCH.md) of tools/leaf_hash_once.py, which launches leaf_hash_kernel on a matrix of the
+    timed shape. Returns {"fetch_bytes_per_launch", "valu_instr_per_launch", "launches"} or None (no rocprofv3, a failing pass)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    script = Path(__file__).resolve().parent / "tools" / "leaf_hash_once.py"
+    if not exe or not script.exists():
+        return None
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "SQ_INSTS_VALU"):
+        tmp = tempfile.mkdtemp(prefix="powdr_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, str(script), str(width), str(log_n)],
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            total, disp = 0.0, set()
+            for f in glob.glob(tmp + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and "leaf_hash_kernel" in r["Kernel_Name"]:
+                        total += float(r["Counter_Value"])
+                        disp.add(r["Dispatch_Id"])
+            if not disp:
+                return None
+            out[counter] = total / len(disp)
+            out["launches"] = len(disp)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    # FETCH_SIZE: KiB, and on gfx950 wide coalesced streaming reads are tallied at half their bytes (same guide, HBM section)
+    return dict(fetch_bytes_per_launch=out["FETCH_SIZE"] * 1024 * 2, valu_instr_per_launch=out["SQ_INSTS_VALU"], launches=out["launches"])
 
 
 def load_profile_json(name):
@@ -572,6 +613,9 @@ def main():
                 if base.startswith("apc_apply_bus"):  # interpreter and fixed-shape kernels share one timer
                     base = "apc_apply_bus_kernel"
                 traffic_db[base] = traffic_db.get(base, 0.0) + v["fetch_bytes_corrected"] + v["write_bytes"]
+        live = None
+        if dom == "leaf_hash_kernel" and world == 1 and not args.no_live_pmc and not args.logup:
+            live = live_pmc_leaf_hash(wl["W"], log_h + 1)
         roof = None
         if dom:
             cnt, ms = per_kernel[dom]
@@ -579,7 +623,11 @@ def main():
             bytes_step = abc * cells_per_step  # summed over one step's launches of that kernel
             achieved = bytes_step / (ms / args.steps * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=traffic_db.get(dom), traffic_unit=f"bytes per step (PMC, profiles/{tprof_name})" if tprof else None,
+                        traffic=(live["fetch_bytes_per_launch"] + 2 * wl["H"] * (8 * 4 + 2 * 32)) if live else traffic_db.get(dom),
+                        traffic_unit=("bytes per step: FETCH_SIZE (KiB x 1024 x 2, the gfx950 correction for wide coalesced reads) of the trace-tree launch, measured "
+                                      "IN THIS RUN by a rocprofv3 --pmc pass of tools/leaf_hash_once.py, + the algorithmic bytes of the 8-column "
+                                      "quotient-tree launch and of the digests written" if live else
+                                      f"bytes per step (PMC, profiles/{tprof_name})" if tprof else None),
                         algorithmic_bytes_per_step=bytes_step, avg_launch_ms=ms / cnt, launches_per_step=cnt / args.steps,
                         algo_bytes_per_cell=abc)
             # the whole step against SURVEY 8d's headline figure: 48 algorithmic bytes per main cell
@@ -593,6 +641,10 @@ def main():
                 vm = load_profile_json("r02_valu_model.json")
                 perms = 2 * wl["H"] * ((wl["W"] + 7) // 8) + 2 * wl["H"]  # trace LDE rows + 8-col quotient LDE rows
                 perms += 2 * wl["H"] * ((perm_cols + 7) // 8)            # + the permutation matrix's rows (--logup)
+                if vm and live:  # instructions per permutation as counted in this run (SQ_INSTS_VALU of the trace-tree launch)
+                    vm = dict(vm, valu_instr_per_perm=live["valu_instr_per_launch"] / (2 * wl["H"] * ((wl["W"] + 7) // 8) / 64),
+                              source="SQ_INSTS_VALU of leaf_hash_kernel measured in this run (rocprofv3 --pmc pass of tools/leaf_hash_once.py); issue cost "
+                                     "from profiles/r02_microbench_opcodes.txt via profiles/r02_valu_model.json")
                 if vm and vm.get("valu_instr_per_perm") and vm.get("cycles_per_wave_instr"):
                     wave_instr = perms * vm["valu_instr_per_perm"] / 64
                     peak = 1024 * 2.4e9 / vm["cycles_per_wave_instr"]  # SIMDs x clock / measured cycles per wave instruction of this mix
@@ -600,7 +652,7 @@ def main():
                     roof["valu"] = dict(permutations_per_step=perms, valu_instr_per_perm=vm["valu_instr_per_perm"],
                                         cycles_per_wave_instr=vm["cycles_per_wave_instr"],
                                         achieved_G_wave_instr_s=rate / 1e9, peak_G_wave_instr_s=peak / 1e9, frac=rate / peak,
-                                        source="profiles/r02_valu_model.json: " + vm.get("source", ""),
+                                        source=(vm.get("source", "") if live else "profiles/r02_valu_model.json: " + vm.get("source", "")),
                                         mfma="utilisation 0 by design; measured alternative in profiles/r02_microbench_mfma_mds.txt")
                 else:
                     roof["valu"] = None

@@ -44,6 +44,14 @@ def test_default_line_has_the_contract_fields():
     ms = d["multi_segment"]
     assert ms["shape"] == "C4" and ms["scaling"] == "strong" and ms["n_segments"] == 8 and ms["airs_per_segment"] == 29
     assert ms["value"] > 0 and ms["proof_bytes_per_segment"] > 0 and ms["segments_on_rank0"] == 8
+    # the dominant kernel's HBM bytes and VALU instructions are measured in the run itself (two rocprofv3 --pmc passes)
+    if r["kernel"] == "leaf_hash_kernel":
+        import shutil
+        if shutil.which("rocprofv3"):
+            lde_bytes = 2 * d["config"]["rows"] * d["config"]["cols"] * 4
+            assert r["traffic"] is not None and "IN THIS RUN" in r["traffic_unit"]
+            assert 0.5 * lde_bytes < r["traffic"] < 2.0 * lde_bytes  # the kernel reads the LDE matrix once
+            assert r["valu"] and "measured in this run" in r["valu"]["source"] and 2500 < r["valu"]["valu_instr_per_perm"] < 6000
     # no per-kernel HBM fraction for the quotient kernel (it reads only the referenced columns)
     assert "quotient_kernel" not in d["roofline_by_kernel"]
 
