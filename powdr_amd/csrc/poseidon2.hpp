@@ -8,8 +8,8 @@
 // The state is held as SIGNED representatives (babybear.hpp, "signed representatives"): a signed Montgomery reduction
 // needs no conditional subtraction, so x^7 is 4 products x 3 instructions = 12 (the unsigned form needs 14 to 18), the
 // fifteen passive words of a partial round cost 3 instructions each, and the linear layers are sums in signed 64-bit
-// accumulators (v_mad_i64_i32: one instruction per term or per small-constant multiply-add) with one 3-instruction
-// reduction per output. Per permutation 3 697 VALU instructions (PMC; the first version of round 1 took 7 089); every
+// accumulators (v_mad_i64_i32: one instruction per term or per small-constant multiply-add) with one 2-instruction
+// Montgomery reduction per output (per-stage scale factors ride in the constant tables, see Params). Per permutation 3 697 VALU instructions (PMC; the first version of round 1 took 7 089); every
 // range the code relies on is computed exactly by tools/poseidon2_bounds.py and exercised by field_selftest.hpp.
 // The MDS layer is not a dense contraction worth an MFMA (measured: DESIGN.md 3.4).
 #pragma once
@@ -51,8 +51,8 @@ struct Params {
     // all times the scale of the layer's inputs
     int64_t ext_fold[8][16];
     int32_t entry_c;         // int_rc[0] at the scale the first half ends in: added to s_0 before the first partial round
-    // partial round r (internal_layer): s_0 leaves its S-box at scale lambda_in^7, the other words are at lambda_in, all leave
-    // at lambda_out (round 0: first-half scale -> second-half scale; then lambda_in = lambda_out)
+    // partial rounds (internal_layer): s_0 leaves its S-box at scale lambda_in^7, the other words are at lambda_in, all leave
+    // at lambda_out.
     // [0]: the first partial round (first-half scale -> second-half scale), [1]: the other twelve (lambda_in = lambda_out) — two
     // sets, so that the twelve rounds of the loop keep theirs in scalar registers
     int32_t part_kappa[2];     // lambda_in / lambda_in^7: brings s_0 to the others' scale inside the 16-term sum
@@ -196,7 +196,7 @@ PW_HD void external_layer(int32_t* s, const int64_t* fold) {
 // enters the 16-term sum through kappa = lambda / lambda^7, the sum is Montgomery-reduced (2 instructions) and re-enters
 // through rho; s_0 leaves with the constant it meets next already added (`next_c`), an S-box input again.
 // Ranges (tools/poseidon2_bounds.py): |kappa|, |rho|, |m_i| <= p / 2; |sum| < 0.74 p, |sum * rho| < 0.37 p^2; a word below
-// B p in magnitude gives (0.37 + B / 2) p^2 / 2^32 + p / 2, fixed point B = 0.88; every product stays below 0.9 p^2 (the
+// B p in magnitude gives (0.37 + B / 2) p^2 / 2^32 + p / 2, at most 0.91 p; every product stays below 0.9 p^2 (the
 // reduction takes 1.209 p^2).
 // LAST: the last partial round also adds the constants of the external round that follows (`exit_c`, Params::exit_fold).
 template <bool LAST>
