@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 namespace pw {
@@ -274,7 +275,8 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
     }
 }
 
-template <bool DIF, int LOGT, bool EXPAND>
+// TWT: `tw` is the group's twiddle TABLE (tile-invariant groups, see group_twiddles) instead of the transform's root table
+template <bool DIF, int LOGT, bool EXPAND, bool TWT = false>
 __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                            size_t in_stride, size_t out_stride, GroupParams gp,
                                                            const uint32_t* __restrict__ tw,
@@ -289,13 +291,13 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     im.n_tiles = (size_t)gp.n_tiles;
     const uint32_t* src = in + (size_t)blockIdx.y * in_stride;
     uint32_t* dst = out + (size_t)blockIdx.y * out_stride;
-    uint32_t tw_base = load_twiddle_base<DIF>(im, gp, 0, 0, tid, tw);
+    uint32_t tw_base = TWT ? 0u : load_twiddle_base<DIF>(im, gp, 0, 0, tid, tw);
     for (int r = 0; r < gp.n_rounds; ++r) {
         switch (gp.logr[r]) {
-            case 1: run_round<DIF, 1, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
-            case 2: run_round<DIF, 2, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
-            case 3: run_round<DIF, 3, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
-            default: run_round<DIF, 4, EPT, EXPAND>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            case 1: run_round<DIF, 1, EPT, EXPAND, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            case 2: run_round<DIF, 2, EPT, EXPAND, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            case 3: run_round<DIF, 3, EPT, EXPAND, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            default: run_round<DIF, 4, EPT, EXPAND, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
         }
         if (r + 1 < gp.n_rounds) __syncthreads();  // the next round reads what this round wrote
     }
@@ -468,6 +470,53 @@ std::vector<GroupParams> plan_groups(bool dif, int n, int first, int& logt_out, 
     return out;
 }
 
+// Twiddle table of ONE tile-invariant stage group (lowbits == c: the group's factors depend on the tile-local index only —
+// the last stages of an inverse / the first stages of a forward transform). Per round [stage-major twiddle index j <
+// 2^logr - 1][g < 2^rb]: the roots of order 2^(rb + logr) to the power g, times the constant 2^(q+1)-th roots of the stage.
+void append_group_table(std::vector<uint32_t>& h, const GroupParams& gp, bool dif, unsigned* offs, size_t base) {
+    const uint32_t w16 = field::root_of_unity(4), w16i = bb::inv(w16);
+    uint32_t roots[8];
+    { uint32_t a = bb::R_MOD_P; for (int r = 0; r < 8; ++r) { roots[r] = a; a = bb::mul(a, dif ? w16i : w16); } }
+    for (int r = 0; r < gp.n_rounds; ++r) {
+        const int rb = gp.rb[r], logr = gp.logr[r];
+        offs[r] = (unsigned)(h.size() - base);
+        const size_t G = (size_t)1 << rb, J = ((size_t)1 << logr) - 1;
+        h.resize(h.size() + J * G);
+        uint32_t* tab = h.data() + base + offs[r];
+        uint32_t om = field::root_of_unity(rb + logr);
+        if (dif) om = bb::inv(om);
+        uint32_t bt = bb::R_MOD_P;  // om^g
+        for (size_t g = 0; g < G; ++g) {
+            uint32_t bq[4];
+            bq[logr - 1] = bt;
+            for (int q = logr - 2; q >= 0; --q) bq[q] = bb::sqr(bq[q + 1]);
+            for (int q = 0; q < logr; ++q)
+                for (int rr = 0; rr < (1 << q); ++rr)
+                    tab[(((size_t)1 << q) - 1 + rr) * G + g] = rr == 0 ? bq[q] : bb::mul(bq[q], roots[rr << (3 - q)]);
+            bt = bb::mul(bt, om);
+        }
+    }
+}
+struct GroupTwiddles { uint32_t* d = nullptr; unsigned off[4] = {0, 0, 0, 0}; };
+std::map<std::tuple<int, int, int, int>, GroupTwiddles> g_group_tw;  // (device, dif, c, k)
+// nullptr: the group is not tile-invariant (or the table could not be built): the kernel derives its twiddles
+const GroupTwiddles* group_twiddles(const GroupParams& gp, bool dif) {
+    if (gp.lowbits != gp.c || getenv("POWDR_NTT_NO_TABLES")) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    const auto key = std::make_tuple(device, dif ? 1 : 0, gp.c, gp.k);
+    auto it = g_group_tw.find(key);
+    if (it != g_group_tw.end()) return &it->second;
+    GroupTwiddles gt;
+    std::vector<uint32_t> h;
+    append_group_table(h, gp, dif, gt.off, 0);
+    if (h.empty()) return nullptr;
+    if (hipMalloc(&gt.d, h.size() * 4) != hipSuccess) return nullptr;
+    if (hipMemcpy(gt.d, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;  // synchronous: published complete
+    return &g_group_tw.emplace(key, gt).first->second;
+}
+
 template <bool DIF>
 void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n,
                 int first_stage, const uint32_t* tw, const uint32_t* expand_scale_br, const char* name) {
@@ -481,13 +530,16 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
         const size_t tiles = (size_t)1 << (n - g.B);
         const size_t per_wg = (size_t)1 << (logt - g.B);
         const unsigned wgs = (unsigned)((tiles + per_wg - 1) / per_wg);
+        const GroupTwiddles* gt = group_twiddles(g, DIF);  // tile-invariant groups read their twiddles from a table
+        if (gt) for (int r = 0; r < 4; ++r) g.twt_off[r] = gt->off[r];
         for (uint32_t c0 = 0; c0 < cols; c0 += 65535u) {
             uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;
             ScopedKernelTimer t(name);
             const uint32_t* s_ = src + (size_t)c0 * src_stride;
             uint32_t* d_ = out + (size_t)c0 * out_stride;
             dim3 grid(wgs, cc), block(kBlock);
-#define PW_LAUNCH_NTT(LT, EX) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, EX>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br)
+#define PW_LAUNCH_NTT(LT, EX) do { if (gt) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, EX, true>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, gt->d, expand_scale_br); \
+                                   else hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, EX, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br); } while (0)
             if (logt == 13) { if (expand) PW_LAUNCH_NTT(13, true); else PW_LAUNCH_NTT(13, false); }
             else            { if (expand) PW_LAUNCH_NTT(12, true); else PW_LAUNCH_NTT(12, false); }
 #undef PW_LAUNCH_NTT
@@ -574,33 +626,9 @@ const FusedTwiddles* fused_twiddles(int ka, const GroupParams& ga, const GroupPa
     if (it != g_fused_tw.end()) return &it->second;
     FusedTwiddles ft;
     std::vector<uint32_t> h;
-    auto build = [&](const GroupParams& gp, bool dif, unsigned* offs, size_t base) {
-        const uint32_t w16 = field::root_of_unity(4), w16i = bb::inv(w16);
-        uint32_t roots[8];
-        { uint32_t a = bb::R_MOD_P; for (int r = 0; r < 8; ++r) { roots[r] = a; a = bb::mul(a, dif ? w16i : w16); } }
-        for (int r = 0; r < gp.n_rounds; ++r) {
-            const int rb = gp.rb[r], logr = gp.logr[r];
-            offs[r] = (unsigned)(h.size() - base);
-            const size_t G = (size_t)1 << rb, J = ((size_t)1 << logr) - 1;
-            h.resize(h.size() + J * G);
-            uint32_t* tab = h.data() + base + offs[r];
-            uint32_t om = field::root_of_unity(rb + logr);
-            if (dif) om = bb::inv(om);
-            uint32_t bt = bb::R_MOD_P;  // om^g
-            for (size_t g = 0; g < G; ++g) {
-                uint32_t bq[4];
-                bq[logr - 1] = bt;
-                for (int q = logr - 2; q >= 0; --q) bq[q] = bb::sqr(bq[q + 1]);
-                for (int q = 0; q < logr; ++q)
-                    for (int rr = 0; rr < (1 << q); ++rr)
-                        tab[(((size_t)1 << q) - 1 + rr) * G + g] = rr == 0 ? bq[q] : bb::mul(bq[q], roots[rr << (3 - q)]);
-                bt = bb::mul(bt, om);
-            }
-        }
-    };
-    build(ga, true, ft.dif_off, 0);
+    append_group_table(h, ga, true, ft.dif_off, 0);
     ft.dit_base = h.size();
-    build(gd, false, ft.dit_off, ft.dit_base);
+    append_group_table(h, gd, false, ft.dit_off, ft.dit_base);
     if (hipMalloc(&ft.d, h.size() * 4) != hipSuccess) return nullptr;
     if (hipMemcpy(ft.d, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;  // synchronous: published complete
     return &g_fused_tw.emplace(std::make_pair(device, ka), ft).first->second;
