@@ -41,7 +41,8 @@ namespace pw {
 namespace {
 
 constexpr int kBlock = 256;
-static int kStridedC = 4;  // 2^c neighbouring elements ride along in strided tiles (4: 64-byte segments)
+// 2^c neighbouring elements ride along in strided tiles: 64-byte segments (c = 4) up to 2^17 rows, 128-byte ones (c = 5) from
+// 2^18 rows on, where the strided passes run at 3.5 TB/s with 64-byte segments (profiles/r02_bench_ntt.txt); POWDR_NTT_C forces one
 
 __constant__ uint32_t c_roots16[2][8];  // [0]: w16^r forward, [1]: inverse (Montgomery), r < 8
 
@@ -421,6 +422,7 @@ const Tables* tables(int n) {
 // of stages instead of greedy-full groups followed by a short one.
 std::vector<GroupParams> plan_groups(bool dif, int n, int first, int& logt_out, int end = -1, bool balance = false) {
     std::vector<GroupParams> out;
+    int kStridedC = (n - (dif ? 0 : 1)) >= 18 ? 5 : 4;  // n = log2 of the transform: the LDE's forward half has one bit more
     if (const char* e = getenv("POWDR_NTT_C")) { int v = atoi(e); if (v >= 0 && v <= 6) kStridedC = v; }
     if (end < 0) end = n;
     const int total = end - first;

@@ -159,10 +159,10 @@ int lde_matrix(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_
         const uint32_t pc = (uint32_t)(cols - c0 < L.panel_cols ? cols - c0 : L.panel_cols);
         // Fused schedule (three passes, the coefficient array never touches HBM) where it measured faster than the four-pass
         // one; both read the twiddles of their contiguous stages from tables (profiles/r02_bench_ntt.txt: 1.33x at 2^12 rows —
-        // one launch per LDE —, 1.05-1.19x at 2^15..2^21; 0.85-0.97x at 2^13, 2^14 and 2^22, where the split of the strided
+        // one launch per LDE —, 1.03-1.19x at 2^15..2^20; 0.85-0.98x at 2^13, 2^14, 2^21 and 2^22, where the split of the strided
         // stages is worse); POWDR_LDE_FUSED=0/1 forces one of them.
         const char* ef = getenv("POWDR_LDE_FUSED");
-        const bool fused = ef ? atoi(ef) != 0 : (log_h <= 12 || (log_h >= 15 && log_h <= 21));
+        const bool fused = ef ? atoi(ef) != 0 : (log_h <= 12 || (log_h >= 15 && log_h <= 20));
         if (!fused) {
             TRY(intt_dif(m + c0 * L.H, d_coef, L.H, L.H, pc, (int)log_h));
             TRY(coset_lde_from_coeffs(d_coef, out + c0 * L.N, L.H, L.N, pc, (int)log_h));
