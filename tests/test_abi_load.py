@@ -44,3 +44,16 @@ def test_field_helpers_selftest():
     abi.lib.powdr_field_selftest.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
     for seed in (1, 2, 0xDEADBEEF):
         assert abi.lib.powdr_field_selftest(seed, 20000) == 0
+
+
+def test_poseidon2_range_analysis_holds():
+    """tools/poseidon2_bounds.py recomputes, with exact integer arithmetic, every range the signed Poseidon2 (csrc/poseidon2.hpp)
+    relies on — int32, the domain of the signed Montgomery reduction, the wide reductions — and asserts them."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    out = subprocess.run([sys.executable, str(root / "tools" / "poseidon2_bounds.py")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert "partial rounds" in out.stdout and "last layer" in out.stdout
