@@ -172,7 +172,10 @@ __global__ __launch_bounds__(kBlock) void pow_kernel(const uint32_t* __restrict_
 // its other waves by __threadfence_block() + the barrier. Replaces ~11 tiny launches per tree
 // (22 trees per proof).
 constexpr size_t kTailNodes = 2048;
-__global__ __launch_bounds__(1024) void compress_tail_kernel(uint32_t* __restrict__ digests, size_t n_first) {
+// `root_out` (optional, host-mapped pinned memory): the root also goes straight to the host, which reads it after its next
+// stream synchronisation — a 32-byte hipMemcpyAsync D2H is a blit dispatch that starts ~40 us after the kernel it follows
+// (profiles/r02_segment_gaps.txt), 27 times per proof.
+__global__ __launch_bounds__(1024) void compress_tail_kernel(uint32_t* __restrict__ digests, size_t n_first, uint32_t* __restrict__ root_out) {
     size_t off = 0;
     for (size_t n = n_first; n > 1; n >>= 1) {
         const size_t parents = n >> 1;
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(1024) void compress_tail_kernel(uint32_t* __restric
         __threadfence_block();
         __syncthreads();
     }
+    if (root_out && threadIdx.x < 8) root_out[threadIdx.x] = digests[off + threadIdx.x];
 }
 
 int hash_min_waves() {
@@ -197,7 +201,15 @@ int hash_min_waves() {
     return e ? atoi(e) : 6;
 }
 
-int build_levels(uint32_t* digests, size_t n_leaves) {
+// per host thread: 8 words of host-mapped pinned memory for the root of the tree being built
+struct RootMailbox {
+    uint32_t* host = nullptr;
+    uint32_t* dev = nullptr;
+    int device = -1;
+};
+thread_local RootMailbox g_mailbox;
+
+int build_levels(uint32_t* digests, size_t n_leaves, uint32_t* root_out = nullptr) {
     size_t off = 0;
     size_t n = n_leaves;
     for (; n > kTailNodes; n >>= 1) {
@@ -207,9 +219,9 @@ int build_levels(uint32_t* digests, size_t n_leaves) {
                            parents, digests + off + n * 8);
         off += n * 8;
     }
-    if (n > 1) {
+    if (n > 1 || root_out) {  // a single leaf is its own root: the kernel only forwards it
         ScopedKernelTimer t("compress_tail_kernel");
-        hipLaunchKernelGGL(compress_tail_kernel, dim3(1), dim3(1024), 0, stream(), digests + off, n);
+        hipLaunchKernelGGL(compress_tail_kernel, dim3(1), dim3(1024), 0, stream(), digests + off, n, root_out);
     }
     return (int)hipGetLastError();
 }
@@ -234,7 +246,25 @@ int poseidon2_upload_params() {
     return 0;
 }
 
-int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests) {
+// Host-mapped landing place of the calling thread for a tree's root (valid after the next synchronisation of the stream the
+// tree was built on); nullptr if pinned memory cannot be had — callers then copy the root with hipMemcpyAsync.
+uint32_t* merkle_root_mailbox(uint32_t** device_ptr) {
+    RootMailbox& mb = g_mailbox;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    if (mb.host && mb.device != device) { (void)hipHostFree(mb.host); mb.host = nullptr; }
+    if (!mb.host) {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return nullptr; }
+        mb.host = (uint32_t*)h; mb.dev = (uint32_t*)d; mb.device = device;
+    }
+    *device_ptr = mb.dev;
+    return mb.host;
+}
+
+int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests, uint32_t* root_out) {
     int rc = poseidon2_upload_params();
     if (rc) return rc;
     {
@@ -244,7 +274,7 @@ int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_
         else
             hipLaunchKernelGGL(leaf_hash_kernel<6>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width, col_stride, digests);
     }
-    return build_levels(digests, height);
+    return build_levels(digests, height, root_out);
 }
 
 int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, uint32_t* d_inject) {
@@ -282,14 +312,14 @@ int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, 
     return (int)hipGetLastError();
 }
 
-int merkle_commit_ext_pairs(const bb::Ext* v, size_t half, uint32_t* digests) {
+int merkle_commit_ext_pairs(const bb::Ext* v, size_t half, uint32_t* digests, uint32_t* root_out) {
     int rc = poseidon2_upload_params();
     if (rc) return rc;
     {
         ScopedKernelTimer t("ext_pair_leaf_kernel");
         hipLaunchKernelGGL(ext_pair_leaf_kernel, dim3(div_up(half, kBlock)), dim3(kBlock), 0, stream(), v, half, digests);
     }
-    return build_levels(digests, half);
+    return build_levels(digests, half, root_out);
 }
 
 int pow_grind(const uint32_t* d_state16, const uint32_t* d_pending, uint32_t in_len, uint32_t bits, uint32_t* d_best,

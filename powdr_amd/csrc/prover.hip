@@ -472,9 +472,13 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         const size_t half = (N >> l) / 2;
         bb::Ext* v = d_v + layer_off[l];
         uint32_t* dg = d_fdig + tree_off[l];
-        TRY(merkle_commit_ext_pairs(v, half, dg));
-        PW_HIP_TRY(hipMemcpyAsync(root, dg + merkle_words(half) - 8, 32, hipMemcpyDeviceToHost, st));
+        // the tree's tail kernel writes the root into host-mapped memory: no copy dispatch between the layers
+        uint32_t* d_mail = nullptr;
+        uint32_t* h_mail = merkle_root_mailbox(&d_mail);
+        TRY(merkle_commit_ext_pairs(v, half, dg, h_mail ? d_mail : nullptr));
+        if (!h_mail) PW_HIP_TRY(hipMemcpyAsync(root, dg + merkle_words(half) - 8, 32, hipMemcpyDeviceToHost, st));
         PW_HIP_TRY(hipStreamSynchronize(st));
+        if (h_mail) memcpy(root, h_mail, 32);
         put_monty(root, 8);
         ch.observe_words(root, 8);
         const bb::Ext beta = ch.sample_ext();

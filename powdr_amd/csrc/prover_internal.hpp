@@ -35,7 +35,9 @@ const uint32_t* shift_table(int n);  // s^k / 2^n (Montgomery), k < 2^n, device
 // all levels concatenated: total (2*n_leaves - 1) * 8 words. root = last 8 words.
 const p2::Params& poseidon2_params_host();
 int poseidon2_upload_params();
-int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests);
+int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests, uint32_t* root_out = nullptr);
+// the calling thread's host-mapped landing place for a root (`root_out` above is its device address); nullptr: not available
+uint32_t* merkle_root_mailbox(uint32_t** device_ptr);
 // Mixed-height commitment of a segment (oracle/stark_segment.inc `MixedTree`): by_log[k] = the columns of all matrices of
 // height 2^k (device array of device column pointers, AIR order; n_cols = 0 if there is none), k = 0..L, by_log[L] non-empty.
 // digests: levels of 2^L, 2^(L-1), ..., 1 nodes concatenated ((2^(L+1) - 1) * 8 words), level of n nodes:
@@ -46,7 +48,7 @@ struct MixedLevelCols { const uint32_t* const* d_cols; uint32_t n_cols; };
 // by ONE launch (widest level first); L <= 27.
 int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, uint32_t* d_inject);
 // leaves = hash of the 8 words (v[i], v[i + half]) of an Ext vector of length 2*half
-int merkle_commit_ext_pairs(const bb::Ext* v, size_t half, uint32_t* digests);
+int merkle_commit_ext_pairs(const bb::Ext* v, size_t half, uint32_t* digests, uint32_t* root_out = nullptr);
 inline size_t merkle_words(size_t n_leaves) { return (2 * n_leaves - 1) * 8; }
 inline size_t merkle_level_offset(size_t n_leaves, int level) {  // in words
     size_t off = 0, n = n_leaves;
