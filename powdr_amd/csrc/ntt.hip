@@ -229,15 +229,26 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
                 if (EXPAND) {
                     const size_t q0 = g0 >> 1;
                     const int qshift = gshift - 1;  // the EXPAND group has lowbits = c = 1, so gshift = rb >= 1
+                    // one test per slot, not one predicated load per element: the R loads issue back to back
+                    if (valid) {
+                        uint32_t cf[R], sc[R];
 #pragma unroll
-                    for (int rho = 0; rho < R; ++rho) {
-                        const size_t q = q0 + ((size_t)rho << qshift);
-                        x[rho] = valid ? bb::mul(src[q], scale_br[q]) : 0u;
+                        for (int rho = 0; rho < R; ++rho) { const size_t q = q0 + ((size_t)rho << qshift); cf[rho] = src[q]; sc[rho] = scale_br[q]; }
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) x[rho] = bb::mul(cf[rho], sc[rho]);
+                    } else {
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) x[rho] = 0u;
                     }
                 } else {
                     const uint32_t* ps = src + g0;
+                    if (valid) {
 #pragma unroll
-                    for (int rho = 0; rho < R; ++rho) x[rho] = valid ? ps[(size_t)rho << gshift] : 0u;
+                        for (int rho = 0; rho < R; ++rho) x[rho] = ps[(size_t)rho << gshift];
+                    } else {
+#pragma unroll
+                        for (int rho = 0; rho < R; ++rho) x[rho] = 0u;
+                    }
                 }
             }
         } else {
