@@ -1,3 +1,6 @@
+# The round's profile set in one GPU visit (gpurun -- 'bash tools/collect_profiles.sh'): bench line, rocprofv3 kernel stats of the
+# headline leg, FETCH_SIZE / WRITE_SIZE PMC passes, C4, C5, reth-shaped segment, keccak fixture -> gpurun_out/r02_*; copy what is
+# to be kept into profiles/.
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 ( timeout 900 python bench.py --steps 10 --warmup 3 ) > gpurun_out/r02_bench_c2.json 2> gpurun_out/r02_bench_c2.err

@@ -1,3 +1,4 @@
+# PMC issue counters of every kernel of one C2 step -> gpurun_out/r02_pmc_kernels_c2.txt
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -1,3 +1,4 @@
+# PMC counters (two passes) of the LogUp kernels at 2^18 rows -> gpurun_out/r02_pmc_logup_kernels.txt
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -1,3 +1,6 @@
+# Times several builds of tools/microbench_hash.hip against each other (+ PMC instruction counts). Build them first, e.g.
+#   B="hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ipowdr_amd/csrc -Iinclude tools/microbench_hash.hip"; mkdir -p tools/_hb
+#   $B -o tools/_hb/scaled; $B -DHB_MINW=8 -o tools/_hb/scaled_w8; (older variants: check out the revision, build under another name)
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/r02_microbench_hash2.txt

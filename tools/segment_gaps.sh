@@ -1,3 +1,4 @@
+# rocprofv3 --kernel-trace of bench.py --shape C5 + tools/gap_analysis.py -> gpurun_out/r02_segment_gaps.txt
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
