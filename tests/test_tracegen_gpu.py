@@ -618,3 +618,42 @@ def test_column_structured_substitutions_parity(gpu, calls, seed):
     tg.apc_tracegen(out, airs, subs, calls)
     torch.cuda.synchronize()
     assert (from_dev(out.buf) == want).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"POWDR_GATHER_SPARSE_PCT": "200"}, {"POWDR_GATHER_SPARSE": "0"}])
+@pytest.mark.parametrize("calls", [3, 700])
+def test_gather_forms_forced(gpu, monkeypatch, env, calls):
+    """The same substitutions through the cell-by-cell jobs everywhere (also where streaming would move fewer bytes: dense
+    columns, duplicate source cells, rows reaching into the next call's block) and through the streaming jobs only."""
+    torch, abi, tg = gpu
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(1000 * calls + len(env) + sum(map(len, env.values())))  # a plan of its own per case (plans are cached by content)
+    dims = [(7, 40), (5, 3), (9, 130)]
+    H = max(synth.next_pow2_or_zero(calls), 2)
+    bufs, hs, airs = [], [], []
+    for w, b in dims:
+        h = max(synth.next_pow2_or_zero(b * (calls + 1)), 4)  # room for rows that reach past the last call's block
+        src = rng.integers(0, om.P, size=w * h, dtype=np.uint32)
+        bufs.append(src); hs.append(h)
+        airs.append((to_dev(torch, src), w, h, b))
+    recs = []
+    for a, (w, b) in enumerate(dims):
+        for col in range(w):
+            dense = col % 3 == 0
+            rows = range(b) if dense else sorted(rng.choice(b + 2, size=min(b, 5), replace=False).tolist())
+            for r in rows:
+                if dense and rng.random() < 0.3:
+                    continue
+                recs.append((a, col, int(r)))
+                if rng.random() < 0.1:
+                    recs.append((a, col, int(r)))  # the same source cell twice
+    recs = [(a, c, r, i) for i, (a, c, r) in enumerate(recs)]
+    subs = np.array(recs, np.int32)[rng.permutation(len(recs))]
+    W = len(recs)
+    want = om.c_apc_tracegen(H, W, bufs, hs, [b for _, b in dims], subs, calls)
+    out = tg.DeviceMatrix.zeros(H, W)
+    tg.apc_tracegen(out, airs, subs, calls)
+    torch.cuda.synchronize()
+    assert (from_dev(out.buf) == want).all()
