@@ -271,8 +271,8 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
         int v = atoi(e);
         if (v >= 2048 && v <= 16384) kMaxTileWords = v;
     }
-    if (const char* e = getenv("POWDR_GATHER_SPARSE")) g_sparse_jobs = atoi(e) != 0;
-    if (const char* e = getenv("POWDR_GATHER_SPARSE_PCT")) { int v = atoi(e); if (v >= 10 && v <= 200) g_sparse_pct = v; }
+    { const char* e = getenv("POWDR_GATHER_SPARSE"); g_sparse_jobs = e ? atoi(e) != 0 : true; }
+    { const char* e = getenv("POWDR_GATHER_SPARSE_PCT"); const int v = e ? atoi(e) : 100; g_sparse_pct = (v >= 10 && v <= 200) ? v : 100; }
     if (const char* e = getenv("POWDR_GATHER_MIN_R")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) kMinR = v; }
     kMaxChunkJ = kMaxTileWords / kMinR - 1;
     const size_t n = subs_in.size();
