@@ -187,6 +187,14 @@ void* powdr_gpu_get_stream(void);
 void powdr_gpu_timing_enable(int enable);
 size_t powdr_gpu_timing_report(char* buf, size_t cap);
 
+/* Diagnostics: which code paths the CALLING THREAD's library calls took since the last reset — 16 counters:
+ * [0] gather jobs that fetch cell by cell, [1] that stream whole row blocks, [2] that stream row chunks (summed over the
+ * _apc_tracegen calls), [3] _apc_tracegen calls; [4] bus interactions replayed by the fixed-shape small-form kernel,
+ * [5] by the interpreter, [6] row windows of the binned histogram path, [7] bus calls that used direct atomics, [8] bus
+ * calls on plan-compiled (xbc) code; [9] launches of run-time specialised (hiprtc) expression kernels, [10] launches of
+ * their interpreter twins; the rest reserved. Parity tests use it to assert that a workload really covered a path. */
+void powdr_gpu_call_stats(uint64_t* out16, int reset);
+
 /* Library/ABI self-description for load checks. */
 const char* powdr_gpu_version(void);
 

@@ -70,6 +70,8 @@ def _load():
     lib.powdr_gpu_timing_report.argtypes = [C.c_char_p, sz]
     lib.powdr_gpu_timing_report.restype = sz
     lib.powdr_gpu_version.restype = C.c_char_p
+    lib.powdr_gpu_call_stats.argtypes = [vp, i32]
+    lib.powdr_gpu_call_stats.restype = None
     return lib
 
 
@@ -83,6 +85,18 @@ class HipError(RuntimeError):
 def check(rc: int, what: str):
     if rc != 0:
         raise HipError(f"{what} failed with hipError {rc}")
+
+
+CALL_STATS = ("gather_sparse_jobs", "gather_whole_jobs", "gather_chunk_jobs", "gather_calls", "bus_fast_interactions",
+              "bus_interpreted_interactions", "bus_binned_windows", "bus_direct_calls", "bus_xbc_calls", "jit_launches",
+              "interpreter_launches")
+
+
+def call_stats(reset: bool = False) -> dict:
+    """powdr_gpu_call_stats of the calling thread as {name: count}."""
+    a = (C.c_uint64 * 16)()
+    lib.powdr_gpu_call_stats(a, 1 if reset else 0)
+    return {n: int(a[i]) for i, n in enumerate(CALL_STATS)}
 
 
 def timing_report() -> dict:

@@ -584,6 +584,10 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
     const uint32_t n_x = use_fast ? plan->n_slow : plan->total_slots;
     chunking(use_xbc ? n_x : (uint32_t)n_interactions, xchunks, x_per_chunk);
     if (use_fast) chunking(plan->n_fast, fchunks, f_per_chunk);
+    uint64_t* stats = pw::call_stats();
+    stats[pw::kStatBusFastInteractions] += use_fast ? plan->n_fast : 0;
+    stats[pw::kStatBusInterpretedInteractions] += use_xbc ? n_x : plan->total_slots;
+    stats[pw::kStatBusXbcCalls] += use_xbc ? 1 : 0;
 
     // ---- long traces: binned path ---------------------------------------------------------------
     if (want_binned && table_bins[0] <= (1u << kItemBinBits) && table_bins[1] <= (1u << kItemBinBits)) {
@@ -605,6 +609,7 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
             p.slot_range = plan->d_slot_range;
             for (size_t row0 = 0; row0 < all_rows; row0 += window) {
                 const size_t stride = all_rows - row0 < window ? all_rows - row0 : window;
+                stats[pw::kStatBusBinnedWindows] += 1;
                 {
                     pw::ScopedKernelTimer t("apc_apply_bus_kernel");
                     if (use_fast && plan->n_fast)
@@ -641,6 +646,7 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
             return (int)hipGetLastError();
         }
     }
+    stats[pw::kStatBusDirectCalls] += 1;
     pw::ScopedKernelTimer t("apc_apply_bus_kernel");
     if (use_fast && plan->n_fast)
         hipLaunchKernelGGL(apc_apply_bus_fast_kernel<false>, dim3(row_blocks, fchunks), dim3(kBlock), 0, pw::stream(), d_output,

@@ -73,6 +73,7 @@ struct Plan {
     PlanSub* d_subs = nullptr;
     std::vector<RClass> classes;
     size_t n_jobs = 0, n_subs = 0;
+    uint32_t n_sparse = 0, n_whole = 0, n_chunk = 0;  // jobs by form (powdr_gpu_call_stats)
     // what the plan was built from: a cache hit is confirmed by comparing contents, never by the hash alone
     std::vector<Subst> key_subs;
     std::vector<int32_t> key_bsize;
@@ -381,6 +382,9 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
     plan.classes.clear();
     for (size_t i = 0; i < jorder.size(); ++i) {
         sorted[i] = jobs[jorder[i]];
+        if (sorted[i].sparse) ++plan.n_sparse;
+        else if (sorted[i].J == sorted[i].b) ++plan.n_whole;
+        else ++plan.n_chunk;
         int R = jobR[jorder[i]];
         size_t lds = (size_t)R * sorted[i].pitch * 4 + (sorted[i].sparse ? (size_t)sorted[i].J * 4 : 0);
         if (plan.classes.empty() || plan.classes.back().R != R)
@@ -453,6 +457,13 @@ static int tracegen_with_host_tables(PowdrFp* d_output, size_t H, const Original
         plan->last_use = ++g_plan_clock;
     }
 
+    {
+        uint64_t* st = pw::call_stats();
+        st[pw::kStatGatherSparseJobs] += plan->n_sparse;
+        st[pw::kStatGatherWholeJobs] += plan->n_whole;
+        st[pw::kStatGatherChunkJobs] += plan->n_chunk;
+        st[pw::kStatGatherCalls] += 1;
+    }
     pw::ScopedKernelTimer t("apc_gather_tile_kernel");
     uint32_t* out = d_output;
     for (const RClass& c : plan->classes) {

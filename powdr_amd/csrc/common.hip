@@ -22,6 +22,9 @@ struct TimedLaunch {
 };
 static std::vector<TimedLaunch> g_launches;
 
+static thread_local uint64_t g_call_stats[kStatCount] = {0};
+uint64_t* call_stats() { return g_call_stats; }
+
 hipStream_t stream() { return g_stream; }
 void set_stream(hipStream_t s) { g_stream = s; }
 bool timing_enabled() { return g_timing; }
@@ -88,6 +91,12 @@ size_t powdr_gpu_timing_report(char* buf, size_t cap) {
         buf[n] = 0;
     }
     return out.size() + 1;
+}
+
+void powdr_gpu_call_stats(uint64_t* out16, int reset) {
+    uint64_t* s = pw::call_stats();
+    if (out16) memcpy(out16, s, pw::kStatCount * sizeof(uint64_t));
+    if (reset) memset(s, 0, pw::kStatCount * sizeof(uint64_t));
 }
 
 const char* powdr_gpu_version(void) { return "powdr_gpu-mi355x 0.1 (gfx950; Fp=BabyBear Montgomery R=2^32)"; }

@@ -38,4 +38,13 @@ inline int hip_status(hipError_t e) { return (int)e; }
 
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// Which code paths the calling thread's library calls took (powdr_gpu_call_stats): parity tests assert that a workload
+// really exercised the job forms / kernels it is meant to cover instead of inferring it from sizes.
+enum CallStat : int {
+    kStatGatherSparseJobs = 0, kStatGatherWholeJobs, kStatGatherChunkJobs, kStatGatherCalls,
+    kStatBusFastInteractions, kStatBusInterpretedInteractions, kStatBusBinnedWindows, kStatBusDirectCalls,
+    kStatBusXbcCalls, kStatJitKernelLaunches, kStatInterpreterKernelLaunches, kStatCount = 16
+};
+uint64_t* call_stats();  // this thread's kStatCount counters
+
 }  // namespace pw

@@ -101,6 +101,7 @@ extern "C" {
     pub fn powdr_gpu_get_stream() -> *mut c_void;
     pub fn powdr_gpu_timing_enable(enable: c_int);
     pub fn powdr_gpu_timing_report(buf: *mut c_char, cap: usize) -> usize;
+    pub fn powdr_gpu_call_stats(out16: *mut u64, reset: c_int);
     pub fn powdr_gpu_version() -> *const c_char;
 }
 
