@@ -127,7 +127,8 @@ int powdr_apc_apply_bus_cols(const PowdrFp* d_output, size_t output_height, int 
  * before uploading them, cuda/mod.rs:272-332): `h_original_airs` / `h_subs` are host copies of what `d_original_airs`
  * (still needed: the kernels read buffer pointers and heights from it) and the Subst table contain. The reference
  * entry point has to copy both tables back and synchronise the stream twice to find its cached gather plan; this
- * one only enqueues kernels. Same result. */
+ * one only enqueues kernels. Same result. With n_airs <= 16 the records travel as kernel arguments and
+ * d_original_airs may be NULL (no device table at all); every Subst must name an AIR < n_airs. */
 int powdr_apc_tracegen_host_tables(PowdrFp* d_output, size_t output_height, const OriginalAir* d_original_airs,
                                    const OriginalAir* h_original_airs, size_t n_airs, const Subst* h_subs,
                                    size_t n_subs, int num_apc_calls);
@@ -150,7 +151,8 @@ int powdr_apc_apply_bus_host_tables(const PowdrFp* d_output, size_t output_heigh
  * the last SubstCM wins. An original chip would produce this layout by writing, per record, only the cells named by the
  * APC's (row, column) -> slot map instead of its full rows (the reference materialises full column-major traces,
  * cuda/mod.rs:228-253, of which an optimised APC keeps a few percent). Tables are HOST arrays (buffers inside are device
- * pointers); at most 16 AIRs. The reference layout stays served by _apc_tracegen. */
+ * pointers); at most 16 AIRs; a slot feeds ONE APC column (two different apc_col for the same (air, slot) are rejected with
+ * hipErrorInvalidValue: the producer writes such a cell into two slots). The reference layout stays served by _apc_tracegen. */
 typedef struct {
     const PowdrFp* buffer;  /* device: num_apc_calls x cells_per_call, Montgomery */
     int32_t cells_per_call;

@@ -199,8 +199,24 @@ int pw_lde_fused(const uint32_t* d_trace, uint32_t width, uint32_t log_height, u
  * leaves first, root last. */
 int pw_merkle_commit(const uint32_t* d_matrix, size_t height, uint32_t width, uint32_t* d_digests);
 
-/* Host-side Poseidon2 permutation used by the transcript (canonical words in/out). */
+/* Host-side Poseidon2 permutation used by the transcript (canonical words in/out). This is also the known-answer-test
+ * hook: after pw_set_poseidon2_constants a maintainer feeds it the vector of the backend's own Poseidon2 test. */
 void pw_poseidon2_permute_host(uint32_t* state16);
+
+/* The hash parameters are ONE table installed at run time. The shape is fixed (width 16, x^7, 4 + 13 + 4 rounds, external
+ * layer circ(2 M4, M4, M4, M4) with M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]], internal layer 1 1^T + diag(-2, 1, 2,
+ * 1/2, 3, 4, -1/2, -3, -4, 2^-8, 1/4, 1/8, 2^-27, -2^-8, -1/16, -2^-27) — the shape of p3-baby-bear's width-16 instance);
+ * the ROUND CONSTANTS of the reference's permutation live in the un-vendored crate p3-baby-bear 0.5.2
+ * (/root/reference/number/Cargo.toml:16-19: BABYBEAR_RC16_EXTERNAL_INITIAL / _FINAL / _INTERNAL), so the library starts with a
+ * documented placeholder stream and takes the real table here: ext_rc = 8 x 16 canonical words (the four initial rounds,
+ * then the four final ones), int_rc = 13 canonical words. Both NULL = back to the placeholder. Every derived table (folded
+ * constants, per-stage scales of the device kernels) is rebuilt; host transcript, host verifiers and the device kernels of
+ * every GPU use the new set from the next call on. Call it while no proof is in flight (the device copy is replaced after a
+ * device-wide synchronisation); proofs made under different tables do not verify against each other. Returns 0, or -1 for a
+ * word >= p / one NULL pointer. */
+int pw_set_poseidon2_constants(const uint32_t* ext_rc, const uint32_t* int_rc);
+/* The table in use (canonical words): 128 + 13 round constants and the 16 internal-diagonal entries; NULL = skip. */
+void pw_get_poseidon2_constants(uint32_t* ext_rc, uint32_t* int_rc, uint32_t* diag);
 
 #ifdef __cplusplus
 }

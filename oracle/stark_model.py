@@ -38,6 +38,18 @@ def poseidon2_constants():
     return e, i, d
 
 
+def set_poseidon2_constants(ext_rc=None, int_rc=None) -> None:
+    """Install another round-constant table in the oracle (canonical words, 8 x 16 and 13); None, None = the placeholder."""
+    if ext_rc is None:
+        rc = _lib().or_set_poseidon2_constants(None, None)
+    else:
+        e = np.ascontiguousarray(ext_rc, dtype=np.uint32).reshape(8, 16)
+        i = np.ascontiguousarray(int_rc, dtype=np.uint32).reshape(13)
+        rc = _lib().or_set_poseidon2_constants(_p(e), _p(i))
+    if rc:
+        raise ValueError("round constants must be canonical field elements")
+
+
 def root_of_unity(log_n: int) -> int:
     return int(_lib().or_root_of_unity(C.c_int(log_n)))
 

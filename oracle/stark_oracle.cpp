@@ -133,7 +133,8 @@ struct Poseidon2Constants {
         memcpy(diag, d, sizeof d);
     }
 };
-const Poseidon2Constants& p2c() { static Poseidon2Constants c; return c; }
+Poseidon2Constants& p2c_mut() { static Poseidon2Constants c; return c; }
+const Poseidon2Constants& p2c() { return p2c_mut(); }
 
 inline u32 sbox7(u32 x) { u32 x2 = or_mul(x, x), x3 = or_mul(x2, x), x4 = or_mul(x2, x2); return or_mul(x3, x4); }
 void external_layer(u32* s) {
@@ -1077,6 +1078,16 @@ void or_poseidon2_constants(uint32_t* ext_rc /*8*16*/, uint32_t* int_rc /*13*/, 
     memcpy(ext_rc, p2c().ext_rc, sizeof p2c().ext_rc);
     memcpy(int_rc, p2c().int_rc, sizeof p2c().int_rc);
     memcpy(diag, p2c().diag, sizeof p2c().diag);
+}
+/* twin of pw_set_poseidon2_constants (include/powdr_prover.h): canonical words; both NULL = the placeholder stream */
+int or_set_poseidon2_constants(const uint32_t* ext_rc /*8*16*/, const uint32_t* int_rc /*13*/) {
+    if ((ext_rc == nullptr) != (int_rc == nullptr)) return -1;
+    if (!ext_rc) { p2c_mut() = Poseidon2Constants(); return 0; }
+    for (int i = 0; i < 128; ++i) if (ext_rc[i] >= P) return -1;
+    for (int i = 0; i < 13; ++i) if (int_rc[i] >= P) return -1;
+    memcpy(p2c_mut().ext_rc, ext_rc, sizeof p2c().ext_rc);
+    memcpy(p2c_mut().int_rc, int_rc, sizeof p2c().int_rc);
+    return 0;
 }
 uint32_t or_root_of_unity(int log_n) { return root_of_unity(log_n); }
 void or_ext_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) { Ext x, y; memcpy(x.c, a, 16); memcpy(y.c, b, 16); Ext r = ext_mul(x, y); memcpy(o, r.c, 16); }

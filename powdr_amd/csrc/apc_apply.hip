@@ -354,9 +354,16 @@ std::mutex g_bus_mu;
 std::unordered_map<uint64_t, std::shared_ptr<BusPlan>> g_bus_plans;
 uint64_t g_bus_clock = 0;
 // item buffer of the binned path: one per host thread (= per launch stream)
-thread_local uint32_t* g_items = nullptr;
-thread_local size_t g_items_words = 0;
-thread_local int g_items_device = -1;  // the device the buffer lives on (a host thread may move to another GPU)
+struct ItemBuffer {
+    uint32_t* p = nullptr;
+    size_t words = 0;
+    int device = -1;  // the device the buffer lives on (a host thread may move to another GPU)
+    ~ItemBuffer() { if (p) (void)hipFree(p); }  // a host thread that exits gives its buffer back
+};
+thread_local ItemBuffer g_item_buf;
+#define g_items g_item_buf.p
+#define g_items_words g_item_buf.words
+#define g_items_device g_item_buf.device
 
 // 8 bytes per step (the bytecode of an un-optimised APC is megabytes)
 uint64_t hash_words(const void* p, size_t n, uint64_t h) {

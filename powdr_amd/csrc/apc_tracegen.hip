@@ -89,10 +89,30 @@ struct Plan {
 };
 
 constexpr int kBlock = 256;
-static int kMaxTileWords = 5 * 1024;  // <= 20 KB LDS tiles -> 8 workgroups / CU: 24.9 ms vs 35.5 ms with 48 KB tiles at C2 (POWDR_GATHER_TILE_WORDS)
 constexpr int kMaxR = 1024;
-static int kMinR = 16;  // POWDR_GATHER_MIN_R
-static int kMaxChunkJ = kMaxTileWords / kMinR - 1;  // 383
+// The planner's tuning knobs, read from the environment on every call (unset = default) and part of the plan-cache key, so a
+// plan built under other knobs is never reused.
+struct Knobs {
+    int max_tile_words = 5 * 1024;  // <= 20 KB LDS tiles -> 8 workgroups / CU: 24.9 ms vs 35.5 ms with 48 KB tiles at C2 (POWDR_GATHER_TILE_WORDS)
+    int min_r = 16;                 // POWDR_GATHER_MIN_R
+    int sparse = 1;                 // POWDR_GATHER_SPARSE=0: never use the cell-by-cell form
+    int sparse_pct = 100;           // ... which must move at most this share of the streaming forms' bytes (POWDR_GATHER_SPARSE_PCT)
+    int max_chunk_j() const { return max_tile_words / min_r - 1; }  // 319
+    bool operator==(const Knobs& o) const { return max_tile_words == o.max_tile_words && min_r == o.min_r && sparse == o.sparse && sparse_pct == o.sparse_pct; }
+    static Knobs from_env() {
+        Knobs k;
+        if (const char* e = getenv("POWDR_GATHER_TILE_WORDS")) { const int v = atoi(e); if (v >= 2048 && v <= 16384) k.max_tile_words = v; }
+        if (const char* e = getenv("POWDR_GATHER_SPARSE")) k.sparse = atoi(e) != 0;
+        if (const char* e = getenv("POWDR_GATHER_SPARSE_PCT")) { const int v = atoi(e); if (v >= 10 && v <= 200) k.sparse_pct = v; }
+        if (const char* e = getenv("POWDR_GATHER_MIN_R")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) k.min_r = v; }
+        return k;
+    }
+};
+
+// OriginalAir records handed to the kernels BY VALUE (kernel arguments) when the caller has them on the host and there are at
+// most this many: no device table to allocate, upload or keep alive across the launch.
+constexpr int kInlineAirs = 16;
+struct InlineAirs { OriginalAir a[kInlineAirs]; };
 
 __device__ __forceinline__ uint32_t fast_div(uint32_t e, uint32_t magic, uint32_t /*J*/) {
     // floor(e / J) with magic = ceil(2^32 / J): exact for e < 2^16, J < 2^16; J == 1 is magic == 0
@@ -102,7 +122,7 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t e, uint32_t magic, uint32_
 template <int R>
 __global__ __launch_bounds__(kBlock) void apc_gather_tile_kernel(
     uint32_t* __restrict__ out, size_t H, const OriginalAir* __restrict__ airs,
-    const GatherJob* __restrict__ jobs, const PlanSub* __restrict__ subs, int num_calls) {
+    const GatherJob* __restrict__ jobs, const PlanSub* __restrict__ subs, int num_calls, InlineAirs inl, int use_inl) {
     extern __shared__ uint32_t tile[];
     const GatherJob job = jobs[blockIdx.y];
     const size_t r0 = (size_t)blockIdx.x * R;
@@ -116,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void apc_gather_tile_kernel(
     }
 
     if (valid > 0) {
-        const OriginalAir air = airs[job.air];
+        const OriginalAir air = use_inl ? inl.a[job.air] : airs[job.air];
         const uint32_t* __restrict__ src =
             air.buffer + (size_t)job.col * (size_t)(uint32_t)air.height;
         const int J = job.J, b = job.b, pitch = job.pitch;
@@ -247,9 +267,15 @@ struct PlanKey {
     uint64_t hash;
     size_t n_subs;
     int device;
-    bool operator==(const PlanKey& o) const { return hash == o.hash && n_subs == o.n_subs && device == o.device; }
+    Knobs knobs;
+    bool operator==(const PlanKey& o) const { return hash == o.hash && n_subs == o.n_subs && device == o.device && knobs == o.knobs; }
 };
-struct PlanKeyHash { size_t operator()(const PlanKey& k) const { return (size_t)(k.hash ^ ((uint64_t)k.device << 56)); } };
+struct PlanKeyHash {
+    size_t operator()(const PlanKey& k) const {
+        return (size_t)(k.hash ^ ((uint64_t)k.device << 56) ^ ((uint64_t)k.knobs.max_tile_words << 20) ^ ((uint64_t)k.knobs.min_r << 8) ^
+                        ((uint64_t)k.knobs.sparse << 40) ^ ((uint64_t)k.knobs.sparse_pct << 44));
+    }
+};
 
 // Plans are shared_ptrs: a launch keeps its plan alive while another host thread evicts it from the (bounded) cache.
 constexpr size_t kMaxCachedPlans = 64;
@@ -257,25 +283,17 @@ std::mutex g_plan_mu;
 std::unordered_map<PlanKey, std::shared_ptr<Plan>, PlanKeyHash> g_plans;
 uint64_t g_plan_clock = 0;
 
-bool g_sparse_jobs = true;  // POWDR_GATHER_SPARSE=0: never use the cell-by-cell form
-int g_sparse_pct = 100;     // ... which must move at most this share of the streaming forms' bytes (POWDR_GATHER_SPARSE_PCT)
-
-int pick_R(int J) {
+int pick_R(int J, const Knobs& kn) {
     int pitch = J | 1;
     int R = kMaxR;
-    while (R > kMinR && (size_t)R * pitch > (size_t)kMaxTileWords) R >>= 1;
+    while (R > kn.min_r && (size_t)R * pitch > (size_t)kn.max_tile_words) R >>= 1;
     return R;
 }
 
-int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bsize, Plan& plan) {
-    if (const char* e = getenv("POWDR_GATHER_TILE_WORDS")) {
-        int v = atoi(e);
-        if (v >= 2048 && v <= 16384) kMaxTileWords = v;
-    }
-    { const char* e = getenv("POWDR_GATHER_SPARSE"); g_sparse_jobs = e ? atoi(e) != 0 : true; }
-    { const char* e = getenv("POWDR_GATHER_SPARSE_PCT"); const int v = e ? atoi(e) : 100; g_sparse_pct = (v >= 10 && v <= 200) ? v : 100; }
-    if (const char* e = getenv("POWDR_GATHER_MIN_R")) { int v = atoi(e); if (v == 16 || v == 32 || v == 64) kMinR = v; }
-    kMaxChunkJ = kMaxTileWords / kMinR - 1;
+int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bsize, const Knobs& kn, Plan& plan) {
+    const int max_chunk_j = kn.max_chunk_j();
+    const bool sparse_jobs = kn.sparse != 0;
+    const int sparse_pct = kn.sparse_pct;
     const size_t n = subs_in.size();
     // 1. resolve duplicate destinations like the sequential reference loop: last wins
     std::vector<uint32_t> order(n);
@@ -321,7 +339,7 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
             while (c < ge) {
                 size_t ce = c + 1;
                 int jstart = subs_in[idx[c]].row;
-                while (ce < ge && subs_in[idx[ce]].row - jstart < kMaxChunkJ &&
+                while (ce < ge && subs_in[idx[ce]].row - jstart < max_chunk_j &&
                        // do not bridge gaps that cost more than a fresh segment (128 B edge)
                        subs_in[idx[ce]].row - subs_in[idx[ce - 1]].row <= 48)
                     ++ce;
@@ -335,7 +353,7 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
             cost_chunks += (size_t)J * 4 + 128;
         }
         const int max_row = subs_in[idx[ge - 1]].row;
-        const bool whole_ok = b >= 1 && b <= kMaxChunkJ && max_row < b;
+        const bool whole_ok = b >= 1 && b <= max_chunk_j && max_row < b;
         const size_t cost_whole = (size_t)b * 4;
         // candidate C: fetch the used cells one by one — bytes per call = 64-byte sectors that hold a used row (+ one for the
         // alignment of a call's block, which shifts from call to call)
@@ -343,7 +361,7 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
         size_t cost_sparse = 64;
         for (size_t k = g; k < ge; ++k)
             if (k == g || subs_in[idx[k]].row / 16 != subs_in[idx[k - 1]].row / 16) cost_sparse += 64;
-        const bool sparse_ok = g_sparse_jobs && U <= (size_t)kMaxChunkJ && U >= 1;
+        const bool sparse_ok = sparse_jobs && U <= (size_t)max_chunk_j && U >= 1;
         auto emit = [&](size_t cb, size_t ce, int j0, int J, bool sparse = false) {
             GatherJob job;
             job.sparse = sparse ? 1 : 0; job.pad = 0;
@@ -358,10 +376,10 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
             for (size_t k = cb; k < ce; ++k)
                 psubs.push_back({subs_in[idx[k]].row, subs_in[idx[k]].apc_col});
             jobs.push_back(job);
-            jobR.push_back(pick_R(J));
+            jobR.push_back(pick_R(J, kn));
         };
         // the sparse form pays a request per cell instead of 16-byte streaming loads: it has to save a share of the bytes
-        if (sparse_ok && cost_sparse * 100 <= std::min(whole_ok ? cost_whole : (size_t)-1, cost_chunks) * (size_t)g_sparse_pct) {
+        if (sparse_ok && cost_sparse * 100 <= std::min(whole_ok ? cost_whole : (size_t)-1, cost_chunks) * (size_t)sparse_pct) {
             emit(g, ge, 0, (int)U, true);
         } else if (whole_ok && cost_whole <= cost_chunks) {
             emit(g, ge, 0, b);
@@ -405,14 +423,14 @@ int build_plan(const std::vector<Subst>& subs_in, const std::vector<int32_t>& bs
 
 template <int R>
 void launch_class(const RClass& c, uint32_t* out, size_t H, const OriginalAir* airs,
-                  const Plan& plan, int num_calls) {
+                  const Plan& plan, int num_calls, const InlineAirs& inl, int use_inl) {
     unsigned tiles = pw::div_up(H, R);
     // gridDim.y is limited to 65535 jobs per launch
     for (uint32_t j = 0; j < c.job_count; j += 65535u) {
         uint32_t cnt = std::min<uint32_t>(65535u, c.job_count - j);
         dim3 grid(tiles, cnt, 1);
         hipLaunchKernelGGL(apc_gather_tile_kernel<R>, grid, dim3(kBlock), c.lds_bytes, pw::stream(),
-                           out, H, airs, plan.d_jobs + c.job_begin + j, plan.d_subs, num_calls);
+                           out, H, airs, plan.d_jobs + c.job_begin + j, plan.d_subs, num_calls, inl, use_inl);
     }
 }
 
@@ -421,13 +439,19 @@ void launch_class(const RClass& c, uint32_t* out, size_t H, const OriginalAir* a
 // The gather proper: `subs` / `bsize` are host copies of the Subst table and of the AIRs' row_block_size; the kernels read
 // the OriginalAir records (buffer pointers, heights) from the device table.
 static int tracegen_with_host_tables(PowdrFp* d_output, size_t H, const OriginalAir* d_original_airs,
-                                     const std::vector<Subst>& subs, const std::vector<int32_t>& bsize, int num_apc_calls) {
+                                     const std::vector<Subst>& subs, const std::vector<int32_t>& bsize, int num_apc_calls,
+                                     const OriginalAir* h_airs = nullptr, size_t n_h_airs = 0) {
     const size_t n_subs = subs.size();
+    InlineAirs inl{};
+    const int use_inl = h_airs && n_h_airs <= (size_t)kInlineAirs ? 1 : 0;
+    if (use_inl) memcpy(inl.a, h_airs, n_h_airs * sizeof(OriginalAir));
+    if (!use_inl && !d_original_airs) return (int)hipErrorInvalidValue;
+    const Knobs knobs = Knobs::from_env();
     uint64_t h = fnv1a(subs.data(), n_subs * sizeof(Subst), 1469598103934665603ull);
     h = fnv1a(bsize.data(), bsize.size() * sizeof(int32_t), h);
     int device = 0;
     PW_HIP_TRY(hipGetDevice(&device));
-    const PlanKey key{h, n_subs, device};
+    const PlanKey key{h, n_subs, device, knobs};
 
     std::shared_ptr<Plan> plan;
     {
@@ -446,7 +470,7 @@ static int tracegen_with_host_tables(PowdrFp* d_output, size_t H, const Original
                 g_plans.erase(victim);
             }
             auto p = std::make_shared<Plan>();
-            int rc = build_plan(subs, bsize, *p);
+            int rc = build_plan(subs, bsize, knobs, *p);
             if (rc) return rc;
             p->key_subs = subs;
             p->key_bsize = bsize;
@@ -468,13 +492,13 @@ static int tracegen_with_host_tables(PowdrFp* d_output, size_t H, const Original
     uint32_t* out = d_output;
     for (const RClass& c : plan->classes) {
         switch (c.R) {
-            case 16: launch_class<16>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
-            case 32: launch_class<32>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
-            case 64: launch_class<64>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
-            case 128: launch_class<128>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
-            case 256: launch_class<256>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
-            case 512: launch_class<512>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
-            case 1024: launch_class<1024>(c, out, H, d_original_airs, *plan, num_apc_calls); break;
+            case 16: launch_class<16>(c, out, H, d_original_airs, *plan, num_apc_calls, inl, use_inl); break;
+            case 32: launch_class<32>(c, out, H, d_original_airs, *plan, num_apc_calls, inl, use_inl); break;
+            case 64: launch_class<64>(c, out, H, d_original_airs, *plan, num_apc_calls, inl, use_inl); break;
+            case 128: launch_class<128>(c, out, H, d_original_airs, *plan, num_apc_calls, inl, use_inl); break;
+            case 256: launch_class<256>(c, out, H, d_original_airs, *plan, num_apc_calls, inl, use_inl); break;
+            case 512: launch_class<512>(c, out, H, d_original_airs, *plan, num_apc_calls, inl, use_inl); break;
+            case 1024: launch_class<1024>(c, out, H, d_original_airs, *plan, num_apc_calls, inl, use_inl); break;
             default: return (int)hipErrorInvalidValue;
         }
     }
@@ -490,6 +514,7 @@ static int check_tables(const std::vector<Subst>& subs, size_t n_airs_known, int
     if (n_airs_known && (size_t)max_air >= n_airs_known) return (int)hipErrorInvalidValue;
     return 0;
 }
+constexpr size_t kAirCountUnknown = 0;  // _apc_tracegen: the table's length is not part of the reference ABI
 
 extern "C" int _apc_tracegen(PowdrFp* d_output, size_t output_height,
                              const OriginalAir* d_original_airs, const Subst* d_subs,
@@ -507,7 +532,7 @@ extern "C" int _apc_tracegen(PowdrFp* d_output, size_t output_height,
     PW_HIP_TRY(hipMemcpyAsync(subs.data(), d_subs, n_subs * sizeof(Subst), hipMemcpyDeviceToHost, pw::stream()));
     PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
     int max_air = -1;
-    if (int rc = check_tables(subs, 0, max_air)) return rc;
+    if (int rc = check_tables(subs, kAirCountUnknown, max_air)) return rc;
     std::vector<OriginalAir> airs((size_t)max_air + 1);
     PW_HIP_TRY(hipMemcpyAsync(airs.data(), d_original_airs, airs.size() * sizeof(OriginalAir), hipMemcpyDeviceToHost, pw::stream()));
     PW_HIP_TRY(hipStreamSynchronize(pw::stream()));
@@ -534,13 +559,14 @@ extern "C" int powdr_apc_tracegen_host_tables(PowdrFp* d_output, size_t output_h
     if ((size_t)num_apc_calls > H) num_apc_calls = (int)H;
     std::vector<Subst> subs(h_subs, h_subs + n_subs);
     int max_air = -1;
-    if (int rc = check_tables(subs, n_airs, max_air)) return rc;
+    if (int rc = check_tables(subs, kAirCountUnknown, max_air)) return rc;
+    if ((size_t)max_air >= n_airs) return (int)hipErrorInvalidValue;  // also n_airs == 0 with substitutions present
     std::vector<int32_t> bsize(n_airs);
     for (size_t i = 0; i < n_airs; ++i) {
         bsize[i] = h_original_airs[i].row_block_size;
         if (bsize[i] < 0) return (int)hipErrorInvalidValue;
     }
-    return tracegen_with_host_tables(d_output, H, d_original_airs, subs, bsize, num_apc_calls);
+    return tracegen_with_host_tables(d_output, H, d_original_airs, subs, bsize, num_apc_calls, h_original_airs, n_airs);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -650,7 +676,12 @@ extern "C" int powdr_apc_tracegen_callmajor(PowdrFp* d_output, size_t output_hei
             std::unordered_map<int32_t, size_t> last;
             for (size_t i = 0; i < n_subs; ++i) last[h_subs[i].apc_col] = i;
             for (size_t i = 0; i < n_subs; ++i)
-                if (last[h_subs[i].apc_col] == i) col_of[off[h_subs[i].air_index] + h_subs[i].slot] = h_subs[i].apc_col;
+                if (last[h_subs[i].apc_col] == i) {
+                    int32_t& dst = col_of[off[h_subs[i].air_index] + h_subs[i].slot];
+                    // one slot, one APC column: a producer that feeds two columns from one cell writes it into two slots
+                    if (dst >= 0 && dst != h_subs[i].apc_col) return (int)hipErrorInvalidValue;
+                    dst = h_subs[i].apc_col;
+                }
             std::vector<CMJob> jobs;
             for (size_t a = 0; a < n_airs; ++a)
                 for (int32_t s0 = 0; s0 < cells[a]; s0 += 64)

@@ -280,14 +280,18 @@ struct PowdrApc {
         std::shared_ptr<const std::vector<DevInteraction>> h_inter;
         std::shared_ptr<const std::vector<ExprSpan>> h_spans;
     };
-    std::map<size_t, Compiled> compiled;
-    // substitution tables keyed by the instr_air assignment hash
-    struct SubTables { std::vector<Subst> subs; std::vector<int32_t> air_ids, row_block; Subst* d_subs = nullptr; };
+    std::map<std::pair<int, size_t>, Compiled> compiled;  // (device, height): one process may drive several GPUs
+    // substitution tables keyed by the instr_air assignment hash (host only: the gather takes them from the host)
+    struct SubTables { std::vector<Subst> subs; std::vector<int32_t> air_ids, row_block; };
     std::map<uint64_t, SubTables> sub_tables;
-    // device copies of OriginalAir tables, keyed by content (buffer pointers, heights): immutable once uploaded, so host
-    // threads on different streams can share them — a table is never rewritten under a kernel that still reads it
-    struct AirTable { std::vector<OriginalAir> h; OriginalAir* d = nullptr; uint64_t last_use = 0; };
-    std::vector<AirTable> air_tables;
+    // OriginalAir tables reach the gather as kernel arguments (powdr_apc_tracegen_host_tables, <= 16 AIRs). Only an APC
+    // gathered from more AIRs than that needs a device copy: keyed by (device, content), immutable once uploaded, held by
+    // shared_ptr so that a launch keeps its table alive while another host thread evicts it from the bounded cache.
+    struct AirTable {
+        std::vector<OriginalAir> h; OriginalAir* d = nullptr; int device = 0; uint64_t last_use = 0;
+        ~AirTable() { if (d) (void)hipFree(d); }  // hipFree waits for the kernels already enqueued that read it
+    };
+    std::vector<std::shared_ptr<AirTable>> air_tables;
     uint64_t air_clock = 0;
     std::mutex mu;  // guards the three caches (lookups and insertions; launches run outside it)
 
@@ -296,8 +300,6 @@ struct PowdrApc {
             auto& c = kv.second;
             for (void* q : {(void*)c.d_dbc, (void*)c.d_specs, (void*)c.d_bbc, (void*)c.d_inter, (void*)c.d_spans}) if (q) (void)hipFree(q);
         }
-        for (auto& kv : sub_tables) if (kv.second.d_subs) (void)hipFree(kv.second.d_subs);
-        for (auto& t : air_tables) if (t.d) (void)hipFree(t.d);
     }
 };
 
@@ -803,8 +805,10 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
 
     // ---- OriginalAir / Subst tables (cuda/mod.rs:272-332) ----
     int rc = 0;
+    int device = 0;
+    PW_HIP_TRY(hipGetDevice(&device));
     const PowdrApc::SubTables* stb_p = nullptr;
-    const OriginalAir* d_airs = nullptr;
+    std::shared_ptr<PowdrApc::AirTable> air_table;  // only for more than 16 AIRs; alive until the launch is enqueued
     std::vector<OriginalAir> airs;
     {
         std::lock_guard<std::mutex> lk(apc->mu);
@@ -816,7 +820,6 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
             size_t n = powdr_apc_build_substitutions(apc, instr_air, nullptr, nullptr, nullptr, &n_airs);
             t.subs.resize(n); t.air_ids.resize(n_airs); t.row_block.resize(n_airs);
             powdr_apc_build_substitutions(apc, instr_air, t.subs.data(), t.air_ids.data(), t.row_block.data(), &n_airs);
-            if ((rc = upload(t.d_subs, t.subs))) return rc;
             it = apc->sub_tables.emplace(key, std::move(t)).first;
         }
         stb_p = &it->second;  // std::map nodes are stable; entries are never erased
@@ -829,30 +832,30 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
             airs[k].width = dummy[id].width; airs[k].height = dummy[id].height; airs[k].buffer = dummy[id].buffer;
             airs[k].row_block_size = stb.row_block[k];
         }
-        // the device copy of this exact table (same buffers as last segment: no copy at all)
-        PowdrApc::AirTable* at = nullptr;
-        for (auto& t : apc->air_tables)
-            if (t.h.size() == airs.size() && (airs.empty() || memcmp(t.h.data(), airs.data(), airs.size() * sizeof(OriginalAir)) == 0)) { at = &t; break; }
-        if (!at) {
-            if (apc->air_tables.size() >= 16) {  // bounded: drop the least recently used table (hipFree waits for its readers)
-                size_t v = 0;
-                for (size_t k = 1; k < apc->air_tables.size(); ++k) if (apc->air_tables[k].last_use < apc->air_tables[v].last_use) v = k;
-                if (apc->air_tables[v].d) (void)hipFree(apc->air_tables[v].d);
-                apc->air_tables.erase(apc->air_tables.begin() + (long)v);
+        if (airs.size() > 16) {
+            for (auto& t : apc->air_tables)
+                if (t->device == device && t->h.size() == airs.size() && memcmp(t->h.data(), airs.data(), airs.size() * sizeof(OriginalAir)) == 0) { air_table = t; break; }
+            if (!air_table) {
+                if (apc->air_tables.size() >= 16) {  // bounded: drop the least recently used table (a launch in flight holds its own reference)
+                    size_t v = 0;
+                    for (size_t k = 1; k < apc->air_tables.size(); ++k) if (apc->air_tables[k]->last_use < apc->air_tables[v]->last_use) v = k;
+                    apc->air_tables.erase(apc->air_tables.begin() + (long)v);
+                }
+                air_table = std::make_shared<PowdrApc::AirTable>();
+                air_table->h = airs;
+                air_table->device = device;
+                PW_HIP_TRY(hipMalloc((void**)&air_table->d, airs.size() * sizeof(OriginalAir)));
+                PW_HIP_TRY(hipMemcpy(air_table->d, airs.data(), airs.size() * sizeof(OriginalAir), hipMemcpyHostToDevice));
+                apc->air_tables.push_back(air_table);
             }
-            PowdrApc::AirTable t;
-            t.h = airs;
-            PW_HIP_TRY(hipMalloc((void**)&t.d, (airs.size() ? airs.size() : 1) * sizeof(OriginalAir)));
-            if (!airs.empty()) PW_HIP_TRY(hipMemcpy(t.d, airs.data(), airs.size() * sizeof(OriginalAir), hipMemcpyHostToDevice));
-            apc->air_tables.push_back(std::move(t));
-            at = &apc->air_tables.back();
+            air_table->last_use = ++apc->air_clock;
         }
-        at->last_use = ++apc->air_clock;
-        d_airs = at->d;
     }
     const PowdrApc::SubTables& stb = *stb_p;
-    // host copies of both tables are at hand: no device-to-host round trip to find the gather plan
-    rc = powdr_apc_tracegen_host_tables(d_output, height, d_airs, airs.data(), airs.size(), stb.subs.data(), stb.subs.size(), (int)num_calls);
+    // host copies of both tables are at hand: no device-to-host round trip to find the gather plan, and (<= 16 AIRs) no
+    // device table at all — the records travel as kernel arguments
+    rc = powdr_apc_tracegen_host_tables(d_output, height, air_table ? air_table->d : nullptr, airs.data(), airs.size(), stb.subs.data(),
+                                        stb.subs.size(), (int)num_calls);
     if (rc) return rc;
 
     // ---- derived columns + bus interactions, compiled once per height ----
@@ -860,7 +863,7 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
     // compile with column-index operands and use the *_cols entry points instead.
     const bool wide = (uint64_t)width * (uint64_t)height > 0xffffffffull;
     std::unique_lock<std::mutex> lk(apc->mu);
-    auto ct = apc->compiled.find(height);
+    auto ct = apc->compiled.find({device, height});
     if (ct == apc->compiled.end()) {
         PowdrApc::Compiled c;
         DerivedTables d = compile_derived(*apc, wide ? 1 : height);
@@ -872,7 +875,7 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
         c.h_bbc = std::make_shared<const std::vector<uint32_t>>(std::move(b.bc));
         c.h_inter = std::make_shared<const std::vector<DevInteraction>>(std::move(b.inter));
         c.h_spans = std::make_shared<const std::vector<ExprSpan>>(std::move(b.spans));
-        ct = apc->compiled.emplace(height, c).first;
+        ct = apc->compiled.emplace(std::make_pair(device, height), c).first;
     }
     const PowdrApc::Compiled c = ct->second;  // device tables are immutable once uploaded
     lk.unlock();

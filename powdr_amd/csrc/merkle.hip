@@ -206,6 +206,7 @@ struct RootMailbox {
     uint32_t* host = nullptr;
     uint32_t* dev = nullptr;
     int device = -1;
+    ~RootMailbox() { if (host) (void)hipHostFree(host); }  // worker threads (pw_prove_airs, a caller's pool) come and go
 };
 thread_local RootMailbox g_mailbox;
 
@@ -228,19 +229,48 @@ int build_levels(uint32_t* digests, size_t n_leaves, uint32_t* root_out = nullpt
 
 }  // namespace
 
+static std::mutex g_params_mu;
+
 const p2::Params& poseidon2_params_host() {
     static std::once_flag once;
-    std::call_once(once, [] { p2::generate_params(g_host_params); g_params_ready = true; });
+    std::call_once(once, [] {
+        std::lock_guard<std::mutex> lk(g_params_mu);
+        if (!g_params_ready) { p2::generate_params(g_host_params); g_params_ready = true; }
+    });
     return g_host_params;
 }
 
+// Install another set of round constants (canonical words; nullptr = the placeholder stream): host table now, every
+// device's __constant__ copy at its next use.
+int poseidon2_set_constants(const uint32_t* ext_rc128, const uint32_t* int_rc13) {
+    if ((ext_rc128 == nullptr) != (int_rc13 == nullptr)) return -1;
+    if (ext_rc128) {
+        for (int i = 0; i < 128; ++i) if (ext_rc128[i] >= bb::P) return -1;
+        for (int i = 0; i < 13; ++i) if (int_rc13[i] >= bb::P) return -1;
+    }
+    (void)poseidon2_params_host();
+    std::lock_guard<std::mutex> lk(g_params_mu);
+    p2::Params p{};
+    if (ext_rc128) {
+        for (int r = 0; r < 8; ++r) for (int i = 0; i < 16; ++i) p.ext_rc[r][i] = bb::to_monty(ext_rc128[16 * r + i]);
+        for (int r = 0; r < 13; ++r) p.int_rc[r] = bb::to_monty(int_rc13[r]);
+    } else {
+        p2::default_round_constants(p);
+    }
+    p2::derive_params(p);
+    g_host_params = p;
+    g_params_uploaded = 0;
+    return 0;
+}
+
 int poseidon2_upload_params() {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
+    std::lock_guard<std::mutex> lk(g_params_mu);
     int device = 0;
     PW_HIP_TRY(hipGetDevice(&device));
     if (device < 64 && (g_params_uploaded >> device) & 1) return 0;
-    const p2::Params& p = poseidon2_params_host();
+    if (!g_params_ready) { p2::generate_params(g_host_params); g_params_ready = true; }
+    const p2::Params& p = g_host_params;
+    PW_HIP_TRY(hipDeviceSynchronize());  // kernels in flight (any stream) still read the table being replaced
     PW_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_params), &p, sizeof(p2::Params)));  // synchronous; the current device's copy
     if (device < 64) g_params_uploaded |= 1ull << device;
     return 0;

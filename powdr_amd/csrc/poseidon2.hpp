@@ -65,8 +65,10 @@ struct Params {
     int64_t exit_fold[16];
 };
 
-// host-side generation (Montgomery form)
-inline void generate_params(Params& p) {
+// The placeholder round constants (Montgomery form): a documented splitmix64 stream. The real table of the reference's
+// permutation is EXTERNAL to its checkout (p3-baby-bear 0.5.2, /root/reference/number/Cargo.toml:16-19) and is installed at
+// run time with pw_set_poseidon2_constants (include/powdr_prover.h).
+inline void default_round_constants(Params& p) {
     uint64_t s = 0x506F736569646F6Eull;  // "Poseidon"
     auto next = [&]() -> uint32_t {
         for (;;) {
@@ -82,6 +84,12 @@ inline void generate_params(Params& p) {
     for (int r = 0; r < 8; ++r)
         for (int i = 0; i < 16; ++i) p.ext_rc[r][i] = next();
     for (int r = 0; r < 13; ++r) p.int_rc[r] = next();
+}
+
+// Everything else from ext_rc / int_rc (Montgomery words, already in `p`): the internal diagonal and the derived tables.
+// Nothing here depends on the VALUES of the round constants beyond their being field elements: they enter as centred
+// representatives (|c| <= p / 2), which is what tools/poseidon2_bounds.py assumes for every additive constant.
+inline void derive_params(Params& p) {
     auto m = [](uint32_t c) { return bb::to_monty(c); };
     auto inv2k = [&](int k) { return bb::inv(bb::pow_u32(m(2), (uint32_t)k)); };
     const uint32_t d[16] = {bb::neg(m(2)), m(1), m(2), inv2k(1), m(3), m(4), bb::neg(inv2k(1)), bb::neg(m(3)),
@@ -143,6 +151,12 @@ inline void generate_params(Params& p) {
         p.int_fold[r] = (int64_t)bb::centred((uint32_t)mulm(c, lam_second)) * (int64_t)bb::R_MOD_P;
     }
     for (int i = 0; i < 16; ++i) p.exit_fold[i] = i ? (int64_t)bb::centred((uint32_t)mulm(p.ext_rc[4][i], lam_second)) * (int64_t)bb::R_MOD_P : 0;
+}
+
+// host-side generation with the placeholder constants
+inline void generate_params(Params& p) {
+    default_round_constants(p);
+    derive_params(p);
 }
 
 // x^7 on a signed representative, |x| < 1.09 p (the rounds deliver |x| < 1.024 p): x2 = x x, x3 = x2 x, x4 = x2 x2, x7 = x3 x4, each a signed Montgomery

@@ -629,6 +629,17 @@ extern "C" int pw_merkle_commit(const uint32_t* d_matrix, size_t height, uint32_
     return merkle_commit_matrix(d_matrix, height, width, height, d_digests);
 }
 
+extern "C" int pw_set_poseidon2_constants(const uint32_t* ext_rc, const uint32_t* int_rc) {
+    return poseidon2_set_constants(ext_rc, int_rc);
+}
+
+extern "C" void pw_get_poseidon2_constants(uint32_t* ext_rc, uint32_t* int_rc, uint32_t* diag) {
+    const p2::Params& p = poseidon2_params_host();
+    if (ext_rc) for (int r = 0; r < 8; ++r) for (int i = 0; i < 16; ++i) ext_rc[16 * r + i] = bb::from_monty(p.ext_rc[r][i]);
+    if (int_rc) for (int r = 0; r < 13; ++r) int_rc[r] = bb::from_monty(p.int_rc[r]);
+    if (diag) for (int i = 0; i < 16; ++i) diag[i] = bb::from_monty(p.diag[i]);
+}
+
 extern "C" void pw_poseidon2_permute_host(uint32_t* s) {
     uint32_t m[16];
     for (int i = 0; i < 16; ++i) m[i] = bb::to_monty(s[i] % bb::P);

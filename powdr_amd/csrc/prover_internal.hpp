@@ -34,6 +34,8 @@ const uint32_t* shift_table(int n);  // s^k / 2^n (Montgomery), k < 2^n, device
 // Digest tree layout: level 0 = leaves (n_leaves x 8 words), then n_leaves/2, ... , 1;
 // all levels concatenated: total (2*n_leaves - 1) * 8 words. root = last 8 words.
 const p2::Params& poseidon2_params_host();
+// canonical words, 8 x 16 external and 13 internal round constants; both nullptr = back to the placeholder stream
+int poseidon2_set_constants(const uint32_t* ext_rc128, const uint32_t* int_rc13);
 int poseidon2_upload_params();
 int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests, uint32_t* root_out = nullptr);
 // the calling thread's host-mapped landing place for a root (`root_out` above is its device address); nullptr: not available

@@ -52,6 +52,10 @@ struct DeviceBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
+    DeviceBuf() = default;
+    DeviceBuf(const DeviceBuf&) = delete;
+    DeviceBuf& operator=(const DeviceBuf&) = delete;
+    ~DeviceBuf() { release(); }  // thread_local owners (per-thread segment contexts) give their memory back when the thread exits
 };
 
 // out[i] = arena[offsets[r] + w] for record r, word w (query answers: digests, FRI siblings)

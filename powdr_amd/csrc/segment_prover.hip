@@ -48,6 +48,14 @@ struct SegCtx {
         }
         return 0;
     }
+    // a host thread that proved segments exits: its streams, events and (through ~DeviceBuf) its device buffers go with it
+    ~SegCtx() {
+        int dev = -1;
+        if (n_side == 0 && !fork_ev) return;
+        if (hipGetDevice(&dev) != hipSuccess || dev != side_device) { (void)hipGetLastError(); return; }
+        for (int k = 0; k < n_side; ++k) { (void)hipStreamDestroy(side[k]); (void)hipEventDestroy(done_ev[k]); }
+        if (fork_ev) (void)hipEventDestroy(fork_ev);
+    }
 };
 thread_local SegCtx g_ctx;  // one per host thread (= per launch stream)
 
@@ -90,6 +98,16 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     for (size_t a = 0; a < A; ++a) {
         if (!airs[a].prover || !airs[a].d_trace || airs[a].log_height < 1 || airs[a].log_height > 26) return (int)hipErrorInvalidValue;
         if (lg && !airs[a].prover->logup) return (int)hipErrorInvalidValue;  // needs the interaction tables (pw_prover_create_logup)
+        // the per-AIR device buffers live in the prover object and the AIRs of a segment run concurrently on side streams: one
+        // prover cannot serve two AIRs of the same segment; one FRI / query phase means one configuration for all of them
+        if (airs[a].prover->cfg.num_queries != airs[0].prover->cfg.num_queries || airs[a].prover->cfg.pow_bits != airs[0].prover->cfg.pow_bits)
+            return (int)hipErrorInvalidValue;
+    }
+    {
+        std::vector<const PwProver*> seen(A);
+        for (size_t a = 0; a < A; ++a) seen[a] = airs[a].prover;
+        std::sort(seen.begin(), seen.end());
+        if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) return (int)hipErrorInvalidValue;
     }
     (void)hipGetLastError();
     hipStream_t st = stream();

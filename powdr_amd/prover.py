@@ -15,7 +15,8 @@ class PwStarkConfig(C.Structure):
 
 
 PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_logup_path", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
-                  "pw_lde_batch", "pw_lde_fused", "pw_merkle_commit", "pw_poseidon2_permute_host"]
+                  "pw_lde_batch", "pw_lde_fused", "pw_merkle_commit", "pw_poseidon2_permute_host",
+                  "pw_set_poseidon2_constants", "pw_get_poseidon2_constants"]
 
 lib.pw_prover_create.restype = C.c_void_p
 lib.pw_prover_create.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -235,6 +236,30 @@ def poseidon2_host(state) -> np.ndarray:
     s = np.ascontiguousarray(state, dtype=np.uint32).copy()
     lib.pw_poseidon2_permute_host(s.ctypes.data_as(C.c_void_p))
     return s
+
+
+lib.pw_set_poseidon2_constants.restype = C.c_int
+lib.pw_set_poseidon2_constants.argtypes = [C.c_void_p, C.c_void_p]
+lib.pw_get_poseidon2_constants.restype = None
+lib.pw_get_poseidon2_constants.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+
+
+def set_poseidon2_constants(ext_rc=None, int_rc=None) -> None:
+    """pw_set_poseidon2_constants: 8 x 16 external + 13 internal round constants (canonical); None, None = the placeholder."""
+    if ext_rc is None:
+        rc = lib.pw_set_poseidon2_constants(None, None)
+    else:
+        e = np.ascontiguousarray(ext_rc, dtype=np.uint32).reshape(8, 16)
+        i = np.ascontiguousarray(int_rc, dtype=np.uint32).reshape(13)
+        rc = lib.pw_set_poseidon2_constants(e.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise ValueError("round constants must be canonical field elements")
+
+
+def poseidon2_constants():
+    e, i, d = np.zeros((8, 16), np.uint32), np.zeros(13, np.uint32), np.zeros(16, np.uint32)
+    lib.pw_get_poseidon2_constants(e.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p))
+    return e, i, d
 
 
 class Prover:

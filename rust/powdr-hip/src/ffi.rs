@@ -275,6 +275,8 @@ extern "C" {
     pub fn pw_lde_fused(d_trace: *const u32, width: u32, log_height: u32, d_tmp: *mut u32, d_lde: *mut u32) -> c_int;
     pub fn pw_merkle_commit(d_matrix: *const u32, height: usize, width: u32, d_digests: *mut u32) -> c_int;
     pub fn pw_poseidon2_permute_host(state16: *mut u32);
+    pub fn pw_set_poseidon2_constants(ext_rc: *const u32, int_rc: *const u32) -> c_int;
+    pub fn pw_get_poseidon2_constants(ext_rc: *mut u32, int_rc: *mut u32, diag: *mut u32);
 }
 
 // --------------------------------------------------------------------------------- HIP runtime (libamdhip64), minimal

@@ -271,3 +271,52 @@ def test_two_host_threads_prove_different_segments_concurrently(gpu):
     assert not errors, errors
     for k in range(2):
         assert (results[k] == jobs[k][1]).all()
+
+
+@pytest.mark.gpu
+def test_segment_rejects_a_prover_used_twice_and_mixed_configurations(gpu):
+    """The per-AIR device buffers live in the prover object and the AIRs of a segment run on side streams: the same prover
+    for two AIRs would silently corrupt both -> hipErrorInvalidValue; so do provers of different configurations
+    (one FRI / query phase serves all AIRs)."""
+    torch, abi, prover = gpu
+    airs = synthetic_airs([("T0", 30), ("T0", 30)], seed0=5)
+    pr = [prover.Prover(a[1], a[3], a[4], num_queries=4) for a in airs]
+    t = [to_dev(torch, a[0]) for a in airs]
+    assert len(prover.prove_segment([(pr[0], t[0].data_ptr(), airs[0][2]), (pr[1], t[1].data_ptr(), airs[1][2])], logup=False)) > 0
+    with pytest.raises(abi.HipError):
+        prover.prove_segment([(pr[0], t[0].data_ptr(), airs[0][2]), (pr[0], t[1].data_ptr(), airs[1][2])], logup=False)
+    other = prover.Prover(airs[1][1], airs[1][3], airs[1][4], num_queries=5)
+    with pytest.raises(abi.HipError):
+        prover.prove_segment([(pr[0], t[0].data_ptr(), airs[0][2]), (other, t[1].data_ptr(), airs[1][2])], logup=False)
+    for p in pr + [other]:
+        p.close()
+
+
+@pytest.mark.gpu
+def test_worker_threads_return_their_device_memory(gpu):
+    """Host threads that prove a segment and exit (pw_prove_airs' workers, a caller's thread pool) must not leak their
+    per-thread contexts (pinned root mailbox, segment context buffers, streams): free HBM after 12 such threads
+    is what it was after the first."""
+    import threading
+
+    torch, abi, prover = gpu
+    airs = synthetic_airs([("T1", 3000), ("T1", 700), ("T0", 9), ("T0", 33)], seed0=90)
+    provers = [prover.Prover(a[1], a[3], a[4], num_queries=4, interactions=a[5]) for a in airs]
+    traces = [to_dev(torch, a[0]) for a in airs]
+    seg = [(pr, t.data_ptr(), a[2]) for pr, t, a in zip(provers, traces, airs)]
+    out = []
+
+    def work():
+        out.append(prover.prove_segment(seg, logup=True))
+
+    free = []
+    for k in range(12):
+        th = threading.Thread(target=work)
+        th.start()
+        th.join()
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info()[0])
+    assert all((o == out[0]).all() for o in out)
+    assert free[-1] >= free[0] - (1 << 20), f"free HBM fell from {free[0]} to {free[-1]} over 11 more worker threads"
+    for p in provers:
+        p.close()

@@ -657,3 +657,64 @@ def test_gather_forms_forced(gpu, monkeypatch, env, calls):
     tg.apc_tracegen(out, airs, subs, calls)
     torch.cuda.synchronize()
     assert (from_dev(out.buf) == want).all()
+
+
+def test_host_table_and_callmajor_argument_checks(gpu):
+    """powdr_apc_tracegen_host_tables with substitutions but n_airs = 0 (it used to skip the range check and read
+    the row-block table out of bounds), a Subst naming an AIR beyond the table, and a call-major slot that feeds two
+    different APC columns (it used to drop one silently) are rejected; the inline form (no device table, <= 16 AIRs) equals
+    the reference entry point."""
+    import ctypes as C
+
+    torch, abi, tg = gpu
+    rng = np.random.default_rng(21)
+    calls, H, w, b = 300, 512, 5, 3
+    h = synth.next_pow2_or_zero(b * calls)
+    src = rng.integers(0, om.P, size=w * h, dtype=np.uint32)
+    d_src = to_dev(torch, src)
+    subs = np.array([[0, 1, 2, 0], [0, 4, 0, 1], [0, 2, 1, 2]], np.int32)
+    want = om.c_apc_tracegen(H, 3, [src], [h], [b], subs, calls)
+    airs = (abi.OriginalAir * 1)(abi.OriginalAir(w, h, d_src.data_ptr(), b))
+    f = abi.lib.powdr_apc_tracegen_host_tables
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    out = tg.DeviceMatrix.zeros(H, 3)
+    assert f(out.ptr(), H, None, airs, 1, subs.ctypes.data, len(subs), calls) == 0  # no device table: kernel arguments
+    torch.cuda.synchronize()
+    assert (from_dev(out.buf) == want).all()
+    assert f(out.ptr(), H, None, airs, 0, subs.ctypes.data, len(subs), calls) != 0
+    bad = subs.copy()
+    bad[1, 0] = 1
+    assert f(out.ptr(), H, None, airs, 1, bad.ctypes.data, len(bad), calls) != 0
+    # call-major: slot 1 of AIR 0 named for two different columns
+    U = 4
+    buf = to_dev(torch, rng.integers(0, om.P, calls * U, dtype=np.uint32))
+    with pytest.raises(abi.HipError):
+        tg.apc_tracegen_callmajor(tg.DeviceMatrix.zeros(H, 3), [(buf, U)], np.array([[0, 1, 0], [0, 1, 2], [0, 3, 1]], np.int32), calls)
+
+
+def test_gather_knobs_are_part_of_the_plan_key(gpu, monkeypatch):
+    """the SAME tables under different planner knobs must not share a cached plan."""
+    torch, abi, tg = gpu
+    rng = np.random.default_rng(31)
+    calls, H, w, b = 2000, 2048, 4, 200
+    h = synth.next_pow2_or_zero(b * calls)
+    src = rng.integers(0, om.P, size=w * h, dtype=np.uint32)
+    d_src = to_dev(torch, src)
+    rows = np.sort(rng.choice(b, 9, replace=False))
+    subs = np.array([[0, 2, int(r), i] for i, r in enumerate(rows)], np.int32)
+    want = om.c_apc_tracegen(H, 9, [src], [h], [b], subs, calls)
+    forms = []
+    for env in ({}, {"POWDR_GATHER_SPARSE": "0"}, {}):
+        for k in ("POWDR_GATHER_SPARSE",):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = tg.DeviceMatrix.zeros(H, 9)
+        abi.call_stats(reset=True)
+        tg.apc_tracegen(out, [(d_src, w, h, b)], subs, calls)
+        torch.cuda.synchronize()
+        st = abi.call_stats()
+        forms.append((st["gather_sparse_jobs"], st["gather_whole_jobs"] + st["gather_chunk_jobs"]))
+        assert (from_dev(out.buf) == want).all()
+    assert forms[0] == forms[2] == (1, 0) and forms[1][0] == 0 and forms[1][1] >= 1, forms
