@@ -10,10 +10,20 @@
 // additive form: t = a*b; m = lo32(t) * (-p^-1); (t + m*p) >> 32 < 2p, one
 // conditional subtract. On CDNA4 this is two v_mad_u64_u32 + one v_mul_lo_u32.
 #pragma once
+#if defined(__HIPCC_RTC__)  // hiprtc (csrc/jit.hpp: run-time specialised kernels): no system headers, the runtime is built in
+using __hip_internal::int32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint8_t;
+using __hip_internal::uint32_t;
+using __hip_internal::uint64_t;
+#else
 #include <stdint.h>
+#endif
 
 #if defined(__HIPCC__)
+#if !defined(__HIPCC_RTC__)
 #include <hip/hip_runtime.h>
+#endif
 #define PW_HD __host__ __device__ __forceinline__
 #else
 #define PW_HD inline
