@@ -4,6 +4,7 @@
 #include "prover_internal.hpp"
 #include "xbc.hpp"
 #include "expr_eval.hpp"
+#include "jit_device.hpp"
 
 namespace pw {
 
@@ -35,46 +36,16 @@ __device__ __forceinline__ uint32_t eval_span(const LogupProgram& lp, uint32_t s
     return xbc::eval<kBlock, true>(lp.d_code + 2 * (size_t)off, len, m, r, stk, stride);
 }
 
-struct DenominatorSeeds {
-    int64_t s[4];   // centred(al_k) * (R mod p): the value al_k in the accumulators' domain (k = 0: without the bus)
-    uint32_t al0;
-};
-__device__ __forceinline__ DenominatorSeeds denominator_seeds(const Ext& al) {
-    DenominatorSeeds sd;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sd.s[k] = (int64_t)bb::centred(al.c[k]) * (int64_t)bb::R_MOD_P;
-    sd.al0 = al.c[0];
-    return sd;
-}
+using pwj::DenominatorSeeds;
+using pwj::denominator_seeds;
+// (the accumulation itself lives in jit_device.hpp, shared with the run-time specialised kernels)
 template <bool FAST>
 __device__ __forceinline__ Ext interaction_denominator(const LogupInteraction& it, const LogupProgram& lp, const uint32_t* __restrict__ m,
                                                        size_t stride, size_t r, uint32_t* stk, const DenominatorSeeds& sd,
                                                        const Ext* __restrict__ blpow) {
-    int64_t T[4] = {(int64_t)bb::centred(bb::add(sd.al0, it.bus_monty)) * (int64_t)bb::R_MOD_P, sd.s[1], sd.s[2], sd.s[3]};
-    uint32_t pending = 0;
-    for (uint32_t j = 0; j < it.n_args; ++j) {
-        const int32_t a = (int32_t)eval_span<FAST>(lp, it.first_span + 1 + j, m, stride, r, stk);
-        if (pending == 2) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) T[k] = bb::smul_uniform(bb::smont(T[k]), (int32_t)bb::R_MOD_P);
-            pending = 0;
-        }
-        const Ext b = blpow[j + 1];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) T[k] = bb::swide_mad_uniform(T[k], a, bb::centred(b.c[k]));
-        ++pending;
-    }
-    if (pending == 2) {  // keep the last reduction's result inside (-p, p)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) T[k] = bb::smul_uniform(bb::smont(T[k]), (int32_t)bb::R_MOD_P);
-    }
-    Ext d;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t x = (uint32_t)bb::smont(T[k]);  // in (-0.8 p, 0.8 p)
-        d.c[k] = bb::umin(x, x + bb::P);
-    }
-    return d;
+    pwj::DenominatorAcc acc(sd, it.bus_monty);
+    for (uint32_t j = 0; j < it.n_args; ++j) acc.add(eval_span<FAST>(lp, it.first_span + 1 + j, m, stride, r, stk), blpow[j + 1]);
+    return acc.result();
 }
 template <bool FAST>
 __device__ __forceinline__ uint32_t interaction_mult(const LogupInteraction& it, const LogupProgram& lp, const uint32_t* __restrict__ m,
