@@ -178,6 +178,27 @@ int pw_prover_reserve(PwProver* p, uint32_t log_height);
  * verify, so a key generator checks this once. */
 int pw_prover_max_constraint_degree(const PwProver* p);
 
+/* Run-time specialised expression kernels. The constraint and interaction programs of a prover are wave-uniform bytecode that
+ * the ahead-of-time kernels interpret; for an AIR that is proven segment after segment the library can instead emit them as
+ * straight-line HIP, compile that with hiprtc for gfx950 (translation units concurrently on host threads; hiprtc is loaded
+ * with dlopen, the library works without it) and run the code objects for the quotient and the LogUp permutation columns.
+ * Same proof words either way. By default a prover is specialised at its first proof of a trace of at least 2^18 rows
+ * (POWDR_JIT_MIN_LOG_HEIGHT), which costs seconds of host time once; POWDR_JIT=0 never, POWDR_JIT=1 at every first proof.
+ * pw_prover_specialise does it now (set-up time, like pw_prover_reserve): 0 = the prover has specialised kernels, 1 = it
+ * keeps the interpreter (no hiprtc, POWDR_JIT=0, programs that did not compile to xbc, a compiler error).
+ * pw_prover_specialised returns the state (1 specialised, 0 not tried yet, -1 interpreter only) and the number of compiled
+ * kernels, their code-object bytes and the number of code chunks (each NULL = skip). */
+int pw_prover_specialise(PwProver* p);
+int pw_prover_specialised(const PwProver* p, size_t* n_kernels, size_t* code_bytes, size_t* n_chunks);
+/* The same code generation + hiprtc compilation for an AIR given by its tables (as for pw_prover_create / _create_logup;
+ * interactions == NULL: constraints only) WITHOUT touching a GPU — hiprtc cross-compiles — so build machines and CPU test
+ * suites can check that an AIR's specialised kernels compile. Returns pw_prover_specialise's code (-2: malformed tables);
+ * err (may be NULL) receives the compiler's message. */
+int pw_jit_compile_check(uint32_t width, const uint32_t* cons_bytecode, size_t bytecode_len, const uint32_t* cons_spans, size_t n_constraints,
+                         const uint32_t* interactions, size_t n_interactions, const uint32_t* inter_spans, size_t n_inter_spans,
+                         const uint32_t* inter_bytecode, size_t inter_bytecode_len, size_t* n_kernels, size_t* code_bytes, size_t* n_chunks,
+                         char* err, size_t err_cap);
+
 /* Number of main-trace columns the prover was created for. */
 uint32_t pw_prover_width(const PwProver* p);
 

@@ -213,6 +213,60 @@ __global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* 
     for (int k = 0; k < 4; ++k) q[(size_t)k * N + j] = bb::mul(acc.c[k], zi);
 }
 
+// ---- the same quotient when the constraint / group terms come from run-time specialised kernels (jit_codegen.hpp) -----------
+// part[(c * 4 + k) * N + j]: the partial sums of the chunks; the boundary terms need sum_g q_g at rows j and j + 2: by linearity
+// of the LDE that is the LDE of the per-row sums the permutation kernels computed anyway (4 extra columns next to the
+// committed ones, `plde_sumq`), so the perm matrix is read once per group and not a second time at the next row.
+__global__ __launch_bounds__(kBlock) void quotient_logup_tail_kernel(const uint32_t* __restrict__ part, uint32_t n_chunks,
+                                                                      const uint32_t* __restrict__ plde_phi, const uint32_t* __restrict__ plde_sumq,
+                                                                      size_t N, const Ext* __restrict__ apow_tail, Ext S, uint32_t zval_even,
+                                                                      uint32_t zval_odd, uint32_t shift, uint32_t wN, uint32_t ginv,
+                                                                      uint32_t* __restrict__ q) {
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= N) return;
+    const size_t jn = (j + 2) & (N - 1);
+    Ext acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint64_t a = 0;  // < 2^32 chunks of canonical words
+        for (uint32_t c = 0; c < n_chunks; ++c) a += part[((size_t)c * 4 + k) * N + j];
+        acc.c[k] = (uint32_t)(a % bb::P);
+    }
+    const Ext phi = {{plde_phi[j], plde_phi[N + j], plde_phi[2 * N + j], plde_phi[3 * N + j]}};
+    const Ext phin = {{plde_phi[jn], plde_phi[N + jn], plde_phi[2 * N + jn], plde_phi[3 * N + jn]}};
+    const Ext sumq = {{plde_sumq[j], plde_sumq[N + j], plde_sumq[2 * N + j], plde_sumq[3 * N + j]}};
+    const Ext sumq_next = {{plde_sumq[jn], plde_sumq[N + jn], plde_sumq[2 * N + jn], plde_sumq[3 * N + jn]}};
+    const uint32_t x = bb::mul(shift, bb::pow_u32(wN, (uint32_t)j));
+    const uint32_t Z = (j & 1) ? zval_odd : zval_even;
+    const uint32_t one = bb::R_MOD_P;
+    const uint32_t is_first = bb::mul(Z, bb::inv(bb::sub(x, one)));
+    const uint32_t is_last = bb::mul(Z, bb::inv(bb::sub(x, ginv)));
+    const uint32_t is_trans = bb::sub(x, ginv);
+    acc = bb::ext_add(acc, bb::ext_mul(apow_tail[0], bb::ext_scale(bb::ext_sub(phi, sumq), is_first)));
+    acc = bb::ext_add(acc, bb::ext_mul(apow_tail[1], bb::ext_scale(bb::ext_sub(bb::ext_sub(phin, phi), sumq_next), is_trans)));
+    acc = bb::ext_add(acc, bb::ext_mul(apow_tail[2], bb::ext_scale(bb::ext_sub(phi, S), is_last)));
+    const uint32_t zi = bb::inv(Z);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[(size_t)k * N + j] = bb::mul(acc.c[k], zi);
+}
+
+// rowsum[r] = sum over the chunks of a specialised permutation kernel's partial row sums; also as four columns (the input of
+// the extra LDE columns quotient_logup_tail_kernel reads)
+__global__ __launch_bounds__(kBlock) void rowsum_combine_kernel(const uint32_t* __restrict__ part, uint32_t n_chunks, size_t H,
+                                                                 Ext* __restrict__ rowsum, uint32_t* __restrict__ cols4) {
+    const size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= H) return;
+    Ext s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint64_t a = 0;
+        for (uint32_t c = 0; c < n_chunks; ++c) a += part[((size_t)c * 4 + k) * H + r];
+        s.c[k] = (uint32_t)(a % bb::P);
+        cols4[(size_t)k * H + r] = s.c[k];
+    }
+    rowsum[r] = s;
+}
+
 // ---- DEEP with two opening points ------------------------------------------------------------------------
 // v[j] = (sum_{k<K1} g^k f_k(x_j) - sum1) / (x_j - zeta) + (sum_{k<Wp} g^(K1+k) p_k(x_j) - sum2) / (x_j - g zeta)
 __global__ __launch_bounds__(kBlock) void deep_logup_kernel(const uint32_t* __restrict__ lde, uint32_t W, const uint32_t* __restrict__ plde,
@@ -240,19 +294,39 @@ __global__ __launch_bounds__(kBlock) void deep_logup_kernel(const uint32_t* __re
 
 }  // namespace
 
-int logup_perm_trace(const uint32_t* trace, size_t H, const LogupProgram& lp, bb::Ext al, const bb::Ext* d_blpow, uint32_t* perm,
-                     bb::Ext* d_rowsum, bb::Ext* d_block_totals) {
-    {
-        ScopedKernelTimer t("logup_perm_kernel");
-        if (lp.d_forms) hipLaunchKernelGGL(logup_perm_kernel<true>, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), trace, H, lp, al, d_blpow, perm, d_rowsum);
-        else hipLaunchKernelGGL(logup_perm_kernel<false>, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), trace, H, lp, al, d_blpow, perm, d_rowsum);
-    }
+int logup_scan(const bb::Ext* d_rowsum, size_t H, bb::Ext* d_block_totals, uint32_t* phi_cols) {
     const uint32_t blocks = div_up(H, kScanChunk);
     ScopedKernelTimer t("logup_scan_kernels");
     hipLaunchKernelGGL(scan_block_totals_kernel, dim3(blocks), dim3(kBlock), 0, stream(), d_rowsum, H, d_block_totals);
     hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(64), 0, stream(), d_block_totals, blocks);
-    hipLaunchKernelGGL(scan_write_kernel, dim3(blocks), dim3(kBlock), 0, stream(), d_rowsum, H, d_block_totals,
-                       perm + (size_t)(4 * lp.n_groups) * H);
+    hipLaunchKernelGGL(scan_write_kernel, dim3(blocks), dim3(kBlock), 0, stream(), d_rowsum, H, d_block_totals, phi_cols);
+    return (int)hipGetLastError();
+}
+
+int logup_perm_trace(const uint32_t* trace, size_t H, const LogupProgram& lp, bb::Ext al, const bb::Ext* d_blpow, uint32_t* perm,
+                     bb::Ext* d_rowsum, bb::Ext* d_block_totals) {
+    {
+        ScopedKernelTimer t("logup_perm_kernel");
+        call_stats()[kStatInterpreterKernelLaunches] += 1;
+        if (lp.d_forms) hipLaunchKernelGGL(logup_perm_kernel<true>, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), trace, H, lp, al, d_blpow, perm, d_rowsum);
+        else hipLaunchKernelGGL(logup_perm_kernel<false>, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), trace, H, lp, al, d_blpow, perm, d_rowsum);
+    }
+    return logup_scan(d_rowsum, H, d_block_totals, perm + (size_t)(4 * lp.n_groups) * H);
+}
+
+int logup_rowsum_combine(const uint32_t* part, uint32_t n_chunks, size_t H, bb::Ext* d_rowsum, uint32_t* cols4) {
+    ScopedKernelTimer t("logup_rowsum_combine_kernel");
+    hipLaunchKernelGGL(rowsum_combine_kernel, dim3(div_up(H, kBlock)), dim3(kBlock), 0, stream(), part, n_chunks, H, d_rowsum, cols4);
+    return (int)hipGetLastError();
+}
+
+int quotient_logup_tail(const uint32_t* part, uint32_t n_chunks, const uint32_t* plde_phi, const uint32_t* plde_sumq, size_t N, int logN,
+                        const bb::Ext* d_apow_tail, bb::Ext S, uint32_t zval_even, uint32_t zval_odd, uint32_t* q) {
+    const uint32_t shift = bb::to_monty(field::kCosetShift), wN = field::root_of_unity(logN);
+    const uint32_t ginv = bb::inv(field::root_of_unity(logN - 1));
+    ScopedKernelTimer t("quotient_logup_tail_kernel");
+    hipLaunchKernelGGL(quotient_logup_tail_kernel, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), part, n_chunks, plde_phi, plde_sumq, N,
+                       d_apow_tail, S, zval_even, zval_odd, shift, wN, ginv, q);
     return (int)hipGetLastError();
 }
 
@@ -262,6 +336,7 @@ int quotient_eval_logup(const uint32_t* lde, const uint32_t* plde, size_t N, int
     const uint32_t shift = bb::to_monty(field::kCosetShift), wN = field::root_of_unity(logN);
     const uint32_t ginv = bb::inv(field::root_of_unity(logN - 1));
     ScopedKernelTimer t("quotient_logup_kernel");
+    call_stats()[kStatInterpreterKernelLaunches] += 1;
 #define PW_LAUNCH_QL(X, F) hipLaunchKernelGGL((quotient_logup_kernel<X, F>), dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, plde, N, \
                                             prog.d_bytecode, prog.d_spans, prog.n_constraints, lp, d_apow, al, d_blpow, S, zval_even, zval_odd, shift, wN, ginv, q)
     if (prog.is_xbc) { if (lp.d_forms) PW_LAUNCH_QL(true, true); else PW_LAUNCH_QL(true, false); }

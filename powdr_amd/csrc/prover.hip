@@ -40,9 +40,12 @@ int gather_records(const uint32_t* arena, const uint64_t* d_offsets, uint32_t wo
 using namespace pw;
 
 extern "C" void pw_prover_destroy(PwProver* p);
+extern "C" int pw_prover_specialise(PwProver* p);
+extern "C" int pw_prover_specialised(const PwProver* p, size_t* n_kernels, size_t* code_bytes, size_t* n_chunks);
 
-extern "C" PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, const uint32_t* bc, size_t bc_len,
-                                      const uint32_t* spans, size_t n_constraints) {
+// `device` = false: host tables only (pw_jit_compile_check: code generation + hiprtc need no GPU)
+static PwProver* create_prover(const PwStarkConfig* cfg, uint32_t width, const uint32_t* bc, size_t bc_len,
+                               const uint32_t* spans, size_t n_constraints, bool device) {
     if (!cfg || !width) return nullptr;
     PwProver* p = new PwProver();
     p->cfg = *cfg;
@@ -73,6 +76,8 @@ extern "C" PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, 
     const uint32_t* up_sp = ok ? xspans.data() : spans;
     const size_t up_bc_len = ok ? code.size() : bc_len;
     p->is_xbc = ok;
+    if (ok) { p->h_xcode = code; p->h_xspans = xspans; }
+    if (!device) return p;
     size_t bl = up_bc_len ? up_bc_len : 1, sl = n_constraints ? 2 * n_constraints : 1;
     if (hipMalloc(&p->d_bytecode, (bl + 2) * 4) != hipSuccess || hipMalloc(&p->d_spans, sl * 4) != hipSuccess) {
         delete p;
@@ -83,10 +88,15 @@ extern "C" PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, 
     return p;
 }
 
-extern "C" PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t width, const uint32_t* bc, size_t bc_len,
-                                            const uint32_t* spans, size_t n_constraints, const uint32_t* inter, size_t n_inter,
-                                            const uint32_t* ispans, size_t n_ispans, const uint32_t* ibc, size_t ibc_len) {
-    PwProver* p = pw_prover_create(cfg, width, bc, bc_len, spans, n_constraints);
+extern "C" PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, const uint32_t* bc, size_t bc_len,
+                                      const uint32_t* spans, size_t n_constraints) {
+    return create_prover(cfg, width, bc, bc_len, spans, n_constraints, true);
+}
+
+static PwProver* create_prover_logup(const PwStarkConfig* cfg, uint32_t width, const uint32_t* bc, size_t bc_len,
+                                     const uint32_t* spans, size_t n_constraints, const uint32_t* inter, size_t n_inter,
+                                     const uint32_t* ispans, size_t n_ispans, const uint32_t* ibc, size_t ibc_len, bool device) {
+    PwProver* p = create_prover(cfg, width, bc, bc_len, spans, n_constraints, device);
     if (!p) return nullptr;
     // interactions: {bus, n_args, first span}; spans [mult, arg0, ...] into ibc (post-fix, column operands)
     std::vector<pw::LogupInteraction> li(n_inter);
@@ -113,6 +123,7 @@ extern "C" PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t w
         }
     }
     auto up = [&](void** d, const void* h, size_t bytes) {
+        if (!device) return true;
         if (hipMalloc(d, bytes ? bytes : 4) != hipSuccess) return false;
         return !bytes || hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
@@ -129,7 +140,33 @@ extern "C" PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t w
     p->logup = true;
     p->n_inter = (uint32_t)n_inter;
     p->n_groups = (uint32_t)gstarts.size() - 1;
+    p->h_icode = std::move(code);
+    p->h_ixspans = std::move(xspans);
+    p->h_inter = std::move(li);
+    p->h_gstarts = std::move(gstarts);
     return p;
+}
+
+extern "C" PwProver* pw_prover_create_logup(const PwStarkConfig* cfg, uint32_t width, const uint32_t* bc, size_t bc_len,
+                                            const uint32_t* spans, size_t n_constraints, const uint32_t* inter, size_t n_inter,
+                                            const uint32_t* ispans, size_t n_ispans, const uint32_t* ibc, size_t ibc_len) {
+    return create_prover_logup(cfg, width, bc, bc_len, spans, n_constraints, inter, n_inter, ispans, n_ispans, ibc, ibc_len, true);
+}
+
+// Code generation + hiprtc compilation of an AIR's specialised kernels WITHOUT a GPU (hiprtc cross-compiles): what
+// pw_prover_specialise would build for a prover created from the same tables. interactions == NULL: constraints only.
+extern "C" int pw_jit_compile_check(uint32_t width, const uint32_t* bc, size_t bc_len, const uint32_t* spans, size_t n_constraints,
+                                    const uint32_t* inter, size_t n_inter, const uint32_t* ispans, size_t n_ispans, const uint32_t* ibc,
+                                    size_t ibc_len, size_t* n_kernels, size_t* code_bytes, size_t* n_chunks, char* err, size_t err_cap) {
+    const PwStarkConfig cfg{1, 0};
+    PwProver* p = inter ? create_prover_logup(&cfg, width, bc, bc_len, spans, n_constraints, inter, n_inter, ispans, n_ispans, ibc, ibc_len, false)
+                        : create_prover(&cfg, width, bc, bc_len, spans, n_constraints, false);
+    if (!p) return -2;
+    const int rc = pw_prover_specialise(p);
+    (void)pw_prover_specialised(p, n_kernels, code_bytes, n_chunks);
+    if (err && err_cap) { strncpy(err, p->jit.error.c_str(), err_cap - 1); err[err_cap - 1] = 0; }
+    pw_prover_destroy(p);
+    return rc;
 }
 
 #define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
@@ -219,9 +256,9 @@ int ensure_prove_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
     const uint32_t Wp = lg ? 4 * (n_g + 1) : 0;
     const uint32_t K = W + 2 * Wp + 8;
     const uint32_t M = nc + (lg ? n_g + 3 : 0);
-    if (lg) {
-        TRY(p->perm.ensure((size_t)Wp * H * 4));
-        TRY(p->plde.ensure((size_t)Wp * N * 4));
+    if (lg) {  // + the uncommitted per-row-sum columns of the specialised path (kJitExtraPermCols)
+        TRY(p->perm.ensure((size_t)(Wp + kJitExtraPermCols) * H * 4));
+        TRY(p->plde.ensure((size_t)(Wp + kJitExtraPermCols) * N * 4));
     }
     TRY(p->q.ensure(4 * N * 4));
     if (!lg) {
@@ -300,6 +337,8 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const uint32_t M = nc + (lg ? n_g + 3 : 0);      // folded constraints
     hipStream_t st = stream();
     TRY(poseidon2_upload_params());
+    (void)specialise_provers(&p, 1, &log_h, false);  // run-time specialised expression kernels, compiled once per prover (prover_jit.hip)
+    const bool jit = specialised(p);
 
     // ---- buffers --------------------------------------------------------------------------
     // digest arena: trace tree | quotient tree | (perm tree) | FRI trees
@@ -373,8 +412,9 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         { bb::Ext b = bb::ext_one(); for (auto& x : blpow) { x = b; b = bb::ext_mul(b, bl); } }
         PW_HIP_TRY(hipMemcpyAsync(d_blpow, blpow.data(), blpow.size() * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
         PW_HIP_TRY(hipStreamSynchronize(st));
-        TRY(logup_perm_trace(d_trace, H, lp, al, d_blpow, d_perm, d_rowsum, d_rowsum + H));
-        TRY(lde_matrix(p, L, log_h, d_perm, Wp, d_plde));
+        if (jit) TRY(logup_perm_trace_jit(p, d_trace, H, al, d_blpow, d_perm, d_rowsum, d_rowsum + H));
+        else TRY(logup_perm_trace(d_trace, H, lp, al, d_blpow, d_perm, d_rowsum, d_rowsum + H));
+        TRY(lde_matrix(p, L, log_h, d_perm, Wp + (jit ? kJitExtraPermCols : 0u), d_plde));
         TRY(merkle_commit_matrix(d_plde, N, Wp, N, d_pdig));
         uint32_t sw[4];
         PW_HIP_TRY(hipMemcpyAsync(root, d_pdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
@@ -404,8 +444,12 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const uint32_t zinv_even = bb::inv(bb::sub(sH, one));
     const uint32_t zinv_odd = bb::inv(bb::sub(bb::neg(sH), one));
     ConstraintProgram prog{p->d_bytecode, p->d_spans, nc, p->is_xbc};
-    if (lg)
+    if (lg && jit)
+        TRY(quotient_eval_logup_jit(p, d_lde, d_plde, N, logN, d_apow, al, d_blpow, S, bb::sub(sH, one), bb::sub(bb::neg(sH), one), d_q));
+    else if (lg)
         TRY(quotient_eval_logup(d_lde, d_plde, N, logN, prog, lp, d_apow, al, d_blpow, S, bb::sub(sH, one), bb::sub(bb::neg(sH), one), d_q));
+    else if (jit && nc)
+        TRY(quotient_eval_jit(p, d_lde, N, d_apow, zinv_even, zinv_odd, d_q));
     else
         TRY(quotient_eval(d_lde, N, prog, d_apow, zinv_even, zinv_odd, d_q, p->qpart.as<uint32_t>(), quotient_chunks(N, nc)));
     TRY(intt_dif(d_q, d_q, N, N, 4, logN));

@@ -73,6 +73,8 @@ int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, 
                   uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q, uint32_t* part, uint32_t n_chunks);
 // evaluate all constraints on all trace rows; d_first_and_count[0] = min(row * nc + c) over violations
 // (caller initialises to ~0), [1] = number of violations
+// q = (sum of n_chunks partial sums) * zinv, partial sums as quotient_eval leaves them in `part`
+int quotient_combine(const uint32_t* part, uint32_t n_chunks, size_t N, uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q);
 int check_constraints(const uint32_t* trace, size_t H, const ConstraintProgram& prog, unsigned long long* d_first_and_count);
 // chunk coefficients from the unscaled DIF-iNTT of q over N = 2H points:
 // out[(4*ch + k)*H + q'] = cbr[k*N + 2q' + ch] * s^-(bitrev(q') + ch*H) / 2   (H-scaled bit-reversed coefficients)
@@ -115,6 +117,13 @@ struct LogupProgram {
 // perm (4(n_groups+1) columns x H): q_g coordinates then phi; d_rowsum: H Ext scratch; d_block_totals: H/4096+1 Ext scratch
 int logup_perm_trace(const uint32_t* trace, size_t H, const LogupProgram& lp, bb::Ext al, const bb::Ext* d_blpow, uint32_t* perm,
                      bb::Ext* d_rowsum, bb::Ext* d_block_totals);
+// the pieces of the two functions above that the run-time specialised path (prover_jit.hip) combines with its own kernels:
+// inclusive scan of the row sums into the four phi columns; sum of the chunks' partial row sums -> rowsum (+ as 4 columns);
+// partial quotient sums + boundary terms -> q
+int logup_scan(const bb::Ext* d_rowsum, size_t H, bb::Ext* d_block_totals, uint32_t* phi_cols);
+int logup_rowsum_combine(const uint32_t* part, uint32_t n_chunks, size_t H, bb::Ext* d_rowsum, uint32_t* cols4);
+int quotient_logup_tail(const uint32_t* part, uint32_t n_chunks, const uint32_t* plde_phi, const uint32_t* plde_sumq, size_t N, int logN,
+                        const bb::Ext* d_apow_tail, bb::Ext S, uint32_t zval_even, uint32_t zval_odd, uint32_t* q);
 int quotient_eval_logup(const uint32_t* lde, const uint32_t* plde, size_t N, int logN, const ConstraintProgram& prog,
                         const LogupProgram& lp, const bb::Ext* d_apow, bb::Ext al, const bb::Ext* d_blpow, bb::Ext S,
                         uint32_t zval_even, uint32_t zval_odd, uint32_t* q);

@@ -1,0 +1,171 @@
+// The prover's use of run-time specialised kernels (jit.hpp, jit_codegen.hpp): which provers get them, compilation of all
+// translation units in one concurrent batch, and the three stages that run them — quotient (constraints only), quotient with
+// the LogUp terms, LogUp permutation columns. The interpreter kernels (stark_kernels.hip, logup_kernels.hip) compute the same
+// canonical words; POWDR_JIT=0 / 1 forces either path, the tests compare proofs made with both.
+#include "prover_state.hpp"
+
+#include <cstdlib>
+#include <thread>
+
+#define PW_TRY_INT(x) do { const int _rc = (x); if (_rc) return _rc; } while (0)
+
+namespace pw {
+
+namespace {
+
+uint32_t env_u32(const char* name, uint32_t dflt, uint32_t lo, uint32_t hi) {
+    if (const char* e = getenv(name)) { const long v = atol(e); if (v >= (long)lo && v <= (long)hi) return (uint32_t)v; }
+    return dflt;
+}
+
+jit::LogupView logup_view(const PwProver* p) {
+    return jit::LogupView{p->h_inter.data(), (uint32_t)p->h_inter.size(), jit::XbcView{p->h_icode.data(), p->h_ixspans.data(), (uint32_t)(p->h_ixspans.size() / 2)},
+                          p->h_gstarts.data(), p->n_groups};
+}
+
+int launch_units(const jit::Generated& g, const std::vector<jit::ProgramPtr>& progs, size_t rows, void** args) {
+    for (size_t u = 0; u < g.units.size(); ++u) {
+        std::string err;
+        hipFunction_t f = jit::kernel(*progs[u], g.units[u].kernel.c_str(), &err);
+        if (!f) return (int)hipErrorSharedObjectInitFailed;
+        const int rc = jit::launch(f, dim3(div_up(rows, 256), g.units[u].n_chunks), dim3(256), args, stream());
+        if (rc) return rc;
+        call_stats()[kStatJitKernelLaunches] += 1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+int specialise_provers(PwProver* const* ps, size_t n, const uint32_t* log_heights, bool force) {
+    // POWDR_JIT: 0 = never, 1 = always, unset = for traces of at least 2^POWDR_JIT_MIN_LOG_HEIGHT rows (default 18: compiling
+    // costs ~0.3 ms of host time per emitted instruction, paid once per prover and amortised over its segments)
+    const char* e = getenv("POWDR_JIT");
+    const bool always = force || (e && atoi(e) == 1);
+    const uint32_t min_log = env_u32("POWDR_JIT_MIN_LOG_HEIGHT", 18, 1, 40);
+    const uint32_t chunk_cost = env_u32("POWDR_JIT_CHUNK_COST", 3500, 200, 1000000);
+    // chunks per translation unit: few enough that every compiler thread gets a unit, at most POWDR_JIT_UNIT_CHUNKS (8)
+    const uint32_t per_unit_max = env_u32("POWDR_JIT_UNIT_CHUNKS", 8, 1, 4096);
+    unsigned hw = std::thread::hardware_concurrency();
+    hw = hw > 32 ? 32 : hw < 1 ? 1 : hw;
+    auto per_unit_for = [&](size_t cost) {
+        const size_t chunks = cost / chunk_cost + 1;
+        const size_t want = (chunks + hw - 1) / hw;
+        return (uint32_t)(want < 1 ? 1 : want > per_unit_max ? per_unit_max : want);
+    };
+    std::vector<PwProver*> todo;
+    for (size_t i = 0; i < n; ++i) {
+        PwProver* p = ps[i];
+        if (!p || p->jit.state != 0) continue;
+        if (!always && (!log_heights || log_heights[i] < min_log)) continue;  // stays untried: a taller trace may come later
+        if (!jit::available() || !p->is_xbc || (p->n_constraints == 0 && !p->logup)) { p->jit.state = -1; p->jit.error = "not available"; continue; }
+        const jit::XbcView cons{p->h_xcode.data(), p->h_xspans.data(), p->n_constraints};
+        const uint32_t per_unit = per_unit_for(6 * (p->h_xcode.size() / 2 + p->h_icode.size() / 2) + 300 * (size_t)p->n_groups);
+        if (p->logup) {
+            const jit::LogupView lv = logup_view(p);
+            p->jit.quotient = jit::gen_quotient(cons, &lv, chunk_cost, per_unit);
+            p->jit.perm = jit::gen_logup_perm(lv, chunk_cost, per_unit);
+            if (p->n_groups && p->jit.perm.units.empty()) { p->jit.state = -1; p->jit.error = "code generation failed"; continue; }
+        } else {
+            p->jit.quotient = jit::gen_quotient(cons, nullptr, chunk_cost, per_unit);
+        }
+        if (p->jit.quotient.units.empty() && (p->n_constraints || p->n_groups)) { p->jit.state = -1; p->jit.error = "code generation failed"; continue; }
+        todo.push_back(p);
+    }
+    if (todo.empty()) return 0;
+    std::vector<std::string> sources;
+    for (PwProver* p : todo) {
+        for (auto& u : p->jit.quotient.units) sources.push_back(u.source);
+        for (auto& u : p->jit.perm.units) sources.push_back(u.source);
+    }
+    std::string err;
+    std::vector<jit::ProgramPtr> progs = jit::compile_all(sources, &err);
+    size_t k = 0;
+    for (PwProver* p : todo) {
+        if (progs.empty()) { p->jit.state = -1; p->jit.error = err; p->jit.quotient = {}; p->jit.perm = {}; continue; }
+        p->jit.quotient_prog.assign(progs.begin() + (long)k, progs.begin() + (long)(k + p->jit.quotient.units.size()));
+        k += p->jit.quotient.units.size();
+        p->jit.perm_prog.assign(progs.begin() + (long)k, progs.begin() + (long)(k + p->jit.perm.units.size()));
+        k += p->jit.perm.units.size();
+        for (auto& u : p->jit.quotient.units) { u.source.clear(); u.source.shrink_to_fit(); }  // the programs keep their text
+        for (auto& u : p->jit.perm.units) { u.source.clear(); u.source.shrink_to_fit(); }
+        p->jit.state = 1;
+    }
+    return 0;
+}
+
+int quotient_eval_jit(PwProver* p, const uint32_t* lde, size_t N, const bb::Ext* d_apow, uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q) {
+    const jit::Generated& g = p->jit.quotient;
+    PW_TRY_INT(p->qpart.ensure((size_t)(g.n_chunks ? g.n_chunks : 1) * 4 * N * 4));
+    uint32_t* part = p->qpart.as<uint32_t>();
+    const uint32_t* none = nullptr;
+    const bb::Ext* no_ext = nullptr;
+    bb::Ext al = bb::ext_zero();
+    uint64_t n64 = N;
+    void* args[] = {(void*)&lde, (void*)&none, (void*)&n64, (void*)&d_apow, (void*)&al, (void*)&no_ext, (void*)&part};
+    {
+        ScopedKernelTimer t("quotient_jit_kernel");
+        const int rc = launch_units(g, p->jit.quotient_prog, N, args);
+        if (rc) return rc;
+    }
+    return quotient_combine(part, g.n_chunks, N, zinv_even, zinv_odd, q);
+}
+
+int quotient_eval_logup_jit(PwProver* p, const uint32_t* lde, const uint32_t* plde, size_t N, int logN, const bb::Ext* d_apow, bb::Ext al,
+                            const bb::Ext* d_blpow, bb::Ext S, uint32_t zval_even, uint32_t zval_odd, uint32_t* q) {
+    const jit::Generated& g = p->jit.quotient;
+    PW_TRY_INT(p->qpart.ensure((size_t)(g.n_chunks ? g.n_chunks : 1) * 4 * N * 4));
+    uint32_t* part = p->qpart.as<uint32_t>();
+    uint64_t n64 = N;
+    void* args[] = {(void*)&lde, (void*)&plde, (void*)&n64, (void*)&d_apow, (void*)&al, (void*)&d_blpow, (void*)&part};
+    {
+        ScopedKernelTimer t("quotient_logup_jit_kernel");
+        const int rc = launch_units(g, p->jit.quotient_prog, N, args);
+        if (rc) return rc;
+    }
+    const uint32_t G = p->n_groups;
+    return quotient_logup_tail(part, g.n_chunks, plde + (size_t)(4 * G) * N, plde + (size_t)(4 * G + 4) * N, N, logN, d_apow + p->n_constraints + G, S,
+                               zval_even, zval_odd, q);
+}
+
+int logup_perm_trace_jit(PwProver* p, const uint32_t* trace, size_t H, bb::Ext al, const bb::Ext* d_blpow, uint32_t* perm, bb::Ext* d_rowsum,
+                         bb::Ext* d_block_totals) {
+    const jit::Generated& g = p->jit.perm;
+    const uint32_t G = p->n_groups;
+    PW_TRY_INT(p->qpart.ensure((size_t)(g.n_chunks ? g.n_chunks : 1) * 4 * H * 4));
+    uint32_t* part = p->qpart.as<uint32_t>();
+    uint64_t h64 = H;
+    void* args[] = {(void*)&trace, (void*)&h64, (void*)&al, (void*)&d_blpow, (void*)&perm, (void*)&part};
+    {
+        ScopedKernelTimer t("logup_perm_jit_kernel");
+        const int rc = launch_units(g, p->jit.perm_prog, H, args);
+        if (rc) return rc;
+    }
+    int rc = logup_rowsum_combine(part, g.n_chunks, H, d_rowsum, perm + (size_t)(4 * G + 4) * H);
+    if (rc) return rc;
+    return logup_scan(d_rowsum, H, d_block_totals, perm + (size_t)(4 * G) * H);
+}
+
+}  // namespace pw
+
+extern "C" int pw_prover_specialise(PwProver* p) {
+    if (!p) return -1;
+    PwProver* ps[1] = {p};
+    (void)pw::specialise_provers(ps, 1, nullptr, true);
+    return p->jit.state == 1 ? 0 : 1;
+}
+
+extern "C" int pw_prover_specialised(const PwProver* p, size_t* n_kernels, size_t* code_bytes, size_t* n_chunks) {
+    if (!p) return -1;
+    size_t k = 0, b = 0, c = 0;
+    if (p->jit.state == 1) {
+        k = p->jit.quotient_prog.size() + p->jit.perm_prog.size();
+        for (auto& pr : p->jit.quotient_prog) b += pw::jit::code_bytes(*pr);
+        for (auto& pr : p->jit.perm_prog) b += pw::jit::code_bytes(*pr);
+        c = p->jit.quotient.n_chunks + p->jit.perm.n_chunks;
+    }
+    if (n_kernels) *n_kernels = k;
+    if (code_bytes) *code_bytes = b;
+    if (n_chunks) *n_chunks = c;
+    return p->jit.state;
+}

@@ -2,6 +2,8 @@
 // segment): the per-AIR prover object, the host transcript, a growable device buffer. Not part of the C ABI.
 #pragma once
 #include "prover_internal.hpp"
+#include "jit_codegen.hpp"
+#include "jit.hpp"
 #include "../../include/powdr_prover.h"
 
 #include <cstring>
@@ -92,6 +94,15 @@ struct PwProver {
     pw::DeviceBuf coef, lde, digests, q, qcoef, qlde, ext_arena, misc;
     pw::DeviceBuf qpart;  // partial quotient sums when the constraint list is split over workgroup rows (short traces)
     std::vector<uint32_t> proof;
+    // host copies of the plan-compiled (xbc) programs: the source of the run-time specialised kernels (jit_codegen.hpp)
+    std::vector<uint32_t> h_xcode, h_xspans, h_icode, h_ixspans, h_gstarts;
+    std::vector<pw::LogupInteraction> h_inter;
+    struct Specialised {
+        int state = 0;  // 0: not tried, 1: ready, -1: not available (no hiprtc, POWDR_JIT=0, post-fix fallback programs, compile error)
+        pw::jit::Generated quotient, perm;
+        std::vector<pw::jit::ProgramPtr> quotient_prog, perm_prog;  // one per unit
+        std::string error;
+    } jit;
 };
 
 namespace pw {
@@ -102,4 +113,20 @@ struct CommitLayout {
 int lde_matrix(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_t* m, uint32_t cols, uint32_t* out);
 // columns per LDE panel for a 2^log_h-row matrix of `widest` columns (POWDR_PANEL_LOG_WORDS, read per call)
 size_t lde_panel_cols(size_t H, size_t widest);
+
+// ---- run-time specialised expression kernels (prover_jit.hip) ---------------------------------------------------------
+// Compile the specialised kernels of every prover in `ps` that qualifies and has none yet (all translation units of all of
+// them in ONE concurrent hiprtc batch). force: regardless of the trace height. Returns 0; failures are not errors — the
+// prover keeps using the interpreter and records why (jit.error).
+int specialise_provers(PwProver* const* ps, size_t n, const uint32_t* log_heights, bool force);
+inline bool specialised(const PwProver* p) { return p->jit.state == 1; }
+// the three stages with the specialised kernels; same contracts as quotient_eval / quotient_eval_logup / logup_perm_trace.
+// `perm` / `plde` must have room for 4 extra columns after the committed ones (the per-row sums and their LDE).
+int quotient_eval_jit(PwProver* p, const uint32_t* lde, size_t N, const bb::Ext* d_apow, uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q);
+int quotient_eval_logup_jit(PwProver* p, const uint32_t* lde, const uint32_t* plde, size_t N, int logN, const bb::Ext* d_apow, bb::Ext al,
+                            const bb::Ext* d_blpow, bb::Ext S, uint32_t zval_even, uint32_t zval_odd, uint32_t* q);
+int logup_perm_trace_jit(PwProver* p, const uint32_t* trace, size_t H, bb::Ext al, const bb::Ext* d_blpow, uint32_t* perm, bb::Ext* d_rowsum,
+                         bb::Ext* d_block_totals);
+// extra (uncommitted) columns the specialised path keeps after the 4 (groups + 1) permutation columns
+constexpr uint32_t kJitExtraPermCols = 4;
 }  // namespace pw

@@ -71,9 +71,9 @@ int ensure_air(PwProver* p, const Shape& s, bool logup, CommitLayout& Lc) {
     Lc.panel_cols = lde_panel_cols(s.H, logup ? std::max<size_t>(s.W, s.Wp) : s.W);
     TRY(p->coef.ensure(Lc.panel_cols * s.H * 4));
     TRY(p->lde.ensure((size_t)s.W * s.N * 4));
-    if (logup) {
-        TRY(p->perm.ensure((size_t)s.Wp * s.H * 4));
-        TRY(p->plde.ensure((size_t)s.Wp * s.N * 4));
+    if (logup) {  // + the uncommitted per-row-sum columns of the specialised path
+        TRY(p->perm.ensure((size_t)(s.Wp + kJitExtraPermCols) * s.H * 4));
+        TRY(p->plde.ensure((size_t)(s.Wp + kJitExtraPermCols) * s.N * 4));
     }
     TRY(p->q.ensure(4 * s.N * 4));
     if (!logup) {
@@ -112,6 +112,12 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     (void)hipGetLastError();
     hipStream_t st = stream();
     TRY(poseidon2_upload_params());
+    {   // run-time specialised expression kernels of all AIRs that qualify, compiled in one concurrent batch (prover_jit.hip)
+        std::vector<PwProver*> ps(A);
+        std::vector<uint32_t> lhs(A);
+        for (size_t a = 0; a < A; ++a) { ps[a] = airs[a].prover; lhs[a] = airs[a].log_height; }
+        (void)specialise_provers(ps.data(), A, lhs.data(), false);
+    }
     SegCtx& cx = g_ctx;
     // The per-AIR stages (LDE, permutation trace, quotient, openings, query rows) of different AIRs are independent chains of
     // small launches; on one stream a segment of 60 AIRs pays ~10 us of dispatch latency between 1 400 dependent kernels
@@ -280,8 +286,9 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             on_air(a);
             PW_HIP_TRY(hipMemcpyAsync(blpow_of(a), keep.back().data(), keep.back().size() * sizeof(bb::Ext), hipMemcpyHostToDevice, stream()));
             bb::Ext* rowsum = weights_of(a) + 2 * sh[a].H;
-            TRY(logup_perm_trace(airs[a].d_trace, sh[a].H, logup_program(a), al, blpow_of(a), p->perm.as<uint32_t>(), rowsum, rowsum + sh[a].H));
-            TRY(lde_matrix(p, Lc[a], sh[a].log_h, p->perm.as<uint32_t>(), sh[a].Wp, p->plde.as<uint32_t>()));
+            if (specialised(p)) TRY(logup_perm_trace_jit(p, airs[a].d_trace, sh[a].H, al, blpow_of(a), p->perm.as<uint32_t>(), rowsum, rowsum + sh[a].H));
+            else TRY(logup_perm_trace(airs[a].d_trace, sh[a].H, logup_program(a), al, blpow_of(a), p->perm.as<uint32_t>(), rowsum, rowsum + sh[a].H));
+            TRY(lde_matrix(p, Lc[a], sh[a].log_h, p->perm.as<uint32_t>(), sh[a].Wp + (specialised(p) ? kJitExtraPermCols : 0u), p->plde.as<uint32_t>()));
             for (int k = 0; k < 4; ++k) sp.push_back(p->perm.as<uint32_t>() + ((size_t)(4 * sh[a].n_g + k) * sh[a].H + (sh[a].H - 1)));  // S = phi(last row)
         }
         TRY(join());
@@ -320,9 +327,14 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             const uint32_t zv_even = bb::sub(sH, one), zv_odd = bb::sub(bb::neg(sH), one);
             ConstraintProgram prog{p->d_bytecode, p->d_spans, s.nc, p->is_xbc};
             uint32_t* d_q = p->q.as<uint32_t>();
-            if (lg)
+            if (lg && specialised(p))
+                TRY(quotient_eval_logup_jit(p, p->lde.as<uint32_t>(), p->plde.as<uint32_t>(), s.N, s.logN, apow_of(a), al, blpow_of(a), S[a], zv_even,
+                                            zv_odd, d_q));
+            else if (lg)
                 TRY(quotient_eval_logup(p->lde.as<uint32_t>(), p->plde.as<uint32_t>(), s.N, s.logN, prog, logup_program(a), apow_of(a), al,
                                         blpow_of(a), S[a], zv_even, zv_odd, d_q));
+            else if (specialised(p) && s.nc)
+                TRY(quotient_eval_jit(p, p->lde.as<uint32_t>(), s.N, apow_of(a), bb::inv(zv_even), bb::inv(zv_odd), d_q));
             else
                 TRY(quotient_eval(p->lde.as<uint32_t>(), s.N, prog, apow_of(a), bb::inv(zv_even), bb::inv(zv_odd), d_q, p->qpart.as<uint32_t>(),
                                   quotient_chunks(s.N, s.nc)));

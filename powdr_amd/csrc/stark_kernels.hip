@@ -274,6 +274,7 @@ uint32_t quotient_chunks(size_t N, uint32_t n_constraints) {
 int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, const bb::Ext* d_alpha_pows,
                   uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q, uint32_t* part, uint32_t n_chunks) {
     ScopedKernelTimer t("quotient_kernel");
+    call_stats()[kStatInterpreterKernelLaunches] += 1;
     if (n_chunks < 1 || !part) n_chunks = 1;
     const uint32_t per_chunk = n_chunks > 1 ? (prog.n_constraints + n_chunks - 1) / n_chunks : (prog.n_constraints ? prog.n_constraints : 1);
     if (n_chunks > 1) n_chunks = (prog.n_constraints + per_chunk - 1) / per_chunk;
@@ -288,6 +289,12 @@ int quotient_eval(const uint32_t* lde, size_t N, const ConstraintProgram& prog, 
     if (n_chunks > 1)
         hipLaunchKernelGGL(quotient_combine_kernel, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), part, n_chunks, N, zinv_even,
                            zinv_odd, q);
+    return (int)hipGetLastError();
+}
+
+int quotient_combine(const uint32_t* part, uint32_t n_chunks, size_t N, uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q) {
+    ScopedKernelTimer t("quotient_combine_kernel");
+    hipLaunchKernelGGL(quotient_combine_kernel, dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), part, n_chunks, N, zinv_even, zinv_odd, q);
     return (int)hipGetLastError();
 }
 

@@ -16,7 +16,7 @@ class PwStarkConfig(C.Structure):
 
 PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_logup_path", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_lde_fused", "pw_merkle_commit", "pw_poseidon2_permute_host",
-                  "pw_set_poseidon2_constants", "pw_get_poseidon2_constants"]
+                  "pw_set_poseidon2_constants", "pw_get_poseidon2_constants", "pw_prover_specialise", "pw_prover_specialised", "pw_jit_compile_check"]
 
 lib.pw_prover_create.restype = C.c_void_p
 lib.pw_prover_create.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -244,6 +244,26 @@ lib.pw_get_poseidon2_constants.restype = None
 lib.pw_get_poseidon2_constants.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 
 
+def jit_compile_check(width: int, cons_bytecode, cons_spans, interactions=None) -> dict:
+    """pw_jit_compile_check: generate + compile the specialised kernels of an AIR on the host (no GPU needed)."""
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    bc = np.ascontiguousarray(cons_bytecode, dtype=np.uint32)
+    sp = np.ascontiguousarray(cons_spans, dtype=np.uint32).reshape(-1, 2)
+    k, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    err = C.create_string_buffer(4096)
+    f = lib.pw_jit_compile_check
+    f.restype = C.c_int
+    f.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                  C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+    if interactions is not None:
+        it, isp, ibc = (np.ascontiguousarray(a, dtype=np.uint32) for a in interactions)
+        isp = isp.reshape(-1, 2)
+        rc = f(width, vp(bc), len(bc), vp(sp), len(sp), vp(it), len(it.reshape(-1, 3)), vp(isp), len(isp), vp(ibc), len(ibc), C.byref(k), C.byref(b), C.byref(c), err, 4096)
+    else:
+        rc = f(width, vp(bc), len(bc), vp(sp), len(sp), None, 0, None, 0, None, 0, C.byref(k), C.byref(b), C.byref(c), err, 4096)
+    return dict(rc=int(rc), kernels=k.value, code_bytes=b.value, chunks=c.value, error=err.value.decode(errors="replace"))
+
+
 def set_poseidon2_constants(ext_rc=None, int_rc=None) -> None:
     """pw_set_poseidon2_constants: 8 x 16 external + 13 internal round constants (canonical); None, None = the placeholder."""
     if ext_rc is None:
@@ -317,6 +337,20 @@ class Prover:
         lib.pw_prover_reserve.restype = C.c_int
         lib.pw_prover_reserve.argtypes = [C.c_void_p, C.c_uint32]
         abi.check(lib.pw_prover_reserve(self._h, log_height), "pw_prover_reserve")
+
+    def specialise(self) -> bool:
+        """pw_prover_specialise: compile the run-time specialised kernels now. True if the prover has them."""
+        lib.pw_prover_specialise.restype = C.c_int
+        lib.pw_prover_specialise.argtypes = [C.c_void_p]
+        return int(lib.pw_prover_specialise(self._h)) == 0
+
+    def specialised(self) -> dict:
+        """pw_prover_specialised: {"state": 1 specialised | 0 not tried | -1 interpreter only, "kernels", "code_bytes", "chunks"}."""
+        lib.pw_prover_specialised.restype = C.c_int
+        lib.pw_prover_specialised.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        k, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        st = int(lib.pw_prover_specialised(self._h, C.byref(k), C.byref(b), C.byref(c)))
+        return dict(state=st, kernels=k.value, code_bytes=b.value, chunks=c.value)
 
     def max_constraint_degree(self) -> int:
         lib.pw_prover_max_constraint_degree.restype = C.c_int

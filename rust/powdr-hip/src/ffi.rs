@@ -274,6 +274,12 @@ extern "C" {
     pub fn pw_lde_batch(d_trace: *const u32, width: u32, log_height: u32, d_coeffs: *mut u32, d_lde: *mut u32) -> c_int;
     pub fn pw_lde_fused(d_trace: *const u32, width: u32, log_height: u32, d_tmp: *mut u32, d_lde: *mut u32) -> c_int;
     pub fn pw_merkle_commit(d_matrix: *const u32, height: usize, width: u32, d_digests: *mut u32) -> c_int;
+    pub fn pw_prover_specialise(p: *mut PwProver) -> c_int;
+    pub fn pw_prover_specialised(p: *const PwProver, n_kernels: *mut usize, code_bytes: *mut usize, n_chunks: *mut usize) -> c_int;
+    pub fn pw_jit_compile_check(width: u32, cons_bytecode: *const u32, bytecode_len: usize, cons_spans: *const u32, n_constraints: usize,
+                                interactions: *const u32, n_interactions: usize, inter_spans: *const u32, n_inter_spans: usize,
+                                inter_bytecode: *const u32, inter_bytecode_len: usize, n_kernels: *mut usize, code_bytes: *mut usize,
+                                n_chunks: *mut usize, err: *mut c_char, err_cap: usize) -> c_int;
     pub fn pw_poseidon2_permute_host(state16: *mut u32);
     pub fn pw_set_poseidon2_constants(ext_rc: *const u32, int_rc: *const u32) -> c_int;
     pub fn pw_get_poseidon2_constants(ext_rc: *mut u32, int_rc: *mut u32, diag: *mut u32);
