@@ -73,6 +73,9 @@ def parse_args():
                          "rho = 4*(n_interactions+1)/W extra committed columns per main column); NOT the headline configuration")
     ap.add_argument("--calls-fraction", type=float, default=1.0,
                     help="APC calls as a fraction of the trace height (SURVEY 8d asks for a 0.75 run: the rest is zero padding)")
+    ap.add_argument("--inproc", action="store_true",
+                    help="--shape C4 / C5 with --gpus N in ONE process: pw_prove_segments_multi (include/powdr_prover.h) — one host thread per "
+                         "GPU behind the C ABI, RCCL all-gather of the commitments — instead of one torch.distributed rank per GPU")
     ap.add_argument("--exact-source-heights", action="store_true",
                     help="allocate dummy traces with b*calls rows instead of next_pow2 (less HBM)")
     return ap.parse_args()
@@ -215,6 +218,66 @@ def gauges_of(stage_ms):
              "stark_prove_excluding_trace_time_ms = ms_per_step - trace_gen_time_ms")
 
 
+def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup, queries, pow_bits, n_workers, abi):
+    """The same strong-scaling workload as segment_bench, driven from ONE process through the C ABI's multi-device entry
+    pw_prove_segments_multi: one host thread per worker (worker w on GPU w mod #GPUs) with its own launch stream and its own
+    replica of the segment's provers and traces; placement by cells; the only exchange is the RCCL all-gather of the 8-word
+    commitments at the end of every step."""
+    from powdr_amd import prover, synth
+
+    shapes = synth.segment_shape(kind, seed=0, max_log_height=max_log_height)
+    cells_seg = sum(w << lh for _, w, lh, _, _ in shapes)
+    n_dev = torch.cuda.device_count()
+    devices = [w % n_dev for w in range(n_workers)]
+    workers = []
+    for w in range(n_workers):
+        with torch.cuda.device(devices[w]):
+            provers, traces = [], []
+            for k, (name, wd, lh, nc, ni) in enumerate(shapes):
+                bc, sp, it = synth.random_air_programs(wd, nc, ni, seed=k)
+                provers.append(prover.Prover(wd, bc, sp, num_queries=queries, pow_bits=pow_bits, interactions=it if logup else None))
+                t = torch.empty(wd << lh, dtype=torch.int32, device="cuda")
+                t.random_(0, P)
+                traces.append(t)
+            workers.append(dict(provers=provers, traces=traces,
+                                seg=[(pr, t.data_ptr(), lh) for pr, t, (_, _, lh, _, _) in zip(provers, traces, shapes)]))
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    hdr = 5 + 4 * len(shapes)
+    last = {}
+
+    def prove_one(segment, worker, device):
+        pf = prover.prove_segment(workers[worker]["seg"], logup=logup, copy=False)
+        last["words"] = len(pf)
+        return pf[hdr:hdr + 8].copy()
+
+    def run_steps(n):
+        for _ in range(n):
+            last["merged"], last["owner"], last["merge"] = prover.prove_segments_multi(devices, [cells_seg] * n_segments, prove_one)
+
+    def barrier():
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+
+    run_steps(warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert (last["merged"] != 0).any(axis=1).all(), "a segment's commitment is missing from the merge"
+    rec = dict(shape=kind, scaling="strong", n_segments=n_segments, workers=n_workers, devices=devices, airs_per_segment=len(shapes),
+               cells_per_segment=cells_seg, value=cells_seg * n_segments * steps / elapsed, unit="cells/s", ms_per_step=elapsed / steps * 1e3,
+               steps=steps, warmup=warmup, logup=bool(logup), proof_bytes_per_segment=int(last["words"]) * 4,
+               segments_per_worker=[int((last["owner"] == w).sum()) for w in range(n_workers)],
+               commitment_merge={1: "RCCL all-gather (ncclCommInitAll over the distinct devices)", 2: "host (RCCL not available)"}[last["merge"]],
+               note="pw_prove_segments_multi: one process, one host thread + launch stream per worker, one pw-stark v1 proof per segment")
+    for wk in workers:
+        for pr in wk["provers"]:
+            pr.close()
+    return rec
+
+
 def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, queries, pow_bits, rank, world, abi, barrier):
     """Multi-AIR segments, STRONG scaling: a fixed number of independent segments is placed on the
     ranks by cell count; every rank proves its segments one after the other — ONE pw-stark v1 proof per segment
@@ -328,6 +391,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.shape in ("C4", "C5") and args.inproc and world == 1:
+        rec = segment_bench_inproc(args.shape, args.segments, args.segment_log_height, args.steps, args.warmup, args.logup, args.queries,
+                                   args.pow_bits, max(1, args.gpus), abi)
+        whole = rec["value"] / max(1, args.gpus) * ALGO_BYTES_PER_CELL / 1e9
+        print(json.dumps(dict(
+            metric="STARK cells/sec (trace rows x cols), multi-segment " + ("guest-pairing-shaped" if args.shape == "C4" else "reth-shaped")
+                   + (" [with the bus argument]" if args.logup else " [constraints-only proofs]"),
+            value=rec["value"], unit="cells/s", n_gpus=max(1, args.gpus), steps=args.steps, warmup=args.warmup, ms_per_step=rec["ms_per_step"],
+            higher_is_better=True, scaling="strong", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
+            config=dict(workload=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs ({rec['cells_per_segment']} cells each), one proof "
+                                 f"per segment, {rec['workers']} in-process workers on devices {rec['devices']} (pw_prove_segments_multi)",
+                        parallelism=f"segments over {rec['workers']} host threads in one process (strong)", proof_bytes=rec["proof_bytes_per_segment"]),
+            roofline=dict(bound="hbm", kernel="whole step", achieved=whole, peak=HBM_PEAK_GBS, unit="GB/s", frac=whole / HBM_PEAK_GBS, traffic=None,
+                          algo_bytes_per_cell=ALGO_BYTES_PER_CELL, note="per GPU, 48 B per cell"),
+            cpu_baseline=None, multi_segment=rec)))
+        return
     if args.shape in ("C4", "C5"):
         # BASELINE configs[3] / configs[4]: multi-AIR segments sharded over the GPUs of the node, strong scaling
         rec = segment_bench(args.shape, args.segments, args.segment_log_height, args.steps, args.warmup, args.logup, args.queries,

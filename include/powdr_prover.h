@@ -165,6 +165,27 @@ int pw_verify_airs(const PwStarkConfig* cfg, const PwAirDescription* airs, size_
                    const uint32_t* const* proofs, const size_t* n_words, int shared_bus_seed, int check_balance,
                    uint32_t* total_sum4);
 
+/* ---- independent segments over the GPUs of one node ------------------------------------------------------------------
+ * The reference proves an execution's segments one after the other on one device (openvm/src/trace_generation.rs:111-141);
+ * they are independent once metered execution has fixed their boundaries. pw_prove_segments_multi runs that loop on
+ * `n_workers` host threads at once: worker w makes devices[w] current, gets a launch stream of its own and proves the
+ * segments placed on it — by `segment_cells` (rows x columns), largest first, each to the least loaded worker
+ * (pw_assign_units) — by calling `prove(user, segment, worker, device, commitment8)`: the caller's per-worker replica of the
+ * segment pipeline (trace generation into that worker's buffers, pw_prove_segment on that worker's provers; a prover belongs
+ * to the device it was created on) which returns the segment's 8-word main commitment (canonical; proof words 5 + 4 n_airs
+ * .. + 8 of a pw_prove_segment proof) and keeps or ships the proof itself. No data-path collective. Afterwards the FINAL
+ * COMMITMENT MERGE: the commitments are all-gathered over RCCL (one rank per distinct device; workers may share a device) and
+ * `commitments` (n_segments x 8 words, host) receives the segment-ordered list every device now holds. RCCL is loaded with
+ * dlopen; without it (or POWDR_MULTI_NO_RCCL=1) the merge happens on the host — pw_multi_last_merge(): 1 = RCCL, 2 = host.
+ * worker_of_segment (may be NULL) receives the placement. Returns 0, the first error of a worker, or a hipError_t. */
+typedef int (*PwSegmentProveFn)(void* user, size_t segment, size_t worker, int device, uint32_t* commitment8);
+int pw_prove_segments_multi(const int* devices, size_t n_workers, const uint64_t* segment_cells, size_t n_segments,
+                            PwSegmentProveFn prove, void* user, uint32_t* commitments, uint32_t* worker_of_segment);
+int pw_multi_last_merge(void);
+/* Largest-first greedy balance of `n_units` proof units over `n_workers` (ties: lower unit index, lower worker index first);
+ * worker_of_unit[u] = the worker unit u is placed on. Returns n_units (0: malformed arguments). */
+size_t pw_assign_units(const uint64_t* cells, size_t n_units, size_t n_workers, uint32_t* worker_of_unit);
+
 /* Digest over an ordered list of 8-word commitments (binary Poseidon2 tree; canonical words). */
 void pw_commitment_digest(const uint32_t* roots8, size_t n, uint32_t* digest8);
 

@@ -16,7 +16,8 @@ class PwStarkConfig(C.Structure):
 
 PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_logup_path", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_lde_fused", "pw_merkle_commit", "pw_poseidon2_permute_host",
-                  "pw_set_poseidon2_constants", "pw_get_poseidon2_constants", "pw_prover_specialise", "pw_prover_specialised", "pw_jit_compile_check"]
+                  "pw_set_poseidon2_constants", "pw_get_poseidon2_constants", "pw_prover_specialise", "pw_prover_specialised", "pw_jit_compile_check",
+                  "pw_prove_segments_multi", "pw_multi_last_merge", "pw_assign_units"]
 
 lib.pw_prover_create.restype = C.c_void_p
 lib.pw_prover_create.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -262,6 +263,53 @@ def jit_compile_check(width: int, cons_bytecode, cons_spans, interactions=None) 
     else:
         rc = f(width, vp(bc), len(bc), vp(sp), len(sp), None, 0, None, 0, None, 0, C.byref(k), C.byref(b), C.byref(c), err, 4096)
     return dict(rc=int(rc), kernels=k.value, code_bytes=b.value, chunks=c.value, error=err.value.decode(errors="replace"))
+
+
+_SEGMENT_PROVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_uint32))
+lib.pw_prove_segments_multi.restype = C.c_int
+lib.pw_prove_segments_multi.argtypes = [C.POINTER(C.c_int), C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, _SEGMENT_PROVE_FN, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+lib.pw_multi_last_merge.restype = C.c_int
+lib.pw_assign_units.restype = C.c_size_t
+lib.pw_assign_units.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, C.c_size_t, C.c_void_p]
+
+
+def assign_units(cells, n_workers: int) -> np.ndarray:
+    """pw_assign_units: worker of every unit (largest first, each to the least loaded worker)."""
+    n = len(cells)
+    out = np.zeros(n, np.uint32)
+    arr = (C.c_uint64 * max(n, 1))(*[int(c) for c in cells])
+    assert lib.pw_assign_units(arr, n, n_workers, out.ctypes.data_as(C.c_void_p)) == n
+    return out
+
+
+def prove_segments_multi(devices, segment_cells, prove_segment):
+    """pw_prove_segments_multi: one host thread per entry of `devices` proves the segments placed on it by calling
+    prove_segment(segment, worker, device) -> 8 commitment words; the commitments are merged over RCCL.
+    Returns (uint32 [n_segments, 8], worker of every segment, merge kind: 1 = RCCL all-gather, 2 = host)."""
+    n = len(segment_cells)
+    errors = []
+
+    def cb(_user, segment, worker, device, out):
+        try:
+            c = np.asarray(prove_segment(int(segment), int(worker), int(device)), dtype=np.uint32).reshape(8)
+            for i in range(8):
+                out[i] = int(c[i])
+            return 0
+        except Exception as e:  # noqa: BLE001 - reported to the caller below
+            errors.append(e)
+            return 1
+
+    fn = _SEGMENT_PROVE_FN(cb)
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    cells = (C.c_uint64 * max(n, 1))(*[int(c) for c in segment_cells])
+    commitments = np.zeros((n, 8), np.uint32)
+    owner = np.zeros(n, np.uint32)
+    rc = lib.pw_prove_segments_multi(devs, len(devices), cells, n, fn, None, commitments.ctypes.data_as(C.c_void_p), owner.ctypes.data_as(C.c_void_p))
+    if errors:
+        raise errors[0]
+    abi.check(rc, "pw_prove_segments_multi")
+    return commitments, owner, int(lib.pw_multi_last_merge())
 
 
 def set_poseidon2_constants(ext_rc=None, int_rc=None) -> None:

@@ -10,6 +10,10 @@ use std::marker::PhantomData;
 pub struct HipError(pub i32);
 
 impl HipError {
+    /// the hipError_t (or library) code
+    pub fn code(&self) -> i32 {
+        self.0
+    }
     /// `CudaError::from_result` of the reference wrappers (cuda_abi.rs:106-115): 0 = success.
     pub fn from_result(rc: i32) -> Result<(), HipError> {
         if rc == 0 {

@@ -197,6 +197,9 @@ extern "C" {
 }
 
 // ------------------------------------------------------------------------------------------- include/powdr_prover.h
+/// `PwSegmentProveFn` of include/powdr_prover.h: one worker's replica of the per-segment pipeline.
+pub type PwSegmentProveFn = unsafe extern "C" fn(user: *mut c_void, segment: usize, worker: usize, device: c_int, commitment8: *mut u32) -> c_int;
+
 #[repr(C)]
 pub struct PwProver {
     _opaque: [u8; 0],
@@ -276,6 +279,10 @@ extern "C" {
     pub fn pw_merkle_commit(d_matrix: *const u32, height: usize, width: u32, d_digests: *mut u32) -> c_int;
     pub fn pw_prover_specialise(p: *mut PwProver) -> c_int;
     pub fn pw_prover_specialised(p: *const PwProver, n_kernels: *mut usize, code_bytes: *mut usize, n_chunks: *mut usize) -> c_int;
+    pub fn pw_prove_segments_multi(devices: *const c_int, n_workers: usize, segment_cells: *const u64, n_segments: usize,
+                                   prove: PwSegmentProveFn, user: *mut c_void, commitments: *mut u32, worker_of_segment: *mut u32) -> c_int;
+    pub fn pw_multi_last_merge() -> c_int;
+    pub fn pw_assign_units(cells: *const u64, n_units: usize, n_workers: usize, worker_of_unit: *mut u32) -> usize;
     pub fn pw_jit_compile_check(width: u32, cons_bytecode: *const u32, bytecode_len: usize, cons_spans: *const u32, n_constraints: usize,
                                 interactions: *const u32, n_interactions: usize, inter_spans: *const u32, n_inter_spans: usize,
                                 inter_bytecode: *const u32, inter_bytecode_len: usize, n_kernels: *mut usize, code_bytes: *mut usize,

@@ -6,6 +6,8 @@
 //! * [`chip`]   — `PowdrChipHip`: `Chip::generate_proving_ctx` -> `powdr_apc_generate_witness_gpu`
 //! * [`engine`] — `HipEngine` (one `pw_prove_segment` call per segment), `SpecializedConfigHipBuilder`,
 //!                `PowdrHipProverExt`
+//! * [`multi`]  — the reference's sequential segment loop (trace_generation.rs:111-141) on N GPUs at once:
+//!                `pw_prove_segments_multi`, RCCL only for the final commitment merge
 //!
 //! Wiring inside powdr-openvm (openvm/src/lib.rs:69-95), next to the `cuda` arm of the `cfg_if!`:
 //! ```ignore
@@ -17,6 +19,7 @@ pub mod chip;
 pub mod device;
 pub mod engine;
 pub mod ffi;
+pub mod multi;
 
 pub use chip::{PowdrChipHip, PowdrPeripheryInstancesHip, PowdrTraceGeneratorHip};
 pub use device::{DeviceBuffer, DeviceMatrix, HipError, MemCopyH2D};

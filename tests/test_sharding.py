@@ -176,3 +176,71 @@ def test_strong_scaling_over_segments_world_size_2_gloo(tmp_path):
         pf = np.load(tmp_path / f"seg_{u}.npy")
         assert prover.verify_segment(descs_of(seg), pf, 3, 0, False)[0] == 0  # the product's host verifier accepts every segment
         assert (pf[5 + 4 * 2:5 + 4 * 2 + 8] == m0[u]).all()  # the merged row IS that segment's main commitment
+
+
+def test_c_abi_placement_equals_python_placement():
+    """pw_assign_units (the placement pw_prove_segments_multi uses) == sharding.assign_units, ties included."""
+    from powdr_amd import prover
+
+    rng = np.random.default_rng(3)
+    for n, w in [(0, 3), (1, 1), (5, 8), (9, 2), (40, 8), (17, 5)]:
+        cells = [int(x) for x in rng.integers(1, 50, n)]  # many ties
+        owner = prover.assign_units(cells, w)
+        want = sharding.assign_units(cells, w)
+        assert [sorted(np.flatnonzero(owner == k).tolist()) for k in range(w)] == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_workers", [1, 3])
+def test_prove_segments_multi_on_one_gpu(n_workers):
+    """pw_prove_segments_multi with every worker on GPU 0 (one-GPU box): host threads with their own streams and prover
+    replicas prove 7 segments of different sizes concurrently; commitments and proofs equal the ones made one after the
+    other; the merge went through an RCCL communicator of size 1 (or says that RCCL is missing)."""
+    import threading
+
+    import torch
+    from powdr_amd import prover, synth
+
+    assert torch.cuda.is_available()
+    P = 0x78000001
+    shapes = [(40, 12), (9, 7), (120, 10), (33, 13), (5, 4), (64, 11), (17, 9)]
+    progs = [synth.random_air_programs(w, 5, 8, seed=k) for k, (w, lh) in enumerate(shapes)]
+    traces = []
+    for w, lh in shapes:
+        t = torch.empty(w << lh, dtype=torch.int32, device="cuda")
+        t.random_(0, P)
+        traces.append(t)
+    torch.cuda.synchronize()
+
+    def make_provers():
+        return [prover.Prover(w, bc, sp, num_queries=4, pow_bits=2, interactions=it) for (w, lh), (bc, sp, it) in zip(shapes, progs)]
+
+    # a "segment" here = two AIRs (s and its neighbour): one pw_prove_segment proof each
+    def prove_with(provers, s):
+        a, b = s, (s + 1) % len(shapes)
+        return prover.prove_segment([(provers[a], traces[a].data_ptr(), shapes[a][1]), (provers[b], traces[b].data_ptr(), shapes[b][1])], logup=True)
+
+    seq = make_provers()
+    want = [prove_with(seq, s) for s in range(len(shapes))]
+    hdr = 5 + 4 * 2
+    per_worker = [make_provers() for _ in range(n_workers)]
+    proofs, lock = {}, threading.Lock()
+
+    def prove_segment(s, worker, device):
+        assert device == 0
+        pf = prove_with(per_worker[worker], s)
+        with lock:
+            proofs[s] = (worker, pf)
+        return pf[hdr:hdr + 8]
+
+    cells = [(shapes[s][0] << shapes[s][1]) + (shapes[(s + 1) % 7][0] << shapes[(s + 1) % 7][1]) for s in range(7)]
+    commitments, owner, merge = prover.prove_segments_multi([0] * n_workers, cells, prove_segment)
+    assert merge in (1, 2)
+    assert (owner == prover.assign_units(cells, n_workers)).all() and len(set(owner.tolist())) == n_workers
+    for s in range(7):
+        assert proofs[s][0] == owner[s]
+        assert (proofs[s][1] == want[s]).all()
+        assert (commitments[s] == want[s][hdr:hdr + 8]).all()
+    for ps in per_worker + [seq]:
+        for p in ps:
+            p.close()
