@@ -48,11 +48,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log-height", type=int, default=16,
                     help="rows (log2) of the CPU-baseline sample of the same AIR (2^16 rows of C2 = 132 M cells: ~25 s on the box's host cores)")
-    ap.add_argument("--no-logup-leg", action="store_true",
-                    help="skip the second timed leg of the default run (the same step WITH the LogUp phase, reported as `logup`)")
+    ap.add_argument("--no-logup-leg", "--no-second-leg", dest="no_logup_leg", action="store_true",
+                    help="skip the second timed leg of the default run (the same step with the OTHER proof kind: `constraints_only`, or `logup` "
+                         "under --constraints-only)")
     ap.add_argument("--no-callmajor-leg", action="store_true",
                     help="skip the measurement of the gather from call-major compacted sources (reported as `tracegen_callmajor`)")
-    ap.add_argument("--logup-steps", type=int, default=3, help="timed steps of the LogUp leg (after one warm-up step)")
+    ap.add_argument("--logup-steps", "--second-steps", dest="logup_steps", type=int, default=3, help="timed steps of the second leg (after one warm-up step)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="skip the two short rocprofv3 --pmc passes that measure the dominant kernel's HBM bytes and VALU instructions in this run")
     ap.add_argument("--no-copy-ceiling", action="store_true",
@@ -65,12 +66,15 @@ def parse_args():
     ap.add_argument("--no-segment-leg", action="store_true",
                     help="skip the multi_segment leg of the default run (C4: 10 APC AIRs + 19 system AIRs per segment, strong scaling)")
     ap.add_argument("--segment-steps", type=int, default=2, help="timed steps of the multi_segment leg (after one warm-up)")
+    ap.add_argument("--no-c3-leg", action="store_true", help="skip the C3-scale leg of the default run (3 731 cols x 2^22 rows, reported as `c3`)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="host threads / HIP streams proving independent segments concurrently on each GPU "
                          "(throughput mode; default 1 = one segment at a time, which keeps per-kernel timings clean)")
-    ap.add_argument("--logup", action="store_true",
-                    help="prove the bus interactions too (pw-stark v0 + LogUp: one extension column per interaction, "
-                         "rho = 4*(n_interactions+1)/W extra committed columns per main column); NOT the headline configuration")
+    ap.add_argument("--constraints-only", action="store_true",
+                    help="headline = the constraints-only proof (the AIR's bus interactions are replayed into the periphery histograms but are "
+                         "not inside the proof); default: the proof includes them (pw-stark v0 + LogUp) — what PowdrAir::eval hands the "
+                         "reference's backend (chip.rs:94-130) — and the constraints-only step is the `constraints_only` sub-record")
+    ap.add_argument("--logup", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--calls-fraction", type=float, default=1.0,
                     help="APC calls as a fraction of the trace height (SURVEY 8d asks for a 0.75 run: the rest is zero padding)")
     ap.add_argument("--inproc", action="store_true",
@@ -78,7 +82,9 @@ def parse_args():
                          "GPU behind the C ABI, RCCL all-gather of the commitments — instead of one torch.distributed rank per GPU")
     ap.add_argument("--exact-source-heights", action="store_true",
                     help="allocate dummy traces with b*calls rows instead of next_pow2 (less HBM)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.logup = not args.constraints_only
+    return args
 
 
 def setup_distributed(n):
@@ -142,7 +148,7 @@ def build_workload(shape_name, log_h, exact_heights, seed, calls_fraction=1.0):
                 calls=calls, log_h=log_h, H=H, W=apc.width, cons=(cons_bc, cons_spans), src_bytes=src_bytes)
 
 
-def cpu_baseline(shape_name, log_h, queries, pow_bits, seed):
+def cpu_baseline(shape_name, log_h, queries, pow_bits, seed, logup=False):
     """The CPU oracle (a restatement, kind 'port') on a bounded sample of the same workload:
     the reference's CPU trace generation (row-major, sequential row loop) + the pw-stark v0 oracle
     prover, on this box's host cores."""
@@ -170,13 +176,18 @@ def cpu_baseline(shape_name, log_h, queries, pow_bits, seed):
     vals = om.c_generate_witness(apc, ct, idx, dummy_rm, dummy_w, calls, per)
     t1 = time.perf_counter()
     flat = np.ascontiguousarray(vals.T).reshape(-1)
-    proof = sm.prove(flat, len(idx), log_h, bc, spans, num_queries=queries, pow_bits=min(pow_bits, 12))
+    if logup:
+        it = sm.compile_interactions(apc, idx)
+        proof = sm.prove_logup(flat, len(idx), log_h, bc, spans, *it, num_queries=queries, pow_bits=min(pow_bits, 12))
+    else:
+        proof = sm.prove(flat, len(idx), log_h, bc, spans, num_queries=queries, pow_bits=min(pow_bits, 12))
     t2 = time.perf_counter()
     cells = len(idx) * calls
     cores = os.cpu_count() or 1
     return dict(value=cells / (t2 - t0), unit="cells/s", cores=cores, kind="port",
                 sample=f"{shape_name} AIR W={len(idx)} at 2^{log_h} rows ({cells} cells): oracle trace generation "
-                       f"(single thread, like the reference's row loop) {t1 - t0:.2f}s + oracle prover (OpenMP, {cores} threads) {t2 - t1:.2f}s",
+                       f"(single thread, like the reference's row loop) {t1 - t0:.2f}s + oracle prover{' with the LogUp phase' if logup else ''} "
+                       f"(OpenMP, {cores} threads) {t2 - t1:.2f}s",
                 trace_gen_s=t1 - t0, prove_s=t2 - t1)
 
 
@@ -210,8 +221,9 @@ def gauges_of(stage_ms):
     return dict(
         trace_gen_time_ms=g("apc_gather_tile_kernel", "apc_apply_derived_expr_kernel", "apc_apply_bus_kernel", "bus_histogram_kernel"),
         main_trace_commit_time_ms=g("ntt_group_kernel<dif>", "lde_fused_kernel", "ntt_group_kernel<dit>", "leaf_hash_kernel", "compress_kernel", "compress_tail_kernel"),
-        perm_trace_time_ms=g("logup_perm_kernel", "logup_scan_kernels"),
-        quotient_poly_compute_time_ms=g("quotient_kernel", "quotient_logup_kernel", "quotient_split_kernel"),
+        perm_trace_time_ms=g("logup_perm_kernel", "logup_perm_jit_kernel", "logup_rowsum_combine_kernel", "logup_scan_kernels"),
+        quotient_poly_compute_time_ms=g("quotient_kernel", "quotient_jit_kernel", "quotient_combine_kernel", "quotient_logup_kernel", "quotient_logup_jit_kernel",
+                                        "quotient_logup_tail_kernel", "quotient_split_kernel"),
         pcs_opening_time_ms=g("barycentric_weights_kernel", "zeta_weights_kernel", "ext_dot_partial_kernel", "deep_kernel", "deep_logup_kernel",
                               "ext_pair_leaf_kernel", "fri_fold_kernel", "gather_rows_kernel"),
         note="main_trace_commit also contains the 8-column quotient commitment (and, with LogUp, the permutation matrix's; same kernels); "
@@ -330,6 +342,90 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
     del traces
     torch.cuda.empty_cache()
     return rec if rank == 0 else None
+
+
+def c3_leg(queries, pow_bits, steps=2):
+    """BASELINE configs[2] (guest-ecrecover autoprecompile, 2^22 rows, "HBM-roofline report") inside the driver-timed line: the
+    C3 AIR (3 731 columns, 3 114 constraints, 2 314 bus interactions; W * H > 2^32, column-index operands) on dense synthetic
+    sources (`C3p`: the real block's ~600 GB of dummy traces fit no single GPU — SURVEY.md §8 row f-1): one trace generation +
+    1 warm-up proof (allocates ~128 GB) + `steps` timed proofs, host-verified; per-kernel algorithmic GB/s against the 8 TB/s peak
+    and the whole step against 48 B per cell. Needs ~190 GB of free HBM: skipped with the reason otherwise."""
+    from powdr_amd import abi, prover
+
+    free = torch.cuda.mem_get_info()[0]
+    if free < 230e9:
+        return dict(skipped=f"needs ~190 GB of HBM for 3 731 x 2^22 (trace 62.6 GB + LDE 125 GB); {free / 1e9:.0f} GB free")
+    log_h = 22
+    wl = build_workload("C3p", log_h, False, seed=0)
+    W, H = wl["W"], wl["H"]
+    torch.cuda.synchronize()
+    abi.lib.powdr_gpu_timing_enable(1)
+    t1 = time.perf_counter()
+    wl["apc"].generate_witness_gpu(wl["instr_air"], wl["dummy"], wl["calls"], wl["out"].data_ptr(), wl["per"])
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t1
+    tg_timing = abi.timing_report()
+    abi.lib.powdr_gpu_timing_enable(0)
+    src_bytes = wl["src_bytes"]
+    wl["dummy"].clear(); wl["tensors"].clear()  # the sources make room for the LDE
+    torch.cuda.empty_cache()
+    pr = prover.Prover(W, *wl["cons"], num_queries=queries, pow_bits=pow_bits)
+    pr.prove(wl["out"].data_ptr(), log_h, copy=False)  # warm-up: allocation of the prover's buffers, specialised kernels
+    torch.cuda.synchronize()
+    abi.lib.powdr_gpu_timing_enable(1)
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        proof = pr.prove(wl["out"].data_ptr(), log_h)
+    torch.cuda.synchronize()
+    t_prove = (time.perf_counter() - t2) / steps
+    timing = abi.timing_report()
+    abi.lib.powdr_gpu_timing_enable(0)
+    rc = prover.verify(proof, W, log_h, *wl["cons"], num_queries=queries, pow_bits=pow_bits)
+    cells = W * H
+    algo = {"apc_gather_tile_kernel": 8.0, "ntt_group_kernel<dif>": 8.0, "lde_fused_kernel": 12.0, "ntt_group_kernel<dit>": 16.0, "leaf_hash_kernel": 8.0,
+            "deep_kernel": 8.0, "ext_dot_partial_kernel": 4.0}
+    kernels = {}
+    for k, (cnt, ms) in sorted(timing.items(), key=lambda kv: -kv[1][1]):
+        e = dict(launches_per_step=cnt / steps, ms=ms / steps)
+        if k in algo:
+            e["algorithmic_GBps"] = algo[k] * cells / (ms / steps * 1e-3) / 1e9
+            e["frac_of_hbm_peak"] = e["algorithmic_GBps"] / HBM_PEAK_GBS
+        kernels[k] = e
+    for k, (cnt, ms) in tg_timing.items():
+        e = dict(launches_per_step=cnt, ms=ms)
+        if k in algo:
+            e["algorithmic_GBps"] = algo[k] * cells / (ms * 1e-3) / 1e9
+            e["frac_of_hbm_peak"] = e["algorithmic_GBps"] / HBM_PEAK_GBS
+        kernels[k] = e
+    step_s = t_prove + t_gen
+    rec = dict(workload=f"C3p guest-ecrecover-shaped AIR: {W} cols x 2^{log_h} rows, {len(wl['cons'][1])} constraints, {wl['apc'].n_bus} bus interactions "
+                        f"(replayed into the histograms; constraints-only proof), dense synthetic sources ({src_bytes / 1e9:.1f} GB)",
+               cells=cells, steps=steps, warmup=1, trace_gen_ms=t_gen * 1e3, prove_ms=t_prove * 1e3, value=cells / step_s, unit="cells/s",
+               cells_per_s_prove_only=cells / t_prove, verify_rc=int(rc), specialised_kernels=pr.specialised(),
+               whole_step_hbm=dict(algo_bytes_per_cell=ALGO_BYTES_PER_CELL, achieved_GBps=cells / step_s * ALGO_BYTES_PER_CELL / 1e9, peak_GBps=HBM_PEAK_GBS,
+                                   frac=cells / step_s * ALGO_BYTES_PER_CELL / 1e9 / HBM_PEAK_GBS),
+               prover_device_bytes=pr.device_bytes(), proof_bytes=int(len(proof) * 4), kernels=kernels)
+    pr.close()
+    wl.clear()
+    torch.cuda.empty_cache()
+    return rec
+
+
+def build_info():
+    """How the library this process loaded was built (the driver's build() runs before the bench; *.so is git-ignored and travels
+    with the snapshot): path, size, age relative to its sources, and whether hipcc is present to rebuild it here."""
+    import hashlib
+    import shutil
+
+    from powdr_amd import build as b
+
+    lib = b.LIB
+    srcs = list(b.CSRC.glob("*.hip")) + list(b.CSRC.glob("*.hpp")) + list((b.CSRC / "host").glob("*.cpp"))
+    newest = max((f.stat().st_mtime for f in srcs), default=0.0)
+    return dict(lib=str(lib.relative_to(ROOT)), bytes=lib.stat().st_size, sha256_16=hashlib.sha256(lib.read_bytes()).hexdigest()[:16],
+                built_after_newest_source=bool(lib.stat().st_mtime >= newest), hipcc_present=bool(shutil.which("hipcc") or Path(b.HIPCC).exists()),
+                build_mode="in-tree, hipcc --offload-arch=gfx950 (powdr_amd/build.py via __graft_entry__.build()); the bench loads this prebuilt .so, "
+                           "expression kernels are additionally specialised at run time with hiprtc")
 
 
 def live_pmc_leaf_hash(width: int, log_n: int):
@@ -600,46 +696,51 @@ def main():
         except Exception as e:
             colstruct_leg = dict(gather_ms=None, error=f"{type(e).__name__}: {e}")
 
-    # ---- second timed leg: the same step WITH the LogUp phase (the bus interactions PowdrAir::eval pushes, chip.rs:117-129,
-    # inside the proof). The headline stays constraints-only (north_star's kernel list has no permutation phase); this leg is
-    # the statement the reference's backend proves. Same inputs, same trace generation; a second prover object.
-    logup_leg = None
-    if not args.logup and not args.no_logup_leg and args.pipeline == 1:
+    # ---- second timed leg: the same step with the OTHER proof kind. Headline (default): the proof includes the bus interactions
+    # PowdrAir::eval pushes (chip.rs:117-129) — the statement the reference's backend proves; second leg: the constraints-only proof
+    # (north_star's kernel list: NTT, quotient, Merkle, FRI — no permutation phase). Same inputs, same trace generation.
+    other_leg = None
+    other_logup = not args.logup
+    if not args.no_logup_leg and args.pipeline == 1:
         pr.close()
         torch.cuda.empty_cache()
         try:
-            pr_lg = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits, interactions=all_inter)
-            lg_worker = dict(apc=wl["apc"], per=wl["per"], out=wl["out"], pr=pr_lg)
-            lg_last = {}
+            pr_o = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits, interactions=all_inter if other_logup else None)
+            o_worker = dict(apc=wl["apc"], per=wl["per"], out=wl["out"], pr=pr_o)
+            o_last = {}
 
-            def run_lg(n):
+            def run_o(n):
                 for _ in range(n):
-                    lg_last["proof"] = run_segment(lg_worker, True)
+                    o_last["proof"] = run_segment(o_worker, other_logup)
 
-            lg_elapsed, lg_timing = timed_leg(run_lg, args.logup_steps, 1, barrier, abi, world)
-            rho = lg_perm_cols / wl["W"]
-            lg_bytes_per_cell = 48 + 4 + 44 * rho
-            lg_value = cells_per_step * args.logup_steps * world / lg_elapsed
-            lg_stage = {k: ms / args.logup_steps for k, (c, ms) in lg_timing.items()}
-            logup_leg = dict(
-                value=lg_value, unit="main cells/s", ms_per_step=lg_elapsed / args.logup_steps * 1e3, steps=args.logup_steps, warmup=1,
-                interaction_groups=lg_perm_cols // 4 - 1, perm_cols=lg_perm_cols, rho=rho,
-                algo_bytes_per_main_cell=lg_bytes_per_cell,
-                whole_step_hbm=dict(achieved_GBps=lg_value * lg_bytes_per_cell / 1e9, peak_GBps=HBM_PEAK_GBS,
-                                    frac=lg_value * lg_bytes_per_cell / 1e9 / HBM_PEAK_GBS),
-                proof_bytes=int(len(lg_last["proof"]) * 4), prover_device_bytes=pr_lg.device_bytes(), stage_ms=lg_stage,
-                gauges=gauges_of(lg_stage),
-                note="same segment, same trace generation, proof = pw-stark v0 + LogUp (proof magic PWS2): the AIR's bus interactions are "
-                     "inside the proof (permutation columns, running sum, extended quotient, openings at zeta and g*zeta)")
-            pr_lg.close()
-            lg_worker.clear()
+            o_elapsed, o_timing = timed_leg(run_o, args.logup_steps, 1, barrier, abi, world)
+            rho = lg_perm_cols / wl["W"] if other_logup else 0.0
+            o_bytes_per_cell = 48 + 4 + 44 * rho if other_logup else ALGO_BYTES_PER_CELL
+            o_value = cells_per_step * args.logup_steps * world / o_elapsed
+            o_stage = {k: ms / args.logup_steps for k, (c, ms) in o_timing.items()}
+            other_leg = dict(
+                value=o_value, unit="main cells/s", ms_per_step=o_elapsed / args.logup_steps * 1e3, steps=args.logup_steps, warmup=1,
+                interaction_groups=(lg_perm_cols // 4 - 1) if other_logup else 0, perm_cols=lg_perm_cols if other_logup else 0, rho=rho,
+                algo_bytes_per_main_cell=o_bytes_per_cell,
+                whole_step_hbm=dict(achieved_GBps=o_value * o_bytes_per_cell / 1e9, peak_GBps=HBM_PEAK_GBS,
+                                    frac=o_value * o_bytes_per_cell / 1e9 / HBM_PEAK_GBS),
+                proof_bytes=int(len(o_last["proof"]) * 4), prover_device_bytes=pr_o.device_bytes(), stage_ms=o_stage,
+                gauges=gauges_of(o_stage), specialised_kernels=pr_o.specialised(),
+                note=("same segment, same trace generation, proof = pw-stark v0 + LogUp (proof magic PWS2): the AIR's bus interactions are "
+                      "inside the proof (permutation columns, running sum, extended quotient, openings at zeta and g*zeta)") if other_logup else
+                     ("same segment, same trace generation, CONSTRAINTS-ONLY proof (proof magic PWS1): the bus interactions are replayed into the "
+                      "periphery histograms but are not inside the proof — the round-1/2 headline"))
+            pr_o.close()
+            o_worker.clear()
         except Exception as e:  # the extra leg must never take the headline down
-            logup_leg = dict(value=None, error=f"{type(e).__name__}: {e}")
+            other_leg = dict(value=None, error=f"{type(e).__name__}: {e}")
+    logup_leg = other_leg if other_logup else None
+    constraints_only_leg = None if other_logup else other_leg
 
     # ---- third leg: multi-AIR segments, strong scaling (BASELINE configs[3]: sharded multi-segment guest-pairing). Every rank takes
     # part; the single-AIR workload's 180 GB are released first.
     segment_leg = None
-    if not args.no_segment_leg and args.pipeline == 1 and not args.logup:
+    if not args.no_segment_leg and args.pipeline == 1:
         try:
             pr.close()
             for k in ("tensors", "dummy", "out"):
@@ -650,10 +751,23 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             seg_log = min(args.segment_log_height, log_h)
-            segment_leg = segment_bench("C4", args.segments, seg_log, args.segment_steps, 1, False, args.queries, args.pow_bits, rank, world,
+            segment_leg = segment_bench("C4", args.segments, seg_log, args.segment_steps, 1, args.logup, args.queries, args.pow_bits, rank, world,
                                         abi, barrier)
         except Exception as e:  # must never take the headline down
             segment_leg = dict(value=None, error=f"{type(e).__name__}: {e}")
+
+    # ---- fourth leg: BASELINE configs[2] at full size on rank 0 (one GPU; everything else has been released by now)
+    c3 = None
+    if rank == 0 and not args.no_c3_leg and not args.no_segment_leg and args.pipeline == 1 and args.shape == "C2" and log_h == 20:
+        try:
+            import gc
+
+            gc.collect()
+            torch.cuda.empty_cache()
+            c3 = c3_leg(args.queries, args.pow_bits)
+        except Exception as e:  # must never take the headline down
+            c3 = dict(value=None, error=f"{type(e).__name__}: {e}")
+            torch.cuda.empty_cache()
 
     if rank == 0:
         per_kernel = {k: (c, ms) for k, (c, ms) in timing.items()}
@@ -664,6 +778,11 @@ def main():
                                "ntt_group_kernel<dif>": 8.0, "lde_fused_kernel": 12.0, "ntt_group_kernel<dit>": 16.0, "deep_kernel": 8.0}
         stage_ms = {k: ms / args.steps for k, (c, ms) in per_kernel.items()}
         gauges = gauges_of(stage_ms)
+        # kernels that run once per COMMITTED column (LDE, leaf hash, DEEP): with the LogUp phase the permutation matrix is
+        # committed like the trace, so their algorithmic bytes are per (main + permutation) cell
+        committed_scale = (wl["W"] + perm_cols) / wl["W"]
+        per_committed = {"leaf_hash_kernel", "ntt_group_kernel<dif>", "lde_fused_kernel", "ntt_group_kernel<dit>", "deep_kernel", "deep_logup_kernel"}
+        algo_bytes_per_cell["deep_logup_kernel"] = 8.0
         copy_gbs = None
         if not args.no_copy_ceiling:
             # device-to-device copy ceiling of THIS box: 4 GiB copies, outside every timed region
@@ -693,25 +812,27 @@ def main():
                     base = "apc_apply_bus_kernel"
                 traffic_db[base] = traffic_db.get(base, 0.0) + v["fetch_bytes_corrected"] + v["write_bytes"]
         live = None
-        if dom == "leaf_hash_kernel" and world == 1 and not args.no_live_pmc and not args.logup:
+        if dom == "leaf_hash_kernel" and world == 1 and not args.no_live_pmc:
             live = live_pmc_leaf_hash(wl["W"], log_h + 1)
         roof = None
         if dom:
             cnt, ms = per_kernel[dom]
             abc = algo_bytes_per_cell.get(dom, 8.0)
-            bytes_step = abc * cells_per_step  # summed over one step's launches of that kernel
+            bytes_step = abc * cells_per_step * (committed_scale if dom in per_committed else 1.0)  # summed over one step's launches of that kernel
             achieved = bytes_step / (ms / args.steps * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=(live["fetch_bytes_per_launch"] + 2 * wl["H"] * (8 * 4 + 2 * 32)) if live else traffic_db.get(dom),
+                        traffic=(live["fetch_bytes_per_launch"] * committed_scale + 2 * wl["H"] * (8 * 4 + (3 if args.logup else 2) * 32)) if live else traffic_db.get(dom),
                         traffic_unit=("bytes per step: FETCH_SIZE (KiB x 1024 x 2, the gfx950 correction for wide coalesced reads) of the trace-tree launch, measured "
-                                      "IN THIS RUN by a rocprofv3 --pmc pass of tools/leaf_hash_once.py, + the algorithmic bytes of the 8-column "
-                                      "quotient-tree launch and of the digests written" if live else
+                                      "IN THIS RUN by a rocprofv3 --pmc pass of tools/leaf_hash_once.py"
+                                      + (f", x {committed_scale:.3f} for the permutation-tree launch of the same kernel ({perm_cols} more columns)" if args.logup else "")
+                                      + ", + the algorithmic bytes of the 8-column quotient-tree launch and of the digests written" if live else
                                       f"bytes per step (PMC, profiles/{tprof_name})" if tprof else None),
                         algorithmic_bytes_per_step=bytes_step, avg_launch_ms=ms / cnt, launches_per_step=cnt / args.steps,
                         algo_bytes_per_cell=abc)
             # the whole step against SURVEY 8d's headline figure: 48 algorithmic bytes per main cell
-            roof["whole_step"] = dict(algo_bytes_per_cell=ALGO_BYTES_PER_CELL, achieved_GBps=value / world * ALGO_BYTES_PER_CELL / 1e9,
-                                      peak_GBps=HBM_PEAK_GBS, frac=value / world * ALGO_BYTES_PER_CELL / 1e9 / HBM_PEAK_GBS,
+            whole_bpc = 48 + 4 + 44 * perm_cols / wl["W"] if args.logup else ALGO_BYTES_PER_CELL  # 48 + 4 + 44 rho with the LogUp phase
+            roof["whole_step"] = dict(algo_bytes_per_cell=whole_bpc, achieved_GBps=value / world * whole_bpc / 1e9,
+                                      peak_GBps=HBM_PEAK_GBS, frac=value / world * whole_bpc / 1e9 / HBM_PEAK_GBS,
                                       note="per GPU; the step is bound by integer VALU issue (Poseidon2, NTT), not by HBM")
             if dom == "leaf_hash_kernel":
                 # The dominant kernel is integer-VALU bound. Its instruction count per permutation and the issue cost of its
@@ -738,7 +859,7 @@ def main():
         by_kernel = {}
         for k, ms in stage_ms.items():
             if k in algo_bytes_per_cell and ms > 0:
-                gbs = algo_bytes_per_cell[k] * cells_per_step / (ms * 1e-3) / 1e9
+                gbs = algo_bytes_per_cell[k] * cells_per_step * (committed_scale if k in per_committed else 1.0) / (ms * 1e-3) / 1e9
                 rec = dict(ms=ms, algorithmic_GBps=gbs, frac_of_peak=gbs / HBM_PEAK_GBS)
                 tb = traffic_db.get(k, traffic_db.get(k.split("<")[0]))
                 if tb:
@@ -748,11 +869,13 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             try:
-                cpu = cpu_baseline(args.shape, min(args.cpu_log_height, log_h), args.queries, args.pow_bits, seed=0)
+                # (the LogUp proof commits 2.7x the columns: half the rows keep the sample at ~20 s)
+                cpu = cpu_baseline(args.shape, min(args.cpu_log_height - (1 if args.logup else 0), log_h), args.queries, args.pow_bits, seed=0, logup=args.logup)
             except Exception as e:  # the baseline must never take the product number down
                 cpu = dict(value=None, unit="cells/s", cores=os.cpu_count(), kind="port", sample=f"failed: {e}")
         line = dict(
-            metric="STARK cells/sec (trace rows x cols) proving guest-keccak" + ("" if args.logup else " [constraints-only proof; `logup` = with the bus argument]"),
+            metric="STARK cells/sec (trace rows x cols) proving guest-keccak" + (" [proof includes the AIR's bus interactions (LogUp); `constraints_only` = without them]"
+                                                                                     if args.logup else " [constraints-only proof; `logup` = with the bus argument]"),
             value=value, unit="cells/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
@@ -767,11 +890,11 @@ def main():
                                  + (f"; {wl['calls']} APC calls, the remaining rows are zero padding" if wl["calls"] != wl["H"] else "")
                                  + "; one segment per step per GPU"
                                  + ("; source heights b*calls (not padded to a power of two)" if args.exact_source_heights else ""),
-                        rows=wl["H"], cols=wl["W"], parallelism=f"segments x{world}" + (f", {args.pipeline} streams per GPU" if args.pipeline > 1 else ""),
+                        rows=wl["H"], cols=wl["W"], perm_cols=perm_cols, parallelism=f"segments x{world}" + (f", {args.pipeline} streams per GPU" if args.pipeline > 1 else ""),
                         source_bytes=wl["src_bytes"], proof_bytes=proof_bytes, prover_device_bytes=prover_bytes,
                         caveat="proof system pw-stark v0 is this repository's own (oracle/stark_oracle.cpp); its Poseidon2 round constants are a "
                                "documented placeholder stream: proofs are byte-exact against the oracle, not interoperable with the reference prover"),
-            roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, multi_segment=segment_leg, tracegen_callmajor=callmajor_leg, tracegen_column_structured=colstruct_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
+            roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, constraints_only=constraints_only_leg, multi_segment=segment_leg, c3=c3, build=build_info(), tracegen_callmajor=callmajor_leg, tracegen_column_structured=colstruct_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
             hbm_copy_GBps_measured=copy_gbs,
         )
         print(json.dumps(line))

@@ -3,14 +3,19 @@
 #include "../common.hpp"
 
 #include <dlfcn.h>
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
-#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+
+extern char** environ;
 
 namespace pw { namespace jit {
 
@@ -80,8 +85,9 @@ namespace {
 std::mutex g_cache_mu;
 std::unordered_map<uint64_t, ProgramPtr> g_cache;
 
-bool compile_one(const std::string& src, Program& out, std::string* err) {
+bool compile_code(const std::string& src, std::vector<char>& code_out, std::string* err) {
     const Rtc& r = rtc();
+    if (!r.ok) { if (err) *err = "hiprtc is not available"; return false; }
     std::vector<const char*> hdrs, names;
     for (int i = 0; i < kNumEmbeddedHeaders; ++i) { hdrs.push_back(kEmbeddedHeaders[i].text); names.push_back(kEmbeddedHeaders[i].name); }
     hiprtcProgram prog = nullptr;
@@ -101,13 +107,92 @@ bool compile_one(const std::string& src, Program& out, std::string* err) {
     }
     size_t n = 0;
     bool ok = r.GetCodeSize(prog, &n) == 0 && n > 0;
-    if (ok) { out.code.resize(n); ok = r.GetCode(prog, out.code.data()) == 0; }
+    if (ok) { code_out.resize(n); ok = r.GetCode(prog, code_out.data()) == 0; }
     (void)r.DestroyProgram(&prog);
     if (!ok && err) *err = "hiprtcGetCode failed";
-    out.source = src;
     return ok;
 }
+
+// path of the helper executable: POWDR_JITC, or "powdr_jitc" next to the shared object this code lives in
+std::string helper_path() {
+    if (const char* e = getenv("POWDR_JITC")) return e;
+    Dl_info info;
+    if (!dladdr((const void*)&helper_path, &info) || !info.dli_fname) return "";
+    std::string p = info.dli_fname;
+    const size_t slash = p.rfind('/');
+    p = slash == std::string::npos ? "powdr_jitc" : p.substr(0, slash + 1) + "powdr_jitc";
+    return access(p.c_str(), X_OK) == 0 ? p : "";
+}
+
+bool read_file(const std::string& path, std::vector<char>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    const bool ok = n > 0 && fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+
+// Compile sources[todo[k]] in `n_procs` helper processes (round robin). false = the helper could not be used at all (the
+// caller falls back to this process); a compiler error is reported through *err with `compiled` left incomplete.
+bool compile_with_helpers(const std::string& helper, const std::vector<std::string>& sources, const std::vector<size_t>& todo,
+                          unsigned n_procs, std::vector<std::vector<char>>& code, bool& compiled, std::string* err) {
+    compiled = false;
+    const char* base = getenv("TMPDIR");
+    std::string dir = std::string(base && *base ? base : "/tmp") + "/powdr_jit_XXXXXX";
+    if (!mkdtemp(&dir[0])) return false;
+    std::vector<std::string> src_path(todo.size()), out_path(todo.size());
+    bool ok = true;
+    for (size_t k = 0; k < todo.size() && ok; ++k) {
+        src_path[k] = dir + "/u" + std::to_string(k) + ".hip";
+        out_path[k] = dir + "/u" + std::to_string(k) + ".co";
+        FILE* f = fopen(src_path[k].c_str(), "wb");
+        ok = f && fwrite(sources[todo[k]].data(), 1, sources[todo[k]].size(), f) == sources[todo[k]].size();
+        if (f) fclose(f);
+    }
+    std::vector<pid_t> pids;
+    if (ok) {
+        for (unsigned p = 0; p < n_procs; ++p) {
+            std::vector<std::string> args{helper};
+            for (size_t k = p; k < todo.size(); k += n_procs) { args.push_back(src_path[k]); args.push_back(out_path[k]); }
+            if (args.size() == 1) continue;
+            std::vector<char*> argv;
+            for (auto& a : args) argv.push_back(&a[0]);
+            argv.push_back(nullptr);
+            pid_t pid = 0;
+            if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ) != 0) { ok = false; break; }
+            pids.push_back(pid);
+        }
+    }
+    bool all_zero = ok;
+    for (pid_t pid : pids) {
+        int status = 0;
+        if (waitpid(pid, &status, 0) != pid || !WIFEXITED(status) || WEXITSTATUS(status) != 0) all_zero = false;
+    }
+    bool usable = ok;
+    if (ok) {
+        compiled = all_zero;
+        for (size_t k = 0; k < todo.size() && compiled; ++k) compiled = read_file(out_path[k], code[k]);
+        if (!compiled) {
+            std::string msg;
+            for (size_t k = 0; k < todo.size() && msg.empty(); ++k) {
+                std::vector<char> e;
+                if (read_file(out_path[k] + ".err", e)) msg.assign(e.begin(), e.end());
+            }
+            if (msg.empty()) usable = false;  // the helper itself failed (missing library, killed): let this process try
+            else if (err) *err = msg;
+        }
+    }
+    for (size_t k = 0; k < todo.size(); ++k) { (void)unlink(src_path[k].c_str()); (void)unlink(out_path[k].c_str()); (void)unlink((out_path[k] + ".err").c_str()); }
+    (void)rmdir(dir.c_str());
+    return usable;
+}
 }  // namespace
+
+bool compile_to_code_object(const std::string& source, std::vector<char>& code, std::string* err) { return compile_code(source, code, err); }
 
 bool available() {
     if (const char* e = getenv("POWDR_JIT")) if (atoi(e) == 0) return false;
@@ -127,38 +212,30 @@ std::vector<ProgramPtr> compile_all(const std::vector<std::string>& sources, std
         }
     }
     if (!todo.empty()) {
-        unsigned n_threads = std::thread::hardware_concurrency();
-        if (n_threads > 32) n_threads = 32;
-        if (const char* e = getenv("POWDR_JIT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_threads = (unsigned)v; }
-        if (n_threads < 1) n_threads = 1;
-        if (n_threads > todo.size()) n_threads = (unsigned)todo.size();
-        std::atomic<size_t> next{0};
-        std::atomic<bool> failed{false};
-        std::mutex err_mu;
-        auto work = [&] {
-            for (;;) {
-                const size_t k = next.fetch_add(1);
-                if (k >= todo.size() || failed.load()) return;
-                const size_t i = todo[k];
-                auto p = std::make_shared<Program>();
-                std::string e;
-                if (!compile_one(sources[i], *p, &e)) {
-                    std::lock_guard<std::mutex> lk(err_mu);
-                    if (!failed.exchange(true) && err) *err = e;
-                    return;
-                }
-                out[i] = std::move(p);
-            }
-        };
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < n_threads; ++t) th.emplace_back(work);
-        work();
-        for (auto& t : th) t.join();
-        if (failed.load()) return {};
+        unsigned n_procs = std::thread::hardware_concurrency();
+        if (n_procs > 32) n_procs = 32;
+        if (const char* e = getenv("POWDR_JIT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_procs = (unsigned)v; }
+        if (n_procs < 1) n_procs = 1;
+        if (n_procs > todo.size()) n_procs = (unsigned)todo.size();
+        std::vector<std::vector<char>> code(todo.size());
+        bool compiled = false;
+        const std::string helper = n_procs > 1 ? helper_path() : std::string();
+        std::string e;
+        if (!helper.empty() && compile_with_helpers(helper, sources, todo, n_procs, code, compiled, &e)) {
+            if (!compiled) { if (err) *err = e; return {}; }
+        } else {
+            for (size_t k = 0; k < todo.size(); ++k)
+                if (!compile_code(sources[todo[k]], code[k], &e)) { if (err) *err = e; return {}; }
+        }
         std::lock_guard<std::mutex> lk(g_cache_mu);
-        for (size_t i : todo) {
-            auto ins = g_cache.emplace(hash64(sources[i]), out[i]);
-            if (!ins.second && ins.first->second->source == sources[i]) out[i] = ins.first->second;  // another thread was faster
+        for (size_t k = 0; k < todo.size(); ++k) {
+            const size_t i = todo[k];
+            auto p = std::make_shared<Program>();
+            p->source = sources[i];
+            p->code = std::move(code[k]);
+            auto ins = g_cache.emplace(hash64(sources[i]), p);
+            out[i] = (!ins.second && ins.first->second->source == sources[i]) ? ins.first->second : p;  // another thread was faster
+            if (ins.second == false && ins.first->second->source != sources[i]) ins.first->second = p;   // hash collision: the newer text takes the slot
         }
     }
     return out;

@@ -74,4 +74,54 @@ __device__ __forceinline__ Ext denominator0(const DenominatorSeeds& sd, uint32_t
     return acc.result();
 }
 
+// d1 m0 + d0 m1 (the numerator of a two-member group): the two products of a coordinate share one Montgomery reduction
+__device__ __forceinline__ Ext scale2(const Ext& a, uint32_t x, const Ext& b, uint32_t y) {
+    return {{bb::mul2(a.c[0], x, b.c[0], y), bb::mul2(a.c[1], x, b.c[1], y), bb::mul2(a.c[2], x, b.c[2], y), bb::mul2(a.c[3], x, b.c[3], y)}};
+}
+
+// Extension-field inversion split around its one base-field inversion (bb::ext_inv: norm to the quadratic subfield, then to
+// the base field), so that several elements can share the ~40-multiplication exponentiation (Montgomery's trick on the norms).
+struct ExtInvPrep { uint32_t d0, d1, n; };
+__device__ __forceinline__ ExtInvPrep ext_inv_prepare(const Ext& a) {
+    const uint32_t W = bb::w11();
+    const uint32_t s0 = bb::add(bb::sqr(a.c[0]), bb::mul(W, bb::sqr(a.c[2])));
+    const uint32_t s1 = bb::double_(bb::mul(a.c[0], a.c[2]));
+    const uint32_t t0 = bb::add(bb::sqr(a.c[1]), bb::mul(W, bb::sqr(a.c[3])));
+    const uint32_t t1 = bb::double_(bb::mul(a.c[1], a.c[3]));
+    ExtInvPrep p;
+    p.d0 = bb::sub(s0, bb::mul(W, t1));
+    p.d1 = bb::sub(s1, t0);
+    p.n = bb::sub(bb::sqr(p.d0), bb::mul(W, bb::sqr(p.d1)));
+    return p;
+}
+__device__ __forceinline__ Ext ext_inv_finish(const Ext& a, const ExtInvPrep& p, uint32_t n_inv) {
+    const uint32_t W = bb::w11();
+    const uint32_t e0 = bb::mul(p.d0, n_inv);
+    const uint32_t e1 = bb::neg(bb::mul(p.d1, n_inv));
+    const uint32_t r00 = bb::add(bb::mul(a.c[0], e0), bb::mul(W, bb::mul(a.c[2], e1)));
+    const uint32_t r01 = bb::add(bb::mul(a.c[0], e1), bb::mul(a.c[2], e0));
+    const uint32_t r10 = bb::neg(bb::add(bb::mul(a.c[1], e0), bb::mul(W, bb::mul(a.c[3], e1))));
+    const uint32_t r11 = bb::neg(bb::add(bb::mul(a.c[1], e1), bb::mul(a.c[3], e0)));
+    return {{r00, r10, r01, r11}};
+}
+// 1 / n[i] for K base-field elements with ONE inversion; a zero stays a zero's partner: the norm of an extension element is
+// zero only for the zero element, whose inverse ext_inv_finish returns as zero whatever factor it is handed (bb::inv(0) = 0
+// in the one-by-one form), so a zero norm is replaced by one here.
+template <int K>
+__device__ __forceinline__ void batch_inverse(const uint32_t (&n)[K], uint32_t (&out)[K]) {
+    uint32_t x[K], pre[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        x[i] = n[i] == 0u ? bb::R_MOD_P : n[i];
+        pre[i] = i ? bb::mul(pre[i - 1], x[i]) : x[i];
+    }
+    uint32_t inv = bb::inv(pre[K - 1]);
+#pragma unroll
+    for (int i = K - 1; i > 0; --i) {
+        out[i] = bb::mul(inv, pre[i - 1]);
+        inv = bb::mul(inv, x[i]);
+    }
+    out[0] = inv;
+}
+
 }  // namespace pwj

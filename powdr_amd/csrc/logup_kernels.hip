@@ -276,8 +276,10 @@ __global__ __launch_bounds__(kBlock) void deep_logup_kernel(const uint32_t* __re
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= N) return;
     bb::ExtWideAcc w1, w2;
+#pragma unroll 4
     for (uint32_t k = 0; k < W; ++k) w1.fma(gpow[k], lde[(size_t)k * N + j]);
     const uint32_t K1 = W + Wp + 8;
+#pragma unroll 4
     for (uint32_t k = 0; k < Wp; ++k) {
         const uint32_t x = plde[(size_t)k * N + j];
         w1.fma(gpow[W + k], x);

@@ -271,7 +271,7 @@ int ensure_prove_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
     TRY(p->ext_arena.ensure((2 * N + (lg ? 3 : 1) * H + H / 4096 + 32) * sizeof(bb::Ext)));
     const uint32_t n_chunks = div_up(H, 8192);
     const uint32_t dot_cols = std::max({W, Wp, 8u});
-    const size_t misc_ext = (size_t)dot_cols * n_chunks + K + K + M + p->max_args + 64;
+    const size_t misc_ext = 2 * (size_t)dot_cols * n_chunks + K + K + M + p->max_args + 64;  // ext_dot_columns2 keeps two sets of partial sums
     const uint32_t nq = p->cfg.num_queries;
     const size_t path_records = (size_t)nq * (L.n_trees * (size_t)logN + (size_t)log_h * logN) + 16;
     const size_t misc_bytes = misc_ext * sizeof(bb::Ext) + (size_t)nq * 4 + (size_t)nq * (W + Wp + 8) * 4 + path_records * (8 + 32) +
@@ -366,7 +366,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     bb::Ext* d_weights2 = d_weights + H;                   // LogUp: weights at g*zeta
     bb::Ext* d_rowsum = d_weights2 + H;                    // LogUp: per-row sums, then block totals
     bb::Ext* d_scratch = p->misc.as<bb::Ext>();            // dot_cols * n_chunks
-    bb::Ext* d_opened = d_scratch + (size_t)dot_cols * n_chunks;  // K
+    bb::Ext* d_opened = d_scratch + 2 * (size_t)dot_cols * n_chunks;  // K
     bb::Ext* d_gpow = d_opened + K;                        // K
     bb::Ext* d_apow = d_gpow + K;                          // M
     bb::Ext* d_blpow = d_apow + M + 4;                     // max_args + 2
@@ -469,10 +469,9 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const bb::Ext gzeta = bb::ext_scale(zeta, field::root_of_unity((int)log_h));
     TRY(barycentric_weights(zeta, (int)log_h, d_weights));
     TRY(ext_dot_columns(d_trace, H, W, H, d_weights, d_opened, d_scratch));
-    if (lg) {
-        TRY(ext_dot_columns(d_perm, H, Wp, H, d_weights, d_opened + W, d_scratch));
+    if (lg) {  // the permutation matrix at zeta and at g zeta: one pass over its columns
         TRY(barycentric_weights(gzeta, (int)log_h, d_weights2));
-        TRY(ext_dot_columns(d_perm, H, Wp, H, d_weights2, d_opened + K1, d_scratch));
+        TRY(ext_dot_columns2(d_perm, H, Wp, H, d_weights, d_weights2, d_opened + W, d_opened + K1, d_scratch));
     }
     TRY(zeta_weights(zeta, (int)log_h, d_weights));
     TRY(ext_dot_columns(d_qcoef, H, 8, H, d_weights, d_opened + W + Wp, d_scratch));

@@ -86,6 +86,10 @@ int barycentric_weights(bb::Ext zeta, int log_h, bb::Ext* weights);
 // out[c] = sum_q cols[c*stride + q] * weights[q]
 int ext_dot_columns(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t len, const bb::Ext* weights, bb::Ext* out,
                     bb::Ext* scratch);
+// the same for two weight vectors in ONE pass over the columns (out2[c] = sum_q cols[c*stride + q] * weights2[q]); scratch: 2 x
+// n_cols x ceil(len / 8192) Ext
+int ext_dot_columns2(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t len, const bb::Ext* weights, const bb::Ext* weights2,
+                     bb::Ext* out, bb::Ext* out2, bb::Ext* scratch);
 // v[j] = (sum_k gpow[k] * M_k[j] - opened_sum) / (x_j - zeta), x_j = s * g^j, over two matrices
 int deep_quotient(const uint32_t* lde_a, uint32_t wa, const uint32_t* lde_b, uint32_t wb, size_t N, int logN,
                   const bb::Ext* d_gpow, bb::Ext opened_sum, bb::Ext zeta, bb::Ext* v);

@@ -43,7 +43,7 @@ int specialise_provers(PwProver* const* ps, size_t n, const uint32_t* log_height
     const char* e = getenv("POWDR_JIT");
     const bool always = force || (e && atoi(e) == 1);
     const uint32_t min_log = env_u32("POWDR_JIT_MIN_LOG_HEIGHT", 18, 1, 40);
-    const uint32_t chunk_cost = env_u32("POWDR_JIT_CHUNK_COST", 3500, 200, 1000000);
+    const uint32_t chunk_cost = env_u32("POWDR_JIT_CHUNK_COST", 8000, 200, 1000000);
     // chunks per translation unit: few enough that every compiler thread gets a unit, at most POWDR_JIT_UNIT_CHUNKS (8)
     const uint32_t per_unit_max = env_u32("POWDR_JIT_UNIT_CHUNKS", 8, 1, 4096);
     unsigned hw = std::thread::hardware_concurrency();

@@ -85,7 +85,7 @@ int ensure_air(PwProver* p, const Shape& s, bool logup, CommitLayout& Lc) {
     TRY(p->ext_arena.ensure((3 * s.H + s.H / 4096 + 32) * sizeof(bb::Ext)));  // weights | weights at g zeta | row sums + block totals
     const uint32_t n_chunks = div_up(s.H, 8192);
     const uint32_t dot_cols = std::max({s.W, s.Wp, 8u});
-    TRY(p->misc.ensure(((size_t)dot_cols * n_chunks + s.M + p->max_args + 64) * sizeof(bb::Ext) + 4096));
+    TRY(p->misc.ensure((2 * (size_t)dot_cols * n_chunks + s.M + p->max_args + 64) * sizeof(bb::Ext) + 4096));  // ext_dot_columns2: two sets of partial sums
     return 0;
 }
 
@@ -263,7 +263,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     // per-AIR scratch pointers
     auto weights_of = [&](size_t a) { return airs[a].prover->ext_arena.as<bb::Ext>(); };
     auto scratch_of = [&](size_t a) { return airs[a].prover->misc.as<bb::Ext>(); };
-    auto apow_of = [&](size_t a) { return scratch_of(a) + (size_t)std::max({sh[a].W, sh[a].Wp, 8u}) * div_up(sh[a].H, 8192); };
+    auto apow_of = [&](size_t a) { return scratch_of(a) + 2 * (size_t)std::max({sh[a].W, sh[a].Wp, 8u}) * div_up(sh[a].H, 8192); };
     auto blpow_of = [&](size_t a) { return apow_of(a) + sh[a].M + 4; };
     auto logup_program = [&](size_t a) {
         const PwProver* p = airs[a].prover;
@@ -365,10 +365,9 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         // trace columns: barycentric evaluation straight from the caller's trace; quotient chunks from their coefficients
         TRY(barycentric_weights(zeta, (int)s.log_h, w1));
         TRY(ext_dot_columns(airs[a].d_trace, s.H, s.W, s.H, w1, o, scratch_of(a)));
-        if (lg) {
-            TRY(ext_dot_columns(p->perm.as<uint32_t>(), s.H, s.Wp, s.H, w1, o + s.W, scratch_of(a)));
+        if (lg) {  // the permutation matrix at zeta and at g zeta: one pass over its columns
             TRY(barycentric_weights(gzeta[a], (int)s.log_h, w2));
-            TRY(ext_dot_columns(p->perm.as<uint32_t>(), s.H, s.Wp, s.H, w2, o + s.W + s.Wp + 8, scratch_of(a)));
+            TRY(ext_dot_columns2(p->perm.as<uint32_t>(), s.H, s.Wp, s.H, w1, w2, o + s.W, o + s.W + s.Wp + 8, scratch_of(a)));
         }
         TRY(zeta_weights(zeta, (int)s.log_h, w1));
         TRY(ext_dot_columns(p->qcoef.as<uint32_t>(), s.H, 8, s.H, w1, o + s.W + s.Wp, scratch_of(a)));

@@ -144,52 +144,69 @@ __global__ __launch_bounds__(kBlock) void barycentric_weights_kernel(bb::Ext zet
 
 constexpr int kDotRowsPerBlock = 8192;
 constexpr int kDotColsPerBlock = 4;  // columns that share one pass over the weights
+// NW = 2: two weight vectors in one pass over the columns (the permutation matrix is opened at zeta AND at g zeta: reading it
+// once instead of twice); partial sums of the second vector go to partial + second_off
+template <int NW>
 __global__ __launch_bounds__(kBlock) void ext_dot_partial_kernel(const uint32_t* __restrict__ cols, size_t stride, size_t len,
                                                                   uint32_t n_cols, const bb::Ext* __restrict__ weights,
-                                                                  bb::Ext* __restrict__ partial, uint32_t n_chunks) {
-    __shared__ uint32_t red[kDotColsPerBlock][4][kBlock / 64];
+                                                                  const bb::Ext* __restrict__ weights2, bb::Ext* __restrict__ partial,
+                                                                  size_t second_off, uint32_t n_chunks) {
+    __shared__ uint32_t red[NW][kDotColsPerBlock][4][kBlock / 64];
     const uint32_t c0 = blockIdx.y * kDotColsPerBlock;
     const uint32_t nc = n_cols - c0 < (uint32_t)kDotColsPerBlock ? n_cols - c0 : (uint32_t)kDotColsPerBlock;  // block-uniform
     const uint32_t* col = cols + (size_t)c0 * stride;
     const size_t q0 = (size_t)blockIdx.x * kDotRowsPerBlock;
     const size_t q1 = q0 + kDotRowsPerBlock < len ? q0 + kDotRowsPerBlock : len;
-    bb::ExtWideAcc wide[kDotColsPerBlock];
+    bb::ExtWideAcc wide[NW][kDotColsPerBlock];
     if (nc == kDotColsPerBlock) {
         for (size_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
             const bb::Ext w = weights[q];
+            const bb::Ext w2 = NW == 2 ? weights2[q] : w;
 #pragma unroll
-            for (int c = 0; c < kDotColsPerBlock; ++c) wide[c].fma(w, col[(size_t)c * stride + q]);
+            for (int c = 0; c < kDotColsPerBlock; ++c) {
+                const uint32_t x = col[(size_t)c * stride + q];
+                wide[0][c].fma(w, x);
+                if (NW == 2) wide[NW - 1][c].fma(w2, x);
+            }
         }
     } else {
         for (size_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
             const bb::Ext w = weights[q];
+            const bb::Ext w2 = NW == 2 ? weights2[q] : w;
 #pragma unroll
             for (int c = 0; c < kDotColsPerBlock; ++c)
-                if ((uint32_t)c < nc) wide[c].fma(w, col[(size_t)c * stride + q]);
+                if ((uint32_t)c < nc) {
+                    const uint32_t x = col[(size_t)c * stride + q];
+                    wide[0][c].fma(w, x);
+                    if (NW == 2) wide[NW - 1][c].fma(w2, x);
+                }
         }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int c = 0; c < kDotColsPerBlock; ++c) {
-        const bb::Ext part = wide[c].result();
+    for (int v = 0; v < NW; ++v)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t r = part.c[k];
+        for (int c = 0; c < kDotColsPerBlock; ++c) {
+            const bb::Ext part = wide[v][c].result();
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) r = bb::add(r, __shfl_down(r, off, 64));  // wave reduction
-            if (lane == 0) red[c][k][wave] = r;
+            for (int k = 0; k < 4; ++k) {
+                uint32_t r = part.c[k];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) r = bb::add(r, __shfl_down(r, off, 64));  // wave reduction
+                if (lane == 0) red[v][c][k][wave] = r;
+            }
         }
-    }
     __syncthreads();
-    if (threadIdx.x < nc) {
+    if (threadIdx.x < nc * NW) {
+        const uint32_t v = threadIdx.x / nc, c = threadIdx.x - v * nc;
         bb::Ext o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint32_t s_ = red[threadIdx.x][k][0];
-            for (int w = 1; w < kBlock / 64; ++w) s_ = bb::add(s_, red[threadIdx.x][k][w]);
+            uint32_t s_ = red[v][c][k][0];
+            for (int w = 1; w < kBlock / 64; ++w) s_ = bb::add(s_, red[v][c][k][w]);
             o.c[k] = s_;
         }
-        partial[(size_t)(c0 + threadIdx.x) * n_chunks + blockIdx.x] = o;
+        partial[(v ? second_off : 0) + (size_t)(c0 + c) * n_chunks + blockIdx.x] = o;
     }
 }
 __global__ void ext_dot_final_kernel(const bb::Ext* __restrict__ partial, uint32_t n_cols, uint32_t n_chunks, bb::Ext* __restrict__ out) {
@@ -341,10 +358,26 @@ int ext_dot_columns(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t
     for (uint32_t c0 = 0; c0 < n_cols; c0 += max_cols) {
         uint32_t cc = n_cols - c0 < max_cols ? n_cols - c0 : max_cols;
         ScopedKernelTimer t("ext_dot_partial_kernel");
-        hipLaunchKernelGGL(ext_dot_partial_kernel, dim3(n_chunks, div_up(cc, kDotColsPerBlock)), dim3(kBlock), 0, stream(),
-                           cols + (size_t)c0 * stride, stride, len, cc, weights, scratch + (size_t)c0 * n_chunks, n_chunks);
+        hipLaunchKernelGGL(ext_dot_partial_kernel<1>, dim3(n_chunks, div_up(cc, kDotColsPerBlock)), dim3(kBlock), 0, stream(),
+                           cols + (size_t)c0 * stride, stride, len, cc, weights, weights, scratch + (size_t)c0 * n_chunks, (size_t)0, n_chunks);
     }
     hipLaunchKernelGGL(ext_dot_final_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, stream(), scratch, n_cols, n_chunks, out);
+    return (int)hipGetLastError();
+}
+
+int ext_dot_columns2(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t len, const bb::Ext* weights, const bb::Ext* weights2,
+                     bb::Ext* out, bb::Ext* out2, bb::Ext* scratch) {
+    const uint32_t n_chunks = div_up(len, kDotRowsPerBlock);
+    const uint32_t max_cols = 65535u * kDotColsPerBlock;
+    const size_t second = (size_t)n_cols * n_chunks;
+    for (uint32_t c0 = 0; c0 < n_cols; c0 += max_cols) {
+        uint32_t cc = n_cols - c0 < max_cols ? n_cols - c0 : max_cols;
+        ScopedKernelTimer t("ext_dot_partial_kernel");
+        hipLaunchKernelGGL(ext_dot_partial_kernel<2>, dim3(n_chunks, div_up(cc, kDotColsPerBlock)), dim3(kBlock), 0, stream(),
+                           cols + (size_t)c0 * stride, stride, len, cc, weights, weights2, scratch + (size_t)c0 * n_chunks, second, n_chunks);
+    }
+    hipLaunchKernelGGL(ext_dot_final_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, stream(), scratch, n_cols, n_chunks, out);
+    hipLaunchKernelGGL(ext_dot_final_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, stream(), scratch + second, n_cols, n_chunks, out2);
     return (int)hipGetLastError();
 }
 
