@@ -246,7 +246,7 @@ def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup,
         with torch.cuda.device(devices[w]):
             provers, traces = [], []
             for k, (name, wd, lh, nc, ni) in enumerate(shapes):
-                bc, sp, it = synth.random_air_programs(wd, nc, ni, seed=k)
+                bc, sp, it = synth.air_programs(name, wd, nc, ni, seed=k)
                 provers.append(prover.Prover(wd, bc, sp, num_queries=queries, pow_bits=pow_bits, interactions=it if logup else None))
                 t = torch.empty(wd << lh, dtype=torch.int32, device="cuda")
                 t.random_(0, P)
@@ -303,7 +303,7 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
     cells_seg = sum(w << lh for _, w, lh, _, _ in shapes)
     provers, traces = [], []
     for k, (name, w, lh, nc, ni) in enumerate(shapes):
-        bc, sp, it = synth.random_air_programs(w, nc, ni, seed=k)
+        bc, sp, it = synth.air_programs(name, w, nc, ni, seed=k)
         provers.append(prover.Prover(w, bc, sp, num_queries=queries, pow_bits=pow_bits, interactions=it if logup else None))
         t = torch.empty(w << lh, dtype=torch.int32, device="cuda")
         t.random_(0, P)

@@ -1,0 +1,172 @@
+"""Parser for the reference's textual AIR snapshots (`# <AIR name>` / `Symbolic machine using N unique main columns:` /
+`// Bus k (NAME):` lines `mult=<expr>, args=[<expr>, ...]` / `// Algebraic constraints:` lines `<expr> = 0`), the format of
+/root/reference/openvm-riscv/tests/openvm_constraints.txt (written by `SymbolicMachine`'s Display, autoprecompiles/src/
+symbolic_machine.rs) — the original RV32IM instruction AIRs an autoprecompile is built from.
+
+Output: the tables pw_prover_create / pw_prover_create_logup take (post-fix bytecode with COLUMN-INDEX operands), so that the
+real constraints of the original chips can be proven and mock-checked (pw_prover_check_constraints) by this library."""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+
+import numpy as np
+
+P = 0x78000001
+OP_PUSH_COL, OP_PUSH_CONST, OP_ADD, OP_SUB, OP_MUL, OP_NEG = 0, 1, 2, 3, 4, 5
+
+_TOKEN = re.compile(r"\s*(?:(\d+)|([A-Za-z_][A-Za-z_0-9]*)|(.))")
+
+
+def _tokens(text):
+    out = []
+    for num, ident, sym in _TOKEN.findall(text):
+        if num:
+            out.append(("num", int(num) % P))
+        elif ident:
+            out.append(("id", ident))
+        elif sym.strip():
+            out.append(("sym", sym))
+    return out
+
+
+class _Parser:
+    """expr := term (('+' | '-') term)* ; term := unary ('*' unary)* ; unary := '-' unary | atom ; atom := num | id | '(' expr ')'
+    emitting post-fix code as it goes (left-associative, like the Display it reads)."""
+
+    def __init__(self, toks, col_index):
+        self.t, self.i, self.col, self.code = toks, 0, col_index, []
+
+    def peek(self):
+        return self.t[self.i] if self.i < len(self.t) else (None, None)
+
+    def eat(self, kind=None, val=None):
+        k, v = self.peek()
+        if k is None or (kind and k != kind) or (val is not None and v != val):
+            raise ValueError(f"unexpected token {self.peek()} at {self.i}")
+        self.i += 1
+        return v
+
+    def expr(self):
+        self.term()
+        while self.peek() in (("sym", "+"), ("sym", "-")):
+            op = self.eat()
+            self.term()
+            self.code.append(OP_ADD if op == "+" else OP_SUB)
+
+    def term(self):
+        self.unary()
+        while self.peek() == ("sym", "*"):
+            self.eat()
+            self.unary()
+            self.code.append(OP_MUL)
+
+    def unary(self):
+        if self.peek() == ("sym", "-"):
+            self.eat()
+            self.unary()
+            self.code.append(OP_NEG)
+        else:
+            self.atom()
+
+    def atom(self):
+        k, v = self.peek()
+        if k == "num":
+            self.eat()
+            self.code += [OP_PUSH_CONST, v]
+        elif k == "id":
+            self.eat()
+            if v not in self.col:
+                raise ValueError(f"unknown column {v}")
+            self.code += [OP_PUSH_COL, self.col[v]]
+        elif (k, v) == ("sym", "("):
+            self.eat()
+            self.expr()
+            self.eat("sym", ")")
+        else:
+            raise ValueError(f"unexpected token {self.peek()}")
+
+
+def compile_expr(text: str, col_index: dict) -> list:
+    p = _Parser(_tokens(text), col_index)
+    p.expr()
+    if p.i != len(p.t):
+        raise ValueError(f"trailing tokens in {text!r}")
+    return p.code
+
+
+def _split_args(s: str):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+            continue
+        depth += ch == "("
+        depth -= ch == ")"
+        cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+@dataclass
+class TextAir:
+    name: str
+    columns: list
+    constraints: list = field(default_factory=list)   # expression texts
+    interactions: list = field(default_factory=list)  # (bus id, mult text, [arg texts])
+
+    @property
+    def width(self):
+        return len(self.columns)
+
+    def tables(self):
+        """(cons_bytecode, cons_spans[n, 2], (interactions[n, 3], inter_spans[m, 2], inter_bytecode)) — pw_prover_create_logup's arguments."""
+        col = {n: i for i, n in enumerate(self.columns)}
+        bc, spans = [], []
+        for c in self.constraints:
+            code = compile_expr(c, col)
+            spans.append((len(bc), len(code)))
+            bc += code
+        ibc, ispans, inter = [], [], []
+        for bus, mult, args in self.interactions:
+            inter.append((bus, len(args), len(ispans)))
+            for e in [mult] + args:
+                code = compile_expr(e, col)
+                ispans.append((len(ibc), len(code)))
+                ibc += code
+        return (np.array(bc, np.uint32), np.array(spans, np.uint32).reshape(-1, 2),
+                (np.array(inter, np.uint32).reshape(-1, 3), np.array(ispans, np.uint32).reshape(-1, 2), np.array(ibc, np.uint32)))
+
+
+def parse_airs(text: str) -> list:
+    airs, cur, mode, bus = [], None, None, None
+    for raw in text.splitlines():
+        line = raw.strip()
+        if raw.startswith("# "):
+            cur = TextAir(raw[2:].strip(), [])
+            airs.append(cur)
+            mode = None
+        elif line.startswith("Symbolic machine using"):
+            mode = "cols"
+        elif line.startswith("// Bus"):
+            bus = int(re.match(r"// Bus (\d+)", line).group(1))
+            mode = "bus"
+        elif line.startswith("// Algebraic constraints"):
+            mode = "cons"
+        elif not line:
+            if mode == "cols":
+                mode = None
+        elif mode == "cols":
+            cur.columns.append(line)
+        elif mode == "bus":
+            m = re.match(r"mult=(.*), args=\[(.*)\]$", line)
+            if not m:
+                raise ValueError(f"cannot parse interaction {line!r}")
+            cur.interactions.append((bus, m.group(1), _split_args(m.group(2))))
+        elif mode == "cons":
+            if not line.endswith("= 0"):
+                raise ValueError(f"cannot parse constraint {line!r}")
+            cur.constraints.append(line[: -len("= 0")].strip())
+    return airs

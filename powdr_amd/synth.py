@@ -383,11 +383,23 @@ def fill_dummy_traces_numpy(s: SynthApc, num_calls: int, seed: int = 0, pow2: bo
 # ---------------------------------------------------------------------------------------------------------------------
 # Multi-AIR segments: shapes only — widths, heights, constraint and interaction counts. The proofs'
 # cost does not depend on the values, so the bench proves random traces against programs of the right size and form.
-SYSTEM_AIR_WIDTHS = [2, 4, 5, 7, 8, 10, 12, 17, 19, 20, 21, 26, 31, 36, 41, 53, 98, 139, 270]  # 19 AIRs, sum 819
-SYSTEM_AIR_LOG_HEIGHTS = [10, 12, 14, 13, 16, 15, 17, 18, 16, 19, 17, 20, 18, 19, 20, 18, 15, 14, 16]
-# /root/reference/openvm-riscv/src/lib.rs:1114-1122: 19 non-powdr machines, main width 819, 643 constraints, 253 interactions
+# /root/reference/openvm-riscv/src/lib.rs:1114-1122: 19 non-powdr machines, main width 819, 643 constraints, 253 interactions.
+# Thirteen of them are the RV32IM instruction AIRs whose ACTUAL constraints and bus interactions the reference snapshots in
+# openvm-riscv/tests/openvm_constraints.txt (456 columns, 307 constraints, 227 interactions; parsed by powdr_amd/air_text.py into
+# tests/golden/openvm_airs.npz): those are proven with their real programs. The other six (program, connector, memory boundary /
+# Merkle, Poseidon2 periphery, range / bitwise lookups: EXTERNAL, no snapshot) carry random programs that make up the pinned totals.
+REFERENCE_AIR_WIDTHS = {"BaseAlu": 36, "LessThan": 37, "Shift": 53, "BranchEqual": 26, "BranchLessThan": 32, "JalLui": 18, "Jalr": 28,
+                        "LoadSignExtend": 36, "LoadStore": 41, "DivRem": 59, "MulH": 39, "Multiplication": 31, "Auipc": 20}
+REFERENCE_AIR_COUNTS = {"BaseAlu": (22, 20), "LessThan": (28, 18), "Shift": (76, 24), "BranchEqual": (11, 11), "BranchLessThan": (25, 13),
+                        "JalLui": (9, 10), "Jalr": (9, 16), "LoadSignExtend": (18, 18), "LoadStore": (25, 17), "DivRem": (64, 25), "MulH": (11, 24),
+                        "Multiplication": (4, 19), "Auipc": (5, 12)}  # (constraints, interactions)
+OTHER_SYSTEM_AIRS = [("connector", 2, 10), ("program", 4, 18), ("boundary", 21, 16), ("merkle", 32, 17), ("range_bitwise", 6, 18), ("poseidon2", 298, 14)]  # (name, width, log height)
+REFERENCE_AIR_LOG_HEIGHTS = {"BaseAlu": 20, "LessThan": 16, "Shift": 19, "BranchEqual": 17, "BranchLessThan": 16, "JalLui": 14, "Jalr": 15,
+                             "LoadSignExtend": 13, "LoadStore": 20, "DivRem": 12, "MulH": 10, "Multiplication": 15, "Auipc": 13}
 SYSTEM_CONSTRAINTS, SYSTEM_INTERACTIONS = 643, 253
-assert sum(SYSTEM_AIR_WIDTHS) == 819 and len(SYSTEM_AIR_WIDTHS) == len(SYSTEM_AIR_LOG_HEIGHTS) == 19
+SYSTEM_AIR_WIDTHS = list(REFERENCE_AIR_WIDTHS.values()) + [w for _, w, _ in OTHER_SYSTEM_AIRS]
+assert sum(SYSTEM_AIR_WIDTHS) == 819 and len(SYSTEM_AIR_WIDTHS) == 19
+assert sum(c for c, _ in REFERENCE_AIR_COUNTS.values()) == 307 and sum(i for _, i in REFERENCE_AIR_COUNTS.values()) == 227
 C4_APC_WIDTHS = [520, 440, 380, 330, 290, 260, 230, 210, 180, 160]  # 10 APC AIRs of a pairing-shaped segment, sum 3000
 
 
@@ -407,8 +419,10 @@ def segment_shape(kind: str, seed: int = 0, max_log_height: int = 20):
     APC AIRs carry constraints / interactions at the keccak APC's densities (187 and 1 734 per 2 022 columns)."""
     shrink = 20 - max_log_height
     airs = []
-    sc, si = _split(SYSTEM_CONSTRAINTS, SYSTEM_AIR_WIDTHS), _split(SYSTEM_INTERACTIONS, SYSTEM_AIR_WIDTHS)
-    system = [(f"sys{k}", w, max(2, lh - shrink), sc[k], si[k]) for k, (w, lh) in enumerate(zip(SYSTEM_AIR_WIDTHS, SYSTEM_AIR_LOG_HEIGHTS))]
+    system = [(n, w, max(2, REFERENCE_AIR_LOG_HEIGHTS[n] - shrink), *REFERENCE_AIR_COUNTS[n]) for n, w in REFERENCE_AIR_WIDTHS.items()]
+    ow = [w for _, w, _ in OTHER_SYSTEM_AIRS]
+    oc, oi = _split(SYSTEM_CONSTRAINTS - 307, ow), _split(SYSTEM_INTERACTIONS - 227, ow)
+    system += [(n, w, max(2, lh - shrink), oc[k], oi[k]) for k, (n, w, lh) in enumerate(OTHER_SYSTEM_AIRS)]
     apc = lambda name, w, lh: (name, w, lh, max(1, round(w * 187 / 2022)), max(1, round(w * 1734 / 2022)))
     if kind == "C4":
         airs = [apc(f"apc{k}", w, max_log_height) for k, w in enumerate(C4_APC_WIDTHS)]
@@ -427,6 +441,30 @@ def segment_shape(kind: str, seed: int = 0, max_log_height: int = 20):
     else:
         raise ValueError(kind)
     return airs + system
+
+
+_REFERENCE_AIRS = None
+
+
+def reference_air_programs(name: str):
+    """(cons_bc, cons_spans, (inter, ispans, ibc)) of one of the reference's RV32IM instruction AIRs (REFERENCE_AIR_WIDTHS) from the
+    committed fixture tests/golden/openvm_airs.npz (made by tests/golden/make_openvm_airs.py from the reference's snapshot)."""
+    global _REFERENCE_AIRS
+    if _REFERENCE_AIRS is None:
+        from pathlib import Path
+
+        z = np.load(Path(__file__).resolve().parents[1] / "tests" / "golden" / "openvm_airs.npz")
+        _REFERENCE_AIRS = {str(n): (z[f"a{k}_bc"], z[f"a{k}_spans"], (z[f"a{k}_inter"], z[f"a{k}_ispans"], z[f"a{k}_ibc"])) for k, n in enumerate(z["names"])}
+    return _REFERENCE_AIRS[name]
+
+
+def air_programs(name: str, width: int, n_constraints: int, n_interactions: int, seed: int):
+    """Programs of one AIR of a segment shape: the real ones for the reference's instruction AIRs, random ones of the given size otherwise."""
+    if name in REFERENCE_AIR_WIDTHS:
+        bc, sp, it = reference_air_programs(name)
+        assert width == REFERENCE_AIR_WIDTHS[name] and len(sp) == n_constraints and len(it[0]) == n_interactions
+        return bc, sp, it
+    return random_air_programs(width, n_constraints, n_interactions, seed)
 
 
 def random_air_programs(width: int, n_constraints: int, n_interactions: int, seed: int):

@@ -235,7 +235,7 @@ def test_c4_c5_segment_proof_bytes_match_oracle(gpu, kind, cap, logup):
     rng = np.random.default_rng(7)
     airs, provers, traces = [], [], []
     for k, (name, w, lh, nc, ni) in enumerate(shapes):
-        bc, sp, it = synth.random_air_programs(w, nc, ni, seed=k)
+        bc, sp, it = synth.air_programs(name, w, nc, ni, seed=k)
         flat = rng.integers(0, P, size=w << lh, dtype=np.uint32)
         airs.append((flat, w, lh, bc, sp, it))
         provers.append(prover.Prover(w, bc, sp, num_queries=5, pow_bits=3, interactions=it if logup else None))
