@@ -644,7 +644,7 @@ def main():
                                  reference_layout_source_bytes=wl["src_bytes"],
                                  note="powdr_apc_tracegen_callmajor: sources = per call only the cells the APC uses, contiguous; what the original "
                                       "chips would have to write for the gather to move 8 B per APC cell (SURVEY 8d) instead of the whole dummy traces")
-            del out2, cm_airs
+            del out2, cm_airs, buf, view, t, base
             torch.cuda.empty_cache()
         except Exception as e:
             callmajor_leg = dict(gather_ms=None, error=f"{type(e).__name__}: {e}")
@@ -691,7 +691,7 @@ def main():
                                  note="_apc_tracegen on the reference's source layout with column-structured substitutions (few columns of every "
                                       "original AIR, present in ~65 % of its instructions: what optimised APCs look like in the reference's snapshots); "
                                       "the timed step uses uniformly scattered cells, the worst case for the gather")
-            del out2, keep
+            del out2, keep, airs_cs, t
             torch.cuda.empty_cache()
         except Exception as e:
             colstruct_leg = dict(gather_ms=None, error=f"{type(e).__name__}: {e}")
@@ -762,6 +762,9 @@ def main():
         try:
             import gc
 
+            for k in ("tensors", "dummy", "out"):  # (the segment leg may have failed before it released the 150 GB of sources)
+                wl.pop(k, None)
+            main_worker.clear()
             gc.collect()
             torch.cuda.empty_cache()
             c3 = c3_leg(args.queries, args.pow_bits)

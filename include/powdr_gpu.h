@@ -164,6 +164,48 @@ typedef struct {
 int powdr_apc_tracegen_callmajor(PowdrFp* d_output, size_t output_height, const PowdrCallMajorAir* h_airs, size_t n_airs,
                                  const PowdrSubstCM* h_subs, size_t n_subs, int num_apc_calls);
 
+/* SURVEY.md §8 row (f)-1, the PRODUCER half: the original RV32IM chips of a keccak autoprecompile on the device, and the APC
+ * gather fused into them. The reference materialises every original AIR's full dummy trace from its record arena
+ * (`chip.generate_proving_ctx(record_arena)`, cuda/mod.rs:228-253) and then gathers the cells the APC keeps; a chip computes
+ * all cells of a row from one small record, so the expansion can run inside the gather and the dummy traces never exist.
+ * Five chips: BaseAlu (ADD SUB XOR OR AND = opcodes 512..516), Shift (SLL SRL SRA = 517..519), LoadStore (LOADW 528, STOREW
+ * 531), BranchEqual (BEQ 544, BNE 545), JalLui (JAL 560, LUI 561); columns and semantics as snapshot in the reference's
+ * openvm-riscv/tests/openvm_constraints.txt (every constraint listed there holds on the rows produced here).
+ *
+ * Instruction table (host): the block's instructions that keep at least one cell, in program order. Records (device, u32,
+ * word-major: d_records[word * num_calls + call]): word 0 = from_state.timestamp of the call's first instruction, then at
+ * `rec_off` per instruction   BaseAlu / Shift: b, c, rd's previous value, prev_timestamp of rs1, rs2, rd (6 words)
+ *                            LoadStore: rs1, the word read, the overwritten word, prev_timestamp of rs1, read, write (6)
+ *                            BranchEqual: a, b, prev_timestamp of rs1, rs2 (4)        JalLui: rd's previous value, its prev_timestamp (2)
+ * (the layout is this library's: the reference's DenseRecordArena layouts are EXTERNAL). */
+enum { POWDR_ORIG_BASE_ALU = 0, POWDR_ORIG_SHIFT = 1, POWDR_ORIG_LOAD_STORE = 2, POWDR_ORIG_BRANCH_EQ = 3, POWDR_ORIG_JAL_LUI = 4 };
+typedef struct {
+    uint32_t kind;      /* POWDR_ORIG_* */
+    uint32_t opcode;    /* global opcode, see above */
+    uint32_t pc;        /* from_state.pc of this instruction */
+    uint32_t a, b, c;   /* operands of the instruction [opcode, a, b, c, d, e, f, g]; c reduced mod p */
+    uint32_t e, f, g;   /* rs2 address space (ALU) / memory address space; needs_write; sign of the immediate */
+    uint32_t ts_delta;  /* from_state.timestamp of this instruction minus the call's first timestamp */
+    uint32_t air_row;   /* row of this instruction inside its AIR's block of row_block_size rows per call */
+    uint32_t rec_off;   /* first record word of this instruction inside a call's record */
+} PowdrOrigInstr;
+typedef struct {
+    int32_t instr;      /* index into the instruction table */
+    int32_t col;        /* column of that instruction's AIR */
+    int32_t apc_col;
+} PowdrRecordSubst;
+/* Full column-major dummy traces of the five AIRs — what the reference's chips hand to _apc_tracegen: h_airs[kind] = {width,
+ * height, device buffer, row_block_size} (an AIR that does not occur: buffer NULL); the row of instruction i of call r is
+ * air_row(i) + r * row_block_size; rows beyond the calls are not touched (zero-initialise the buffers). */
+int powdr_original_airs_expand(const uint32_t* d_records, size_t num_calls, const PowdrOrigInstr* h_instrs, size_t n_instrs,
+                               const OriginalAir* h_airs);
+/* The fused form: out[apc_col * H + r] = r < num_apc_calls ? cell `col` of the row instruction `instr` produces in call r : 0,
+ * straight from the records (duplicate apc_col: the last PowdrRecordSubst wins). Equal to powdr_original_airs_expand followed
+ * by _apc_tracegen on Subst {kind, col, air_row(instr), apc_col}; moves 16 KB of records per call of a keccak block instead of
+ * 110 KB of dummy-trace cells written and read back. */
+int powdr_apc_tracegen_records(PowdrFp* d_output, size_t output_height, const uint32_t* d_records, size_t num_apc_calls,
+                               const PowdrOrigInstr* h_instrs, size_t n_instrs, const PowdrRecordSubst* h_subs, size_t n_subs);
+
 /* Traces of the shared periphery chips (the RECEIVE side of the three lookup buses) from the histograms
  * _apc_apply_bus filled. The chips are EXTERNAL (openvm-circuit-primitives; instantiated in
  * openvm/src/powdr_extension/trace_generator/cuda/periphery.rs:33-85); in-repo is how a lookup becomes a histogram

@@ -86,6 +86,7 @@ class Apc:
     derived_columns: list
     subs: list  # per instruction: [(original_poly_index, apc_poly_id), ...]
     bus_map: dict = field(default_factory=dict)
+    start_pc: int = 0  # pc of the first instruction of the first block
 
     def main_columns(self):
         """Ascending poly ids of all references in constraints and bus interactions."""
@@ -140,6 +141,7 @@ def load_apc(d: dict) -> Apc:
         derived_columns=derived,
         subs=[[(int(s["original_poly_index"]), int(s["apc_poly_id"])) for s in row] for row in d["subs"]],
         bus_map=d.get("bus_map", {}),
+        start_pc=int(d["block"]["blocks"][0].get("start_pc", 0)) if d["block"]["blocks"] else 0,
     )
 
 

@@ -1,0 +1,150 @@
+"""Host side of SURVEY.md §8 row (f)-1's producer half (include/powdr_gpu.h: powdr_original_airs_expand,
+powdr_apc_tracegen_records): the instruction table of an APC block and the record -> APC-cell substitution list.
+
+The reference builds, per APC and segment, dummy chips that turn record arenas into full dummy traces
+(/root/reference/openvm/src/powdr_extension/trace_generator/cuda/mod.rs:201-253) and Subst entries (air, col, row, apc_col) into
+them (:272-328); here the same Subst entries address (instruction, column) of a record expansion instead."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+lib = abi.lib
+P = 0x78000001
+BASE_ALU, SHIFT, LOAD_STORE, BRANCH_EQ, JAL_LUI = range(5)
+KIND_NAMES = ["BaseAlu", "Shift", "LoadStore", "BranchEqual", "JalLui"]
+WIDTHS = [36, 53, 41, 26, 18]
+RECORD_WORDS = [6, 6, 6, 4, 2]
+# from_state.timestamp advances by the number of memory accesses of the instruction (execution-bridge bus of each AIR)
+TIMESTAMP_STEP = [3, 3, 3, 2, 1]
+ORIG_SYMBOLS = ["powdr_original_airs_expand", "powdr_apc_tracegen_records"]
+
+
+def kind_of_opcode(op: int) -> int:
+    if 512 <= op <= 516:
+        return BASE_ALU
+    if 517 <= op <= 519:
+        return SHIFT
+    if op in (528, 531):
+        return LOAD_STORE
+    if op in (544, 545):
+        return BRANCH_EQ
+    if op in (560, 561):
+        return JAL_LUI
+    raise ValueError(f"opcode {op} belongs to none of the five chips")
+
+
+class PowdrOrigInstr(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("kind", "opcode", "pc", "a", "b", "c", "e", "f", "g", "ts_delta", "air_row", "rec_off")]
+
+
+class PowdrRecordSubst(C.Structure):
+    _fields_ = [("instr", C.c_int32), ("col", C.c_int32), ("apc_col", C.c_int32)]
+
+
+assert C.sizeof(PowdrOrigInstr) == 48 and C.sizeof(PowdrRecordSubst) == 12
+
+
+class InstructionTable:
+    """The block's instructions that keep at least one cell (cuda/mod.rs:283-291 drops the others), in program order."""
+
+    def __init__(self, instructions, has_subs, start_pc: int):
+        self.entries = []
+        self.index_of = {}          # index in `instructions` -> index in the table
+        self.row_block_size = [0] * 5
+        self.at = {}                # (kind, air_row) -> index in the table
+        rec_off, ts = 1, 0          # record word 0 = the call's first timestamp
+        for i, ins in enumerate(instructions):
+            op = int(ins[0])
+            k = kind_of_opcode(op)
+            if has_subs[i]:
+                row = self.row_block_size[k]
+                self.index_of[i] = len(self.entries)
+                self.at[(k, row)] = len(self.entries)
+                self.entries.append(PowdrOrigInstr(k, op, start_pc + 4 * i, int(ins[1]), int(ins[2]), int(ins[3]) % P, int(ins[5]), int(ins[6]),
+                                                   int(ins[7]), ts, row, rec_off))
+                self.row_block_size[k] += 1
+                rec_off += RECORD_WORDS[k]
+            ts += TIMESTAMP_STEP[k]
+        self.words_per_call = rec_off
+        self.array = (PowdrOrigInstr * max(len(self.entries), 1))(*self.entries)
+
+    def __len__(self):
+        return len(self.entries)
+
+    def record_substitutions(self, subs, air_kinds):
+        """Subst rows (air_index, col, row, apc_col) of the reference ABI, `air_kinds[air_index]` = chip kind -> PowdrRecordSubst array."""
+        out = (PowdrRecordSubst * max(len(subs), 1))()
+        for n, (a, col, row, apc_col) in enumerate(np.asarray(subs).tolist()):
+            out[n] = PowdrRecordSubst(self.at[(air_kinds[a], row)], col, apc_col)
+        return out, len(subs)
+
+
+lib.powdr_original_airs_expand.restype = C.c_int
+lib.powdr_original_airs_expand.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+lib.powdr_apc_tracegen_records.restype = C.c_int
+lib.powdr_apc_tracegen_records.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+
+
+def dummy_trace_heights(table: InstructionTable, num_calls: int):
+    """next_pow2(row_block_size * calls) per kind (0 for a chip that does not occur), like the original chips' traces."""
+    return [max(4, 1 << (b * num_calls - 1).bit_length()) if b else 0 for b in table.row_block_size]
+
+
+def expand(d_records_ptr: int, num_calls: int, table: InstructionTable, buffers):
+    """powdr_original_airs_expand: buffers[kind] = (device pointer, height) or None."""
+    airs = (abi.OriginalAir * 5)()
+    for k in range(5):
+        if buffers[k] is not None:
+            airs[k] = abi.OriginalAir(WIDTHS[k], buffers[k][1], buffers[k][0], table.row_block_size[k])
+        else:
+            airs[k] = abi.OriginalAir(WIDTHS[k], 0, None, 0)
+    abi.check(lib.powdr_original_airs_expand(d_records_ptr, num_calls, table.array, len(table), airs), "powdr_original_airs_expand")
+
+
+def tracegen_records(d_output_ptr: int, height: int, d_records_ptr: int, num_calls: int, table: InstructionTable, rsubs, n_subs: int):
+    abi.check(lib.powdr_apc_tracegen_records(d_output_ptr, height, d_records_ptr, num_calls, table.array, len(table), rsubs, n_subs),
+              "powdr_apc_tracegen_records")
+
+
+def sanitise_instructions(instructions):
+    """Synthetic APC blocks (powdr_amd/synth.py) draw their operands at random; bring them into the ranges the chips accept:
+    register pointers = 4 x register, rs2 address space in {0, 1}, memory address space 2, needs_write = 1, 16-bit immediates."""
+    out = []
+    for ins in instructions:
+        op, a, b, c, d, e, f, g = (int(x) for x in ins)
+        k = kind_of_opcode(op)
+        a, b = (a % 32) * 4, (b % 32) * 4
+        if k in (BASE_ALU, SHIFT):
+            e &= 1
+            c = (c % 32) * 4 if e else c & 0xFF
+        elif k == LOAD_STORE:
+            c, e, f, g = c & 0xFFFF, 2, 1, 0
+        elif k == BRANCH_EQ:
+            e = 1
+        else:
+            c, f = c & 0xFFFFF, 1
+        out.append([op, a, b, c, 1, e, f, g])
+    return out
+
+
+def random_records_device(table: InstructionTable, num_calls: int, seed: int = 0):
+    """Plausible records on the GPU (word-major int32 tensor [words_per_call * num_calls]) for benchmarks: random data words,
+    timestamps that increase, previous timestamps shortly before each access."""
+    import torch
+
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rec = torch.randint(-(1 << 31), (1 << 31) - 1, (table.words_per_call, num_calls), dtype=torch.int32, device="cuda", generator=g)
+    base = torch.randint(1 << 10, 1 << 26, (num_calls,), dtype=torch.int32, device="cuda", generator=g)
+    rec[0] = base
+    for e in table.entries:
+        n_prev = [3, 3, 3, 2, 1][e.kind]
+        first = e.rec_off + RECORD_WORDS[e.kind] - n_prev
+        gap = torch.randint(1, 1 << 20, (n_prev, num_calls), dtype=torch.int32, device="cuda", generator=g)
+        rec[first:first + n_prev] = torch.clamp(base[None, :] + e.ts_delta - gap, min=0)
+        if e.kind == LOAD_STORE:
+            rec[e.rec_off] &= (1 << 28) - 1
+    return rec.reshape(-1)

@@ -61,6 +61,30 @@ pub struct PowdrSubstCM {
     pub apc_col: i32,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct PowdrOrigInstr {
+    pub kind: u32,
+    pub opcode: u32,
+    pub pc: u32,
+    pub a: u32,
+    pub b: u32,
+    pub c: u32,
+    pub e: u32,
+    pub f: u32,
+    pub g: u32,
+    pub ts_delta: u32,
+    pub air_row: u32,
+    pub rec_off: u32,
+}
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct PowdrRecordSubst {
+    pub instr: i32,
+    pub col: i32,
+    pub apc_col: i32,
+}
+
 extern "C" {
     // ---- the reference ABI, openvm/src/cuda_abi.rs:8-64 ----
     pub fn _apc_tracegen(d_output: *mut PowdrFp, output_height: usize, d_original_airs: *const OriginalAir,
@@ -94,6 +118,10 @@ extern "C" {
                                            d_bitwise_hist: *mut u32) -> i32;
     pub fn powdr_apc_tracegen_callmajor(d_output: *mut PowdrFp, output_height: usize, h_airs: *const PowdrCallMajorAir, n_airs: usize,
                                         h_subs: *const PowdrSubstCM, n_subs: usize, num_apc_calls: i32) -> i32;
+    pub fn powdr_original_airs_expand(d_records: *const u32, num_calls: usize, h_instrs: *const PowdrOrigInstr, n_instrs: usize,
+                                      h_airs: *const OriginalAir) -> i32;
+    pub fn powdr_apc_tracegen_records(d_output: *mut PowdrFp, output_height: usize, d_records: *const u32, num_apc_calls: usize,
+                                      h_instrs: *const PowdrOrigInstr, n_instrs: usize, h_subs: *const PowdrRecordSubst, n_subs: usize) -> i32;
     pub fn powdr_periphery_var_range_trace(d_var_hist: *const u32, var_num_bins: usize, d_out: *mut PowdrFp) -> i32;
     pub fn powdr_periphery_tuple2_trace(d_tuple2_hist: *const u32, tuple2_sz0: u32, tuple2_sz1: u32, d_out: *mut PowdrFp) -> i32;
     pub fn powdr_periphery_bitwise_trace(d_bitwise_hist: *const u32, d_out: *mut PowdrFp) -> i32;

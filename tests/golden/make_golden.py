@@ -100,6 +100,10 @@ def main():
                 bus_inter=inter, bus_spans=spans, bus_bc=bc, bus_apc_pos=apc_positions(bc.tolist()),
                 cons_spans=np.array(cons_spans, dtype=np.uint32).reshape(-1, 2), cons_bc=np.array(cons_bc, dtype=np.uint32),
                 cons_apc_pos=apc_positions(cons_bc), col_bound=column_bounds(apc, idx),
+                # the block itself: [opcode, a, b, c, d, e, f, g] per instruction (operands as field elements) and its first pc —
+                # the input of the original-chip expanders (powdr_amd/original_chips.py)
+                instructions=np.array([[int(x) % om.P for x in ins] for ins in apc.instructions], dtype=np.uint32),
+                start_pc=np.array([apc.start_pc], dtype=np.uint64),
             )
     (OUT / "apc_fixtures_summary.json").write_text(json.dumps(summary, indent=1, sort_keys=True) + "\n")
 

@@ -60,7 +60,7 @@ def rust_struct_fields(name):
 
 
 def test_repr_c_structs_list_the_header_fields_in_order():
-    for name in ("OriginalAir", "Subst", "ExprSpan", "DerivedExprSpec", "DevInteraction", "PowdrDeviceMatrix", "PowdrPeriphery", "PowdrCallMajorAir", "PowdrSubstCM",
+    for name in ("OriginalAir", "Subst", "ExprSpan", "DerivedExprSpec", "DevInteraction", "PowdrDeviceMatrix", "PowdrPeriphery", "PowdrCallMajorAir", "PowdrSubstCM", "PowdrOrigInstr", "PowdrRecordSubst",
                  "PowdrAirStats", "PowdrApcCandidateInfo", "PwStarkConfig", "PwSegmentAir", "PwAirDescription"):
         c, r = c_struct_fields(name), rust_struct_fields(name)
         assert c and r, name
