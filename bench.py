@@ -144,7 +144,7 @@ def build_workload(shape_name, log_h, exact_heights, seed, calls_fraction=1.0):
     out = torch.empty(apc.width * H, dtype=torch.int32, device="cuda")
     per = tg.Periphery.fresh()
     cons_bc, cons_spans = apc.compile_constraints()
-    return dict(synth=s, apc=apc, instr_air=instr_air, dummy=dummy, tensors=tensors, out=out, per=per,
+    return dict(synth=s, apc=apc, instr_air=instr_air, air_names=order, dummy=dummy, tensors=tensors, out=out, per=per,
                 calls=calls, log_h=log_h, H=H, W=apc.width, cons=(cons_bc, cons_spans), src_bytes=src_bytes)
 
 
@@ -737,6 +737,62 @@ def main():
     logup_leg = other_leg if other_logup else None
     constraints_only_leg = None if other_logup else other_leg
 
+    # ---- trace generation FROM RECORDS (producer half): the five original chips expand their records inside the
+    # gather (powdr_apc_tracegen_records) — no dummy traces. Checked at full size against the reference flow on the same records:
+    # powdr_original_airs_expand into the (now overwritten) source buffers, then the timed step's own gather. Not part of `value`.
+    records_leg = None
+    if not args.no_callmajor_leg and args.pipeline == 1 and args.shape == "C2":
+        try:
+            from powdr_amd import original_chips as oc_, tracegen as tg
+
+            doc = wl["synth"].doc
+            ins = oc_.sanitise_instructions(doc["block"]["blocks"][0]["instructions"])
+            table = oc_.InstructionTable(ins, [len(x) > 0 for x in doc["subs"]], int(doc["block"]["blocks"][0]["start_pc"]))
+            subs0, air_ids, rbs = wl["apc"].build_substitutions(wl["instr_air"])
+            kinds = [oc_.KIND_NAMES.index(wl["air_names"][int(a)]) for a in air_ids]
+            assert [table.row_block_size[k] for k in kinds] == [int(b) for b in rbs]
+            rsubs, n_rs = table.record_substitutions(subs0, kinds)
+            calls = wl["calls"]
+            rec = oc_.random_records_device(table, calls, seed=3)
+            out2 = torch.empty_like(wl["out"])
+            oc_.tracegen_records(out2.data_ptr(), wl["H"], rec.data_ptr(), calls, table, rsubs, n_rs)  # warm-up + tables
+            torch.cuda.synchronize()
+            abi.lib.powdr_gpu_timing_enable(1)
+            for _ in range(3):
+                oc_.tracegen_records(out2.data_ptr(), wl["H"], rec.data_ptr(), calls, table, rsubs, n_rs)
+            torch.cuda.synchronize()
+            fused_ms = abi.timing_report()["apc_tracegen_records_kernel"][1] / 3
+            # the reference flow on the same records: full dummy traces (into the source buffers), then the gather of the timed step
+            bufs = [None] * 5
+            for k, a in zip(kinds, air_ids):
+                ptr, w, h = wl["dummy"][int(a)]
+                bufs[k] = (ptr, h)
+            abi.lib.powdr_gpu_timing_enable(1)
+            oc_.expand(rec.data_ptr(), calls, table, bufs)
+            torch.cuda.synchronize()
+            expand_ms = abi.timing_report()["original_airs_expand_kernel"][1]
+            abi.lib.powdr_gpu_timing_enable(0)
+            wl["apc"].generate_witness_gpu(wl["instr_air"], wl["dummy"], calls, wl["out"].data_ptr(), None)
+            torch.cuda.synchronize()
+            cols = sorted(set(int(c) for c in subs0[:, 3]))
+            H_ = wl["H"]
+            same = all(torch.equal(out2[c * H_:(c + 1) * H_], wl["out"][c * H_:(c + 1) * H_]) for c in cols)
+            moved = rec.numel() * 4 + len(cols) * H_ * 4
+            records_leg = dict(fused_ms=fused_ms, record_bytes=int(rec.numel() * 4), record_bytes_per_call=table.words_per_call * 4,
+                               instructions_with_cells=len(table), substitutions=int(n_rs), moved_GBps=moved / (fused_ms * 1e-3) / 1e9,
+                               frac_of_hbm_peak=moved / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               equals_expand_then_gather_at_full_size=bool(same), columns_compared=len(cols),
+                               reference_flow_expand_ms=expand_ms, reference_flow_gather_ms=timing.get("apc_gather_tile_kernel", (0, 0.0))[1] / args.steps,
+                               reference_flow_dummy_trace_bytes=wl["src_bytes"],
+                               note="powdr_apc_tracegen_records: the original chips (BaseAlu, Shift, LoadStore, BranchEqual, JalLui; every constraint of the "
+                                    "reference's openvm_constraints.txt holds on their rows) expand their records inside the gather; only the cells the APC "
+                                    "keeps are written. The reference flow materialises the full dummy traces first (reference_flow_expand_ms on the same "
+                                    "records, strided writes like a chip's) and gathers them (reference_flow_gather_ms)")
+            del out2, rec
+            torch.cuda.empty_cache()
+        except Exception as e:
+            records_leg = dict(fused_ms=None, error=f"{type(e).__name__}: {e}")
+
     # ---- third leg: multi-AIR segments, strong scaling (BASELINE configs[3]: sharded multi-segment guest-pairing). Every rank takes
     # part; the single-AIR workload's 180 GB are released first.
     segment_leg = None
@@ -897,7 +953,7 @@ def main():
                         source_bytes=wl["src_bytes"], proof_bytes=proof_bytes, prover_device_bytes=prover_bytes,
                         caveat="proof system pw-stark v0 is this repository's own (oracle/stark_oracle.cpp); its Poseidon2 round constants are a "
                                "documented placeholder stream: proofs are byte-exact against the oracle, not interoperable with the reference prover"),
-            roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, constraints_only=constraints_only_leg, multi_segment=segment_leg, c3=c3, build=build_info(), tracegen_callmajor=callmajor_leg, tracegen_column_structured=colstruct_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
+            roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, constraints_only=constraints_only_leg, multi_segment=segment_leg, c3=c3, build=build_info(), tracegen_callmajor=callmajor_leg, tracegen_column_structured=colstruct_leg, tracegen_from_records=records_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
             hbm_copy_GBps_measured=copy_gbs,
         )
         print(json.dumps(line))
