@@ -382,7 +382,7 @@ _LIB = None
 
 def build_c_oracle(force=False) -> Path:
     out = _HERE / "_build" / "liboracle.so"
-    srcs = sorted(_HERE.glob("*.c")) + sorted(_HERE.glob("*.cpp"))
+    srcs = sorted(_HERE.glob("*.c")) + [f for f in sorted(_HERE.glob("*.cpp")) if f.name != "tuned_cpu.cpp"]  # (tuned_cpu.cpp: build_tuned_cpu)
     hdrs = sorted(_HERE.glob("*.h")) + sorted(_HERE.glob("*.hpp")) + sorted(_HERE.glob("*.inc"))
     if not force and out.exists() and all(out.stat().st_mtime >= s.stat().st_mtime for s in srcs + hdrs):
         return out
@@ -395,6 +395,44 @@ def build_c_oracle(force=False) -> Path:
         objs.append(str(o))
     subprocess.check_call(["g++", "-shared", "-fopenmp", "-o", str(out)] + objs)
     return out
+
+
+def build_tuned_cpu(force=False):
+    """oracle/tuned_cpu.cpp (the TUNED CPU baseline of bench.py: Montgomery + AVX-512 LDE and Poseidon2 Merkle) as two shared
+    objects, one compiled with the AVX-512 feature flags Zen 4+/Skylake-X+ share and a scalar Montgomery one; tuned_cpu() loads
+    the AVX-512 build only on a CPU that reports avx512f/bw/dq/vl."""
+    src = _HERE / "tuned_cpu.cpp"
+    outs = {}
+    for name, flags in (("avx512", ["-mavx512f", "-mavx512bw", "-mavx512dq", "-mavx512vl"]), ("scalar", [])):
+        out = _HERE / "_build" / f"libtuned_cpu_{name}.so"
+        if force or not out.exists() or out.stat().st_mtime < src.stat().st_mtime:
+            out.parent.mkdir(exist_ok=True)
+            subprocess.check_call(["g++", "-std=c++17", "-O3", "-fPIC", "-fopenmp", "-shared", str(src), "-o", str(out)] + flags)
+        outs[name] = out
+    return outs
+
+
+_TUNED = None
+
+
+def tuned_cpu():
+    """ctypes handle of the tuned CPU baseline with the oracle's Poseidon2 constants installed."""
+    global _TUNED
+    if _TUNED is None:
+        outs = build_tuned_cpu()
+        flags = ""
+        try:
+            flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags"))
+        except Exception:
+            pass
+        wide = all(f" {f}" in flags for f in ("avx512f", "avx512bw", "avx512dq", "avx512vl"))
+        lib = ctypes.CDLL(str(outs["avx512" if wide else "scalar"]))
+        from . import stark_model as sm
+
+        e, i, d = sm.poseidon2_constants()
+        lib.tc_set_poseidon2_constants(_p(np.ascontiguousarray(e.reshape(-1))), _p(i), _p(d))
+        _TUNED = lib
+    return _TUNED
 
 
 def c_oracle():
