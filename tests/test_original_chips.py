@@ -140,8 +140,12 @@ def test_device_expansion_matches_the_restatement_and_the_constraints(gpu, block
         bc, sp, _ = synth.reference_air_programs(name)
         pr = prover.Prover(pc.WIDTHS[k], bc, sp, num_queries=1)
         assert pr.check_constraints(bufs[k].data_ptr(), heights[k].bit_length() - 1) == (0, None, None), name
-        bufs[k][19 * heights[k] + 1] += 1  # one wrong cell (a__0 / rd_data of the second row) is found
-        assert pr.check_constraints(bufs[k].data_ptr(), heights[k].bit_length() - 1)[0] >= 1 or name in ("BranchEqual", "JalLui")
+        # one wrong cell is found: an opcode / validity flag of the first row, off by one (a result limb would not do — XOR / OR / AND
+        # results are only constrained through the bitwise lookup bus, not algebraically)
+        flag_col = {"BaseAlu": 31, "Shift": 31, "LoadStore": 27, "BranchEqual": 20, "JalLui": 16}[name]
+        bufs[k][flag_col * heights[k]] += int(om.to_monty(np.array([1], np.uint32))[0])
+        n_bad, row, _ = pr.check_constraints(bufs[k].data_ptr(), heights[k].bit_length() - 1)
+        assert n_bad >= 1 and row == 0, name
         pr.close()
 
 
