@@ -75,6 +75,49 @@ struct ExtWideAcc {
     }
 };
 
+// The same sums with CENTRED operands in signed 64-bit accumulators (round 3): e_k given as centred representatives (|e| <= p/2,
+// the wave-uniform ones straight from a table the host centred), x_k centred on the fly; a product is below p^2 / 4, so FOUR terms
+// (p^2) fit the signed Montgomery reduction's domain (1.209 p^2) on top of what an earlier fold left (<= 0.14 p^2), and every
+// fourth term `fold` brings the accumulators back: acc <- smont(acc) * (R mod p), the same residue, |.| <= 0.14 p^2. Per term and
+// coordinate 1 multiply-add + 3/4 instruction of folding + a share of the centring, against a multiply-add and a carry chain (3-4).
+struct ExtCentredAcc {
+    int64_t a[4];
+    PW_HD ExtCentredAcc() : a{0, 0, 0, 0} {}
+    // e: centred coordinates, x: centred value; at most four calls between two folds
+    PW_HD void fma(const int32_t (&e)[4], int32_t x) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            int64_t out;
+            asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(out) : "v"(e[k]), "v"(x), "v"(a[k]) : "vcc");
+            a[k] = out;
+#else
+            a[k] += (int64_t)e[k] * x;
+#endif
+        }
+    }
+    PW_HD void fma_uniform(const int32_t (&e)[4], int32_t x) {  // e wave-uniform (scalar registers)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = swide_mad_uniform(a[k], x, e[k]);
+    }
+    PW_HD void fold() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = smul_uniform(smont(a[k]), (int32_t)R_MOD_P);
+    }
+    // the raw products of Montgomery words carry R^2: one signed reduction returns the Montgomery form of the sum
+    PW_HD Ext result() {
+        fold();  // |a| <= 0.14 p^2: the reduction below lands in (-0.57 p, 0.57 p)
+        Ext r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.c[k] = canonical_of(smont(a[k]));
+        return r;
+    }
+};
+PW_HD void ext_centred(const Ext& e, int32_t (&out)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = centred(e.c[k]);
+}
+
 // sum_k a_k * c_k with a_k, c_k in E, reduced once at the end: the seven coefficients of the product polynomial
 // (before X^4 = 11) are sums of at most four raw 64-bit products (4 p^2 < 2^64) and go into 96-bit accumulators — 16
 // multiply-adds + 7 carries per term where ext_mul + ext_add take 87 instructions. Exact for up to 2^32 terms.

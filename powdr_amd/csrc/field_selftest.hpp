@@ -132,6 +132,23 @@ PW_HD int field_selftest_checks(uint64_t seed, uint32_t iterations) {
             pwant = ext_add(pwant, ext_scale(f, v));
         }
         if (!ext_eq(pacc.result(), pwant)) return 24;
+        // centred signed accumulation (ExtCentredAcc): four terms between folds, coordinates at the edges of the centred range
+        // (both neighbours of p / 2, 0, p - 1) in the first rounds — the largest magnitudes the fold's domain has to take
+        ExtCentredAcc cacc, cacc_u;
+        Ext cwant = ext_zero();
+        const uint32_t half_lo = (P - 1) / 2, half_hi = (P + 1) / 2;
+        for (int k = 0; k < 43; ++k) {
+            const uint32_t ev = k < 8 ? ((k & 1) ? half_lo : half_hi) : rp();
+            const Ext e{{k < 8 ? ev : rp(), k < 8 ? ev : rp(), k < 8 ? (P - 1) : rp(), k < 8 ? 0u : rp()}};
+            const uint32_t v = k < 8 ? ((k & 2) ? half_hi : half_lo) : rp();
+            int32_t ec[4];
+            ext_centred(e, ec);
+            cacc.fma(ec, centred(v));
+            cacc_u.fma_uniform(ec, centred(v));
+            cwant = ext_add(cwant, ext_scale(e, v));
+            if ((k & 3) == 3) { cacc.fold(); cacc_u.fold(); }
+        }
+        if (!ext_eq(cacc.result(), cwant) || !ext_eq(cacc_u.result(), cwant)) return 25;
     }
     return 0;
 }

@@ -275,17 +275,40 @@ __global__ __launch_bounds__(kBlock) void deep_logup_kernel(const uint32_t* __re
                                                              uint32_t shift, uint32_t wN, Ext* __restrict__ v) {
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= N) return;
-    bb::ExtWideAcc w1, w2;
-#pragma unroll 4
-    for (uint32_t k = 0; k < W; ++k) w1.fma(gpow[k], lde[(size_t)k * N + j]);
+    // centred gamma powers (host) x centred cells in signed 64-bit accumulators, folded every fourth column (bb::ExtCentredAcc)
+    bb::ExtCentredAcc w1, w2;
+    const int32_t (*g)[4] = reinterpret_cast<const int32_t (*)[4]>(gpow);
     const uint32_t K1 = W + Wp + 8;
-#pragma unroll 4
-    for (uint32_t k = 0; k < Wp; ++k) {
-        const uint32_t x = plde[(size_t)k * N + j];
-        w1.fma(gpow[W + k], x);
-        w2.fma(gpow[K1 + k], x);
+    uint32_t k = 0;
+    for (; k + 4 <= W; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w1.fma_uniform(g[k + u], bb::centred(lde[(size_t)(k + u) * N + j]));
+        w1.fold();
     }
-    for (uint32_t k = 0; k < 8; ++k) w1.fma(gpow[W + Wp + k], qlde[(size_t)k * N + j]);
+    for (; k < W; ++k) w1.fma_uniform(g[k], bb::centred(lde[(size_t)k * N + j]));
+    w1.fold();
+    for (k = 0; k + 4 <= Wp; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int32_t x = bb::centred(plde[(size_t)(k + u) * N + j]);
+            w1.fma_uniform(g[W + k + u], x);
+            w2.fma_uniform(g[K1 + k + u], x);
+        }
+        w1.fold();
+        w2.fold();
+    }
+    for (; k < Wp; ++k) {
+        const int32_t x = bb::centred(plde[(size_t)k * N + j]);
+        w1.fma_uniform(g[W + k], x);
+        w2.fma_uniform(g[K1 + k], x);
+    }
+    w1.fold();
+    w2.fold();
+    for (k = 0; k < 8; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w1.fma_uniform(g[W + Wp + k + u], bb::centred(qlde[(size_t)(k + u) * N + j]));
+        w1.fold();
+    }
     const Ext a1 = w1.result(), a2 = w2.result();
     const uint32_t xj = bb::mul(shift, bb::pow_u32(wN, (uint32_t)j));
     const Ext xe = bb::ext_from_base(xj);

@@ -495,6 +495,8 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         for (uint32_t k = 0; k < K; ++k) { gpow[k] = g; g = bb::ext_mul(g, gamma); }
         for (uint32_t k = 0; k < K1; ++k) opened_sum = bb::ext_add(opened_sum, bb::ext_mul(gpow[k], opened[k]));
         for (uint32_t k = K1; k < K; ++k) opened_sum2 = bb::ext_add(opened_sum2, bb::ext_mul(gpow[k], opened[k]));
+        // the DEEP kernels take the powers as CENTRED representatives (signed 64-bit accumulation, bb::ExtCentredAcc)
+        for (auto& e : gpow) for (auto& c : e.c) c = (uint32_t)bb::centred(c);
         PW_HIP_TRY(hipMemcpyAsync(d_gpow, gpow.data(), K * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
         PW_HIP_TRY(hipStreamSynchronize(st));
     }

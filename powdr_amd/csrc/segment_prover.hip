@@ -382,7 +382,11 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     const bb::Ext gamma = ch.sample_ext();
     std::vector<bb::Ext> gpow(K_total);
     { bb::Ext g = bb::ext_one(); for (auto& x : gpow) { x = g; g = bb::ext_mul(g, gamma); } }
-    PW_HIP_TRY(hipMemcpyAsync(d_gpow, gpow.data(), K_total * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
+    // the DEEP kernels take the powers as CENTRED representatives (signed 64-bit accumulation, bb::ExtCentredAcc); the host sums
+    // below use the canonical ones
+    std::vector<bb::Ext> gpow_c(gpow);
+    for (auto& e : gpow_c) for (auto& c : e.c) c = (uint32_t)bb::centred(c);
+    PW_HIP_TRY(hipMemcpyAsync(d_gpow, gpow_c.data(), K_total * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
     {
         std::vector<char> started(L + 1, 0);
         for (size_t a = 0; a < A; ++a) {

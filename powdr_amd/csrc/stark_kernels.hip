@@ -157,29 +157,26 @@ __global__ __launch_bounds__(kBlock) void ext_dot_partial_kernel(const uint32_t*
     const uint32_t* col = cols + (size_t)c0 * stride;
     const size_t q0 = (size_t)blockIdx.x * kDotRowsPerBlock;
     const size_t q1 = q0 + kDotRowsPerBlock < len ? q0 + kDotRowsPerBlock : len;
-    bb::ExtWideAcc wide[NW][kDotColsPerBlock];
-    if (nc == kDotColsPerBlock) {
-        for (size_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
-            const bb::Ext w = weights[q];
-            const bb::Ext w2 = NW == 2 ? weights2[q] : w;
+    // centred weights x centred cells in signed 64-bit accumulators, folded every fourth row (bb::ExtCentredAcc)
+    bb::ExtCentredAcc wide[NW][kDotColsPerBlock];
+    uint32_t pending = 0;
+    for (size_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
+        int32_t w[4], w2[4];
+        bb::ext_centred(weights[q], w);
+        if (NW == 2) bb::ext_centred(weights2[q], w2);
 #pragma unroll
-            for (int c = 0; c < kDotColsPerBlock; ++c) {
-                const uint32_t x = col[(size_t)c * stride + q];
+        for (int c = 0; c < kDotColsPerBlock; ++c)
+            if ((uint32_t)c < nc) {  // block-uniform
+                const int32_t x = bb::centred(col[(size_t)c * stride + q]);
                 wide[0][c].fma(w, x);
                 if (NW == 2) wide[NW - 1][c].fma(w2, x);
             }
-        }
-    } else {
-        for (size_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
-            const bb::Ext w = weights[q];
-            const bb::Ext w2 = NW == 2 ? weights2[q] : w;
+        if (++pending == 4) {
+            pending = 0;
 #pragma unroll
-            for (int c = 0; c < kDotColsPerBlock; ++c)
-                if ((uint32_t)c < nc) {
-                    const uint32_t x = col[(size_t)c * stride + q];
-                    wide[0][c].fma(w, x);
-                    if (NW == 2) wide[NW - 1][c].fma(w2, x);
-                }
+            for (int v = 0; v < NW; ++v)
+#pragma unroll
+                for (int c = 0; c < kDotColsPerBlock; ++c) wide[v][c].fold();
         }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -224,13 +221,26 @@ __global__ __launch_bounds__(kBlock) void deep_kernel(const uint32_t* __restrict
                                                        uint32_t shift, uint32_t wN, bb::Ext* __restrict__ v) {
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= N) return;
-    // gpow[k] is wave-uniform (scalar loads); the column value is the only vector operand of the multiply-adds
-    bb::ExtWideAcc wide;
+    // gpow[k] is wave-uniform (scalar loads) and CENTRED by the host (deep_gamma_powers); the centred column value is the only
+    // vector operand of the multiply-adds; signed 64-bit accumulators folded every fourth column (bb::ExtCentredAcc)
+    bb::ExtCentredAcc wide;
+    const int32_t (*g)[4] = reinterpret_cast<const int32_t (*)[4]>(gpow);
     const uint32_t* pa = ma + j;
-#pragma unroll 4
-    for (uint32_t k = 0; k < wa; ++k) wide.fma(gpow[k], pa[(size_t)k * N]);
+    uint32_t k = 0;
+    for (; k + 4 <= wa; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wide.fma_uniform(g[k + u], bb::centred(pa[(size_t)(k + u) * N]));
+        wide.fold();
+    }
+    for (; k < wa; ++k) wide.fma_uniform(g[k], bb::centred(pa[(size_t)k * N]));
+    wide.fold();
     const uint32_t* pb = mb + j;
-    for (uint32_t k = 0; k < wb; ++k) wide.fma(gpow[wa + k], pb[(size_t)k * N]);
+    for (k = 0; k + 4 <= wb; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wide.fma_uniform(g[wa + k + u], bb::centred(pb[(size_t)(k + u) * N]));
+        wide.fold();
+    }
+    for (; k < wb; ++k) wide.fma_uniform(g[wa + k], bb::centred(pb[(size_t)k * N]));
     const bb::Ext acc = wide.result();
     const uint32_t xj = bb::mul(shift, bb::pow_u32(wN, (uint32_t)j));
     const bb::Ext den = bb::ext_sub(bb::ext_from_base(xj), zeta);
