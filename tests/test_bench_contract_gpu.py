@@ -82,6 +82,17 @@ def test_segment_shapes_run_as_the_main_workload():
     assert d["multi_segment"]["logup"] is True and d["multi_segment"]["airs_per_segment"] >= 25
 
 
+def test_inproc_multi_device_form():
+    """bench.py --inproc: the multi-segment workload through pw_prove_segments_multi (one process, a host thread per worker,
+    RCCL all-gather of the commitments) — here two workers that share the box's one GPU."""
+    d = run_bench("--shape", "C4", "--segments", "5", "--segment-log-height", "11", "--gpus", "2", "--inproc", "--no-cpu-baseline")
+    ms = d["multi_segment"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and ms["workers"] == 2 and ms["devices"] == [0, 0]
+    assert sum(ms["segments_per_worker"]) == 5 and min(ms["segments_per_worker"]) >= 2 and ms["logup"] is True
+    assert "RCCL" in ms["commitment_merge"] or "host" in ms["commitment_merge"]
+    assert abs(d["value"] - 5 * ms["cells_per_segment"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+
+
 def test_two_ranks_on_one_gpu_weak_and_strong_legs():
     """The N > 1 code path of bench.py as the driver launches it (torch.distributed.run, one process per rank), with both
     ranks on GPU 0 over gloo (POWDR_DIST_BACKEND): weak scaling of the single-AIR step in `value`, strong scaling of the
