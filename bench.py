@@ -87,6 +87,19 @@ def parse_args():
     return args
 
 
+def emit(line: dict):
+    """The ONE JSON line, as the last thing on stdout: RCCL writes a version banner through C stdio when a communicator is created
+    (torch.distributed's nccl backend, pw_prove_segments_multi) and a pipe buffers it until exit, i.e. until after our line."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+
+
 def setup_distributed(n):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -536,7 +549,7 @@ def main():
         rec = segment_bench_inproc(args.shape, args.segments, args.segment_log_height, args.steps, args.warmup, args.logup, args.queries,
                                    args.pow_bits, max(1, args.gpus), abi)
         whole = rec["value"] / max(1, args.gpus) * ALGO_BYTES_PER_CELL / 1e9
-        print(json.dumps(dict(
+        emit(dict(
             metric="STARK cells/sec (trace rows x cols), multi-segment " + ("guest-pairing-shaped" if args.shape == "C4" else "reth-shaped")
                    + (" [with the bus argument]" if args.logup else " [constraints-only proofs]"),
             value=rec["value"], unit="cells/s", n_gpus=max(1, args.gpus), steps=args.steps, warmup=args.warmup, ms_per_step=rec["ms_per_step"],
@@ -546,7 +559,7 @@ def main():
                         parallelism=f"segments over {rec['workers']} host threads in one process (strong)", proof_bytes=rec["proof_bytes_per_segment"]),
             roofline=dict(bound="hbm", kernel="whole step", achieved=whole, peak=HBM_PEAK_GBS, unit="GB/s", frac=whole / HBM_PEAK_GBS, traffic=None,
                           algo_bytes_per_cell=ALGO_BYTES_PER_CELL, note="per GPU, 48 B per cell"),
-            cpu_baseline=None, multi_segment=rec)))
+            cpu_baseline=None, multi_segment=rec))
         return
     if args.shape in ("C4", "C5"):
         # BASELINE configs[3] / configs[4]: multi-AIR segments sharded over the GPUs of the node, strong scaling
@@ -565,7 +578,7 @@ def main():
                         roofline=dict(bound="hbm", kernel="whole step", achieved=whole, peak=HBM_PEAK_GBS, unit="GB/s", frac=whole / HBM_PEAK_GBS,
                                       traffic=None, algo_bytes_per_cell=ALGO_BYTES_PER_CELL, note="per GPU, 48 B per cell (proof stages only use 40 of them)"),
                         cpu_baseline=None, multi_segment=rec)
-            print(json.dumps(line))
+            emit(line)
         if world > 1:
             import torch.distributed as dist
 
@@ -1001,7 +1014,7 @@ def main():
             roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, constraints_only=constraints_only_leg, multi_segment=segment_leg, c3=c3, build=build_info(), tracegen_callmajor=callmajor_leg, tracegen_column_structured=colstruct_leg, tracegen_from_records=records_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
             hbm_copy_GBps_measured=copy_gbs,
         )
-        print(json.dumps(line))
+        emit(line)
     if world > 1:
         import torch.distributed as dist
 
