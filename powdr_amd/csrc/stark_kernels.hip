@@ -143,29 +143,33 @@ __global__ __launch_bounds__(kBlock) void barycentric_weights_kernel(bb::Ext zet
 }
 
 constexpr int kDotRowsPerBlock = 8192;
-constexpr int kDotColsPerBlock = 4;  // columns that share one pass over the weights
+// columns that share one pass over the weights: the weight vector (16 B per row) is re-read once per column group, so with 4 columns
+// per group it costs as much traffic as the columns themselves (PMC r03: 51 GB for 23 GB of cells); 8 halve that share
+// (one weight vector: 8 columns per group at 80 VGPRs; two weight vectors: 4, which keeps 6 waves per SIMD)
+constexpr int kDotColsPerBlock = 8;
+constexpr int kDotColsPerBlock2 = 4;
 // NW = 2: two weight vectors in one pass over the columns (the permutation matrix is opened at zeta AND at g zeta: reading it
 // once instead of twice); partial sums of the second vector go to partial + second_off
-template <int NW>
+template <int NW, int CPB>
 __global__ __launch_bounds__(kBlock) void ext_dot_partial_kernel(const uint32_t* __restrict__ cols, size_t stride, size_t len,
                                                                   uint32_t n_cols, const bb::Ext* __restrict__ weights,
                                                                   const bb::Ext* __restrict__ weights2, bb::Ext* __restrict__ partial,
                                                                   size_t second_off, uint32_t n_chunks) {
-    __shared__ uint32_t red[NW][kDotColsPerBlock][4][kBlock / 64];
-    const uint32_t c0 = blockIdx.y * kDotColsPerBlock;
-    const uint32_t nc = n_cols - c0 < (uint32_t)kDotColsPerBlock ? n_cols - c0 : (uint32_t)kDotColsPerBlock;  // block-uniform
+    __shared__ uint32_t red[NW][CPB][4][kBlock / 64];
+    const uint32_t c0 = blockIdx.y * CPB;
+    const uint32_t nc = n_cols - c0 < (uint32_t)CPB ? n_cols - c0 : (uint32_t)CPB;  // block-uniform
     const uint32_t* col = cols + (size_t)c0 * stride;
     const size_t q0 = (size_t)blockIdx.x * kDotRowsPerBlock;
     const size_t q1 = q0 + kDotRowsPerBlock < len ? q0 + kDotRowsPerBlock : len;
     // centred weights x centred cells in signed 64-bit accumulators, folded every fourth row (bb::ExtCentredAcc)
-    bb::ExtCentredAcc wide[NW][kDotColsPerBlock];
+    bb::ExtCentredAcc wide[NW][CPB];
     uint32_t pending = 0;
     for (size_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
         int32_t w[4], w2[4];
         bb::ext_centred(weights[q], w);
         if (NW == 2) bb::ext_centred(weights2[q], w2);
 #pragma unroll
-        for (int c = 0; c < kDotColsPerBlock; ++c)
+        for (int c = 0; c < CPB; ++c)
             if ((uint32_t)c < nc) {  // block-uniform
                 const int32_t x = bb::centred(col[(size_t)c * stride + q]);
                 wide[0][c].fma(w, x);
@@ -176,14 +180,14 @@ __global__ __launch_bounds__(kBlock) void ext_dot_partial_kernel(const uint32_t*
 #pragma unroll
             for (int v = 0; v < NW; ++v)
 #pragma unroll
-                for (int c = 0; c < kDotColsPerBlock; ++c) wide[v][c].fold();
+                for (int c = 0; c < CPB; ++c) wide[v][c].fold();
         }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int v = 0; v < NW; ++v)
 #pragma unroll
-        for (int c = 0; c < kDotColsPerBlock; ++c) {
+        for (int c = 0; c < CPB; ++c) {
             const bb::Ext part = wide[v][c].result();
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -368,7 +372,7 @@ int ext_dot_columns(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t
     for (uint32_t c0 = 0; c0 < n_cols; c0 += max_cols) {
         uint32_t cc = n_cols - c0 < max_cols ? n_cols - c0 : max_cols;
         ScopedKernelTimer t("ext_dot_partial_kernel");
-        hipLaunchKernelGGL(ext_dot_partial_kernel<1>, dim3(n_chunks, div_up(cc, kDotColsPerBlock)), dim3(kBlock), 0, stream(),
+        hipLaunchKernelGGL((ext_dot_partial_kernel<1, kDotColsPerBlock>), dim3(n_chunks, div_up(cc, kDotColsPerBlock)), dim3(kBlock), 0, stream(),
                            cols + (size_t)c0 * stride, stride, len, cc, weights, weights, scratch + (size_t)c0 * n_chunks, (size_t)0, n_chunks);
     }
     hipLaunchKernelGGL(ext_dot_final_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, stream(), scratch, n_cols, n_chunks, out);
@@ -378,12 +382,12 @@ int ext_dot_columns(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t
 int ext_dot_columns2(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t len, const bb::Ext* weights, const bb::Ext* weights2,
                      bb::Ext* out, bb::Ext* out2, bb::Ext* scratch) {
     const uint32_t n_chunks = div_up(len, kDotRowsPerBlock);
-    const uint32_t max_cols = 65535u * kDotColsPerBlock;
+    const uint32_t max_cols = 65535u * kDotColsPerBlock2;
     const size_t second = (size_t)n_cols * n_chunks;
     for (uint32_t c0 = 0; c0 < n_cols; c0 += max_cols) {
         uint32_t cc = n_cols - c0 < max_cols ? n_cols - c0 : max_cols;
         ScopedKernelTimer t("ext_dot_partial_kernel");
-        hipLaunchKernelGGL(ext_dot_partial_kernel<2>, dim3(n_chunks, div_up(cc, kDotColsPerBlock)), dim3(kBlock), 0, stream(),
+        hipLaunchKernelGGL((ext_dot_partial_kernel<2, kDotColsPerBlock2>), dim3(n_chunks, div_up(cc, kDotColsPerBlock2)), dim3(kBlock), 0, stream(),
                            cols + (size_t)c0 * stride, stride, len, cc, weights, weights2, scratch + (size_t)c0 * n_chunks, second, n_chunks);
     }
     hipLaunchKernelGGL(ext_dot_final_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, stream(), scratch, n_cols, n_chunks, out);
