@@ -602,6 +602,15 @@ def main():
     pr = prover.Prover(wl["W"], *wl["cons"], num_queries=args.queries, pow_bits=args.pow_bits, interactions=inter)
     from powdr_amd import sharding
 
+    # run-time specialisation (hiprtc) is plan work like the tables: done before any step, timed or not. On a multi-rank node rank 0
+    # compiles first, so that the other ranks find the code objects in the shared on-disk compiler cache instead of compiling the same
+    # sources N times next to each other
+    if rank == 0 and log_h >= 18:
+        pr.specialise()
+    barrier()
+    if rank != 0 and log_h >= 18:
+        pr.specialise()
+
     def run_segment(w, with_logup):
         for t in (w["per"].var_hist, w["per"].tuple_hist, w["per"].bitwise_hist):
             t.zero_()
@@ -795,7 +804,7 @@ def main():
     logup_leg = other_leg if other_logup else None
     constraints_only_leg = None if other_logup else other_leg
 
-    # ---- trace generation FROM RECORDS (producer half): the five original chips expand their records inside the
+    # ---- trace generation FROM RECORDS (producer half): the original chips expand their records inside the
     # gather (powdr_apc_tracegen_records) — no dummy traces. Checked at full size against the reference flow on the same records:
     # powdr_original_airs_expand into the (now overwritten) source buffers, then the timed step's own gather. Not part of `value`.
     records_leg = None
@@ -821,7 +830,7 @@ def main():
             torch.cuda.synchronize()
             fused_ms = abi.timing_report()["apc_tracegen_records_kernel"][1] / 3
             # the reference flow on the same records: full dummy traces (into the source buffers), then the gather of the timed step
-            bufs = [None] * 5
+            bufs = [None] * oc_.N_KINDS
             for k, a in zip(kinds, air_ids):
                 ptr, w, h = wl["dummy"][int(a)]
                 bufs[k] = (ptr, h)

@@ -164,21 +164,34 @@ typedef struct {
 int powdr_apc_tracegen_callmajor(PowdrFp* d_output, size_t output_height, const PowdrCallMajorAir* h_airs, size_t n_airs,
                                  const PowdrSubstCM* h_subs, size_t n_subs, int num_apc_calls);
 
-/* SURVEY.md §8 row (f)-1, the PRODUCER half: the original RV32IM chips of a keccak autoprecompile on the device, and the APC
- * gather fused into them. The reference materialises every original AIR's full dummy trace from its record arena
+/* SURVEY.md §8 row (f)-1, the PRODUCER half: the original RV32IM chips an autoprecompile is built from on the device, and the
+ * APC gather fused into them. The reference materialises every original AIR's full dummy trace from its record arena
  * (`chip.generate_proving_ctx(record_arena)`, cuda/mod.rs:228-253) and then gathers the cells the APC keeps; a chip computes
  * all cells of a row from one small record, so the expansion can run inside the gather and the dummy traces never exist.
- * Five chips: BaseAlu (ADD SUB XOR OR AND = opcodes 512..516), Shift (SLL SRL SRA = 517..519), LoadStore (LOADW 528, STOREW
- * 531), BranchEqual (BEQ 544, BNE 545), JalLui (JAL 560, LUI 561); columns and semantics as snapshot in the reference's
- * openvm-riscv/tests/openvm_constraints.txt (every constraint listed there holds on the rows produced here).
+ * All thirteen instruction AIRs of the reference's snapshot openvm-riscv/tests/openvm_constraints.txt (kind: opcodes):
+ *   BaseAlu: ADD SUB XOR OR AND 512..516     Shift: SLL SRL SRA 517..519        LessThan: SLT SLTU 520..521
+ *   LoadStore: LOADW LOADBU LOADHU STOREW STOREH STOREB 528..533                LoadSignExtend: LOADB LOADH 534..535
+ *   BranchEqual: BEQ BNE 544..545            BranchLessThan: BLT BLTU BGE BGEU 549..552
+ *   JalLui: JAL LUI 560..561                 Jalr: 565                          Auipc: 576
+ *   Multiplication: MUL 592                  MulH: MULH MULHSU MULHU 593..595   DivRem: DIV DIVU REM REMU 596..599
+ * Columns and semantics as in that snapshot: every algebraic constraint listed there holds on the rows produced here and every
+ * bus interaction of a row is a legal one (range checks in range, PC lookup = the instruction, memory bus = the RV32IM result).
  *
  * Instruction table (host): the block's instructions that keep at least one cell, in program order. Records (device, u32,
  * word-major: d_records[word * num_calls + call]): word 0 = from_state.timestamp of the call's first instruction, then at
- * `rec_off` per instruction   BaseAlu / Shift: b, c, rd's previous value, prev_timestamp of rs1, rs2, rd (6 words)
- *                            LoadStore: rs1, the word read, the overwritten word, prev_timestamp of rs1, read, write (6)
- *                            BranchEqual: a, b, prev_timestamp of rs1, rs2 (4)        JalLui: rd's previous value, its prev_timestamp (2)
- * (the layout is this library's: the reference's DenseRecordArena layouts are EXTERNAL). */
-enum { POWDR_ORIG_BASE_ALU = 0, POWDR_ORIG_SHIFT = 1, POWDR_ORIG_LOAD_STORE = 2, POWDR_ORIG_BRANCH_EQ = 3, POWDR_ORIG_JAL_LUI = 4 };
+ * `rec_off` per instruction
+ *   BaseAlu / Shift / LessThan / Multiplication / MulH / DivRem: b, c, rd's previous value, prev_timestamp of rs1, rs2, rd (6 words)
+ *   LoadStore / LoadSignExtend: rs1, the aligned word read, the overwritten word, prev_timestamp of rs1, read, write (6)
+ *   BranchEqual / BranchLessThan: a, b, prev_timestamp of rs1, rs2 (4)           Jalr: rs1, rd's previous value, prev_timestamp of rs1, rd (4)
+ *   JalLui / Auipc: rd's previous value, its prev_timestamp (2)
+ * (the layout is this library's: the reference's DenseRecordArena layouts are EXTERNAL). A memory pointer rs1 + imm is taken
+ * modulo 2^29 and the access's alignment (rs1 adjusted to match), a jalr target modulo 2^30: records of a real execution satisfy
+ * both already. */
+enum {
+    POWDR_ORIG_BASE_ALU = 0, POWDR_ORIG_SHIFT = 1, POWDR_ORIG_LOAD_STORE = 2, POWDR_ORIG_BRANCH_EQ = 3, POWDR_ORIG_JAL_LUI = 4,
+    POWDR_ORIG_LESS_THAN = 5, POWDR_ORIG_BRANCH_LT = 6, POWDR_ORIG_JALR = 7, POWDR_ORIG_LOAD_SIGN_EXTEND = 8, POWDR_ORIG_DIV_REM = 9,
+    POWDR_ORIG_MUL_H = 10, POWDR_ORIG_MUL = 11, POWDR_ORIG_AUIPC = 12, POWDR_ORIG_KIND_COUNT = 13
+};
 typedef struct {
     uint32_t kind;      /* POWDR_ORIG_* */
     uint32_t opcode;    /* global opcode, see above */
@@ -194,9 +207,9 @@ typedef struct {
     int32_t col;        /* column of that instruction's AIR */
     int32_t apc_col;
 } PowdrRecordSubst;
-/* Full column-major dummy traces of the five AIRs — what the reference's chips hand to _apc_tracegen: h_airs[kind] = {width,
- * height, device buffer, row_block_size} (an AIR that does not occur: buffer NULL); the row of instruction i of call r is
- * air_row(i) + r * row_block_size; rows beyond the calls are not touched (zero-initialise the buffers). */
+/* Full column-major dummy traces of the AIRs — what the reference's chips hand to _apc_tracegen: h_airs[kind] = {width,
+ * height, device buffer, row_block_size}, POWDR_ORIG_KIND_COUNT entries (an AIR that does not occur: buffer NULL); the row of
+ * instruction i of call r is air_row(i) + r * row_block_size; rows beyond the calls are not touched (zero-initialise the buffers). */
 int powdr_original_airs_expand(const uint32_t* d_records, size_t num_calls, const PowdrOrigInstr* h_instrs, size_t n_instrs,
                                const OriginalAir* h_airs);
 /* The fused form: out[apc_col * H + r] = r < num_apc_calls ? cell `col` of the row instruction `instr` produces in call r : 0,

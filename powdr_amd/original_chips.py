@@ -14,27 +14,28 @@ from . import abi
 
 lib = abi.lib
 P = 0x78000001
-BASE_ALU, SHIFT, LOAD_STORE, BRANCH_EQ, JAL_LUI = range(5)
-KIND_NAMES = ["BaseAlu", "Shift", "LoadStore", "BranchEqual", "JalLui"]
-WIDTHS = [36, 53, 41, 26, 18]
-RECORD_WORDS = [6, 6, 6, 4, 2]
-# from_state.timestamp advances by the number of memory accesses of the instruction (execution-bridge bus of each AIR)
-TIMESTAMP_STEP = [3, 3, 3, 2, 1]
+# POWDR_ORIG_* (include/powdr_gpu.h): the thirteen instruction AIRs of the reference's snapshot openvm-riscv/tests/openvm_constraints.txt
+BASE_ALU, SHIFT, LOAD_STORE, BRANCH_EQ, JAL_LUI, LESS_THAN, BRANCH_LT, JALR, LOAD_SIGN_EXTEND, DIV_REM, MUL_H, MUL, AUIPC = range(13)
+N_KINDS = 13
+KIND_NAMES = ["BaseAlu", "Shift", "LoadStore", "BranchEqual", "JalLui", "LessThan", "BranchLessThan", "Jalr", "LoadSignExtend", "DivRem", "MulH",
+              "Multiplication", "Auipc"]
+WIDTHS = [36, 53, 41, 26, 18, 37, 32, 28, 36, 59, 39, 31, 20]
+RECORD_WORDS = [6, 6, 6, 4, 2, 6, 4, 4, 6, 6, 6, 6, 2]
+# trailing record words that are previous timestamps = memory accesses of the instruction = what from_state.timestamp advances by
+# (execution-bridge bus of each AIR)
+N_PREV_TS = [3, 3, 3, 2, 1, 3, 2, 2, 3, 3, 3, 3, 1]
+TIMESTAMP_STEP = N_PREV_TS
+OPCODE_RANGES = [(512, 516, BASE_ALU), (517, 519, SHIFT), (520, 521, LESS_THAN), (528, 533, LOAD_STORE), (534, 535, LOAD_SIGN_EXTEND),
+                 (544, 545, BRANCH_EQ), (549, 552, BRANCH_LT), (560, 561, JAL_LUI), (565, 565, JALR), (576, 576, AUIPC), (592, 592, MUL),
+                 (593, 595, MUL_H), (596, 599, DIV_REM)]
 ORIG_SYMBOLS = ["powdr_original_airs_expand", "powdr_apc_tracegen_records"]
 
 
 def kind_of_opcode(op: int) -> int:
-    if 512 <= op <= 516:
-        return BASE_ALU
-    if 517 <= op <= 519:
-        return SHIFT
-    if op in (528, 531):
-        return LOAD_STORE
-    if op in (544, 545):
-        return BRANCH_EQ
-    if op in (560, 561):
-        return JAL_LUI
-    raise ValueError(f"opcode {op} belongs to none of the five chips")
+    for lo, hi, k in OPCODE_RANGES:
+        if lo <= op <= hi:
+            return k
+    raise ValueError(f"opcode {op} belongs to none of the thirteen RV32IM chips")
 
 
 class PowdrOrigInstr(C.Structure):
@@ -54,7 +55,7 @@ class InstructionTable:
     def __init__(self, instructions, has_subs, start_pc: int):
         self.entries = []
         self.index_of = {}          # index in `instructions` -> index in the table
-        self.row_block_size = [0] * 5
+        self.row_block_size = [0] * N_KINDS
         self.at = {}                # (kind, air_row) -> index in the table
         rec_off, ts = 1, 0          # record word 0 = the call's first timestamp
         for i, ins in enumerate(instructions):
@@ -96,9 +97,9 @@ def dummy_trace_heights(table: InstructionTable, num_calls: int):
 
 def expand(d_records_ptr: int, num_calls: int, table: InstructionTable, buffers):
     """powdr_original_airs_expand: buffers[kind] = (device pointer, height) or None."""
-    airs = (abi.OriginalAir * 5)()
-    for k in range(5):
-        if buffers[k] is not None:
+    airs = (abi.OriginalAir * N_KINDS)()
+    for k in range(N_KINDS):
+        if k < len(buffers) and buffers[k] is not None:
             airs[k] = abi.OriginalAir(WIDTHS[k], buffers[k][1], buffers[k][0], table.row_block_size[k])
         else:
             airs[k] = abi.OriginalAir(WIDTHS[k], 0, None, 0)
@@ -111,22 +112,30 @@ def tracegen_records(d_output_ptr: int, height: int, d_records_ptr: int, num_cal
 
 
 def sanitise_instructions(instructions):
-    """Synthetic APC blocks (powdr_amd/synth.py) draw their operands at random; bring them into the ranges the chips accept:
-    register pointers = 4 x register, rs2 address space in {0, 1}, memory address space 2, needs_write = 1, 16-bit immediates."""
+    """Synthetic APC blocks (powdr_amd/synth.py) draw their operands at random; bring them into the shape the program ROM holds for
+    each chip (the PC-lookup tuple of every AIR in openvm_constraints.txt): register pointers = 4 x register, d = 1, rs2 address space
+    in {0, 1}, memory address space 2, needs_write = 1, 16-bit immediates with their sign in g, operands a chip does not have zero."""
     out = []
     for ins in instructions:
         op, a, b, c, d, e, f, g = (int(x) for x in ins)
         k = kind_of_opcode(op)
         a, b = (a % 32) * 4, (b % 32) * 4
-        if k in (BASE_ALU, SHIFT):
+        if k in (BASE_ALU, SHIFT, LESS_THAN):
             e &= 1
             c = (c % 32) * 4 if e else c & 0xFF
-        elif k == LOAD_STORE:
-            c, e, f, g = c & 0xFFFF, 2, 1, 0
-        elif k == BRANCH_EQ:
-            e = 1
-        else:
-            c, f = c & 0xFFFFF, 1
+            f = g = 0
+        elif k in (LOAD_STORE, LOAD_SIGN_EXTEND):
+            c, e, f, g = c & 0xFFFF, 2, 1, g & 1
+        elif k in (BRANCH_EQ, BRANCH_LT):
+            e, f, g = 1, 0, 0
+        elif k == JAL_LUI:
+            b, c, e, f, g = 0, c & 0xFFFFF, 0, 1, 0
+        elif k == JALR:
+            c, e, f, g = c & 0xFFFF, 0, 1, g & 1
+        elif k == AUIPC:
+            b, c, e, f, g = 0, c & 0xFFFFFF, 0, 0, 0
+        else:  # DivRem, MulH, Multiplication: three registers
+            c, e, f, g = (c % 32) * 4, 0, 0, 0
         out.append([op, a, b, c, 1, e, f, g])
     return out
 
@@ -141,10 +150,8 @@ def random_records_device(table: InstructionTable, num_calls: int, seed: int = 0
     base = torch.randint(1 << 10, 1 << 26, (num_calls,), dtype=torch.int32, device="cuda", generator=g)
     rec[0] = base
     for e in table.entries:
-        n_prev = [3, 3, 3, 2, 1][e.kind]
+        n_prev = N_PREV_TS[e.kind]
         first = e.rec_off + RECORD_WORDS[e.kind] - n_prev
         gap = torch.randint(1, 1 << 20, (n_prev, num_calls), dtype=torch.int32, device="cuda", generator=g)
         rec[first:first + n_prev] = torch.clamp(base[None, :] + e.ts_delta - gap, min=0)
-        if e.kind == LOAD_STORE:
-            rec[e.rec_off] &= (1 << 28) - 1
     return rec.reshape(-1)

@@ -61,6 +61,10 @@ pub struct PowdrSubstCM {
     pub apc_col: i32,
 }
 
+/// `POWDR_ORIG_*` (include/powdr_gpu.h): the thirteen instruction AIRs of openvm-riscv/tests/openvm_constraints.txt, keyed by the
+/// short AIR name `OriginalAirs::opcode_to_air` resolves to
+pub const POWDR_ORIG_KINDS: [&str; 13] = ["BaseAlu", "Shift", "LoadStore", "BranchEqual", "JalLui", "LessThan", "BranchLessThan", "Jalr",
+                                          "LoadSignExtend", "DivRem", "MulH", "Multiplication", "Auipc"];
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct PowdrOrigInstr {

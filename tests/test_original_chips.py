@@ -1,11 +1,13 @@
-"""SURVEY.md §8 row (f)-1, producer half: the five original RV32IM chips of a keccak autoprecompile as record -> row expanders
-(powdr_amd/csrc/original_chips.hip), and the APC gather fused into them (powdr_apc_tracegen_records).
+"""SURVEY.md §8 row (f)-1, producer half: the thirteen original RV32IM chips an autoprecompile is built from as record -> row
+expanders (powdr_amd/csrc/original_chips.hip), and the APC gather fused into them (powdr_apc_tracegen_records).
 
-The chips are EXTERNAL to the reference checkout; their columns and constraints are not (openvm-riscv/tests/
+The chips are EXTERNAL to the reference checkout; their columns, constraints and bus interactions are not (openvm-riscv/tests/
 openvm_constraints.txt, parsed into tests/golden/openvm_airs.npz). CPU: the numpy restatement (oracle/original_chips.py)
-satisfies every one of those constraints — for all opcodes, and for the reference's real keccak block, whose own pre-optimisation
-APC constraints (28 627) then hold on the gathered APC trace. GPU: device expansion == restatement, the device's mock prover
-finds no violation, fused == expand + _apc_tracegen == oracle."""
+satisfies every one of those constraints and every row's bus interactions are legal ones (range checks in range, PC lookup = the
+instruction, memory bus = a word-level RV32IM model) — for all 36 opcodes, on edge records, and for the reference's real keccak
+block, whose own pre-optimisation APC constraints (28 627) then hold on the gathered APC trace; a mutation sweep shows the two
+checks pin every cell the reference's proof pins. GPU: device expansion == restatement, the device's mock prover finds no
+violation, fused == expand + _apc_tracegen == oracle."""
 from pathlib import Path
 
 import numpy as np
@@ -19,15 +21,17 @@ GOLDEN = Path(__file__).parent / "golden"
 P = om.P
 
 
-def all_opcode_block(seed=5, copies=4):
+def all_opcode_block(seed=5, copies=3):
     rng = np.random.default_rng(seed)
     ins = []
-    for op in [512, 513, 514, 515, 516, 517, 518, 519, 528, 531, 544, 545, 560, 561] * copies:
+    for op in oc.ALL_OPCODES * copies:
         ins.append([op] + [int(x) for x in rng.integers(0, 1 << 20, size=7)])
     ins = oc.sanitise_instructions(ins)
-    # a load into x0 (needs_write = 0), a JAL that does not write, a store with a negative offset, a large shift immediate
+    # a load into x0 (needs_write = 0), a JAL that does not write, a store with a negative offset, a large shift immediate, negative
+    # immediates for SUB / SLT / SLTU, a backward branch, a JALR and a LOADB that do not write
     ins += [[528, 0, 8, 0xFFF0, 1, 2, 0, 1], [560, 0, 0, 16, 1, 0, 0, 0], [531, 12, 8, 0x8000, 1, 2, 1, 1], [519, 4, 8, 31, 1, 0, 0, 0],
-            [518, 4, 8, 0, 1, 0, 0, 0], [513, 4, 8, 0xFFFFFF, 1, 0, 0, 0]]
+            [518, 4, 8, 0, 1, 0, 0, 0], [513, 4, 8, 0xFFFFFF, 1, 0, 0, 0], [520, 4, 8, 0xFFFF80, 1, 0, 0, 0], [521, 4, 8, 0xFFFF80, 1, 0, 0, 0],
+            [549, 4, 8, P - 64, 1, 1, 0, 0], [565, 0, 8, 0xFFFC, 1, 0, 0, 1], [534, 0, 8, 3, 1, 2, 0, 0]]
     return ins
 
 
@@ -40,30 +44,69 @@ def edge_records(table, wpc, calls, seed):
     rec = oc.random_records(table, wpc, calls, seed=seed)
     for ins in table:  # data words at their extremes in the first calls (timestamps stay consistent)
         o, k = int(ins["rec_off"]), int(ins["kind"])
-        n_data = oc.RECORD_WORDS[k] - {0: 3, 1: 3, 2: 3, 3: 2, 4: 1}[k]
+        n_data = oc.RECORD_WORDS[k] - oc.N_PREV_TS[k]
         for w in range(n_data):
-            rec[o + w, 0] = 0
-            rec[o + w, 1] = 0xFFFFFFFF if k != oc.KIND_LOAD_STORE or w else 0x0FFFFFFC
-            rec[o + w, 2] = 0x80000000 if k != oc.KIND_LOAD_STORE or w else 0x00000004
+            rec[o + w, 0], rec[o + w, 1], rec[o + w, 2] = 0, 0xFFFFFFFF, 0x80000000
+        if n_data >= 2 and calls >= 8:  # the division corner cases (and whatever they mean to the other two-operand chips)
+            for call, (x, y) in enumerate([(0x80000000, 0xFFFFFFFF), (7, 0), (0xFFFFFFF9, 2), (7, 0xFFFFFFFE), (0xFFFFFFFF, 5)], start=3):
+                rec[o, call], rec[o + 1, call] = x, y
     return rec
 
 
 @pytest.mark.parametrize("block", ["all_opcodes", "keccak"])
-def test_restatement_satisfies_the_reference_constraints(block):
+def test_restatement_satisfies_the_reference_constraints_and_lookups(block):
     if block == "keccak":
         z, ins, start_pc = keccak_block()
     else:
         ins, start_pc = all_opcode_block(), 0x200000
     table, idx, rbs, wpc = oc.build_instruction_table(ins, [True] * len(ins), start_pc)
     calls = 40
-    traces = oc.expand_dummy_traces(table, edge_records(table, wpc, calls, seed=1), rbs)
-    for k, name in enumerate(oc.KIND_NAMES):
+    rec = edge_records(table, wpc, calls, seed=1)
+    traces = oc.expand_dummy_traces(table, rec, rbs)
+    assert sorted(traces) == [k for k in range(oc.N_KINDS) if rbs[k]] and (block == "keccak" or len(traces) == 13)
+    for k, t in traces.items():
+        name = oc.KIND_NAMES[k]
         bc, sp, _ = synth.reference_air_programs(name)
-        t = traces[k]
         assert t.shape[0] == oc.WIDTHS[k] == synth.REFERENCE_AIR_WIDTHS[name]
         bad, first = oc.check_constraints(bc, sp, [t[c] for c in range(t.shape[0])])  # padding rows (all zero) included
         assert bad == 0, (name, first)
         assert int(np.count_nonzero(t[:, : rbs[k] * calls])) > 0
+    # every bus interaction of every row: range checks in range, bitwise rows, PC lookup = the instruction (for the keccak block: the
+    # reference's REAL instructions), execution bridge and memory bus = the word-level RV32IM model
+    for ins_row in table:
+        fails = oc.check_interactions(synth.reference_air_programs(oc.KIND_NAMES[int(ins_row["kind"])])[2], ins_row, rec, oc.expand_rows(ins_row, rec, rec[0]))
+        assert not fails, fails[:3]
+
+
+def test_constraints_and_lookups_pin_every_cell_the_proof_pins():
+    """Mutation sweep: +1 on any single column of any opcode's rows is caught by the algebraic constraints or by the interaction
+    checks — except for the columns the reference's AIRs themselves leave free (auxiliary columns of a disabled memory access,
+    r_inv of an unsigned division)."""
+    ins = all_opcode_block(copies=1)
+    table, idx, rbs, wpc = oc.build_instruction_table(ins, [True] * len(ins), 0x200000)
+    rec = edge_records(table, wpc, 24, seed=4)
+    z = np.load(GOLDEN / "openvm_airs.npz")
+    names = [str(x) for x in z["names"]]
+    free_ok = ("prev_timestamp", "timestamp_lt_aux", "prev_data", "r_inv")
+    seen = set()
+    for t in table:
+        key = (int(t["opcode"]), int(t["e"]), int(t["f"]))
+        if key in seen:
+            continue
+        seen.add(key)
+        name = oc.KIND_NAMES[int(t["kind"])]
+        bc, sp, inter = synth.reference_air_programs(name)
+        colnames = [str(x) for x in z[f"a{names.index(name)}_columns"]]
+        rows = [np.asarray(r).astype(np.int64) % P for r in oc.expand_rows(t, rec, rec[0])]
+        for c in range(len(rows)):
+            mut = list(rows)
+            mut[c] = (rows[c] + 1) % P
+            if oc.check_constraints(bc, sp, mut)[0] or oc.check_interactions(inter, t, rec, mut):
+                continue
+            assert any(x in colnames[c] for x in free_ok), (name, key, colnames[c])
+            disabled = (int(t["e"]) == 0 and "reads_aux__1" in colnames[c]) or int(t["f"]) == 0 or (name == "DivRem" and key[0] in (597, 599))
+            assert disabled, (name, key, colnames[c])
+    assert {key[0] for key in seen} == set(oc.ALL_OPCODES) and len(oc.ALL_OPCODES) == 36
 
 
 def test_keccak_block_apc_constraints_hold_on_the_gathered_trace():
@@ -114,7 +157,7 @@ def _device_traces(gpu, t, rec, calls):
     torch, abi, pc, prover, tg = gpu
     d_rec = torch.from_numpy(rec.view(np.int32).reshape(-1).copy()).cuda()
     heights = pc.dummy_trace_heights(t, calls)
-    bufs = [torch.zeros(pc.WIDTHS[k] * heights[k], dtype=torch.int32, device="cuda") if heights[k] else None for k in range(5)]
+    bufs = [torch.zeros(pc.WIDTHS[k] * heights[k], dtype=torch.int32, device="cuda") if heights[k] else None for k in range(pc.N_KINDS)]
     pc.expand(d_rec.data_ptr(), calls, t, [(b.data_ptr(), heights[k]) if b is not None else None for k, b in enumerate(bufs)])
     torch.cuda.synchronize()
     return d_rec, bufs, heights
@@ -133,7 +176,9 @@ def test_device_expansion_matches_the_restatement_and_the_constraints(gpu, block
     rec = edge_records(table, wpc, calls, seed=2)
     want = oc.expand_dummy_traces(table, rec, rbs)
     d_rec, bufs, heights = _device_traces(gpu, t, rec, calls)
-    for k, name in enumerate(oc.KIND_NAMES):
+    assert sorted(want) == [k for k in range(pc.N_KINDS) if heights[k]]
+    for k in sorted(want):
+        name = oc.KIND_NAMES[k]
         got = om.from_monty(bufs[k].cpu().numpy().view(np.uint32)).reshape(pc.WIDTHS[k], heights[k])
         assert heights[k] == want[k].shape[1] and (got == want[k]).all(), name
         # the device's mock prover (the reference's prove_mock / debug_proving_ctx) on the chip's own constraints: no violation
@@ -142,7 +187,8 @@ def test_device_expansion_matches_the_restatement_and_the_constraints(gpu, block
         assert pr.check_constraints(bufs[k].data_ptr(), heights[k].bit_length() - 1) == (0, None, None), name
         # one wrong cell is found: an opcode / validity flag of the first row, off by one (a result limb would not do — XOR / OR / AND
         # results are only constrained through the bitwise lookup bus, not algebraically)
-        flag_col = {"BaseAlu": 31, "Shift": 31, "LoadStore": 27, "BranchEqual": 20, "JalLui": 16}[name]
+        flag_col = {"BaseAlu": 31, "Shift": 31, "LoadStore": 27, "BranchEqual": 20, "JalLui": 16, "LessThan": 28, "BranchLessThan": 20, "Jalr": 23,
+                    "LoadSignExtend": 23, "DivRem": 55, "MulH": 36, "Multiplication": 30, "Auipc": 10}[name]
         bufs[k][flag_col * heights[k]] += int(om.to_monty(np.array([1], np.uint32))[0])
         n_bad, row, _ = pr.check_constraints(bufs[k].data_ptr(), heights[k].bit_length() - 1)
         assert n_bad >= 1 and row == 0, name
@@ -212,3 +258,37 @@ def test_fused_keccak_block_satisfies_the_apc_constraints_on_the_device(gpu):
     with pytest.raises(abi.HipError):  # a column beyond the chip's width
         bad = (pc.PowdrRecordSubst * 1)(pc.PowdrRecordSubst(0, 60, 0))
         pc.tracegen_records(out.ptr(), H, d_rec.data_ptr(), calls, t, bad, 1)
+
+
+@pytest.mark.gpu
+def test_one_segment_proof_of_all_thirteen_chips_from_records_verifies(gpu):
+    """Records -> the thirteen instruction AIRs on the device -> ONE segment proof (pw_prove_segment) with the reference's REAL
+    constraints and bus interactions of every AIR (LogUp phase included) -> accepted by the product's and the oracle's verifier;
+    with one flag cell of one AIR off by one the constraint identity of exactly that AIR fails."""
+    from oracle import stark_model as sm
+
+    torch, abi, pc, prover, tg = gpu
+    ins = all_opcode_block()
+    t = pc.InstructionTable(ins, [True] * len(ins), 0x200000)
+    table, _, rbs, wpc = oc.build_instruction_table(ins, [True] * len(ins), 0x200000)
+    calls = 100
+    rec = edge_records(table, wpc, calls, seed=11)
+    d_rec, bufs, heights = _device_traces(gpu, t, rec, calls)
+    nq = 6
+    provers, airs, descs = [], [], []
+    for k, name in enumerate(oc.KIND_NAMES):
+        bc, sp, it = synth.reference_air_programs(name)
+        lh = heights[k].bit_length() - 1
+        provers.append(prover.Prover(pc.WIDTHS[k], bc, sp, interactions=it, num_queries=nq))
+        airs.append((provers[-1], bufs[k].data_ptr(), lh))
+        descs.append((pc.WIDTHS[k], lh, bc, sp, it))
+    proof = prover.prove_segment(airs, logup=True)
+    assert prover.verify_segment(descs, proof, nq, 0, True)[0] == 0
+    oracle_airs = [(None, pc.WIDTHS[k], descs[k][1], descs[k][2], descs[k][3], descs[k][4]) for k in range(pc.N_KINDS)]  # traces are not needed to verify
+    assert sm.verify_segment(proof, oracle_airs, nq, 0, True)[0] == 0
+    victim = pc.DIV_REM
+    bufs[victim][55 * heights[victim] + 1] += int(om.to_monty(np.array([1], np.uint32))[0])  # opcode_div_flag of the second row
+    bad = prover.prove_segment(airs, logup=True)
+    assert prover.verify_segment(descs, bad, nq, 0, True)[0] == ((victim + 1) << 8) | 2
+    for pr in provers:
+        pr.close()
