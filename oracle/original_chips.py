@@ -79,9 +79,10 @@ def sanitise_instructions(instructions):
     return out
 
 
-def build_instruction_table(instructions, has_subs, start_pc=0x200000):
+def build_instruction_table(instructions, has_subs, start_pc=0x200000, pcs=None):
     """instructions: [[opcode, a, b, c, d, e, f, g], ...] of the APC block (autoprecompiles Instr wire format);
-    has_subs[i]: the instruction keeps at least one cell (only those rows exist in the dummy traces, cuda/mod.rs:283-291).
+    has_subs[i]: the instruction keeps at least one cell (only those rows exist in the dummy traces, cuda/mod.rs:283-291);
+    pcs: the instructions' pcs when the block is a superblock of several basic blocks (default: start_pc + 4 i).
     Returns (table[INSTR_DTYPE] of the instructions WITH substitutions in program order, index of each in `instructions`,
     row_block_size per kind, words per call record)."""
     rows, idx = [], []
@@ -90,7 +91,7 @@ def build_instruction_table(instructions, has_subs, start_pc=0x200000):
     for i, ins in enumerate(instructions):
         kind = OPCODE_KIND[int(ins[0])]
         if has_subs[i]:
-            rows.append((kind, int(ins[0]), start_pc + 4 * i, int(ins[1]), int(ins[2]), int(ins[3]) % P, int(ins[5]), int(ins[6]), int(ins[7]), ts,
+            rows.append((kind, int(ins[0]), start_pc + 4 * i if pcs is None else int(pcs[i]), int(ins[1]), int(ins[2]), int(ins[3]) % P, int(ins[5]), int(ins[6]), int(ins[7]), ts,
                          air_rows[kind], rec_off))
             idx.append(i)
             air_rows[kind] += 1
@@ -446,7 +447,7 @@ def expand_rows(ins, rec, base_ts):
         rd_data = [const((rdw >> (8 * i)) & 0xFF) for i in range(4)]
         t = _ts_decomp(ts, rec[o + 1]) if needs_write else [const(0)] * 3
         prev = _bytes(rec[o]) if needs_write else [const(0)] * 4
-        return [const(pc), ts, const(A if needs_write else 0)] + t + prev + [const(needs_write), const(C_)] + rd_data + [const(int(is_jal)), const(int(not is_jal))]
+        return [const(pc), ts, const(A)] + t + prev + [const(needs_write), const(C_)] + rd_data + [const(int(is_jal)), const(int(not is_jal))]
     if k == KIND_JALR:
         needs_write = int(ins["f"]) & 1
         ext = _imm_ext(ins)

@@ -170,3 +170,40 @@ def parse_airs(text: str) -> list:
                 raise ValueError(f"cannot parse constraint {line!r}")
             cur.constraints.append(line[: -len("= 0")].strip())
     return airs
+
+
+# ---- APC snapshots: `Instructions:` / `APC advantage:` / `Symbolic machine ...` (openvm/src/test_utils.rs:63-66 writes them, the
+# reference's apc_builder_* tests compare against openvm-riscv/tests/apc_snapshots/**) -----------------------------------------
+MNEMONICS = {"ADD": 512, "SUB": 513, "XOR": 514, "OR": 515, "AND": 516, "SLL": 517, "SRL": 518, "SRA": 519, "SLT": 520, "SLTU": 521,
+             "LOADW": 528, "LOADBU": 529, "LOADHU": 530, "STOREW": 531, "STOREH": 532, "STOREB": 533, "LOADB": 534, "LOADH": 535,
+             "BEQ": 544, "BNE": 545, "BLT": 549, "BLTU": 550, "BGE": 551, "BGEU": 552, "JAL": 560, "LUI": 561, "JALR": 565, "AUIPC": 576,
+             "MUL": 592, "MULH": 593, "MULHSU": 594, "MULHU": 595, "DIV": 596, "DIVU": 597, "REM": 598, "REMU": 599}
+
+
+def parse_instruction(text: str) -> list:
+    """One line of the reference's instruction formatter (openvm-riscv/src/isa/instruction_formatter.rs:6-48) back into the wire
+    format [opcode, a, b, c, d, e, f, g] (c reduced mod p): `ADD rd_ptr = 8, rs1_ptr = 8, rs2 = 1, rs2_as = 0`,
+    `LOADW rd_rs2_ptr = 60, rs1_ptr = 56, imm = 0, mem_as = 2, needs_write = 1, imm_sign = 0`, `BLTU 44 48 -44 1 1`, `MUL 8 7 5 1 0`."""
+    name, _, rest = text.strip().partition(" ")
+    op = MNEMONICS[name]
+    if "=" in rest:
+        v = {k.strip(): int(x) for k, x in (kv.split("=") for kv in rest.split(","))}
+        if 512 <= op <= 521:
+            return [op, v["rd_ptr"], v["rs1_ptr"], v["rs2"] % P, 1, v["rs2_as"], 0, 0]
+        return [op, v["rd_rs2_ptr"], v["rs1_ptr"], v["imm"] % P, 1, v["mem_as"], v["needs_write"], v["imm_sign"]]
+    a, b, c, d, e = (int(x) for x in rest.split())
+    return [op, a % P, b % P, c % P, d, e, 0, 0]  # the formatter prints five operands: f = g = 0 (symbolic_instruction_builder.rs:6-35)
+
+
+def parse_apc_snapshot(text: str):
+    """-> ([(pc, [opcode, a, b, c, d, e, f, g])], TextAir of the optimised machine). Column `<original column>_<k>` of the machine is
+    the cell `<original column>` of the k-th instruction's row (its AIR: the opcode's); `is_valid` and optimiser-made columns
+    (`free_var_*`, `inv_of_sum_*`: derived columns whose definitions the text does not carry) are the rest."""
+    head, _, rest = text.partition("Symbolic machine using")
+    instrs = []
+    for line in head.split("Instructions:")[1].split("APC advantage:")[0].splitlines():
+        if line.strip():
+            pc, _, ins = line.partition(":")
+            instrs.append((int(pc), parse_instruction(ins)))
+    (air,) = parse_airs("# apc\nSymbolic machine using" + rest)
+    return instrs, air

@@ -244,7 +244,7 @@ __device__ __forceinline__ void expand_jal_lui(const PowdrOrigInstr& in, const u
     const bool is_jal = in.opcode == 560u;
     const uint32_t needs_write = in.f & 1u;
     const uint32_t rd = is_jal ? in.pc + 4u : in.c << 12;
-    o(0, in.pc); o(1, ts); o(2, needs_write ? in.a : 0u);
+    o(0, in.pc); o(1, ts); o(2, in.a);  // rd_ptr is the PC-lookup tuple's `a` whether or not rd is written
     put_ts(o, 3, ts, rec[1], needs_write != 0);
     put_bytes(o, 6, needs_write ? rec[0] : 0u);
     o(10, needs_write); o(11, in.c);

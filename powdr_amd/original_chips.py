@@ -52,7 +52,8 @@ assert C.sizeof(PowdrOrigInstr) == 48 and C.sizeof(PowdrRecordSubst) == 12
 class InstructionTable:
     """The block's instructions that keep at least one cell (cuda/mod.rs:283-291 drops the others), in program order."""
 
-    def __init__(self, instructions, has_subs, start_pc: int):
+    def __init__(self, instructions, has_subs, start_pc: int, pcs=None):
+        """pcs: the instructions' pcs when the block is a superblock of several basic blocks (default: start_pc + 4 i)"""
         self.entries = []
         self.index_of = {}          # index in `instructions` -> index in the table
         self.row_block_size = [0] * N_KINDS
@@ -65,7 +66,7 @@ class InstructionTable:
                 row = self.row_block_size[k]
                 self.index_of[i] = len(self.entries)
                 self.at[(k, row)] = len(self.entries)
-                self.entries.append(PowdrOrigInstr(k, op, start_pc + 4 * i, int(ins[1]), int(ins[2]), int(ins[3]) % P, int(ins[5]), int(ins[6]),
+                self.entries.append(PowdrOrigInstr(k, op, start_pc + 4 * i if pcs is None else int(pcs[i]), int(ins[1]), int(ins[2]), int(ins[3]) % P, int(ins[5]), int(ins[6]),
                                                    int(ins[7]), ts, row, rec_off))
                 self.row_block_size[k] += 1
                 rec_off += RECORD_WORDS[k]

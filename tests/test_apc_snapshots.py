@@ -1,0 +1,289 @@
+"""The reference's GOLDEN APC machines as a result pin for trace generation ("post-opt text machines
+openvm-riscv/tests/apc_snapshots/**"): 62 optimised autoprecompiles — what the reference's apc_builder_* tests compare the
+optimiser's output against — parsed into tests/golden/apc_snapshots.json.gz (tests/golden/make_apc_snapshots.py).
+
+For every snapshot: a small RV32IM executor (oracle/rv32_vm.py) runs the block on random initial states and produces consistent
+call records; the original chips expand them into rows (oracle/original_chips.py; on the GPU powdr_apc_tracegen_records) and the
+APC trace is the substitution `<original column>_<k>` <- cell `<original column>` of instruction k's row (a1), `is_valid` = 1 and
+the optimiser-made derived columns solved from the constraint that defines them (a2). Then
+  * every algebraic constraint of the reference's optimised machine vanishes on every row,
+  * its range / bitwise / tuple-range lookups are rows of their tables,
+  * its execution-bridge interactions go from the block's first (pc, timestamp) to the executor's exit pc and last timestamp,
+  * its memory-bus interactions net out to exactly "receive every touched location's initial (word, timestamp), send its final
+    one" of the executor.
+This is the reference's own correctness statement for an APC trace (its proof of the APC AIR enforces exactly these), checked on
+reference-held machines with values produced by this repository's trace generation."""
+import gzip
+import json
+import re
+from collections import Counter
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import apc_model as om
+from oracle import original_chips as oc
+from oracle import rv32_vm as vm
+from powdr_amd import air_text
+
+GOLDEN = Path(__file__).parent / "golden"
+P = oc.P
+SNAPSHOTS = json.loads(gzip.open(GOLDEN / "apc_snapshots.json.gz").read())
+ORIGINAL = np.load(GOLDEN / "openvm_airs.npz")
+ORIGINAL_COLUMNS = {str(n): [str(c) for c in ORIGINAL[f"a{i}_columns"]] for i, n in enumerate(ORIGINAL["names"])}
+
+
+def block_of(name):
+    snap = SNAPSHOTS[name]
+    pcs = [row[0] for row in snap["instructions"]]
+    wires = [row[1:] for row in snap["instructions"]]
+    table, _, rbs, wpc = oc.build_instruction_table(wires, [True] * len(wires), pcs=pcs)
+    return snap, pcs, wires, table, rbs, wpc
+
+
+def column_sources(snap, table):
+    """per APC column: (k, column of instruction k's AIR) | "is_valid" | None (optimiser-made)"""
+    out = []
+    for c in snap["columns"]:
+        m = re.match(r"(.*)_(\d+)$", c)
+        if c == "is_valid":
+            out.append("is_valid")
+        elif m and int(m.group(2)) < len(table) and m.group(1) in ORIGINAL_COLUMNS[oc.KIND_NAMES[int(table[int(m.group(2))]["kind"])]]:
+            k = int(m.group(2))
+            out.append((k, ORIGINAL_COLUMNS[oc.KIND_NAMES[int(table[k]["kind"])]].index(m.group(1))))
+        else:
+            out.append(None)
+    return out
+
+
+def columns_of(bc):
+    ops, used, i = [int(x) for x in bc], set(), 0
+    while i < len(ops):
+        if ops[i] in (0, 1):
+            if ops[i] == 0:
+                used.add(ops[i + 1])
+            i += 2
+        else:
+            i += 1
+    return used
+
+
+def with_column_fixed(bc, col, value):
+    out, ops, i = [], [int(x) for x in bc], 0
+    while i < len(ops):
+        if ops[i] in (0, 1):
+            out += [1, value] if (ops[i] == 0 and ops[i + 1] == col) else ops[i:i + 2]
+            i += 2
+        else:
+            out.append(ops[i])
+            i += 1
+    return out
+
+
+def derived_definitions(unknown, cons):
+    """The optimiser's derived columns (free_var_*, inv_of_sum_*: QuotientOrZero columns, constraint_system.rs:128-137; their
+    definitions are not in the text): each is fixed by a constraint c that is linear in it and mentions no other unsolved column —
+    u = e1 * inv_or_zero(e2) with e1 = -c(u = 0), e2 = c(u = 1) - c(u = 0). -> [(column, e1 bytecode, e2 bytecode)] in solving order
+    (post-fix, column-index operands)."""
+    left, out = list(unknown), []
+    progress = True
+    while left and progress:
+        progress = False
+        for u in list(left):
+            for bc in cons:
+                used = columns_of(bc)
+                if u in used and not any(v in used for v in left if v != u):
+                    c0, c1 = with_column_fixed(bc, u, 0), with_column_fixed(bc, u, 1)
+                    out.append((u, c0 + [5], c1 + c0 + [3]))
+                    left.remove(u)
+                    progress = True
+                    break
+    assert not left, left
+    return out
+
+
+def solve_derived(cols, definitions):
+    for u, e1, e2 in definitions:
+        cols[u] = oc.eval_postfix(e1, cols) * oc._inv(oc.eval_postfix(e2, cols)) % P + np.zeros_like(cols[0])
+
+
+def apc_trace(snap, table, rec):
+    rows = [[np.asarray(v).astype(np.int64) % P for v in oc.expand_rows(ins, rec, rec[0])] for ins in table]
+    src = column_sources(snap, table)
+    n = rec.shape[1]
+    cols = [np.ones(n, np.int64) if s == "is_valid" else np.zeros(n, np.int64) if s is None else rows[s[0]][s[1]] for s in src]
+    air = air_text.TextAir("apc", snap["columns"], snap["constraints"], [(b, m, a) for b, m, a in snap["interactions"]])
+    bc, spans, (inter, ispans, ibc) = air.tables()
+    cons = [bc[o:o + ln] for o, ln in spans.tolist()]
+    definitions = derived_definitions([i for i, s in enumerate(src) if s is None], cons)
+    solve_derived(cols, definitions)
+    return cols, (src, definitions), (bc, spans), (inter, ispans, ibc)
+
+
+def check_machine(name, cols, info, first_ts, pcs, table, cons, interactions):
+    bc, spans = cons
+    bad, first = oc.check_constraints(bc, spans, cols)
+    assert bad == 0, (name, SNAPSHOTS[name]["constraints"][first])
+    inter, ispans, ibc = interactions
+    n = len(cols[0])
+    ev = lambda s: np.broadcast_to(oc.eval_postfix(ibc[int(ispans[s][0]):int(ispans[s][0]) + int(ispans[s][1])], cols), (n,)).astype(np.int64)
+    signed = lambda m: np.where(m > P // 2, m - P, m)
+    memory = [Counter() for _ in range(n)]
+    bridge = []
+    for i, (bus, n_args, s0) in enumerate(np.asarray(inter).tolist()):
+        mult, args = ev(s0), [ev(s0 + 1 + j) for j in range(n_args)]
+        on = mult != 0
+        where = (name, f"interaction {i} on bus {bus}")
+        if bus == oc.BUS_VAR_RANGE:
+            assert np.isin(mult, (0, 1)).all() and not (on & (args[0] >= (1 << args[1]))).any(), where
+        elif bus == oc.BUS_BITWISE:
+            assert np.isin(mult, (0, 1)).all() and not (on & ((args[0] >= 256) | (args[1] >= 256))).any(), where
+            assert not (on & (args[3] == 0) & (args[2] != 0)).any() and not (on & (args[3] == 1) & (args[2] != (args[0] ^ args[1]))).any(), where
+            assert not (on & ~np.isin(args[3], (0, 1))).any(), where
+        elif bus == oc.BUS_TUPLE_RANGE:
+            assert np.isin(mult, (0, 1)).all() and not (on & ((args[0] >= 256) | (args[1] >= 2048))).any(), where
+        elif bus == oc.BUS_EXECUTION:
+            bridge.append((signed(mult), args))
+        elif bus == oc.BUS_MEMORY:
+            assert all((a < 256).all() for a in args[2:6]), where  # data limbs are bytes
+            word = args[2] + (args[3] << 8) + (args[4] << 16) + (args[5] << 24)
+            for r in range(n):
+                if mult[r]:
+                    memory[r][(int(args[0][r]), int(args[1][r]), int(word[r]), int(args[6][r]))] += int(signed(mult)[r])
+        else:
+            raise AssertionError(where)
+    # the execution bridge: in at the block's first pc and the call's first timestamp, out at the executor's exit pc after all accesses
+    total_ts = sum(oc.TS_STEP[int(t["kind"])] for t in table)
+    assert len(bridge) == 2 and (bridge[0][0] == -1).all() and (bridge[1][0] == 1).all(), name
+    assert (bridge[0][1][0] == pcs[0] % P).all() and (bridge[0][1][1] == first_ts).all(), name
+    assert (bridge[1][1][0] == np.array([exit_pc for _, _, exit_pc in info])).all(), name
+    assert ((bridge[1][1][1] - bridge[0][1][1]) % P == total_ts).all(), name
+    # the memory bus nets out to: receive every touched location's initial (word, timestamp), send its final one
+    for r, (initial, final, _) in enumerate(info):
+        want = Counter()
+        for (space, ptr), (word, ts) in initial.items():
+            want[(space, ptr % P, word, ts)] -= 1
+        for (space, ptr), (word, ts) in final.items():
+            want[(space, ptr % P, word, ts)] += 1
+        got = {k: v for k, v in memory[r].items() if v}
+        want = {k: v for k, v in want.items() if v}
+        assert got == want, (name, r, sorted(set(got.items()) ^ set(want.items()))[:4])
+
+
+@pytest.mark.parametrize("name", sorted(SNAPSHOTS))
+def test_trace_generation_satisfies_the_reference_golden_apc_machine(name):
+    snap, pcs, wires, table, rbs, wpc = block_of(name)
+    calls = 48
+    rec, info = vm.execute_block(table, pcs, wpc, calls, seed=len(name) * 7 + len(wires))
+    # the executor's records are the kind the chips expect: every original AIR's own constraints and lookups hold on its rows
+    from powdr_amd import synth
+
+    for ins in table:
+        air = oc.KIND_NAMES[int(ins["kind"])]
+        row = oc.expand_rows(ins, rec, rec[0])
+        bc, sp, it = synth.reference_air_programs(air)
+        assert oc.check_constraints(bc, sp, [np.asarray(v).astype(np.int64) % P for v in row])[0] == 0, (name, air)
+        assert not oc.check_interactions(it, ins, rec, row), (name, air)
+    cols, _, cons, interactions = apc_trace(snap, table, rec)
+    check_machine(name, cols, info, rec[0].astype(np.int64), pcs, table, cons, interactions)
+
+
+def test_the_fixture_is_the_reference_directory(reference_dir):
+    files = sorted((reference_dir / "openvm-riscv" / "tests" / "apc_snapshots").glob("*/*.txt"))
+    assert sorted(SNAPSHOTS) == [f"{f.parent.name}/{f.stem}" for f in files] and len(files) == 62
+    for f in files:
+        instrs, air = air_text.parse_apc_snapshot(f.read_text())
+        snap = SNAPSHOTS[f"{f.parent.name}/{f.stem}"]
+        assert [[pc] + ins for pc, ins in instrs] == snap["instructions"] and air.columns == snap["columns"] and air.constraints == snap["constraints"]
+        # the header's own counts: "Main columns: 36 -> 12", "Bus interactions: 20 -> 8", "Constraints: 22 -> 5"
+        head = f.read_text()
+        after = [int(x) for x in re.findall(r"-> (\d+) \(", head)[:3]]
+        assert after == [len(air.columns), len(air.interactions), len(air.constraints)], f.name
+        before = [int(x) for x in re.findall(r": (\d+) -> ", head)[:3]]
+        kinds = [oc.KIND_NAMES[oc.OPCODE_KIND[ins[0]]] for _, ins in instrs]
+        assert before[0] == sum(len(ORIGINAL_COLUMNS[k]) for k in kinds), f.name  # the unoptimised block: the original AIRs' columns
+
+
+def test_the_checks_pin_every_column_of_every_golden_machine():
+    """+1 on any of the 1 681 columns of the 62 machines is caught by the machine's constraints or by the lookup / execution-bridge /
+    memory-bus checks above: nothing an APC trace holds goes unchecked."""
+    total = 0
+    for name in sorted(SNAPSHOTS):
+        snap, pcs, wires, table, rbs, wpc = block_of(name)
+        rec, info = vm.execute_block(table, pcs, wpc, 12, seed=3)
+        cols, _, cons, interactions = apc_trace(snap, table, rec)
+        for c in range(len(cols)):
+            mut = list(cols)
+            mut[c] = (cols[c] + 1) % P
+            with pytest.raises(AssertionError):
+                check_machine(name, mut, info, rec[0].astype(np.int64), pcs, table, cons, interactions)
+        total += len(cols)
+    assert total == 1681
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(SNAPSHOTS))
+def test_device_trace_generation_satisfies_the_golden_machine(name):
+    """The same on the device, through the library's entry points: records -> powdr_apc_tracegen_records (a1 from records) ->
+    _apc_apply_derived_expr for is_valid = Constant(1) and the optimiser's QuotientOrZero columns (a2) -> the trace equals the
+    restatement's word for word; _apc_apply_bus on the machine's own interactions fills the periphery histograms like the oracle
+    (a3); pw_prover_check_constraints finds no violation of the machine's constraints on any of the H rows (padding included)."""
+    import torch
+    from powdr_amd import abi, original_chips as pc, prover, tracegen as tg
+
+    snap, pcs, wires, table, rbs, wpc = block_of(name)
+    calls, H = 48, 64
+    rec, info = vm.execute_block(table, pcs, wpc, calls, seed=len(name) * 7 + len(wires))
+    cols, (src, definitions), (bc, spans), (inter, ispans, ibc) = apc_trace(snap, table, rec)
+    W = len(cols)
+    t = pc.InstructionTable(wires, [True] * len(wires), 0, pcs=pcs)
+    subs = [(s[0], s[1], c) for c, s in enumerate(src) if isinstance(s, tuple)]
+    rsubs = (pc.PowdrRecordSubst * max(len(subs), 1))(*[pc.PowdrRecordSubst(*x) for x in subs])
+    d_rec = torch.from_numpy(rec.view(np.int32).reshape(-1).copy()).cuda()
+    out = tg.DeviceMatrix.zeros(H, W)
+    pc.tracegen_records(out.ptr(), H, d_rec.data_ptr(), calls, t, rsubs, len(subs))
+    # derived columns in their order of definition: operands become element offsets col * H (cuda/mod.rs:61-63)
+    def to_offsets(code):
+        out, i = [], 0
+        while i < len(code):
+            if code[i] in (0, 1):
+                out += [code[i], code[i + 1] * (H if code[i] == 0 else 1)]
+                i += 2
+            else:
+                out.append(code[i])
+                i += 1
+        return out
+
+    col_base, offs, lens, dbc = [], [], [], []
+    for c, s in enumerate(src):
+        if s == "is_valid":
+            col_base.append(c * H); offs.append(len(dbc)); lens.append(2); dbc += [1, 1]
+    for u, e1, e2 in definitions:
+        code = to_offsets(e2) + [6] + to_offsets(e1) + [4]  # inv_or_zero(e2) * e1 (cuda/mod.rs:100-141)
+        col_base.append(u * H); offs.append(len(dbc)); lens.append(len(code)); dbc += code
+    keep = tg.apc_apply_derived_expr(out, calls, col_base, offs, lens, dbc)
+    torch.cuda.synchronize()
+    got = om.from_monty(out.buf.cpu().numpy().view(np.uint32)).reshape(W, H)
+    want = np.zeros((W, H), np.uint32)
+    want[:, :calls] = np.stack(cols).astype(np.uint32)
+    assert (got == want).all(), [snap["columns"][c] for c in np.nonzero((got != want).any(axis=1))[0][:5]]
+    # a3: the machine's interactions replayed into the periphery histograms
+    per = tg.Periphery.fresh()
+    dev_ibc = to_offsets([int(x) for x in ibc])
+    keep2 = tg.apc_apply_bus(out, calls, dev_ibc, inter, ispans, per)
+    torch.cuda.synchronize()
+    var_h, tup_h, bit_h = (np.zeros(x.numel(), np.uint32) for x in (per.var_hist, per.tuple_hist, per.bitwise_hist))
+    om.c_apc_apply_bus(want.reshape(-1), calls, np.array(dev_ibc, np.uint32), inter, ispans, per.var_bus, var_h, per.tuple_bus, tup_h, per.tuple_sizes[0],
+                       per.tuple_sizes[1], per.bitwise_bus, bit_h)
+    for mine, theirs in ((per.var_hist, var_h), (per.tuple_hist, tup_h), (per.bitwise_hist, bit_h)):
+        assert (mine.cpu().numpy().view(np.uint32) == theirs).all()
+    sent = sum(int(np.broadcast_to(oc.eval_postfix(ibc[int(ispans[s0][0]):int(ispans[s0][0]) + int(ispans[s0][1])], cols), (calls,)).sum()) if b in (3, 6, 7) else 0
+               for b, _, s0 in np.asarray(inter).tolist())
+    assert sent > 0 or not any(b in (3, 6, 7) for b, _, _ in snap["interactions"])
+    assert int(var_h.sum()) + int(tup_h.sum()) + int(bit_h.sum()) == sent  # every lookup of every call landed in a bin
+    pr = prover.Prover(W, bc, spans, num_queries=1)
+    assert pr.check_constraints(out.ptr(), 6) == (0, None, None)
+    pr.close()
+    del keep, keep2
