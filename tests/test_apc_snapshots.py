@@ -124,13 +124,12 @@ def apc_trace(snap, table, rec):
 def check_machine(name, cols, info, first_ts, pcs, table, cons, interactions):
     bc, spans = cons
     bad, first = oc.check_constraints(bc, spans, cols)
-    assert bad == 0, (name, SNAPSHOTS[name]["constraints"][first])
+    assert bad == 0, (name, SNAPSHOTS[name]["constraints"][first] if name in SNAPSHOTS else first)
     inter, ispans, ibc = interactions
     n = len(cols[0])
     ev = lambda s: np.broadcast_to(oc.eval_postfix(ibc[int(ispans[s][0]):int(ispans[s][0]) + int(ispans[s][1])], cols), (n,)).astype(np.int64)
     signed = lambda m: np.where(m > P // 2, m - P, m)
-    memory = [Counter() for _ in range(n)]
-    bridge = []
+    memory, bridge, program = [Counter() for _ in range(n)], [Counter() for _ in range(n)], [Counter() for _ in range(n)]
     for i, (bus, n_args, s0) in enumerate(np.asarray(inter).tolist()):
         mult, args = ev(s0), [ev(s0 + 1 + j) for j in range(n_args)]
         on = mult != 0
@@ -144,21 +143,29 @@ def check_machine(name, cols, info, first_ts, pcs, table, cons, interactions):
         elif bus == oc.BUS_TUPLE_RANGE:
             assert np.isin(mult, (0, 1)).all() and not (on & ((args[0] >= 256) | (args[1] >= 2048))).any(), where
         elif bus == oc.BUS_EXECUTION:
-            bridge.append((signed(mult), args))
+            for r in np.nonzero(on)[0]:
+                bridge[r][(int(args[0][r]), int(args[1][r]))] += int(signed(mult)[r])
+        elif bus == oc.BUS_PC_LOOKUP:
+            assert np.isin(mult, (0, 1)).all(), where
+            for r in np.nonzero(on)[0]:
+                program[r][tuple(int(a[r]) for a in args)] += 1
         elif bus == oc.BUS_MEMORY:
             assert all((a < 256).all() for a in args[2:6]), where  # data limbs are bytes
             word = args[2] + (args[3] << 8) + (args[4] << 16) + (args[5] << 24)
-            for r in range(n):
-                if mult[r]:
-                    memory[r][(int(args[0][r]), int(args[1][r]), int(word[r]), int(args[6][r]))] += int(signed(mult)[r])
+            for r in np.nonzero(on)[0]:
+                memory[r][(int(args[0][r]), int(args[1][r]), int(word[r]), int(args[6][r]))] += int(signed(mult)[r])
         else:
             raise AssertionError(where)
-    # the execution bridge: in at the block's first pc and the call's first timestamp, out at the executor's exit pc after all accesses
+    # the execution bridge nets out to: in at the block's first pc and the call's first timestamp, out at the executor's exit pc after
+    # all accesses (an optimised machine holds just these two, an unoptimised one a pair per instruction that cancel along the path)
     total_ts = sum(oc.TS_STEP[int(t["kind"])] for t in table)
-    assert len(bridge) == 2 and (bridge[0][0] == -1).all() and (bridge[1][0] == 1).all(), name
-    assert (bridge[0][1][0] == pcs[0] % P).all() and (bridge[0][1][1] == first_ts).all(), name
-    assert (bridge[1][1][0] == np.array([exit_pc for _, _, exit_pc in info])).all(), name
-    assert ((bridge[1][1][1] - bridge[0][1][1]) % P == total_ts).all(), name
+    for r, (_, _, exit_pc) in enumerate(info):
+        got = {k: v for k, v in bridge[r].items() if v}
+        assert got == {(pcs[0] % P, int(first_ts[r])): -1, (exit_pc, (int(first_ts[r]) + total_ts) % P): 1}, (name, r, got)
+    # the PC lookup (an unoptimised machine still has it; the optimiser removes it): exactly the block's instructions, once each
+    listing = Counter((int(t["pc"]), int(t["opcode"]), int(t["a"]), int(t["b"]), int(t["c"]), 1, int(t["e"]), int(t["f"]), int(t["g"])) for t in table)
+    for r in range(n):
+        assert not program[r] or program[r] == listing, (name, r)
     # the memory bus nets out to: receive every touched location's initial (word, timestamp), send its final one
     for r, (initial, final, _) in enumerate(info):
         want = Counter()
@@ -287,3 +294,27 @@ def test_device_trace_generation_satisfies_the_golden_machine(name):
     assert pr.check_constraints(out.ptr(), 6) == (0, None, None)
     pr.close()
     del keep, keep2
+
+
+def test_the_real_keccak_block_end_to_end_with_executor_records():
+    """The reference's REAL keccak block (autoprecompiles/tests/keccak_apc_pre_opt.json.gz: 677 instructions, the UNOPTIMISED machine:
+    27 521 columns, 28 627 constraints, 13 262 bus interactions) on the records of an execution: every constraint vanishes, every
+    lookup is a table row, the PC-lookup interactions list exactly the block's 677 instructions, the 1 354 execution-bridge
+    interactions cancel along the path and the 3 900-odd memory-bus interactions net out to the executor's initial -> final state."""
+    z = np.load(GOLDEN / "keccak_apc_pre_opt.apc.npz")
+    wires = z["instructions"].tolist()
+    start_pc = int(z["start_pc"][0])
+    pcs = [start_pc + 4 * i for i in range(len(wires))]
+    table, _, rbs, wpc = oc.build_instruction_table(wires, [True] * len(wires), start_pc)
+    calls = 6
+    rec, info = vm.execute_block(table, pcs, wpc, calls, seed=77)
+    rows = [[np.asarray(v).astype(np.int64) % P for v in oc.expand_rows(ins, rec, rec[0])] for ins in table]
+    kind_of = {str(n): oc.KIND_NAMES.index(str(n)) for n in z["air_names"]}
+    at = {(int(t["kind"]), int(t["air_row"])): i for i, t in enumerate(table)}
+    cols = [None] * len(z["poly_ids"])
+    for air, col, row, apc_col in z["subs"].tolist():
+        cols[apc_col] = rows[at[(kind_of[str(z["air_names"][air])], row)]][col]
+    assert all(c is not None for c in cols)
+    check_machine("keccak_apc_pre_opt", cols, info, rec[0].astype(np.int64), pcs, table, (z["cons_bc"], z["cons_spans"]),
+                  (z["bus_inter"], z["bus_spans"], z["bus_bc"]))
+    assert len(z["bus_inter"]) == 13262 and int((z["bus_inter"][:, 0] == oc.BUS_PC_LOOKUP).sum()) == 677
