@@ -23,7 +23,7 @@ from oracle import apc_model as om  # noqa: E402
 REF = Path("/root/reference/autoprecompiles/tests")
 OUT = Path(__file__).resolve().parent
 FIXTURES = ["keccak_apc_pre_opt", "ecrecover_apc_pre_opt", "single_div_nondet", "wasm_register_reuse", "apc_reth_op_bug"]
-NPZ = ["keccak_apc_pre_opt", "single_div_nondet"]
+NPZ = ["keccak_apc_pre_opt", "ecrecover_apc_pre_opt", "single_div_nondet"]
 
 
 def max_depth(bc):

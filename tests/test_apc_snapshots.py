@@ -296,12 +296,15 @@ def test_device_trace_generation_satisfies_the_golden_machine(name):
     del keep, keep2
 
 
-def test_the_real_keccak_block_end_to_end_with_executor_records():
-    """The reference's REAL keccak block (autoprecompiles/tests/keccak_apc_pre_opt.json.gz: 677 instructions, the UNOPTIMISED machine:
-    27 521 columns, 28 627 constraints, 13 262 bus interactions) on the records of an execution: every constraint vanishes, every
-    lookup is a table row, the PC-lookup interactions list exactly the block's 677 instructions, the 1 354 execution-bridge
-    interactions cancel along the path and the 3 900-odd memory-bus interactions net out to the executor's initial -> final state."""
-    z = np.load(GOLDEN / "keccak_apc_pre_opt.apc.npz")
+@pytest.mark.parametrize("fixture,n_instr,n_cons,n_inter", [("keccak_apc_pre_opt", 677, 28627, 13262), ("ecrecover_apc_pre_opt", 750, 23629, 14161),
+                                                             ("single_div_nondet", 1, 74, 25)])
+def test_the_reference_real_blocks_end_to_end_with_executor_records(fixture, n_instr, n_cons, n_inter):
+    """The reference's REAL blocks (autoprecompiles/tests/*.json.gz, the UNOPTIMISED machines; keccak: 677 instructions, 27 521 columns,
+    28 627 constraints, 13 262 bus interactions; ecrecover: 750 instructions with MUL / MULHU / SLTU / AUIPC / JALR; a single DIV) on the
+    records of an execution: every constraint vanishes, every lookup is a table row, the PC-lookup interactions list exactly the
+    block's instructions, the execution-bridge interactions cancel along the path and the memory-bus interactions net out to the
+    executor's initial -> final state."""
+    z = np.load(GOLDEN / f"{fixture}.apc.npz")
     wires = z["instructions"].tolist()
     start_pc = int(z["start_pc"][0])
     pcs = [start_pc + 4 * i for i in range(len(wires))]
@@ -309,12 +312,12 @@ def test_the_real_keccak_block_end_to_end_with_executor_records():
     calls = 6
     rec, info = vm.execute_block(table, pcs, wpc, calls, seed=77)
     rows = [[np.asarray(v).astype(np.int64) % P for v in oc.expand_rows(ins, rec, rec[0])] for ins in table]
-    kind_of = {str(n): oc.KIND_NAMES.index(str(n)) for n in z["air_names"]}
+    kind_of = lambda air: oc.KIND_NAMES.index({"Mul": "Multiplication"}.get(air, air))  # oracle/apc_model.py names the MUL AIR "Mul"
     at = {(int(t["kind"]), int(t["air_row"])): i for i, t in enumerate(table)}
     cols = [None] * len(z["poly_ids"])
     for air, col, row, apc_col in z["subs"].tolist():
-        cols[apc_col] = rows[at[(kind_of[str(z["air_names"][air])], row)]][col]
+        cols[apc_col] = rows[at[(kind_of(str(z["air_names"][air])), row)]][col]
     assert all(c is not None for c in cols)
-    check_machine("keccak_apc_pre_opt", cols, info, rec[0].astype(np.int64), pcs, table, (z["cons_bc"], z["cons_spans"]),
-                  (z["bus_inter"], z["bus_spans"], z["bus_bc"]))
-    assert len(z["bus_inter"]) == 13262 and int((z["bus_inter"][:, 0] == oc.BUS_PC_LOOKUP).sum()) == 677
+    assert len(wires) == n_instr and len(z["cons_spans"]) == n_cons and len(z["bus_inter"]) == n_inter
+    assert int((z["bus_inter"][:, 0] == oc.BUS_PC_LOOKUP).sum()) == n_instr
+    check_machine(fixture, cols, info, rec[0].astype(np.int64), pcs, table, (z["cons_bc"], z["cons_spans"]), (z["bus_inter"], z["bus_spans"], z["bus_bc"]))

@@ -237,27 +237,44 @@ def test_fused_records_gather_equals_expand_then_gather(gpu, calls):
 
 
 @pytest.mark.gpu
-def test_fused_keccak_block_satisfies_the_apc_constraints_on_the_device(gpu):
-    """The reference's real keccak block end to end on the device: records -> powdr_apc_tracegen_records -> the 27 521-column
-    pre-optimisation APC trace; pw_prover_check_constraints with the APC's own 28 627 constraints finds no violation."""
+@pytest.mark.parametrize("fixture", ["keccak_apc_pre_opt", "ecrecover_apc_pre_opt"])
+def test_fused_real_blocks_satisfy_the_apc_constraints_on_the_device(gpu, fixture):
+    """The reference's real blocks end to end on the device: records -> powdr_apc_tracegen_records -> the pre-optimisation APC trace
+    (keccak: 27 521 columns; ecrecover: 750 instructions incl. MUL / MULHU / SLTU / AUIPC / JALR, on the records of an execution);
+    pw_prover_check_constraints with the APC's own constraints (28 627 / 23 629) finds no violation, and the trace equals the
+    restatement's gather word for word."""
+    from oracle import rv32_vm
+
     torch, abi, pc, prover, tg = gpu
-    z, ins, start_pc = keccak_block()
+    z = np.load(GOLDEN / f"{fixture}.apc.npz")
+    ins, start_pc = z["instructions"].tolist(), int(z["start_pc"][0])
     t = pc.InstructionTable(ins, [True] * len(ins), start_pc)
     table, _, rbs, wpc = oc.build_instruction_table(ins, [True] * len(ins), start_pc)
-    calls, H, W = 256, 256, len(z["poly_ids"])  # no padding rows: the unoptimised machine's constraints pin pcs and operands on every row
-    rec = oc.random_records(table, wpc, calls, seed=9)
+    W = len(z["poly_ids"])
+    if fixture.startswith("keccak"):
+        calls = H = 256  # no padding rows: the unoptimised machine's constraints pin pcs and operands on every row
+        rec = oc.random_records(table, wpc, calls, seed=9)
+    else:
+        calls = H = 8
+        rec, _ = rv32_vm.execute_block(table, [start_pc + 4 * i for i in range(len(ins))], wpc, calls, seed=5)
     d_rec = torch.from_numpy(rec.view(np.int32).reshape(-1).copy()).cuda()
-    kinds = [oc.KIND_NAMES.index(str(n)) for n in z["air_names"]]
+    kinds = [oc.KIND_NAMES.index({"Mul": "Multiplication"}.get(str(n), str(n))) for n in z["air_names"]]
     rsubs, n = t.record_substitutions(z["subs"], kinds)
     out = tg.DeviceMatrix.zeros(H, W)
     pc.tracegen_records(out.ptr(), H, d_rec.data_ptr(), calls, t, rsubs, n)
     torch.cuda.synchronize()
     pr = prover.Prover(W, z["cons_bc"], z["cons_spans"], num_queries=1)
-    assert pr.check_constraints(out.ptr(), 8) == (0, None, None)
+    assert pr.check_constraints(out.ptr(), H.bit_length() - 1) == (0, None, None)
     pr.close()
+    traces = oc.expand_dummy_traces(table, rec, rbs)
+    want = om.c_apc_tracegen(H, W, [traces[k].reshape(-1) for k in kinds], [traces[k].shape[1] for k in kinds], z["row_block_size"].tolist(), z["subs"], calls)
+    assert (om.from_monty(out.buf.cpu().numpy().view(np.uint32)) == want).all()
     with pytest.raises(abi.HipError):  # a column beyond the chip's width
         bad = (pc.PowdrRecordSubst * 1)(pc.PowdrRecordSubst(0, 60, 0))
         pc.tracegen_records(out.ptr(), H, d_rec.data_ptr(), calls, t, bad, 1)
+    with pytest.raises(abi.HipError):  # one source cell to two APC columns
+        twice = (pc.PowdrRecordSubst * 2)(pc.PowdrRecordSubst(0, 1, 0), pc.PowdrRecordSubst(0, 1, 1))
+        pc.tracegen_records(out.ptr(), H, d_rec.data_ptr(), calls, t, twice, 2)
 
 
 @pytest.mark.gpu
