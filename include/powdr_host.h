@@ -144,6 +144,16 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
                                    size_t n_dummy, size_t num_apc_calls, PowdrFp* d_output,
                                    const PowdrPeriphery* periphery);
 
+/* The same orchestration with the original chips' work folded in: the APC trace comes straight from the
+ * call records of the block (include/powdr_gpu.h: powdr_apc_tracegen_records) — the dummy traces of the original AIRs never
+ * exist — then derived columns and bus replay as above. The instruction table (which instruction keeps a cell, its pc =
+ * block start_pc + 4 j, timestamp offset, row inside its AIR's block, record offset) follows from the APC's own block and
+ * substitutions; powdr_apc_instruction_table returns it (out == NULL: only the count; (size_t)-1: an opcode outside the thirteen
+ * RV32IM chips) together with the size of one call's record, so that the caller can lay the records out. */
+size_t powdr_apc_instruction_table(const PowdrApc* apc, PowdrOrigInstr* out, size_t* words_per_call);
+int powdr_apc_generate_witness_from_records(PowdrApc* apc, const uint32_t* d_records, size_t num_apc_calls, PowdrFp* d_output,
+                                            const PowdrPeriphery* periphery);
+
 /* Test hook for the plan-time expression compiler (csrc/xbc.hpp): compiles the reference post-fix
  * program `postfix` into the accumulator code the kernels run and evaluates it on the host over a
  * Montgomery-form trace (`trace[operand + r]`). Returns 0, or < 0 if the program is malformed /

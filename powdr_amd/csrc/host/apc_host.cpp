@@ -1,6 +1,7 @@
 // Host side of GPU APC trace generation (see include/powdr_host.h for what it mirrors).
 #include "../../../include/powdr_host.h"
 #include "../common.hpp"
+#include "../original_chips_tables.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -262,6 +263,7 @@ struct PowdrApc {
     std::vector<BusInteraction> buses;
     std::vector<Derived> derived;
     std::vector<std::vector<uint32_t>> instructions;   // [opcode, a..g]
+    std::vector<uint64_t> instr_pc;                    // pc of each instruction (block start_pc + 4 j; several blocks: a superblock)
     std::vector<std::vector<Sub>> subs;
     std::vector<uint64_t> poly_ids;                    // ascending
     std::unordered_map<uint64_t, uint32_t> id_to_index;
@@ -292,6 +294,9 @@ struct PowdrApc {
         ~AirTable() { if (d) (void)hipFree(d); }  // hipFree waits for the kernels already enqueued that read it
     };
     std::vector<std::shared_ptr<AirTable>> air_tables;
+    // instruction table + record substitutions of the block (powdr_apc_generate_witness_from_records), built at first use
+    struct RecordTables { std::vector<PowdrOrigInstr> instrs; std::vector<PowdrRecordSubst> subs; };
+    std::shared_ptr<const RecordTables> record_tables;
     uint64_t air_clock = 0;
     std::mutex mu;  // guards the three caches (lookups and insertions; launches run outside it)
 
@@ -507,7 +512,11 @@ std::unique_ptr<PowdrApc> build_apc_from_dom(const JVal& root) {
     for (auto& b : blocks->arr) {
         const JVal* ins = b->get("instructions");
         if (!ins) throw std::runtime_error("missing instructions");
+        const JVal* spc = b->get("start_pc");
+        uint64_t pc = spc && spc->kind == JVal::Num ? spc->u : 0;
         for (auto& i : ins->arr) {
+            apc->instr_pc.push_back(pc);
+            pc += 4;
             std::vector<uint32_t> v;
             if (i->kind == JVal::Arr) {  // export files: SimpleInstruction = [opcode, a, b, c, d, e, f, g] (export.rs:221-251)
                 for (auto& x : i->arr) v.push_back((uint32_t)x->u);
@@ -780,28 +789,39 @@ size_t powdr_apc_build_substitutions(const PowdrApc* apc, const int32_t* instr_a
     return n;
 }
 
+}  // extern "C"
+
+namespace {
+
+// cuda/mod.rs:266-269 zero-fills the whole matrix so that columns covered by neither a substitution nor a derived expression
+// read as zero. The gather and the derived-column kernel write EVERY row of the columns they cover (padding rows included), so
+// only the uncovered columns are cleared here (normally none: at C2 this saves an 8.5 GB memset per segment).
+int clear_uncovered_columns(const PowdrApc* apc, PowdrFp* d_output, size_t height) {
+    const size_t width = apc->poly_ids.size();
+    std::vector<char> covered(width, 0);
+    for (auto& row : apc->subs) for (auto& s : row) covered[apc->id_to_index.at(s.apc_poly_id)] = 1;
+    for (auto& d : apc->derived) covered[apc->id_to_index.at(d.poly_id)] = 1;
+    for (size_t c = 0; c < width;) {
+        if (covered[c]) { ++c; continue; }
+        size_t e = c;
+        while (e < width && !covered[e]) ++e;
+        PW_HIP_TRY(hipMemsetAsync(d_output + c * height, 0, (e - c) * height * sizeof(PowdrFp), pw::stream()));
+        c = e;
+    }
+    return 0;
+}
+
+int apply_derived_and_bus(PowdrApc* apc, size_t height, size_t num_calls, PowdrFp* d_output, const PowdrPeriphery* per);
+
+}  // namespace
+
+extern "C" {
+
 int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, const PowdrDeviceMatrix* dummy, size_t n_dummy,
                                    size_t num_calls, PowdrFp* d_output, const PowdrPeriphery* per) {
-    const size_t width = apc->poly_ids.size();
     const size_t height = (size_t)next_pow2_or_zero(num_calls);
     if (height == 0) return 0;  // the APC was not called: DeviceMatrix::dummy()
-    hipStream_t st = pw::stream();
-    // cuda/mod.rs:266-269 zero-fills the whole matrix so that columns covered by neither a substitution
-    // nor a derived expression read as zero. The gather and the derived-column kernel write EVERY row of
-    // the columns they cover (padding rows included), so only the uncovered columns are cleared here
-    // (normally none: at C2 this saves an 8.5 GB memset per segment).
-    {
-        std::vector<char> covered(width, 0);
-        for (auto& row : apc->subs) for (auto& s : row) covered[apc->id_to_index.at(s.apc_poly_id)] = 1;
-        for (auto& d : apc->derived) covered[apc->id_to_index.at(d.poly_id)] = 1;
-        for (size_t c = 0; c < width;) {
-            if (covered[c]) { ++c; continue; }
-            size_t e = c;
-            while (e < width && !covered[e]) ++e;
-            PW_HIP_TRY(hipMemsetAsync(d_output + c * height, 0, (e - c) * height * sizeof(PowdrFp), st));
-            c = e;
-        }
-    }
+    if (int rc0 = clear_uncovered_columns(apc, d_output, height)) return rc0;
 
     // ---- OriginalAir / Subst tables (cuda/mod.rs:272-332) ----
     int rc = 0;
@@ -857,7 +877,76 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
     rc = powdr_apc_tracegen_host_tables(d_output, height, air_table ? air_table->d : nullptr, airs.data(), airs.size(), stb.subs.data(),
                                         stb.subs.size(), (int)num_calls);
     if (rc) return rc;
+    return apply_derived_and_bus(apc, height, num_calls, d_output, per);
+}
 
+// The instruction table of the APC's block for the record expanders (include/powdr_gpu.h): the instructions that keep at least
+// one cell (cuda/mod.rs:283-291 drops the others) in program order, with their pcs, timestamp offsets (every instruction of the
+// block advances the timestamp by its accesses, kept or not), rows inside their AIR's block and record offsets. Returns their
+// number ((size_t)-1: an opcode outside the thirteen chips); *words_per_call = size of one call's record.
+size_t powdr_apc_instruction_table(const PowdrApc* apc, PowdrOrigInstr* out, size_t* words_per_call) {
+    uint32_t air_rows[orig::kKinds] = {};
+    uint32_t rec_off = 1, ts = 0;  // record word 0 = the call's first timestamp
+    size_t n = 0;
+    for (size_t i = 0; i < apc->instructions.size(); ++i) {
+        const auto& ins = apc->instructions[i];
+        const int k = ins.empty() ? -1 : orig::kind_of_opcode(ins[0]);
+        if (k < 0) return (size_t)-1;
+        if (!apc->subs[i].empty()) {
+            if (out) {
+                auto f = [&](size_t j) { return j < ins.size() ? ins[j] : 0u; };
+                out[n] = PowdrOrigInstr{(uint32_t)k, ins[0], (uint32_t)apc->instr_pc[i], f(1), f(2), f(3), f(5), f(6), f(7), ts, air_rows[k], rec_off};
+            }
+            ++n;
+            ++air_rows[k];
+            rec_off += (uint32_t)orig::kRecordWords[k];
+        }
+        ts += (uint32_t)orig::kAccesses[k];
+    }
+    if (words_per_call) *words_per_call = rec_off;
+    return n;
+}
+
+// try_generate_witness (cuda/mod.rs:201-401) with the original chips' work folded in: the APC trace straight from the call
+// records (powdr_apc_tracegen_records: no dummy traces), then derived columns and bus replay as above.
+int powdr_apc_generate_witness_from_records(PowdrApc* apc, const uint32_t* d_records, size_t num_calls, PowdrFp* d_output,
+                                            const PowdrPeriphery* per) {
+    const size_t height = (size_t)next_pow2_or_zero(num_calls);
+    if (height == 0) return 0;
+    if (int rc0 = clear_uncovered_columns(apc, d_output, height)) return rc0;
+    std::shared_ptr<const PowdrApc::RecordTables> rt;
+    {
+        std::lock_guard<std::mutex> lk(apc->mu);
+        if (!apc->record_tables) {
+            auto t = std::make_shared<PowdrApc::RecordTables>();
+            const size_t n = powdr_apc_instruction_table(apc, nullptr, nullptr);
+            if (n == (size_t)-1) return (int)hipErrorInvalidValue;
+            t->instrs.resize(n);
+            powdr_apc_instruction_table(apc, t->instrs.data(), nullptr);
+            int32_t k = 0;
+            for (size_t i = 0; i < apc->instructions.size(); ++i) {
+                if (apc->subs[i].empty()) continue;
+                for (auto& s : apc->subs[i]) t->subs.push_back(PowdrRecordSubst{k, (int32_t)s.original_poly_index, (int32_t)apc->id_to_index.at(s.apc_poly_id)});
+                ++k;
+            }
+            apc->record_tables = t;
+        }
+        rt = apc->record_tables;
+    }
+    int rc = powdr_apc_tracegen_records(d_output, height, d_records, num_calls, rt->instrs.data(), rt->instrs.size(), rt->subs.data(), rt->subs.size());
+    if (rc) return rc;
+    return apply_derived_and_bus(apc, height, num_calls, d_output, per);
+}
+
+}  // extern "C"
+
+namespace {
+
+int apply_derived_and_bus(PowdrApc* apc, size_t height, size_t num_calls, PowdrFp* d_output, const PowdrPeriphery* per) {
+    const size_t width = apc->poly_ids.size();
+    int rc = 0;
+    int device = 0;
+    PW_HIP_TRY(hipGetDevice(&device));
     // ---- derived columns + bus interactions, compiled once per height ----
     // Traces with width*height >= 2^32 cannot be addressed by the reference's u32 element offsets:
     // compile with column-index operands and use the *_cols entry points instead.
@@ -893,4 +982,4 @@ int powdr_apc_generate_witness_gpu(PowdrApc* apc, const int32_t* instr_air, cons
     return 0;
 }
 
-}  // extern "C"
+}  // namespace

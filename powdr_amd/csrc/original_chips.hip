@@ -19,6 +19,7 @@
 #include "babybear.hpp"
 #include "common.hpp"
 #include "../../include/powdr_gpu.h"
+#include "original_chips_tables.hpp"
 
 #include <cstring>
 #include <memory>
@@ -31,11 +32,10 @@ namespace {
 constexpr int kCalls = 128;      // calls per workgroup (= threads)
 constexpr int kMaxWidth = 59;    // widest of the thirteen AIRs (DivRem)
 constexpr int kInstrPerBlock = 16;
-constexpr int kKinds = POWDR_ORIG_KIND_COUNT;
-// per kind (POWDR_ORIG_* order): columns of the AIR, first / last opcode
-constexpr int kWidths[kKinds] = {36, 53, 41, 26, 18, 37, 32, 28, 36, 59, 39, 31, 20};
-constexpr uint32_t kOpcodeLo[kKinds] = {512, 517, 528, 544, 560, 520, 549, 565, 534, 596, 593, 592, 576};
-constexpr uint32_t kOpcodeHi[kKinds] = {516, 519, 533, 545, 561, 521, 552, 565, 535, 599, 595, 592, 576};
+using orig::kKinds;
+using orig::kWidths;
+using orig::kOpcodeLo;
+using orig::kOpcodeHi;
 
 // Where an expander puts cell `c` of this lane's row (canonical value). Two sinks:
 struct DenseSink {  // a full dummy trace: every cell, Montgomery form

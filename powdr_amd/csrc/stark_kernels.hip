@@ -143,71 +143,80 @@ __global__ __launch_bounds__(kBlock) void barycentric_weights_kernel(bb::Ext zet
 }
 
 constexpr int kDotRowsPerBlock = 8192;
-// columns that share one pass over the weights: the weight vector (16 B per row) is re-read once per column group, so with 4 columns
-// per group it costs as much traffic as the columns themselves (PMC r03: 51 GB for 23 GB of cells); 8 halve that share
-// (one weight vector: 8 columns per group at 80 VGPRs; two weight vectors: 4, which keeps 6 waves per SIMD)
-constexpr int kDotColsPerBlock = 8;
-constexpr int kDotColsPerBlock2 = 4;
-// NW = 2: two weight vectors in one pass over the columns (the permutation matrix is opened at zeta AND at g zeta: reading it
-// once instead of twice); partial sums of the second vector go to partial + second_off
-template <int NW, int CPB>
+constexpr int kDotTile = 64;  // columns per workgroup (= lanes of a wave) and rows per LDS tile
+// sum_q w(q) * col_c(q) for the columns of a matrix (the openings at zeta). A lane owns a COLUMN: the weight of a row is then
+// wave-uniform — it arrives through scalar loads and enters the multiply-adds from scalar registers — and is fetched once per 64
+// columns; nothing is reduced across lanes. (The first form gave a lane rows and a workgroup 4-8 columns: every group re-read the
+// 16-byte weights, 28 GB of weight traffic for 23 GB of cells at C2 with LogUp — PMC r03: 51 GB fetched — and finished with 6
+// shuffle steps per sum. Measured: the traffic is gone, the time is not — 11.8 ms either way at C2, 3.0 ms for the 8.5 GB main trace
+// and 8.2 ms for the 14.6 GB permutation matrix; what holds this kernel at 2 TB/s is not understood yet)
+// The cells come in coalesced, 64 rows x 64 columns at a time, and turn through LDS (padded: conflict-free both ways).
+// NW = 2: two weight vectors in one pass (the permutation matrix is opened at zeta AND at g zeta: read once instead of twice);
+// partial sums of the second vector go to partial + second_off. Centred weights x centred cells in signed 64-bit accumulators,
+// folded every fourth row (bb::ExtCentredAcc).
+template <int NW>
 __global__ __launch_bounds__(kBlock) void ext_dot_partial_kernel(const uint32_t* __restrict__ cols, size_t stride, size_t len,
                                                                   uint32_t n_cols, const bb::Ext* __restrict__ weights,
                                                                   const bb::Ext* __restrict__ weights2, bb::Ext* __restrict__ partial,
                                                                   size_t second_off, uint32_t n_chunks) {
-    __shared__ uint32_t red[NW][CPB][4][kBlock / 64];
-    const uint32_t c0 = blockIdx.y * CPB;
-    const uint32_t nc = n_cols - c0 < (uint32_t)CPB ? n_cols - c0 : (uint32_t)CPB;  // block-uniform
+    constexpr int kWaves = kBlock / 64, kRowsPerWave = kDotTile / kWaves;
+    __shared__ uint32_t tile[kDotTile][kDotTile + 1];
+    __shared__ uint32_t red[NW][4][kWaves][kDotTile];
+    const uint32_t c0 = blockIdx.y * kDotTile;
+    const uint32_t nc = n_cols - c0 < (uint32_t)kDotTile ? n_cols - c0 : (uint32_t)kDotTile;  // block-uniform
     const uint32_t* col = cols + (size_t)c0 * stride;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const size_t q0 = (size_t)blockIdx.x * kDotRowsPerBlock;
     const size_t q1 = q0 + kDotRowsPerBlock < len ? q0 + kDotRowsPerBlock : len;
-    // centred weights x centred cells in signed 64-bit accumulators, folded every fourth row (bb::ExtCentredAcc)
-    bb::ExtCentredAcc wide[NW][CPB];
-    uint32_t pending = 0;
-    for (size_t q = q0 + threadIdx.x; q < q1; q += kBlock) {
-        int32_t w[4], w2[4];
-        bb::ext_centred(weights[q], w);
-        if (NW == 2) bb::ext_centred(weights2[q], w2);
+    bb::ExtCentredAcc acc[NW];
+    for (size_t t0 = q0; t0 < q1; t0 += kDotTile) {
+        // in: wave w brings columns w*16 .. w*16+15, a lane one row of each (256 contiguous bytes per wave and column)
 #pragma unroll
-        for (int c = 0; c < CPB; ++c)
-            if ((uint32_t)c < nc) {  // block-uniform
-                const int32_t x = bb::centred(col[(size_t)c * stride + q]);
-                wide[0][c].fma(w, x);
-                if (NW == 2) wide[NW - 1][c].fma(w2, x);
-            }
-        if (++pending == 4) {
-            pending = 0;
-#pragma unroll
-            for (int v = 0; v < NW; ++v)
-#pragma unroll
-                for (int c = 0; c < CPB; ++c) wide[v][c].fold();
+        for (int j = 0; j < kRowsPerWave; ++j) {
+            const uint32_t c = (uint32_t)(wave * kRowsPerWave + j);
+            tile[lane][c] = (c < nc && t0 + lane < q1) ? __builtin_nontemporal_load(col + (size_t)c * stride + t0 + lane) : 0u;
         }
+        __syncthreads();
+        // out: wave w takes rows w*16 .. w*16+15 of the tile, a lane its column
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r) {
+            const size_t q = t0 + (size_t)(wave * kRowsPerWave + r);  // wave-uniform
+            if (q < q1) {
+                const int32_t x = bb::centred(tile[wave * kRowsPerWave + r][lane]);
+                int32_t w[4];
+                bb::ext_centred(weights[q], w);
+                acc[0].fma_uniform(w, x);
+                if (NW == 2) {
+                    bb::ext_centred(weights2[q], w);
+                    acc[NW - 1].fma_uniform(w, x);
+                }
+            }
+            if ((r & 3) == 3) {
+#pragma unroll
+                for (int v = 0; v < NW; ++v) acc[v].fold();
+            }
+        }
+        __syncthreads();
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int v = 0; v < NW; ++v)
+    for (int v = 0; v < NW; ++v) {
+        const bb::Ext part = acc[v].result();
 #pragma unroll
-        for (int c = 0; c < CPB; ++c) {
-            const bb::Ext part = wide[v][c].result();
+        for (int k = 0; k < 4; ++k) red[v][k][wave][lane] = part.c[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < NW * kDotTile) {
+        const uint32_t v = threadIdx.x / kDotTile, c = threadIdx.x % kDotTile;
+        if (c < nc) {
+            bb::Ext o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                uint32_t r = part.c[k];
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) r = bb::add(r, __shfl_down(r, off, 64));  // wave reduction
-                if (lane == 0) red[v][c][k][wave] = r;
+                uint32_t s_ = red[v][k][0][c];
+                for (int w = 1; w < kWaves; ++w) s_ = bb::add(s_, red[v][k][w][c]);
+                o.c[k] = s_;
             }
+            partial[(v ? second_off : 0) + (size_t)(c0 + c) * n_chunks + blockIdx.x] = o;
         }
-    __syncthreads();
-    if (threadIdx.x < nc * NW) {
-        const uint32_t v = threadIdx.x / nc, c = threadIdx.x - v * nc;
-        bb::Ext o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t s_ = red[v][c][k][0];
-            for (int w = 1; w < kBlock / 64; ++w) s_ = bb::add(s_, red[v][c][k][w]);
-            o.c[k] = s_;
-        }
-        partial[(v ? second_off : 0) + (size_t)(c0 + c) * n_chunks + blockIdx.x] = o;
     }
 }
 __global__ void ext_dot_final_kernel(const bb::Ext* __restrict__ partial, uint32_t n_cols, uint32_t n_chunks, bb::Ext* __restrict__ out) {
@@ -368,11 +377,11 @@ int barycentric_weights(bb::Ext zeta, int log_h, bb::Ext* weights) {
 int ext_dot_columns(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t len, const bb::Ext* weights, bb::Ext* out,
                     bb::Ext* scratch) {
     const uint32_t n_chunks = div_up(len, kDotRowsPerBlock);
-    const uint32_t max_cols = 65535u * kDotColsPerBlock;
+    const uint32_t max_cols = 65535u * kDotTile;
     for (uint32_t c0 = 0; c0 < n_cols; c0 += max_cols) {
         uint32_t cc = n_cols - c0 < max_cols ? n_cols - c0 : max_cols;
         ScopedKernelTimer t("ext_dot_partial_kernel");
-        hipLaunchKernelGGL((ext_dot_partial_kernel<1, kDotColsPerBlock>), dim3(n_chunks, div_up(cc, kDotColsPerBlock)), dim3(kBlock), 0, stream(),
+        hipLaunchKernelGGL(ext_dot_partial_kernel<1>, dim3(n_chunks, div_up(cc, kDotTile)), dim3(kBlock), 0, stream(),
                            cols + (size_t)c0 * stride, stride, len, cc, weights, weights, scratch + (size_t)c0 * n_chunks, (size_t)0, n_chunks);
     }
     hipLaunchKernelGGL(ext_dot_final_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, stream(), scratch, n_cols, n_chunks, out);
@@ -382,12 +391,12 @@ int ext_dot_columns(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t
 int ext_dot_columns2(const uint32_t* cols, size_t stride, uint32_t n_cols, size_t len, const bb::Ext* weights, const bb::Ext* weights2,
                      bb::Ext* out, bb::Ext* out2, bb::Ext* scratch) {
     const uint32_t n_chunks = div_up(len, kDotRowsPerBlock);
-    const uint32_t max_cols = 65535u * kDotColsPerBlock2;
+    const uint32_t max_cols = 65535u * kDotTile;
     const size_t second = (size_t)n_cols * n_chunks;
     for (uint32_t c0 = 0; c0 < n_cols; c0 += max_cols) {
         uint32_t cc = n_cols - c0 < max_cols ? n_cols - c0 : max_cols;
         ScopedKernelTimer t("ext_dot_partial_kernel");
-        hipLaunchKernelGGL((ext_dot_partial_kernel<2, kDotColsPerBlock2>), dim3(n_chunks, div_up(cc, kDotColsPerBlock2)), dim3(kBlock), 0, stream(),
+        hipLaunchKernelGGL(ext_dot_partial_kernel<2>, dim3(n_chunks, div_up(cc, kDotTile)), dim3(kBlock), 0, stream(),
                            cols + (size_t)c0 * stride, stride, len, cc, weights, weights2, scratch + (size_t)c0 * n_chunks, second, n_chunks);
     }
     hipLaunchKernelGGL(ext_dot_final_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, stream(), scratch, n_cols, n_chunks, out);

@@ -213,6 +213,32 @@ class Apc:
                                                 C.byref(per) if per is not None else None)
         abi.check(rc, "powdr_apc_generate_witness_gpu")
 
+    def instruction_table(self):
+        """powdr_apc_instruction_table: (ctypes array of PowdrOrigInstr for the instructions that keep a cell, words per call record)."""
+        from .original_chips import PowdrOrigInstr
+
+        lib.powdr_apc_instruction_table.restype = C.c_size_t
+        lib.powdr_apc_instruction_table.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
+        words = C.c_size_t()
+        n = lib.powdr_apc_instruction_table(self._h, None, C.byref(words))
+        if n == C.c_size_t(-1).value:
+            raise ValueError("the block uses an opcode outside the thirteen RV32IM chips")
+        out = (PowdrOrigInstr * max(n, 1))()
+        lib.powdr_apc_instruction_table(self._h, out, None)
+        return out, n, words.value
+
+    def generate_witness_from_records(self, d_records_ptr: int, num_calls: int, d_output_ptr: int, periphery=None):
+        """powdr_apc_generate_witness_from_records: the whole of a1-a3 from call records (no dummy traces)."""
+        per = None
+        if periphery is not None:
+            p = periphery
+            per = PowdrPeriphery(p.var_bus, p.var_hist.data_ptr(), p.var_hist.numel(), p.tuple_bus, p.tuple_hist.data_ptr(),
+                                 p.tuple_sizes[0], p.tuple_sizes[1], p.bitwise_bus, p.bitwise_hist.data_ptr())
+        lib.powdr_apc_generate_witness_from_records.restype = C.c_int
+        lib.powdr_apc_generate_witness_from_records.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        rc = lib.powdr_apc_generate_witness_from_records(self._h, d_records_ptr, num_calls, d_output_ptr, C.byref(per) if per is not None else None)
+        abi.check(rc, "powdr_apc_generate_witness_from_records")
+
     def close(self):
         if self._h:
             lib.powdr_apc_free(self._h)

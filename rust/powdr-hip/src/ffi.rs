@@ -222,6 +222,9 @@ extern "C" {
     pub fn powdr_apc_generate_witness_gpu(apc: *mut PowdrApc, instr_air: *const i32, dummy_by_air: *const PowdrDeviceMatrix,
                                           n_dummy: usize, num_apc_calls: usize, d_output: *mut PowdrFp,
                                           periphery: *const PowdrPeriphery) -> c_int;
+    pub fn powdr_apc_instruction_table(apc: *const PowdrApc, out: *mut PowdrOrigInstr, words_per_call: *mut usize) -> usize;
+    pub fn powdr_apc_generate_witness_from_records(apc: *mut PowdrApc, d_records: *const u32, num_apc_calls: usize, d_output: *mut PowdrFp,
+                                                   periphery: *const PowdrPeriphery) -> c_int;
     pub fn powdr_xbc_eval_host(postfix: *const u32, len: u32, trace: *const u32, r: usize, result: *mut u32, n_instr: *mut u32) -> c_int;
     pub fn powdr_small_form_eval_host(postfix: *const u32, len: u32, trace: *const u32, r: usize, result: *mut u32, flags: *mut u32) -> c_int;
     pub fn powdr_field_selftest(seed: u64, iterations: u32) -> c_int;

@@ -143,6 +143,24 @@ def test_product_host_table_equals_the_restatement():
     assert pc.sanitise_instructions(all_opcode_block()[:56]) == oc.sanitise_instructions(all_opcode_block()[:56])
 
 
+def test_library_instruction_table_equals_the_restatement():
+    """powdr_apc_instruction_table (C++ host library, from the APC's own block and substitutions) == the Python mirror == the
+    restatement, for the synthetic C2 APC (instructions without a surviving cell have no entry but still advance the timestamp)."""
+    from powdr_amd import host, original_chips as pc
+
+    s = synth.generate("C2", seed=0)
+    doc = s.doc
+    blk = doc["block"]["blocks"][0]
+    has = [len(x) > 0 for x in doc["subs"]]
+    h_apc = host.Apc(doc)
+    arr, n, words = h_apc.instruction_table()
+    table, idx, rbs, wpc = oc.build_instruction_table(blk["instructions"], has, int(blk["start_pc"]))
+    assert n == len(table) == sum(has) and words == wpc
+    for e, o in zip(arr, table):
+        assert [getattr(e, name) for name, _ in pc.PowdrOrigInstr._fields_] == [int(o[name]) for name in o.dtype.names]
+    h_apc.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU
 @pytest.fixture(scope="module")
 def gpu():
@@ -309,3 +327,46 @@ def test_one_segment_proof_of_all_thirteen_chips_from_records_verifies(gpu):
     assert prover.verify_segment(descs, bad, nq, 0, True)[0] == ((victim + 1) << 8) | 2
     for pr in provers:
         pr.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("calls", [100, 1024])
+def test_generate_witness_from_records_equals_the_reference_flow(gpu, calls):
+    """powdr_apc_generate_witness_from_records (a1-a3 from call records, one host call) == powdr_original_airs_expand on the same
+    records followed by powdr_apc_generate_witness_gpu (the reference flow: dummy traces -> gather -> derived -> bus): the same trace
+    in every column and the same three periphery histograms."""
+    from powdr_amd import host
+
+    torch, abi, pc, prover, tg = gpu
+    s = synth.generate("C2", seed=0)
+    doc = dict(s.doc)
+    blk = dict(doc["block"]["blocks"][0])
+    blk["instructions"] = oc.sanitise_instructions(blk["instructions"])
+    doc["block"] = dict(doc["block"], blocks=[blk])
+    h_apc = host.Apc(doc)
+    has = [len(x) > 0 for x in doc["subs"]]
+    t = pc.InstructionTable(blk["instructions"], has, int(blk["start_pc"]))
+    arr, n, words = h_apc.instruction_table()
+    assert n == len(t) and words == t.words_per_call
+    rec = pc.random_records_device(t, calls, seed=calls)
+    H, W = synth.next_pow2_or_zero(calls), h_apc.width
+    # the reference flow: full dummy traces, then the three-stage witness generation
+    apc = om.load_apc(doc)
+    gt = om.build_gpu_tables(apc, apc.poly_id_to_index())
+    names = list(dict.fromkeys(om.opcode_air(int(i[0])) for i, h_ in zip(blk["instructions"], has) if h_))
+    kind = lambda name: oc.KIND_NAMES.index({"Mul": "Multiplication"}.get(name, name))
+    heights = pc.dummy_trace_heights(t, calls)
+    bufs = [torch.zeros(pc.WIDTHS[k] * heights[k], dtype=torch.int32, device="cuda") if heights[k] else None for k in range(pc.N_KINDS)]
+    pc.expand(rec.data_ptr(), calls, t, [(b.data_ptr(), heights[k]) if b is not None else None for k, b in enumerate(bufs)])
+    instr_air = [names.index(om.opcode_air(int(i[0]))) for i in blk["instructions"]]
+    dummy = [(bufs[kind(nm)].data_ptr(), pc.WIDTHS[kind(nm)], heights[kind(nm)]) for nm in names]
+    out1, out2 = tg.DeviceMatrix.zeros(H, W), tg.DeviceMatrix(torch.full((H * W,), 0x55, dtype=torch.int32, device="cuda"), H, W)
+    per1, per2 = tg.Periphery.fresh(), tg.Periphery.fresh()
+    h_apc.generate_witness_gpu(instr_air, dummy, calls, out1.ptr(), per1)
+    h_apc.generate_witness_from_records(rec.data_ptr(), calls, out2.ptr(), per2)
+    torch.cuda.synchronize()
+    assert torch.equal(out1.buf, out2.buf)
+    for a, b in ((per1.var_hist, per2.var_hist), (per1.tuple_hist, per2.tuple_hist), (per1.bitwise_hist, per2.bitwise_hist)):
+        assert torch.equal(a, b)
+    assert int(per2.var_hist.sum()) > 0
+    h_apc.close()
