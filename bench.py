@@ -851,9 +851,12 @@ def main():
                                equals_expand_then_gather_at_full_size=bool(same), columns_compared=len(cols),
                                reference_flow_expand_ms=expand_ms, reference_flow_gather_ms=timing.get("apc_gather_tile_kernel", (0, 0.0))[1] / args.steps,
                                reference_flow_dummy_trace_bytes=wl["src_bytes"],
-                               note="powdr_apc_tracegen_records: the original chips (BaseAlu, Shift, LoadStore, BranchEqual, JalLui; every constraint of the "
-                                    "reference's openvm_constraints.txt holds on their rows) expand their records inside the gather; only the cells the APC "
-                                    "keeps are written. The reference flow materialises the full dummy traces first (reference_flow_expand_ms on the same "
+                               step_ms_with_trace_from_records=elapsed / args.steps * 1e3 - timing.get("apc_gather_tile_kernel", (0, 0.0))[1] / args.steps + fused_ms,
+                               step_note="derived, not timed: the headline step with its gather kernel replaced by the fused kernel's time (the headline itself "
+                                         "keeps _apc_tracegen, the entry point cuda_abi.rs binds); powdr_apc_generate_witness_from_records is the one-call form",
+                               note="powdr_apc_tracegen_records: the original chips (all thirteen RV32IM instruction AIRs; every constraint and lookup of the "
+                                    "reference's openvm_constraints.txt holds on their rows; this block uses BaseAlu, Shift, LoadStore, BranchEqual, JalLui) expand "
+                                    "their records inside the gather; only the cells the APC keeps are written, straight into their columns. The reference flow materialises the full dummy traces first (reference_flow_expand_ms on the same "
                                     "records, strided writes like a chip's) and gathers them (reference_flow_gather_ms)")
             del out2, rec
             torch.cuda.empty_cache()

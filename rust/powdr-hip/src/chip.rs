@@ -5,7 +5,7 @@
 //! rebuilt and re-uploaded per segment (cuda/mod.rs:272-398) — the C++ host mirror behind `powdr_apc_generate_witness_gpu`
 //! (include/powdr_host.h) compiles them once per APC and keeps them on the device; the chip hands over only what changes
 //! per segment: the dummy traces' device pointers and the call count.
-use crate::device::{DeviceMatrix, HipError};
+use crate::device::{DeviceBuffer, DeviceMatrix, HipError};
 use crate::ffi;
 use std::cell::RefCell;
 use std::collections::HashMap;
@@ -134,6 +134,42 @@ impl<ISA: OpenVmISA> PowdrTraceGeneratorHip<ISA> {
         HipError::from_result(rc).unwrap(); // the reference unwraps as well (cuda/mod.rs:334,345,398)
         drop(keep_alive); // hipFree waits for the gather kernels that still read the dummy traces
         Some(output)
+    }
+
+    /// The same with the original chips' work folded in (include/powdr_host.h: powdr_apc_generate_witness_from_records): no dummy
+    /// chip complex, no dummy traces — the APC trace comes straight from the call records. `records` is the word-major device
+    /// buffer of include/powdr_gpu.h's layout (`record_layout()` says which words each instruction owns); the executor
+    /// (`PowdrExecutor::execute`, executor/mod.rs:457-528) writes into it what it writes into the per-AIR arenas today: operand
+    /// words, overwritten words and previous timestamps of every access.
+    pub fn try_generate_witness_from_records(&self, records: &DeviceBuffer<u32>, num_apc_calls: usize) -> Option<DeviceMatrix<BabyBear>> {
+        if num_apc_calls == 0 {
+            return None;
+        }
+        let width = unsafe { ffi::powdr_apc_width(self.handle.0) } as usize;
+        let height = num_apc_calls.next_power_of_two();
+        let output = DeviceMatrix::<BabyBear>::with_capacity(height, width);
+        let rc = unsafe {
+            ffi::powdr_apc_generate_witness_from_records(
+                self.handle.0,
+                records.as_ptr(),
+                num_apc_calls,
+                output.buffer().as_mut_ptr() as *mut u32,
+                &self.periphery.real,
+            )
+        };
+        HipError::from_result(rc).unwrap();
+        Some(output)
+    }
+
+    /// (instruction table of the block, u32 words of one call's record): which instruction keeps a cell, its pc, timestamp offset, row
+    /// inside its AIR's block and first record word.
+    pub fn record_layout(&self) -> (Vec<ffi::PowdrOrigInstr>, usize) {
+        let mut words = 0usize;
+        let n = unsafe { ffi::powdr_apc_instruction_table(self.handle.0, core::ptr::null_mut(), &mut words) };
+        assert!(n != usize::MAX, "the block uses an opcode outside the thirteen RV32IM chips");
+        let mut table = vec![unsafe { core::mem::zeroed::<ffi::PowdrOrigInstr>() }; n];
+        unsafe { ffi::powdr_apc_instruction_table(self.handle.0, table.as_mut_ptr(), core::ptr::null_mut()) };
+        (table, words)
     }
 }
 
