@@ -79,6 +79,7 @@ int check_constraints(const uint32_t* trace, size_t H, const ConstraintProgram& 
 // chunk coefficients from the unscaled DIF-iNTT of q over N = 2H points:
 // out[(4*ch + k)*H + q'] = cbr[k*N + 2q' + ch] * s^-(bitrev(q') + ch*H) / 2   (H-scaled bit-reversed coefficients)
 int quotient_split(const uint32_t* cbr, size_t H, int log_h, uint32_t* out);
+// Both weight vectors are stored as CENTRED words (int32 bit patterns, |w| <= p / 2): ext_dot_columns is their only consumer.
 // weights[q] = z^(bitrev_n(q)) / 2^n  (Ext), for coefficient vectors as intt_dif leaves them
 int zeta_weights(bb::Ext z, int log_h, bb::Ext* weights);
 // weights[i] = (zeta^H - 1)/H * g^i / (zeta - g^i): f(zeta) = sum_i f(g^i) weights[i] for natural-order evaluations

@@ -124,11 +124,19 @@ __global__ __launch_bounds__(kBlock) void quotient_split_kernel(const uint32_t* 
 }
 
 // ---- openings ----------------------------------------------------------------------------
+// Both weight kernels store CENTRED representatives (|w_k| <= p / 2 as int32 bit patterns): the only consumer is
+// ext_dot_partial_kernel, where a weight is wave-uniform and centring it there would run on the scalar unit once per row and wave.
+__device__ __forceinline__ bb::Ext centred_words(const bb::Ext& e) {
+    bb::Ext r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.c[k] = (uint32_t)bb::centred(e.c[k]);
+    return r;
+}
 __global__ __launch_bounds__(kBlock) void zeta_weights_kernel(bb::Ext z, int log_h, uint32_t ninv, bb::Ext* __restrict__ w) {
     const size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (q >= ((size_t)1 << log_h)) return;
     const uint32_t k = log_h ? (__brev((uint32_t)q) >> (32 - log_h)) : 0u;
-    w[q] = bb::ext_scale(bb::ext_pow(z, k), ninv);
+    w[q] = centred_words(bb::ext_scale(bb::ext_pow(z, k), ninv));
 }
 
 // w[i] = scale * g^i / (zeta - g^i): Lagrange weights of the order-2^n subgroup at zeta, so that
@@ -139,14 +147,14 @@ __global__ __launch_bounds__(kBlock) void barycentric_weights_kernel(bb::Ext zet
     if (i >= ((size_t)1 << log_h)) return;
     const uint32_t gi = bb::pow_u32(g, (uint32_t)i);
     const bb::Ext den = bb::ext_sub(zeta, bb::ext_from_base(gi));
-    w[i] = bb::ext_mul(bb::ext_scale(scale, gi), bb::ext_inv(den));
+    w[i] = centred_words(bb::ext_mul(bb::ext_scale(scale, gi), bb::ext_inv(den)));
 }
 
 constexpr int kDotRowsPerBlock = 8192;
 constexpr int kDotTile = 64;  // columns per workgroup (= lanes of a wave) and rows per LDS tile
 // sum_q w(q) * col_c(q) for the columns of a matrix (the openings at zeta). A lane owns a COLUMN: the weight of a row is then
-// wave-uniform — it arrives through scalar loads and enters the multiply-adds from scalar registers — and is fetched once per 64
-// columns; nothing is reduced across lanes. (The first form gave a lane rows and a workgroup 4-8 columns: every group re-read the
+// wave-uniform — a tile's 64 weights come in once (1 KB, coalesced), sit in LDS and are read back by broadcast — and is fetched
+// once per 64 columns; nothing is reduced across lanes. (The first form gave a lane rows and a workgroup 4-8 columns: every group re-read the
 // 16-byte weights, 28 GB of weight traffic for 23 GB of cells at C2 with LogUp — PMC r03: 51 GB fetched — and finished with 6
 // shuffle steps per sum. Measured: the traffic is gone, the time is not — 11.8 ms either way at C2, 3.0 ms for the 8.5 GB main trace
 // and 8.2 ms for the 14.6 GB permutation matrix; what holds this kernel at 2 TB/s is not understood yet)
@@ -161,6 +169,7 @@ __global__ __launch_bounds__(kBlock) void ext_dot_partial_kernel(const uint32_t*
                                                                   size_t second_off, uint32_t n_chunks) {
     constexpr int kWaves = kBlock / 64, kRowsPerWave = kDotTile / kWaves;
     __shared__ uint32_t tile[kDotTile][kDotTile + 1];
+    __shared__ uint4 wts[NW][kDotTile];  // the tile's weights: read back at a wave-uniform address (an LDS broadcast)
     __shared__ uint32_t red[NW][4][kWaves][kDotTile];
     const uint32_t c0 = blockIdx.y * kDotTile;
     const uint32_t nc = n_cols - c0 < (uint32_t)kDotTile ? n_cols - c0 : (uint32_t)kDotTile;  // block-uniform
@@ -169,27 +178,38 @@ __global__ __launch_bounds__(kBlock) void ext_dot_partial_kernel(const uint32_t*
     const size_t q0 = (size_t)blockIdx.x * kDotRowsPerBlock;
     const size_t q1 = q0 + kDotRowsPerBlock < len ? q0 + kDotRowsPerBlock : len;
     bb::ExtCentredAcc acc[NW];
-    for (size_t t0 = q0; t0 < q1; t0 += kDotTile) {
-        // in: wave w brings columns w*16 .. w*16+15, a lane one row of each (256 contiguous bytes per wave and column)
+    // in: wave w brings columns w*16 .. w*16+15, a lane one row of each (256 contiguous bytes per wave and column), and wave v < NW the
+    // tile's 64 weights of vector v (1 KB); the NEXT tile is requested before the current one is consumed (registers as the second buffer)
+    uint32_t cells[kRowsPerWave];
+    uint4 wq = make_uint4(0u, 0u, 0u, 0u);
+    auto fetch = [&](size_t t0) {
 #pragma unroll
         for (int j = 0; j < kRowsPerWave; ++j) {
             const uint32_t c = (uint32_t)(wave * kRowsPerWave + j);
-            tile[lane][c] = (c < nc && t0 + lane < q1) ? __builtin_nontemporal_load(col + (size_t)c * stride + t0 + lane) : 0u;
+            cells[j] = (c < nc && t0 + lane < q1) ? __builtin_nontemporal_load(col + (size_t)c * stride + t0 + lane) : 0u;
         }
+        if (wave < NW) {
+            const uint4* src = reinterpret_cast<const uint4*>(wave == 0 ? weights : weights2);
+            wq = t0 + lane < q1 ? src[t0 + lane] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    fetch(q0);
+    for (size_t t0 = q0; t0 < q1; t0 += kDotTile) {
+#pragma unroll
+        for (int j = 0; j < kRowsPerWave; ++j) tile[lane][wave * kRowsPerWave + j] = cells[j];
+        if (wave < NW) wts[wave][lane] = wq;
         __syncthreads();
+        if (t0 + kDotTile < q1) fetch(t0 + kDotTile);
         // out: wave w takes rows w*16 .. w*16+15 of the tile, a lane its column
 #pragma unroll
         for (int r = 0; r < kRowsPerWave; ++r) {
-            const size_t q = t0 + (size_t)(wave * kRowsPerWave + r);  // wave-uniform
-            if (q < q1) {
-                const int32_t x = bb::centred(tile[wave * kRowsPerWave + r][lane]);
-                int32_t w[4];
-                bb::ext_centred(weights[q], w);
-                acc[0].fma_uniform(w, x);
-                if (NW == 2) {
-                    bb::ext_centred(weights2[q], w);
-                    acc[NW - 1].fma_uniform(w, x);
-                }
+            const int row = wave * kRowsPerWave + r;  // wave-uniform; rows beyond q1 hold zero cells and zero weights
+            const int32_t x = bb::centred(tile[row][lane]);
+#pragma unroll
+            for (int v = 0; v < NW; ++v) {
+                const uint4 e = wts[v][row];  // centred already (the weight kernels above)
+                const int32_t w[4] = {(int32_t)e.x, (int32_t)e.y, (int32_t)e.z, (int32_t)e.w};
+                acc[v].fma(w, x);
             }
             if ((r & 3) == 3) {
 #pragma unroll

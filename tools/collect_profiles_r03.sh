@@ -35,15 +35,16 @@ timeout 900 python bench.py --shape C4 --steps 2 --warmup 1 --gpus 1 --inproc > 
 ( POWDR_JIT=1 timeout 900 python tools/bench_keccak_fixture.py 2>&1 ) | grep -v amdgpu.ids > gpurun_out/r03_keccak_preopt_fixture_jit.txt
 python - <<P
 import json
-d=json.load(open('gpurun_out/r03_bench_c2.json'))
+load=lambda p: json.loads([l for l in open(p) if l.startswith('{')][-1])
+d=load('gpurun_out/r03_bench_c2.json')
 print("headline", d['value']/1e9, d['ms_per_step'], "constraints-only", d['constraints_only']['ms_per_step'], d['constraints_only']['value']/1e9, "multi", d['multi_segment']['value']/1e9, "c3", (d['c3'] or {}).get('value'))
 r=d['roofline']; print(r['frac'], r['traffic'], (r.get('valu') or {}).get('frac'), r['whole_step']['frac'])
 print(sorted(d['stage_ms'].items(), key=lambda kv:-kv[1])[:12])
 print("records", d['tracegen_from_records'].get('fused_ms'), "cpu", d['cpu_baseline']['value'], (d['cpu_baseline'].get('tuned') or {}))
-u=json.load(open('gpurun_out/r03_bench_c2_under_rocprofv3.json')); print('under rocprof', u['ms_per_step'])
+u=load('gpurun_out/r03_bench_c2_under_rocprofv3.json'); print('under rocprof', u['ms_per_step'])
 for k in ('c4','c5','c4_inproc'):
     try:
-        x=json.load(open(f'gpurun_out/r03_bench_{k}.json')); print(k, x['value']/1e9, x['ms_per_step'], x['multi_segment'].get('commitment_merge'))
+        x=load(f'gpurun_out/r03_bench_{k}.json'); print(k, x['value']/1e9, x['ms_per_step'], x['multi_segment'].get('commitment_merge'))
     except Exception as e: print(k, 'ERR', e)
 P
 head -12 gpurun_out/r03_kernel_stats_c2.csv | cut -c1-160; tail -3 gpurun_out/r03_keccak_preopt_fixture.txt | cut -c1-400; tail -3 gpurun_out/r03_keccak_preopt_fixture_jit.txt | cut -c1-400
