@@ -154,10 +154,10 @@ constexpr int kDotRowsPerBlock = 8192;
 constexpr int kDotTile = 64;  // columns per workgroup (= lanes of a wave) and rows per LDS tile
 // sum_q w(q) * col_c(q) for the columns of a matrix (the openings at zeta). A lane owns a COLUMN: the weight of a row is then
 // wave-uniform — a tile's 64 weights come in once (1 KB, coalesced), sit in LDS and are read back by broadcast — and is fetched
-// once per 64 columns; nothing is reduced across lanes. (The first form gave a lane rows and a workgroup 4-8 columns: every group re-read the
-// 16-byte weights, 28 GB of weight traffic for 23 GB of cells at C2 with LogUp — PMC r03: 51 GB fetched — and finished with 6
-// shuffle steps per sum. Measured: the traffic is gone, the time is not — 11.8 ms either way at C2, 3.0 ms for the 8.5 GB main trace
-// and 8.2 ms for the 14.6 GB permutation matrix; what holds this kernel at 2 TB/s is not understood yet)
+// once per 64 columns; nothing is reduced across lanes. (The first form gave a lane rows and a workgroup 4-8 columns: every group
+// re-read the 16-byte weights — 28 GB of weight traffic for 23 GB of cells at C2 with LogUp, PMC r03: 51 GB fetched — and finished
+// with 6 shuffle steps per sum: 11.8 ms. Lane = column with the weights through scalar loads: still 11.8 ms, the scalar path had
+// become the limit; weights through LDS and the next tile prefetched into registers: 4.9 ms, 4.7 TB/s. DESIGN.md §7d.)
 // The cells come in coalesced, 64 rows x 64 columns at a time, and turn through LDS (padded: conflict-free both ways).
 // NW = 2: two weight vectors in one pass (the permutation matrix is opened at zeta AND at g zeta: read once instead of twice);
 // partial sums of the second vector go to partial + second_off. Centred weights x centred cells in signed 64-bit accumulators,
