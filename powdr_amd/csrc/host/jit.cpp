@@ -7,9 +7,11 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -77,13 +79,21 @@ struct Program {
     std::mutex mu;
     std::map<int, hipModule_t> modules;  // device -> loaded module
     ~Program() {
-        for (auto& kv : modules) (void)hipModuleUnload(kv.second);
+        int current = 0;
+        const bool have = hipGetDevice(&current) == hipSuccess;
+        for (auto& kv : modules)
+            if (hipSetDevice(kv.first) == hipSuccess) (void)hipModuleUnload(kv.second);
+        if (have) (void)hipSetDevice(current);
+        (void)hipGetLastError();
     }
 };
 
 namespace {
+// Programs are shared between the provers that are alive (two provers of the same AIR, the same chunk in two AIRs) and go away with
+// the last of them: the cache holds weak references, so a long-running process that sees many different AIRs does not accumulate
+// code objects and loaded modules.
 std::mutex g_cache_mu;
-std::unordered_map<uint64_t, ProgramPtr> g_cache;
+std::unordered_map<uint64_t, std::weak_ptr<Program>> g_cache;
 
 bool compile_code(const std::string& src, std::vector<char>& code_out, std::string* err) {
     const Rtc& r = rtc();
@@ -170,7 +180,9 @@ bool compile_with_helpers(const std::string& helper, const std::vector<std::stri
     bool all_zero = ok;
     for (pid_t pid : pids) {
         int status = 0;
-        if (waitpid(pid, &status, 0) != pid || !WIFEXITED(status) || WEXITSTATUS(status) != 0) all_zero = false;
+        pid_t got;
+        do got = waitpid(pid, &status, 0); while (got == -1 && errno == EINTR);
+        if (got != pid || !WIFEXITED(status) || WEXITSTATUS(status) != 0) all_zero = false;
     }
     bool usable = ok;
     if (ok) {
@@ -207,7 +219,8 @@ std::vector<ProgramPtr> compile_all(const std::vector<std::string>& sources, std
         std::lock_guard<std::mutex> lk(g_cache_mu);
         for (size_t i = 0; i < sources.size(); ++i) {
             auto it = g_cache.find(hash64(sources[i]));
-            if (it != g_cache.end() && it->second->source == sources[i]) out[i] = it->second;
+            ProgramPtr hit = it != g_cache.end() ? it->second.lock() : nullptr;
+            if (hit && hit->source == sources[i]) out[i] = hit;
             else todo.push_back(i);
         }
     }
@@ -233,10 +246,13 @@ std::vector<ProgramPtr> compile_all(const std::vector<std::string>& sources, std
             auto p = std::make_shared<Program>();
             p->source = sources[i];
             p->code = std::move(code[k]);
-            auto ins = g_cache.emplace(hash64(sources[i]), p);
-            out[i] = (!ins.second && ins.first->second->source == sources[i]) ? ins.first->second : p;  // another thread was faster
-            if (ins.second == false && ins.first->second->source != sources[i]) ins.first->second = p;   // hash collision: the newer text takes the slot
+            std::weak_ptr<Program>& slot = g_cache[hash64(sources[i])];
+            ProgramPtr other = slot.lock();
+            if (other && other->source == sources[i]) out[i] = other;  // another thread was faster
+            else { slot = p; out[i] = p; }                             // empty / expired slot, or a hash collision: the newer text takes it
         }
+        if (g_cache.size() > 4096)  // expired slots of AIRs long gone
+            for (auto it = g_cache.begin(); it != g_cache.end();) it = it->second.expired() ? g_cache.erase(it) : std::next(it);
     }
     return out;
 }

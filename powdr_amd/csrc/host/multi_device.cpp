@@ -97,7 +97,7 @@ extern "C" int pw_prove_segments_multi(const int* devices, size_t n_workers, con
     std::vector<uint32_t> owner(n_segments);
     pw_assign_units(segment_cells, n_segments, n_workers, owner.data());
     if (worker_of_segment) memcpy(worker_of_segment, owner.data(), n_segments * 4);
-    memset(commitments, 0, n_segments * 8 * 4);
+    if (n_segments) memset(commitments, 0, n_segments * 8 * 4);
     int caller_device = 0;
     (void)hipGetDevice(&caller_device);
 
@@ -109,6 +109,7 @@ extern "C" int pw_prove_segments_multi(const int* devices, size_t n_workers, con
         hipStream_t st = nullptr;
         if (!rc) rc = (int)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         if (!rc) {
+            const hipStream_t callers = pw::stream();  // worker 0 runs on the caller's thread: its launch stream comes back afterwards
             pw::set_stream(st);
             for (size_t s = 0; s < n_segments && !first_error.load(); ++s) {
                 if (owner[s] != w) continue;
@@ -120,7 +121,7 @@ extern "C" int pw_prove_segments_multi(const int* devices, size_t n_workers, con
             }
             const int rs = (int)hipStreamSynchronize(st);
             if (!rc) rc = rs;
-            pw::set_stream(nullptr);
+            pw::set_stream(callers);
             (void)hipStreamDestroy(st);
         }
         int expected = 0;
