@@ -236,7 +236,8 @@ def test_device_trace_generation_satisfies_the_golden_machine(name):
     """The same on the device, through the library's entry points: records -> powdr_apc_tracegen_records (a1 from records) ->
     _apc_apply_derived_expr for is_valid = Constant(1) and the optimiser's QuotientOrZero columns (a2) -> the trace equals the
     restatement's word for word; _apc_apply_bus on the machine's own interactions fills the periphery histograms like the oracle
-    (a3); pw_prover_check_constraints finds no violation of the machine's constraints on any of the H rows (padding included)."""
+    (a3); pw_prover_check_constraints finds no violation of the machine's constraints on any of the H rows (padding included); the
+    LogUp proof of the machine on this trace verifies (a6, a9)."""
     import torch
     from powdr_amd import abi, original_chips as pc, prover, tracegen as tg
 
@@ -290,8 +291,15 @@ def test_device_trace_generation_satisfies_the_golden_machine(name):
                for b, _, s0 in np.asarray(inter).tolist())
     assert sent > 0 or not any(b in (3, 6, 7) for b, _, _ in snap["interactions"])
     assert int(var_h.sum()) + int(tup_h.sum()) + int(bit_h.sum()) == sent  # every lookup of every call landed in a bin
-    pr = prover.Prover(W, bc, spans, num_queries=1)
+    pr = prover.Prover(W, bc, spans, num_queries=6, interactions=(inter, ispans, ibc))
     assert pr.check_constraints(out.ptr(), 6) == (0, None, None)
+    # and the proof of the reference's machine on this trace — constraints AND its bus interactions as LogUp terms — is accepted by
+    # the product's verifier and by the oracle's
+    from oracle import stark_model as sm
+
+    proof = pr.prove(out.ptr(), 6)
+    assert prover.verify_logup(proof, W, 6, bc, spans, (inter, ispans, ibc), num_queries=6)[0] == 0
+    assert sm.verify_logup(proof, W, 6, bc, spans, inter, ispans, ibc, num_queries=6) == 0
     pr.close()
     del keep, keep2
 
