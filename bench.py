@@ -996,7 +996,7 @@ def main():
                     rec["pmc_GBps"] = tb / (ms * 1e-3) / 1e9
                 by_kernel[k] = rec
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the contract: rank 0 at N = 1 only
             try:
                 # (the LogUp proof commits 2.7x the columns: half the rows keep the sample at ~20 s)
                 cpu = cpu_baseline(args.shape, min(args.cpu_log_height - (1 if args.logup else 0), log_h), args.queries, args.pow_bits, seed=0, logup=args.logup)
