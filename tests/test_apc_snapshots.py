@@ -329,3 +329,90 @@ def test_the_reference_real_blocks_end_to_end_with_executor_records(fixture, n_i
     assert len(wires) == n_instr and len(z["cons_spans"]) == n_cons and len(z["bus_inter"]) == n_inter
     assert int((z["bus_inter"][:, 0] == oc.BUS_PC_LOOKUP).sum()) == n_instr
     check_machine(fixture, cols, info, rec[0].astype(np.int64), pcs, table, (z["cons_bc"], z["cons_spans"]), (z["bus_inter"], z["bus_spans"], z["bus_bc"]))
+
+
+def unoptimised_machine(table):
+    """The machine the reference's APC builder starts from (autoprecompiles/src/lib.rs: every instruction's AIR instantiated on its own
+    columns, before any optimisation), assembled from the snapshot of the original AIRs: the columns of instruction k's AIR side by
+    side, its constraints and interactions with their column operands shifted."""
+    cons, spans, inter, ispans, ibc = [], [], [], [], []
+    base = 0
+    for ins in table:
+        name = oc.KIND_NAMES[int(ins["kind"])]
+        i = [str(n) for n in ORIGINAL["names"]].index(name)
+
+        def shifted(code):
+            code, out, j = [int(x) for x in code], [], 0
+            while j < len(code):
+                if code[j] in (0, 1):
+                    out += [code[j], code[j + 1] + (base if code[j] == 0 else 0)]
+                    j += 2
+                else:
+                    out.append(code[j])
+                    j += 1
+            return out
+
+        for off, ln in ORIGINAL[f"a{i}_spans"].tolist():
+            code = shifted(ORIGINAL[f"a{i}_bc"][off:off + ln])
+            spans.append((len(cons), len(code)))
+            cons += code
+        for bus, n_args, s0 in ORIGINAL[f"a{i}_inter"].tolist():
+            inter.append((bus, n_args, len(ispans)))
+            for s in range(s0, s0 + 1 + n_args):
+                off, ln = ORIGINAL[f"a{i}_ispans"][s].tolist()
+                code = shifted(ORIGINAL[f"a{i}_ibc"][off:off + ln])
+                ispans.append((len(ibc), len(code)))
+                ibc += code
+        base += oc.WIDTHS[int(ins["kind"])]
+    u = lambda a, shape=None: np.array(a, np.uint32).reshape(shape) if shape else np.array(a, np.uint32)
+    return (u(cons), u(spans, (-1, 2))), (u(inter, (-1, 3)), u(ispans, (-1, 2)), u(ibc))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_programs_execute_consistently(seed):
+    """Random straight-line programs over all 36 opcodes (registers reused heavily, loads and stores through a few base registers,
+    forward branches that are not taken or jump to the next listed instruction): executor -> records -> chips; on the unoptimised
+    machine of the block every constraint and lookup holds, the PC lookups list the program, and the execution-bridge and memory-bus
+    interactions of all rows cancel down to the executor's entry -> exit state. (The machine is assembled here from the snapshot of
+    the original AIRs; for the reference's own blocks see the tests above.)"""
+    rng = np.random.default_rng(1000 + seed)
+    regs = [4 * int(r) for r in rng.choice(np.arange(1, 32), size=5, replace=False)]
+    bases = [4 * int(r) for r in rng.choice(np.arange(1, 32), size=2, replace=False)]
+    R = lambda: int(rng.choice(regs))
+    wires, pcs, pc = [], [], 0x1000
+    n = int(rng.integers(6, 24))
+    for i in range(n):
+        op = int(rng.choice(oc.ALL_OPCODES))
+        k = oc.OPCODE_KIND[op]
+        last = i == n - 1
+        if k in (oc.KIND_JALR,) and not last:
+            op, k = 512, oc.KIND_BASE_ALU  # a jump to a data-dependent target ends a block
+        if k in (oc.KIND_BASE_ALU, oc.KIND_SHIFT, oc.KIND_LESS_THAN):
+            reg2 = bool(rng.integers(0, 2))
+            ins = [op, R(), R(), R() if reg2 else int(rng.choice([0, 1, 31, 255, 0xFFFFFF, 0xFFFF80])), 1, int(reg2), 0, 0]
+        elif k in (oc.KIND_LOAD_STORE, oc.KIND_LOAD_SIGN_EXTEND):
+            size = oc.ACCESS_ALIGN[op] + 1
+            ins = [op, R(), int(rng.choice(bases)), int(rng.integers(0, 64)) * size, 1, 2, 1, 0]
+        elif k in (oc.KIND_BRANCH_EQ, oc.KIND_BRANCH_LT):
+            ins = [op, R(), R(), 8, 1, 1, 0, 0]  # taken: skips one instruction slot; not taken: falls through
+        elif k == oc.KIND_JAL_LUI:
+            ins = [op, R(), 0, 8 if op == 560 else int(rng.integers(0, 1 << 20)), 1, 0, 1, 0]
+        elif k == oc.KIND_JALR:
+            ins = [op, R(), int(rng.choice(bases)), int(rng.integers(0, 256)) * 4, 1, 0, 1, 0]
+        elif k == oc.KIND_AUIPC:
+            ins = [op, R(), 0, int(rng.integers(0, 1 << 16)), 1, 0, 0, 0]
+        else:
+            ins = [op, R(), R(), R(), 1, 0, 0, 0]
+        # base registers must stay pointers: nothing writes them
+        if k not in (oc.KIND_BRANCH_EQ, oc.KIND_BRANCH_LT) and ins[1] in bases and not (k == oc.KIND_LOAD_STORE and op >= 531):
+            ins[1] = regs[0] if regs[0] not in bases else 4 * 31
+        wires.append(ins)
+        pcs.append(pc)
+        # a branch / JAL either falls through (next slot) or lands 8 further: list the next instruction at one of the two
+        pc += 8 if (k in (oc.KIND_BRANCH_EQ, oc.KIND_BRANCH_LT) and rng.random() < 0.5) or op == 560 else 4
+    table, _, rbs, wpc = oc.build_instruction_table(wires, [True] * n, pcs=pcs)
+    rec, info = vm.execute_block(table, pcs, wpc, 6, seed=seed, max_tries=20000)
+    rows = [[np.asarray(v).astype(np.int64) % P for v in oc.expand_rows(ins, rec, rec[0])] for ins in table]
+    cols = [c for r in rows for c in r]
+    cons, interactions = unoptimised_machine(table)
+    check_machine(f"random program {seed}", cols, info, rec[0].astype(np.int64), pcs, table, cons, interactions)
