@@ -340,7 +340,7 @@ def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup,
                cells_per_segment=cells_seg, value=cells_seg * n_segments * steps / elapsed, unit="cells/s", ms_per_step=elapsed / steps * 1e3,
                steps=steps, warmup=warmup, logup=bool(logup), proof_bytes_per_segment=int(last["words"]) * 4,
                segments_per_worker=[int((last["owner"] == w).sum()) for w in range(n_workers)],
-               commitment_merge={1: "RCCL all-gather (ncclCommInitAll over the distinct devices)", 2: "host (RCCL not available)"}[last["merge"]],
+               commitment_merge={1: "RCCL all-gather (one communicator per device set, ncclCommInitAll at first use)", 2: "host (RCCL not available)"}[last["merge"]],
                note="pw_prove_segments_multi: one process, one host thread + launch stream per worker, one pw-stark v1 proof per segment")
     for wk in workers:
         for pr in wk["provers"]:

@@ -6,7 +6,8 @@
 // independent, so a host with N GPUs runs N of these loops side by side: one host thread per worker (hipSetDevice, a launch
 // stream of its own — the library's state is per device / per host thread), segments placed on the workers by cells, largest
 // first, NO data-path collective. The only exchange is north_star's "final commitment merge": the 8-word main commitment of
-// every segment, all-gathered over RCCL (xGMI) so that every device — and the host — holds the full, segment-ordered list.
+// every segment, all-gathered over RCCL (xGMI) so that every device — and the host — holds the full, segment-ordered list (one communicator
+// per device set, made at first use and kept).
 //
 // RCCL is loaded with dlopen (the library keeps working without it: the merge then happens on the host and
 // pw_multi_last_merge() says so). Two workers may share a device (tests on a one-GPU box; two streams per GPU): the
@@ -20,6 +21,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -63,6 +65,16 @@ const Rccl& rccl() {
     });
     return r;
 }
+
+struct MergeContext {
+    std::vector<int> devices;  // the distinct devices, in rank order
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> sts;
+    std::vector<uint32_t*> d_send, d_recv;
+    size_t slot_words = 0;     // capacity of d_send[r]; d_recv[r] holds ranks x that
+};
+std::mutex g_merge_mu;
+std::vector<std::unique_ptr<MergeContext>> g_merge;  // never torn down: communicators live until the process exits
 
 thread_local int g_last_merge = 0;  // 0 none yet, 1 RCCL all-gather, 2 host merge (RCCL not available / disabled / failed)
 
@@ -154,34 +166,47 @@ extern "C" int pw_prove_segments_multi(const int* devices, size_t n_workers, con
     bool merged = false;
     const Rccl& nc = rccl();
     if (nc.ok) {
-        std::vector<ncclComm_t> comms(R, nullptr);
-        std::vector<uint32_t*> d_send(R, nullptr), d_recv(R, nullptr);
-        std::vector<hipStream_t> sts(R, nullptr);
-        bool ok = nc.CommInitAll(comms.data(), (int)R, ranks.data()) == 0;
-        for (size_t r = 0; r < R && ok; ++r) {
-            ok = hipSetDevice(ranks[r]) == hipSuccess && hipStreamCreateWithFlags(&sts[r], hipStreamNonBlocking) == hipSuccess &&
-                 hipMalloc(&d_send[r], slot * 4) == hipSuccess && hipMalloc(&d_recv[r], R * slot * 4) == hipSuccess &&
-                 hipMemcpyAsync(d_send[r], send[r].data(), slot * 4, hipMemcpyHostToDevice, sts[r]) == hipSuccess;
+        // the communicator of a device set, its streams and staging buffers are made once and kept for the life of the process
+        // (ncclCommInitAll costs ~0.5 s: a per-call communicator made the in-process C4 step 12 % slower than its merge-free twin)
+        std::lock_guard<std::mutex> lk(g_merge_mu);
+        MergeContext* mc = nullptr;
+        for (auto& c : g_merge) if (c->devices == ranks) mc = c.get();
+        bool ok = true;
+        if (!mc) {
+            std::unique_ptr<MergeContext> c(new MergeContext());
+            c->devices = ranks;
+            c->comms.assign(R, nullptr); c->sts.assign(R, nullptr); c->d_send.assign(R, nullptr); c->d_recv.assign(R, nullptr);
+            ok = nc.CommInitAll(c->comms.data(), (int)R, ranks.data()) == 0;
+            for (size_t r = 0; r < R && ok; ++r)
+                ok = hipSetDevice(ranks[r]) == hipSuccess && hipStreamCreateWithFlags(&c->sts[r], hipStreamNonBlocking) == hipSuccess;
+            if (ok) { g_merge.push_back(std::move(c)); mc = g_merge.back().get(); }
+            // (a half-built context is dropped without ncclCommDestroy: destroying communicators after a failed init can hang)
         }
+        if (ok && mc->slot_words < slot) {
+            for (size_t r = 0; r < R && ok; ++r) {
+                ok = hipSetDevice(ranks[r]) == hipSuccess;
+                if (ok && mc->d_send[r]) (void)hipFree(mc->d_send[r]);
+                if (ok && mc->d_recv[r]) (void)hipFree(mc->d_recv[r]);
+                mc->d_send[r] = mc->d_recv[r] = nullptr;
+                ok = ok && hipMalloc(&mc->d_send[r], slot * 4) == hipSuccess && hipMalloc(&mc->d_recv[r], R * slot * 4) == hipSuccess;
+            }
+            mc->slot_words = ok ? slot : 0;
+        }
+        for (size_t r = 0; r < R && ok; ++r)
+            ok = hipSetDevice(ranks[r]) == hipSuccess &&
+                 hipMemcpyAsync(mc->d_send[r], send[r].data(), slot * 4, hipMemcpyHostToDevice, mc->sts[r]) == hipSuccess;
         if (ok) {
             ok = nc.GroupStart() == 0;
-            for (size_t r = 0; r < R && ok; ++r) ok = nc.AllGather(d_send[r], d_recv[r], slot, kNcclUint32, comms[r], sts[r]) == 0;
+            for (size_t r = 0; r < R && ok; ++r) ok = nc.AllGather(mc->d_send[r], mc->d_recv[r], slot, kNcclUint32, mc->comms[r], mc->sts[r]) == 0;
             ok = nc.GroupEnd() == 0 && ok;
         }
-        for (size_t r = 0; r < R && ok; ++r) ok = hipSetDevice(ranks[r]) == hipSuccess && hipStreamSynchronize(sts[r]) == hipSuccess;
+        for (size_t r = 0; r < R && ok; ++r) ok = hipSetDevice(ranks[r]) == hipSuccess && hipStreamSynchronize(mc->sts[r]) == hipSuccess;
         // every rank holds the same table; the host reads rank 0's copy (and checks the last rank's against it)
-        if (ok) ok = hipSetDevice(ranks[0]) == hipSuccess && hipMemcpy(gathered.data(), d_recv[0], R * slot * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok) ok = hipSetDevice(ranks[0]) == hipSuccess && hipMemcpy(gathered.data(), mc->d_recv[0], R * slot * 4, hipMemcpyDeviceToHost) == hipSuccess;
         if (ok && R > 1) {
             std::vector<uint32_t> other(R * slot);
-            ok = hipSetDevice(ranks[R - 1]) == hipSuccess && hipMemcpy(other.data(), d_recv[R - 1], R * slot * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+            ok = hipSetDevice(ranks[R - 1]) == hipSuccess && hipMemcpy(other.data(), mc->d_recv[R - 1], R * slot * 4, hipMemcpyDeviceToHost) == hipSuccess &&
                  other == gathered;
-        }
-        for (size_t r = 0; r < R; ++r) {
-            if (hipSetDevice(ranks[r]) != hipSuccess) continue;
-            if (d_send[r]) (void)hipFree(d_send[r]);
-            if (d_recv[r]) (void)hipFree(d_recv[r]);
-            if (sts[r]) (void)hipStreamDestroy(sts[r]);
-            if (comms[r]) (void)nc.CommDestroy(comms[r]);
         }
         (void)hipGetLastError();
         merged = ok;
