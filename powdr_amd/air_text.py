@@ -207,3 +207,27 @@ def parse_apc_snapshot(text: str):
             instrs.append((int(pc), parse_instruction(ins)))
     (air,) = parse_airs("# apc\nSymbolic machine using" + rest)
     return instrs, air
+
+
+def postfix_to_wire(code, ref_of_column):
+    """Post-fix code (this module's encoding, column-index operands) -> the serde wire format of an `AlgebraicExpression`
+    (expression/src/lib.rs:209-246: a number, "name@id", [left, op, right] or ["-", e]); ref_of_column[c] = "name@id"."""
+    st, i, code = [], 0, [int(x) for x in code]
+    while i < len(code):
+        op = code[i]
+        if op == OP_PUSH_COL:
+            st.append(ref_of_column[code[i + 1]])
+            i += 2
+        elif op == OP_PUSH_CONST:
+            st.append(code[i + 1])
+            i += 2
+        elif op == OP_NEG:
+            st.append(["-", st.pop()])
+            i += 1
+        else:
+            r, l = st.pop(), st.pop()
+            st.append([l, {OP_ADD: "+", OP_SUB: "-", OP_MUL: "*"}[op], r])
+            i += 1
+    if len(st) != 1:
+        raise ValueError("malformed post-fix code")
+    return st[0]

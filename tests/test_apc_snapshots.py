@@ -212,6 +212,85 @@ def test_the_fixture_is_the_reference_directory(reference_dir):
         assert before[0] == sum(len(ORIGINAL_COLUMNS[k]) for k in kinds), f.name  # the unoptimised block: the original AIRs' columns
 
 
+def apc_document(snap, pcs, wires, table, src, definitions, cons):
+    """The snapshot as the JSON document the reference exports for an APC (`ApcWithBusMap`, autoprecompiles/src/export.rs:77-93: block,
+    machine {constraints, bus_interactions, derived_columns}, subs): poly id = column index, `is_valid` = Constant(1), the optimiser's
+    columns = QuotientOrZero(e1, e2) — what the product's host library and the oracle's restatement of the reference's CPU path read."""
+    refs = [f"{c}@{i}" for i, c in enumerate(snap["columns"])]
+    wire = lambda code: air_text.postfix_to_wire(code, refs)
+    air = air_text.TextAir("apc", snap["columns"], snap["constraints"], [(b, m, a) for b, m, a in snap["interactions"]])
+    col = {n: i for i, n in enumerate(snap["columns"])}
+    machine = dict(constraints=[wire(air_text.compile_expr(c, col)) for c in snap["constraints"]],
+                   bus_interactions=[dict(id=b, mult=wire(air_text.compile_expr(m, col)), args=[wire(air_text.compile_expr(a, col)) for a in args])
+                                     for b, m, args in snap["interactions"]],
+                   derived_columns=[[refs[c], {"Constant": 1}] for c, s in enumerate(src) if s == "is_valid"]
+                   + [[refs[u], {"QuotientOrZero": [wire(e1), wire(e2)]}] for u, e1, e2 in definitions])
+    subs = [[] for _ in wires]
+    for c, s in enumerate(src):
+        if isinstance(s, tuple):
+            subs[s[0]].append(dict(original_poly_index=s[1], apc_poly_id=c))
+    blocks = []
+    for pc, w in zip(pcs, wires):  # a superblock: one basic block per run of consecutive pcs
+        if blocks and pc == blocks[-1]["start_pc"] + 4 * len(blocks[-1]["instructions"]):
+            blocks[-1]["instructions"].append(list(w))
+        else:
+            blocks.append(dict(start_pc=pc, instructions=[list(w)]))
+    return dict(block=dict(blocks=blocks), machine=machine, subs=subs)
+
+
+@pytest.mark.parametrize("name", sorted(SNAPSHOTS))
+def test_the_restated_reference_cpu_path_generates_the_golden_machine_trace(name):
+    """The same through the oracle's line-by-line restatement of the reference's CPU trace generation (or_generate_witness:
+    cpu/mod.rs:156-228, trace_handler.rs:68-124, cpu/periphery.rs:176-237) and through the product's host library: the snapshot
+    becomes the APC document the reference exports, the chips' rows become the dummy traces; the restated CPU path's APC trace is the
+    one the checks above accept, its periphery histograms hold one count per lookup, and the product's host library compiles the
+    same constraint and bus programs from the document."""
+    from powdr_amd import host
+
+    snap, pcs, wires, table, rbs, wpc = block_of(name)
+    calls = 16
+    rec, info = vm.execute_block(table, pcs, wpc, calls, seed=5)
+    cols, (src, definitions), cons, (inter, ispans, ibc) = apc_trace(snap, table, rec)
+    doc = apc_document(snap, pcs, wires, table, src, definitions, cons)
+    apc = om.load_apc(doc)
+    idx = apc.poly_id_to_index()
+    assert sorted(idx) == list(range(len(cols)))  # every column of the machine is referenced
+    kind = lambda air: oc.KIND_NAMES.index({"Mul": "Multiplication"}.get(air, air))
+    ct = om.build_cpu_tables(apc, idx, air_of=lambda ins: oc.KIND_NAMES[oc.OPCODE_KIND[int(ins[0])]])
+    # dummy traces as the reference lays them out: only instructions that keep a cell have a row (cuda/mod.rs:283-291)
+    has = [len(x) > 0 for x in doc["subs"]]
+    block_size = [sum(1 for t_, h_ in zip(table, has) if h_ and int(t_["kind"]) == k) for k in range(oc.N_KINDS)]
+    traces = {k: np.zeros((oc.WIDTHS[k], block_size[k] * calls), np.uint32) for k in range(oc.N_KINDS) if block_size[k]}
+    next_row = [0] * oc.N_KINDS
+    for ins, h_ in zip(table, has):
+        if h_:
+            k = int(ins["kind"])
+            for c, v in enumerate(oc.expand_rows(ins, rec, rec[0])):
+                traces[k][c, next_row[k] + np.arange(calls) * block_size[k]] = (np.asarray(v) % P).astype(np.uint32)
+            next_row[k] += 1
+    dummy_rm = [np.ascontiguousarray(traces[kind(n)].T) for n in ct.air_names]
+    per = dict(var_bus=3, var_hist=np.zeros(1 << 18, np.uint32), tuple_bus=7, tuple_hist=np.zeros(256 * 2048, np.uint32), sz0=256, sz1=2048, bitwise_bus=6,
+               bitwise_hist=np.zeros(2 * 65536, np.uint32))
+    vals = om.c_generate_witness(apc, ct, idx, dummy_rm, [oc.WIDTHS[kind(n)] for n in ct.air_names], calls, per)
+    assert vals.shape == (16, len(cols)) and (vals.T == np.stack(cols).astype(np.uint32)).all()
+    n = cols[0].shape[0]
+    lookups = sum(int(np.broadcast_to(oc.eval_postfix(ibc[int(ispans[s0][0]):int(ispans[s0][0]) + int(ispans[s0][1])], cols), (n,)).sum())
+                  for b, _, s0 in np.asarray(inter).tolist() if b in (3, 6, 7))
+    assert int(per["var_hist"].sum()) + int(per["tuple_hist"].sum()) + int(per["bitwise_hist"].sum()) == lookups
+    # the product's host library reads the same document: same width, same constraint and bus programs as the oracle's compiler
+    h_apc = host.Apc(doc)
+    assert h_apc.width == len(cols) and h_apc.n_constraints == len(snap["constraints"]) and h_apc.n_bus == len(snap["interactions"])
+    o_inter, o_spans, o_bc = om.compile_bus(apc, idx, 1)
+    p_inter, p_spans, p_bc = h_apc.compile_bus(1)
+    assert (p_inter == o_inter).all() and (p_spans == o_spans).all() and (p_bc == o_bc).all()
+    table_lib, n_lib, words_lib = h_apc.instruction_table()  # only the instructions that keep a cell have an entry and a record
+    kept, _, _, kept_words = oc.build_instruction_table(wires, [len(x) > 0 for x in doc["subs"]], pcs=pcs)
+    assert n_lib == len(kept) and words_lib == kept_words
+    for e, o in zip(table_lib, kept):
+        assert [getattr(e, f) for f in ("kind", "opcode", "pc", "a", "b", "c", "e", "f", "g", "ts_delta", "air_row", "rec_off")] == [int(o[f]) for f in o.dtype.names]
+    h_apc.close()
+
+
 def test_the_checks_pin_every_column_of_every_golden_machine():
     """+1 on any of the 1 681 columns of the 62 machines is caught by the machine's constraints or by the lookup / execution-bridge /
     memory-bus checks above: nothing an APC trace holds goes unchecked."""
@@ -416,3 +495,67 @@ def test_random_programs_execute_consistently(seed):
     cols = [c for r in rows for c in r]
     cons, interactions = unoptimised_machine(table)
     check_machine(f"random program {seed}", cols, info, rec[0].astype(np.int64), pcs, table, cons, interactions)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(SNAPSHOTS))
+def test_product_host_orchestration_on_the_golden_machines(name):
+    """The golden machine as the APC document the reference exports, through the PRODUCT's host orchestration (a4): host.Apc parses
+    it, powdr_apc_generate_witness_from_records (records of the instructions that keep a cell) and powdr_apc_generate_witness_gpu
+    (the reference flow: the chips' dummy traces laid out like cuda/mod.rs:283-291) give the same trace — the one the checks accept —
+    and the same periphery histograms; the prover built from the library's own compile_constraints / compile_bus output proves the
+    machine and both verifiers accept."""
+    import torch
+    from oracle import stark_model as sm
+    from powdr_amd import host, original_chips as pc, prover, tracegen as tg
+
+    snap, pcs, wires, table, rbs, wpc = block_of(name)
+    calls, H = 48, 64
+    rec, info = vm.execute_block(table, pcs, wpc, calls, seed=len(name) * 7 + len(wires))
+    cols, (src, definitions), cons, _ = apc_trace(snap, table, rec)
+    doc = apc_document(snap, pcs, wires, table, src, definitions, cons)
+    h_apc = host.Apc(doc)
+    W = h_apc.width
+    assert W == len(cols)
+    want = np.zeros((W, H), np.uint32)
+    want[:, :calls] = np.stack(cols).astype(np.uint32)
+    # records in the layout of the library's instruction table: only instructions that keep a cell own record words
+    has = [len(x) > 0 for x in doc["subs"]]
+    lib_table, n_lib, words = h_apc.instruction_table()
+    packed = np.zeros((words, calls), np.uint32)
+    packed[0] = rec[0]
+    kept = [t_ for t_, h_ in zip(table, has) if h_]
+    assert n_lib == len(kept)
+    for e, full in zip(lib_table, kept):
+        nw = oc.RECORD_WORDS[int(full["kind"])]
+        packed[e.rec_off:e.rec_off + nw] = rec[int(full["rec_off"]):int(full["rec_off"]) + nw]
+    d_rec = torch.from_numpy(packed.view(np.int32).reshape(-1).copy()).cuda()
+    out_a = tg.DeviceMatrix(torch.full((H * W,), 0x55, dtype=torch.int32, device="cuda"), H, W)
+    per_a = tg.Periphery.fresh()
+    h_apc.generate_witness_from_records(d_rec.data_ptr(), calls, out_a.ptr(), per_a)
+    torch.cuda.synchronize()
+    assert (om.from_monty(out_a.buf.cpu().numpy().view(np.uint32)).reshape(W, H) == want).all()
+    # the reference flow on the same records
+    t = pc.InstructionTable(wires, has, 0, pcs=pcs)
+    heights = pc.dummy_trace_heights(t, calls)
+    bufs = [torch.zeros(pc.WIDTHS[k] * heights[k], dtype=torch.int32, device="cuda") if heights[k] else None for k in range(pc.N_KINDS)]
+    pc.expand(d_rec.data_ptr(), calls, t, [(b.data_ptr(), heights[k]) if b is not None else None for k, b in enumerate(bufs)])
+    kinds_present = list(dict.fromkeys(int(k_["kind"]) for k_ in kept))
+    instr_air = [kinds_present.index(oc.OPCODE_KIND[int(w[0])]) if h_ else 0 for w, h_ in zip(wires, has)]
+    dummy = [(bufs[k].data_ptr(), pc.WIDTHS[k], heights[k]) for k in kinds_present]
+    out_b, per_b = tg.DeviceMatrix.zeros(H, W), tg.Periphery.fresh()
+    h_apc.generate_witness_gpu(instr_air, dummy, calls, out_b.ptr(), per_b)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a.buf, out_b.buf)
+    for a, b in ((per_a.var_hist, per_b.var_hist), (per_a.tuple_hist, per_b.tuple_hist), (per_a.bitwise_hist, per_b.bitwise_hist)):
+        assert torch.equal(a, b)
+    # the prover from the library's own programs
+    bc, spans = h_apc.compile_constraints()
+    it = h_apc.compile_bus(1)
+    pr = prover.Prover(W, bc, spans, num_queries=6, interactions=it)
+    assert pr.check_constraints(out_a.ptr(), 6) == (0, None, None)
+    proof = pr.prove(out_a.ptr(), 6)
+    assert prover.verify_logup(proof, W, 6, bc, spans, it, num_queries=6)[0] == 0
+    assert sm.verify_logup(proof, W, 6, bc, spans, *it, num_queries=6) == 0
+    pr.close()
+    h_apc.close()
