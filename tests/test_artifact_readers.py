@@ -170,3 +170,56 @@ def test_apc_candidates_json_v4():
     assert version == 3 and apcs[0]["n_blocks"] == 1 and apcs[0]["n_instructions"] == 1
     with pytest.raises(ValueError):
         host.read_apc_candidates(b'{"version": 4}')
+
+
+def test_mutated_apc_documents_are_rejected_or_read_never_crash():
+    """Structural fuzz of the host library's document reader (JSON -> DOM -> PowdrApc): keys dropped, values replaced by the wrong
+    type, expression nodes malformed, substitutions pointing nowhere. Every mutant is either rejected with an error message or read
+    into a handle whose table compilers run — the C++ side never lets an exception or a bad index through the C ABI."""
+    import copy
+    import random
+
+    from powdr_amd import synth
+
+    doc = synth.generate("C1", seed=3).doc
+    rng = random.Random(7)
+    junk = [None, 1, "x", [], {}, -5, 2 ** 40, "a@b", "noat", [1, "^", 2], ["-"], [1, 2, 3, 4], "is_valid@999999"]
+
+    def mutate(x):
+        if isinstance(x, dict) and x:
+            k = rng.choice(list(x.keys()))
+            r = rng.random()
+            if r < 0.15:
+                x.pop(k)
+            elif r < 0.3:
+                x[k] = rng.choice(junk)
+            else:
+                mutate(x[k])
+        elif isinstance(x, list) and x:
+            i = rng.randrange(len(x))
+            r = rng.random()
+            if r < 0.15:
+                x.pop(i)
+            elif r < 0.3:
+                x[i] = rng.choice(junk)
+            else:
+                mutate(x[i])
+
+    read = rejected = 0
+    for _ in range(250):
+        d = copy.deepcopy(doc)
+        for _ in range(rng.randrange(1, 4)):
+            mutate(d)
+        try:
+            h = host.Apc(d)
+        except (ValueError, RuntimeError, TypeError, KeyError, OverflowError):
+            rejected += 1
+            continue
+        for call in (lambda: h.compile_bus(1), h.compile_constraints, lambda: h.compile_derived(1), h.instruction_table):
+            try:
+                call()
+            except (ValueError, RuntimeError):
+                pass
+        h.close()
+        read += 1
+    assert read + rejected == 250 and rejected > 60 and read > 5
