@@ -3,7 +3,8 @@
 //! * [`ffi`]    — `extern "C"` blocks for include/powdr_gpu.h (= openvm/src/cuda_abi.rs:8-64 + extensions),
 //!                include/powdr_host.h and include/powdr_prover.h
 //! * [`device`] — `DeviceBuffer` / `DeviceMatrix` over hipMalloc (stand-ins for openvm-cuda-common / -backend types)
-//! * [`chip`]   — `PowdrChipHip`: `Chip::generate_proving_ctx` -> `powdr_apc_generate_witness_gpu`
+//! * [`chip`]   — `PowdrChipHip`: `Chip::generate_proving_ctx` -> `powdr_apc_generate_witness_gpu`; from call records without dummy
+//!                chips: `PowdrTraceGeneratorHip::try_generate_witness_from_records` -> `powdr_apc_generate_witness_from_records`
 //! * [`engine`] — `HipEngine` (one `pw_prove_segment` call per segment), `SpecializedConfigHipBuilder`,
 //!                `PowdrHipProverExt`
 //! * [`multi`]  — the reference's sequential segment loop (trace_generation.rs:111-141) on N GPUs at once:
