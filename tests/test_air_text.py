@@ -80,3 +80,22 @@ def test_malformed_text_is_rejected():
         air_text.parse_instruction("FROB 1 2 3 1 0")
     assert air_text.parse_instruction("BLTU 44 48 -44 1 1") == [550, 44, 48, P - 44, 1, 1, 0, 0]
     assert air_text.parse_instruction("LOADW rd_rs2_ptr = 60, rs1_ptr = 56, imm = 0, mem_as = 2, needs_write = 1, imm_sign = 0") == [528, 60, 56, 0, 1, 2, 1, 0]
+
+
+def test_the_air_fixture_is_the_reference_snapshot(reference_dir):
+    """tests/golden/openvm_airs.npz == a fresh parse of the reference's openvm-riscv/tests/openvm_constraints.txt (the file its own
+    `machine_extraction` test compares against): 13 AIRs, and per AIR the header's own column count."""
+    import re
+    from pathlib import Path
+
+    text = (reference_dir / "openvm-riscv" / "tests" / "openvm_constraints.txt").read_text()
+    airs = air_text.parse_airs(text)
+    z = np.load(Path(__file__).parent / "golden" / "openvm_airs.npz")
+    assert len(airs) == 13 == len(z["names"])
+    declared = [int(x) for x in re.findall(r"Symbolic machine using (\d+) unique main columns", text)]
+    assert [a.width for a in airs] == declared == z["widths"].tolist()
+    assert sum(len(a.constraints) for a in airs) == 307 and sum(len(a.interactions) for a in airs) == 227
+    for k, a in enumerate(airs):
+        bc, spans, (inter, ispans, ibc) = a.tables()
+        assert a.columns == [str(c) for c in z[f"a{k}_columns"]] and str(z["full_names"][k]) == a.name
+        assert (bc == z[f"a{k}_bc"]).all() and (spans == z[f"a{k}_spans"]).all() and (inter == z[f"a{k}_inter"]).all() and (ibc == z[f"a{k}_ibc"]).all()
