@@ -219,6 +219,11 @@ int powdr_original_airs_expand(const uint32_t* d_records, size_t num_calls, cons
 int powdr_apc_tracegen_records(PowdrFp* d_output, size_t output_height, const uint32_t* d_records, size_t num_apc_calls,
                                const PowdrOrigInstr* h_instrs, size_t n_instrs, const PowdrRecordSubst* h_subs, size_t n_subs);
 
+/* Test hook: the row ONE instruction produces from its (up to six) record words, computed on the HOST by the same expander code
+ * the kernels run (host-device templates over the cell sink): lets a CPU-only test suite check the product's expanders against the
+ * restatement. row_out: the AIR's cells, canonical; returns the AIR's width, or -1 for an instruction no chip accepts. */
+int powdr_original_row_expand_host(const PowdrOrigInstr* instr, const uint32_t* record_words6, uint32_t timestamp, uint32_t* row_out);
+
 /* Traces of the shared periphery chips (the RECEIVE side of the three lookup buses) from the histograms
  * _apc_apply_bus filled. The chips are EXTERNAL (openvm-circuit-primitives; instantiated in
  * openvm/src/powdr_extension/trace_generator/cuda/periphery.rs:33-85); in-repo is how a lookup becomes a histogram

@@ -54,23 +54,23 @@ struct SparseSink {  // the fused gather: only the cells the APC keeps, straight
 };
 
 template <class Sink>
-__device__ __forceinline__ void put_bytes(const Sink& o, int c, uint32_t w) {
+PW_HD void put_bytes(const Sink& o, int c, uint32_t w) {
     o(c, w & 0xffu); o(c + 1, (w >> 8) & 0xffu); o(c + 2, (w >> 16) & 0xffu); o(c + 3, w >> 24);
 }
 // prev_timestamp, and timestamp - prev - 1 split into 17 + 12 bits (the `timestamp_lt_aux` columns)
 template <class Sink>
-__device__ __forceinline__ void put_ts(const Sink& o, int c, uint32_t ts, uint32_t prev, bool enabled) {
+PW_HD void put_ts(const Sink& o, int c, uint32_t ts, uint32_t prev, bool enabled) {
     const uint32_t d = ts - prev - 1u;
     o(c, enabled ? prev : 0u); o(c + 1, enabled ? d & 0x1ffffu : 0u); o(c + 2, enabled ? d >> 17 : 0u);
 }
-__device__ __forceinline__ uint32_t field_inv(uint32_t canonical) { return bb::from_monty(bb::inv(bb::to_monty(canonical))); }
-__device__ __forceinline__ uint32_t field_of(int32_t v) { return v < 0 ? bb::P - (uint32_t)(-v) : (uint32_t)v; }
-__device__ __forceinline__ uint32_t byte_of(uint32_t w, uint32_t i) { return (w >> (8u * i)) & 0xffu; }
+PW_HD uint32_t field_inv(uint32_t canonical) { return bb::from_monty(bb::inv(bb::to_monty(canonical))); }
+PW_HD uint32_t field_of(int32_t v) { return v < 0 ? bb::P - (uint32_t)(-v) : (uint32_t)v; }
+PW_HD uint32_t byte_of(uint32_t w, uint32_t i) { return (w >> (8u * i)) & 0xffu; }
 
 // `rec`: this call's record words of the instruction; `ts`: from_state.timestamp of the instruction in this call.
 // Rv32BaseAluAdapter (BaseAlu, Shift, LessThan): columns 0..18
 template <class Sink>
-__device__ __forceinline__ void put_alu_adapter(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o, bool reg) {
+PW_HD void put_alu_adapter(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o, bool reg) {
     o(0, in.pc); o(1, ts); o(2, in.a); o(3, in.b); o(4, in.c); o(5, reg ? 1u : 0u);
     put_ts(o, 6, ts, rec[3], true);
     put_ts(o, 9, ts + 1u, rec[4], reg);
@@ -79,7 +79,7 @@ __device__ __forceinline__ void put_alu_adapter(const PowdrOrigInstr& in, const 
 }
 // the most significant limb where x and y differ gets the marker, diff_val the positive difference there (LessThan cores)
 template <class Sink>
-__device__ __forceinline__ void put_diff_marker(const Sink& o, int c_marker, int c_val, const int32_t* x, const int32_t* y, bool lt) {
+PW_HD void put_diff_marker(const Sink& o, int c_marker, int c_val, const int32_t* x, const int32_t* y, bool lt) {
     bool done = false;
     uint32_t val = 0u;
 #pragma unroll
@@ -93,7 +93,7 @@ __device__ __forceinline__ void put_diff_marker(const Sink& o, int c_marker, int
 }
 
 template <class Sink>
-__device__ __forceinline__ void expand_alu_shift_lt(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void expand_alu_shift_lt(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     const bool reg = in.e != 0;
     const uint32_t bw = rec[0];
     // immediate: 24-bit value, its top byte repeated (openvm_constraints.txt:82-85)
@@ -142,7 +142,7 @@ __device__ __forceinline__ void expand_alu_shift_lt(const PowdrOrigInstr& in, co
 // Rv32LoadStoreAdapter (LoadStore, LoadSignExtend): columns 0..22. The pointer rs1 + imm is taken modulo 2^29 and the access's
 // alignment, rs1 adjusted to match (the record of a real execution satisfies both already). Returns the pointer.
 template <class Sink>
-__device__ __forceinline__ uint32_t put_load_store_adapter(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o, uint32_t align_mask) {
+PW_HD uint32_t put_load_store_adapter(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o, uint32_t align_mask) {
     const uint32_t imm = in.c & 0xffffu, imm_sign = in.g & 1u, ext = imm | (imm_sign ? 0xffff0000u : 0u);
     const uint32_t ptr = (rec[0] + ext) & 0x1fffffffu & ~align_mask;
     const uint32_t rs1 = ptr - ext;
@@ -159,7 +159,7 @@ __device__ __forceinline__ uint32_t put_load_store_adapter(const PowdrOrigInstr&
 }
 
 template <class Sink>
-__device__ __forceinline__ void expand_load_store(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void expand_load_store(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     const uint32_t op = in.opcode - 528u;  // 0 LOADW, 1 LOADBU, 2 LOADHU, 3 STOREW, 4 STOREH, 5 STOREB
     const uint32_t nbytes = (op == 0 || op == 3) ? 4u : (op == 2 || op == 4) ? 2u : 1u;
     const uint32_t s = put_load_store_adapter(in, rec, ts, o, nbytes - 1u) & 3u;
@@ -182,7 +182,7 @@ __device__ __forceinline__ void expand_load_store(const PowdrOrigInstr& in, cons
 }
 
 template <class Sink>
-__device__ __forceinline__ void expand_load_sign_extend(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void expand_load_sign_extend(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     const bool loadb = in.opcode == 534u;
     const uint32_t s = put_load_store_adapter(in, rec, ts, o, loadb ? 0u : 1u) & 3u;
     const uint32_t read = rec[1];
@@ -195,7 +195,7 @@ __device__ __forceinline__ void expand_load_sign_extend(const PowdrOrigInstr& in
 
 // Rv32BranchAdapter (BranchEqual, BranchLessThan): columns 0..17
 template <class Sink>
-__device__ __forceinline__ void put_branch_adapter(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void put_branch_adapter(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     o(0, in.pc); o(1, ts); o(2, in.a); o(3, in.b);
     put_ts(o, 4, ts, rec[2], true);
     put_ts(o, 7, ts + 1u, rec[3], true);
@@ -203,7 +203,7 @@ __device__ __forceinline__ void put_branch_adapter(const PowdrOrigInstr& in, con
 }
 
 template <class Sink>
-__device__ __forceinline__ void expand_branch_eq(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void expand_branch_eq(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     const uint32_t aw = rec[0], bw = rec[1];
     const bool beq = in.opcode == 544u, eq = aw == bw;
     put_branch_adapter(in, rec, ts, o);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void expand_branch_eq(const PowdrOrigInstr& in, const
 }
 
 template <class Sink>
-__device__ __forceinline__ void expand_branch_lt(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void expand_branch_lt(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     const uint32_t op = in.opcode - 549u;  // 0 BLT, 1 BLTU, 2 BGE, 3 BGEU
     const uint32_t aw = rec[0], bw = rec[1];
     const bool sgn = (op & 1u) == 0, lt = sgn ? (int32_t)aw < (int32_t)bw : aw < bw;
@@ -240,7 +240,7 @@ __device__ __forceinline__ void expand_branch_lt(const PowdrOrigInstr& in, const
 }
 
 template <class Sink>
-__device__ __forceinline__ void expand_jal_lui(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void expand_jal_lui(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     const bool is_jal = in.opcode == 560u;
     const uint32_t needs_write = in.f & 1u;
     const uint32_t rd = is_jal ? in.pc + 4u : in.c << 12;
@@ -253,7 +253,7 @@ __device__ __forceinline__ void expand_jal_lui(const PowdrOrigInstr& in, const u
 }
 
 template <class Sink>
-__device__ __forceinline__ void expand_jalr(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void expand_jalr(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     const uint32_t imm = in.c & 0xffffu, imm_sign = in.g & 1u, ext = imm | (imm_sign ? 0xffff0000u : 0u);
     const uint32_t to_pc = (rec[0] + ext) & 0x3fffffffu;  // jump targets lie below 2^30 (to_pc_limbs: 15 + 14 bits)
     const uint32_t needs_write = in.f & 1u, rd = in.pc + 4u;
@@ -269,7 +269,7 @@ __device__ __forceinline__ void expand_jalr(const PowdrOrigInstr& in, const uint
 }
 
 template <class Sink>
-__device__ __forceinline__ void expand_auipc(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void expand_auipc(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     const uint32_t rd = in.pc + (in.c << 8);
     o(0, in.pc); o(1, ts); o(2, in.a);
     put_ts(o, 3, ts, rec[1], true);
@@ -280,7 +280,7 @@ __device__ __forceinline__ void expand_auipc(const PowdrOrigInstr& in, const uin
 
 // Rv32MultAdapter (Multiplication, MulH, DivRem): columns 0..17
 template <class Sink>
-__device__ __forceinline__ void put_mult_adapter(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void put_mult_adapter(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     o(0, in.pc); o(1, ts); o(2, in.a); o(3, in.b); o(4, in.c);
     put_ts(o, 5, ts, rec[3], true);
     put_ts(o, 8, ts + 1u, rec[4], true);
@@ -289,7 +289,7 @@ __device__ __forceinline__ void put_mult_adapter(const PowdrOrigInstr& in, const
 }
 
 template <class Sink>
-__device__ __forceinline__ void expand_mul(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void expand_mul(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     const uint32_t bw = rec[0], cw = rec[1];
     put_mult_adapter(in, rec, ts, o);
     if (in.kind == POWDR_ORIG_MUL) {
@@ -310,7 +310,7 @@ __device__ __forceinline__ void expand_mul(const PowdrOrigInstr& in, const uint3
 }
 
 template <class Sink>
-__device__ __forceinline__ void expand_div_rem(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void expand_div_rem(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     const uint32_t op = in.opcode - 596u;  // 0 DIV, 1 DIVU, 2 REM, 3 REMU
     const bool sgn = (op & 1u) == 0;
     const uint32_t bw = rec[0], cw = rec[1];
@@ -349,13 +349,13 @@ __device__ __forceinline__ void expand_div_rem(const PowdrOrigInstr& in, const u
     for (uint32_t j = 0; j < 4; ++j) o(55 + j, op == j ? 1u : 0u);
 }
 
-__device__ __forceinline__ int record_words(uint32_t kind) {
+PW_HD int record_words(uint32_t kind) {
     return (kind == POWDR_ORIG_JAL_LUI || kind == POWDR_ORIG_AUIPC) ? 2
          : (kind == POWDR_ORIG_BRANCH_EQ || kind == POWDR_ORIG_BRANCH_LT || kind == POWDR_ORIG_JALR) ? 4 : 6;
 }
 
 template <class Sink>
-__device__ __forceinline__ void expand(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
+PW_HD void expand(const PowdrOrigInstr& in, const uint32_t* rec, uint32_t ts, const Sink& o) {
     switch (in.kind) {
         case POWDR_ORIG_BASE_ALU: case POWDR_ORIG_SHIFT: case POWDR_ORIG_LESS_THAN: expand_alu_shift_lt(in, rec, ts, o); break;
         case POWDR_ORIG_LOAD_STORE: expand_load_store(in, rec, ts, o); break;
@@ -369,6 +369,11 @@ __device__ __forceinline__ void expand(const PowdrOrigInstr& in, const uint32_t*
         default: expand_auipc(in, rec, ts, o); break;
     }
 }
+
+struct HostSink {  // the test hook below: canonical values into a plain row
+    uint32_t* row;
+    void operator()(int c, uint32_t v) const { row[c] = v; }
+};
 
 struct AirSlots { uint32_t* buffer[kKinds]; uint32_t height[kKinds]; uint32_t row_block[kKinds]; };
 
@@ -556,4 +561,16 @@ extern "C" int powdr_apc_tracegen_records(PowdrFp* d_output, size_t output_heigh
     hipLaunchKernelGGL(apc_tracegen_records_kernel, dim3(pw::div_up(H, kCalls), pw::div_up(n_instrs, kInstrPerBlock)), dim3(kCalls), 0, pw::stream(),
                        d_output, H, d_records, num_apc_calls, plan->d_instrs, plan->d_wanted, plan->d_dst, (uint32_t)n_instrs);
     return (int)hipGetLastError();
+}
+
+// Test hook: the row ONE instruction produces from its record words, computed on the HOST by the very expander code the kernels run
+// (the expanders are host-device templates over their sink). row_out receives the canonical cells; returns the AIR's width or -1.
+extern "C" int powdr_original_row_expand_host(const PowdrOrigInstr* instr, const uint32_t* record_words6, uint32_t timestamp, uint32_t* row_out) {
+    if (!instr || !record_words6 || !row_out || check_instrs(instr, 1)) return -1;
+    uint32_t rec[6];
+    const int n = record_words(instr->kind);
+    for (int w = 0; w < 6; ++w) rec[w] = w < n ? record_words6[w] : 0u;
+    for (int c = 0; c < kWidths[instr->kind]; ++c) row_out[c] = 0u;
+    expand(*instr, rec, timestamp, HostSink{row_out});
+    return kWidths[instr->kind];
 }

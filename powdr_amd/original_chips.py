@@ -28,7 +28,7 @@ TIMESTAMP_STEP = N_PREV_TS
 OPCODE_RANGES = [(512, 516, BASE_ALU), (517, 519, SHIFT), (520, 521, LESS_THAN), (528, 533, LOAD_STORE), (534, 535, LOAD_SIGN_EXTEND),
                  (544, 545, BRANCH_EQ), (549, 552, BRANCH_LT), (560, 561, JAL_LUI), (565, 565, JALR), (576, 576, AUIPC), (592, 592, MUL),
                  (593, 595, MUL_H), (596, 599, DIV_REM)]
-ORIG_SYMBOLS = ["powdr_original_airs_expand", "powdr_apc_tracegen_records"]
+ORIG_SYMBOLS = ["powdr_original_airs_expand", "powdr_apc_tracegen_records", "powdr_original_row_expand_host"]
 
 
 def kind_of_opcode(op: int) -> int:
@@ -89,6 +89,22 @@ lib.powdr_original_airs_expand.restype = C.c_int
 lib.powdr_original_airs_expand.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
 lib.powdr_apc_tracegen_records.restype = C.c_int
 lib.powdr_apc_tracegen_records.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+
+
+lib.powdr_original_row_expand_host.restype = C.c_int
+lib.powdr_original_row_expand_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+
+
+def expand_row_host(instr: PowdrOrigInstr, record_words, timestamp: int) -> np.ndarray:
+    """powdr_original_row_expand_host: the canonical cells of the row `instr` produces from its record words — the library's own
+    expander code run on the host (a test hook: no GPU needed)."""
+    rec = np.zeros(6, np.uint32)
+    rec[:len(record_words)] = record_words
+    row = np.zeros(64, np.uint32)
+    w = lib.powdr_original_row_expand_host(C.byref(instr), rec.ctypes.data, int(timestamp) & 0xFFFFFFFF, row.ctypes.data)
+    if w < 0:
+        raise ValueError("no chip accepts this instruction")
+    return row[:w]
 
 
 def dummy_trace_heights(table: InstructionTable, num_calls: int):

@@ -126,6 +126,7 @@ extern "C" {
                                       h_airs: *const OriginalAir) -> i32;
     pub fn powdr_apc_tracegen_records(d_output: *mut PowdrFp, output_height: usize, d_records: *const u32, num_apc_calls: usize,
                                       h_instrs: *const PowdrOrigInstr, n_instrs: usize, h_subs: *const PowdrRecordSubst, n_subs: usize) -> i32;
+    pub fn powdr_original_row_expand_host(instr: *const PowdrOrigInstr, record_words6: *const u32, timestamp: u32, row_out: *mut u32) -> i32;
     pub fn powdr_periphery_var_range_trace(d_var_hist: *const u32, var_num_bins: usize, d_out: *mut PowdrFp) -> i32;
     pub fn powdr_periphery_tuple2_trace(d_tuple2_hist: *const u32, tuple2_sz0: u32, tuple2_sz1: u32, d_out: *mut PowdrFp) -> i32;
     pub fn powdr_periphery_bitwise_trace(d_bitwise_hist: *const u32, d_out: *mut PowdrFp) -> i32;

@@ -143,6 +143,31 @@ def test_product_host_table_equals_the_restatement():
     assert pc.sanitise_instructions(all_opcode_block()[:56]) == oc.sanitise_instructions(all_opcode_block()[:56])
 
 
+def test_library_expanders_on_the_host_equal_the_restatement():
+    """The product's OWN expander code (csrc/original_chips.hip: host-device templates, here run on the host through
+    powdr_original_row_expand_host) against the numpy restatement: every cell of every opcode's row, on edge records and on random
+    ones — the check the GPU tests repeat on the device, available to a CPU-only run."""
+    from powdr_amd import original_chips as pc
+
+    ins = all_opcode_block()
+    t = pc.InstructionTable(ins, [True] * len(ins), 0x200000)
+    table, idx, rbs, wpc = oc.build_instruction_table(ins, [True] * len(ins), 0x200000)
+    calls = 24
+    rec = edge_records(table, wpc, calls, seed=8)
+    seen = set()
+    for entry, row in zip(t.entries, table):
+        want = np.stack([np.asarray(v) % P for v in oc.expand_rows(row, rec, rec[0])]).astype(np.uint32)  # [width, calls]
+        o, n = int(row["rec_off"]), oc.RECORD_WORDS[int(row["kind"])]
+        for r in range(calls):
+            got = pc.expand_row_host(entry, rec[o:o + n, r], int(rec[0, r]) + int(row["ts_delta"]))
+            assert (got == want[:, r]).all(), (oc.KIND_NAMES[int(row["kind"])], int(row["opcode"]), r, np.nonzero(got != want[:, r])[0][:4])
+        seen.add(int(row["opcode"]))
+    assert seen == set(oc.ALL_OPCODES)
+    bad = pc.PowdrOrigInstr(0, 9999, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1)
+    with pytest.raises(ValueError):
+        pc.expand_row_host(bad, [0] * 6, 0)
+
+
 def test_library_instruction_table_equals_the_restatement():
     """powdr_apc_instruction_table (C++ host library, from the APC's own block and substitutions) == the Python mirror == the
     restatement, for the synthetic C2 APC (instructions without a surviving cell have no entry but still advance the timestamp)."""
