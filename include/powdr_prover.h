@@ -211,6 +211,10 @@ int pw_prover_max_constraint_degree(const PwProver* p);
  * kernels, their code-object bytes and the number of code chunks (each NULL = skip). */
 int pw_prover_specialise(PwProver* p);
 int pw_prover_specialised(const PwProver* p, size_t* n_kernels, size_t* code_bytes, size_t* n_chunks);
+/* Compiled code objects are kept on disk across processes: $POWDR_JIT_CACHE_DIR, else $XDG_CACHE_HOME/powdr_jit, else
+ * $HOME/.cache/powdr_jit (POWDR_JIT_CACHE=0: off); an entry is keyed by the unit's source, the embedded headers and the compile options
+ * and confirmed by comparing the stored source. Translation units this process compiled / loaded from disk so far: */
+void pw_jit_cache_stats(uint64_t* units_compiled, uint64_t* units_from_disk);
 /* The same code generation + hiprtc compilation for an AIR given by its tables (as for pw_prover_create / _create_logup;
  * interactions == NULL: constraints only) WITHOUT touching a GPU — hiprtc cross-compiles — so build machines and CPU test
  * suites can check that an AIR's specialised kernels compile. Returns pw_prover_specialise's code (-2: malformed tables);

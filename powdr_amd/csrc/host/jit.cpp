@@ -4,9 +4,11 @@
 
 #include <dlfcn.h>
 #include <spawn.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -204,7 +206,80 @@ bool compile_with_helpers(const std::string& helper, const std::vector<std::stri
 }
 }  // namespace
 
+// ---- on-disk cache of code objects -------------------------------------------------------------------------------------------
+// A code object depends on the unit's source, the embedded headers and the compile options only, so it is kept across processes:
+// $POWDR_JIT_CACHE_DIR, else $XDG_CACHE_HOME/powdr_jit, else $HOME/.cache/powdr_jit (POWDR_JIT_CACHE=0: no disk cache). Every rank
+// of a node, every test process and every later run of a prover then loads what the first one compiled. An entry holds the
+// environment hash and the FULL source next to the code, a hit is confirmed by comparing them (the file name is only a hash);
+// entries are written to a private temporary name and renamed into place.
+namespace {
+constexpr char kDiskMagic[8] = {'P', 'W', 'J', 'C', '0', '0', '0', '1'};
+std::atomic<uint64_t> g_units_compiled{0}, g_units_from_disk{0};  // process-wide, for pw_jit_cache_stats
+
+uint64_t environment_hash() {
+    static const uint64_t h = [] {
+        std::string all = "--offload-arch=gfx950 -O3 -std=c++17";
+        for (int i = 0; i < kNumEmbeddedHeaders; ++i) { all += '\0'; all += kEmbeddedHeaders[i].name; all += '\0'; all += kEmbeddedHeaders[i].text; }
+        return hash64(all);
+    }();
+    return h;
+}
+
+std::string disk_cache_dir() {
+    if (const char* e = getenv("POWDR_JIT_CACHE")) if (atoi(e) == 0) return "";
+    std::string dir;
+    if (const char* e = getenv("POWDR_JIT_CACHE_DIR")) dir = e;
+    else if (const char* x = getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/powdr_jit";
+    else if (const char* h = getenv("HOME")) dir = std::string(h) + "/.cache/powdr_jit";
+    if (dir.empty()) return "";
+    for (size_t i = 1; i <= dir.size(); ++i)  // mkdir -p
+        if (i == dir.size() || dir[i] == '/') { const std::string part = dir.substr(0, i); if (mkdir(part.c_str(), 0755) != 0 && errno != EEXIST) return ""; }
+    return dir;
+}
+
+std::string disk_entry_path(const std::string& dir, const std::string& source) {
+    char name[64];
+    snprintf(name, sizeof name, "/%016llx-%016llx.pwjc", (unsigned long long)environment_hash(), (unsigned long long)hash64(source));
+    return dir + name;
+}
+
+bool disk_load(const std::string& dir, const std::string& source, std::vector<char>& code) {
+    std::vector<char> f;
+    if (dir.empty() || !read_file(disk_entry_path(dir, source), f)) return false;
+    const size_t head = 8 + 8 + 8;
+    if (f.size() < head + 8 || memcmp(f.data(), kDiskMagic, 8) != 0) return false;
+    uint64_t env = 0, src_len = 0, code_len = 0;
+    memcpy(&env, f.data() + 8, 8); memcpy(&src_len, f.data() + 16, 8);
+    if (env != environment_hash() || src_len != source.size() || f.size() < head + src_len + 8) return false;
+    if (memcmp(f.data() + head, source.data(), src_len) != 0) return false;
+    memcpy(&code_len, f.data() + head + src_len, 8);
+    if (code_len == 0 || f.size() != head + src_len + 8 + code_len) return false;
+    code.assign(f.begin() + (long)(head + src_len + 8), f.end());
+    return true;
+}
+
+void disk_store(const std::string& dir, const std::string& source, const std::vector<char>& code) {
+    if (dir.empty() || code.empty()) return;
+    static std::atomic<unsigned> serial{0};
+    const std::string path = disk_entry_path(dir, source);
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const uint64_t env = environment_hash(), src_len = source.size(), code_len = code.size();
+    bool ok = fwrite(kDiskMagic, 1, 8, f) == 8 && fwrite(&env, 8, 1, f) == 1 && fwrite(&src_len, 8, 1, f) == 1 &&
+              fwrite(source.data(), 1, source.size(), f) == source.size() && fwrite(&code_len, 8, 1, f) == 1 &&
+              fwrite(code.data(), 1, code.size(), f) == code.size();
+    ok = fclose(f) == 0 && ok;
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+}
+}  // namespace
+
 bool compile_to_code_object(const std::string& source, std::vector<char>& code, std::string* err) { return compile_code(source, code, err); }
+
+void cache_stats(uint64_t* compiled, uint64_t* from_disk) {
+    if (compiled) *compiled = g_units_compiled.load();
+    if (from_disk) *from_disk = g_units_from_disk.load();
+}
 
 bool available() {
     if (const char* e = getenv("POWDR_JIT")) if (atoi(e) == 0) return false;
@@ -224,6 +299,32 @@ std::vector<ProgramPtr> compile_all(const std::vector<std::string>& sources, std
             else todo.push_back(i);
         }
     }
+    // what an earlier process left on disk
+    const std::string cache_dir = todo.empty() ? std::string() : disk_cache_dir();
+    std::vector<std::pair<size_t, std::vector<char>>> from_disk;
+    if (!cache_dir.empty()) {
+        std::vector<size_t> still;
+        for (size_t i : todo) {
+            std::vector<char> c;
+            if (disk_load(cache_dir, sources[i], c)) from_disk.emplace_back(i, std::move(c));
+            else still.push_back(i);
+        }
+        todo.swap(still);
+        g_units_from_disk += from_disk.size();
+    }
+    auto publish = [&](size_t i, std::vector<char>&& code_i) {  // under g_cache_mu
+        auto p = std::make_shared<Program>();
+        p->source = sources[i];
+        p->code = std::move(code_i);
+        std::weak_ptr<Program>& slot = g_cache[hash64(sources[i])];
+        ProgramPtr other = slot.lock();
+        if (other && other->source == sources[i]) out[i] = other;  // another thread was faster
+        else { slot = p; out[i] = p; }                             // empty / expired slot, or a hash collision: the newer text takes it
+    };
+    if (!from_disk.empty()) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto& e : from_disk) publish(e.first, std::move(e.second));
+    }
     if (!todo.empty()) {
         unsigned n_procs = std::thread::hardware_concurrency();
         if (n_procs > 32) n_procs = 32;
@@ -240,17 +341,10 @@ std::vector<ProgramPtr> compile_all(const std::vector<std::string>& sources, std
             for (size_t k = 0; k < todo.size(); ++k)
                 if (!compile_code(sources[todo[k]], code[k], &e)) { if (err) *err = e; return {}; }
         }
+        g_units_compiled += todo.size();
+        for (size_t k = 0; k < todo.size(); ++k) disk_store(cache_dir, sources[todo[k]], code[k]);
         std::lock_guard<std::mutex> lk(g_cache_mu);
-        for (size_t k = 0; k < todo.size(); ++k) {
-            const size_t i = todo[k];
-            auto p = std::make_shared<Program>();
-            p->source = sources[i];
-            p->code = std::move(code[k]);
-            std::weak_ptr<Program>& slot = g_cache[hash64(sources[i])];
-            ProgramPtr other = slot.lock();
-            if (other && other->source == sources[i]) out[i] = other;  // another thread was faster
-            else { slot = p; out[i] = p; }                             // empty / expired slot, or a hash collision: the newer text takes it
-        }
+        for (size_t k = 0; k < todo.size(); ++k) publish(todo[k], std::move(code[k]));
         if (g_cache.size() > 4096)  // expired slots of AIRs long gone
             for (auto it = g_cache.begin(); it != g_cache.end();) it = it->second.expired() ? g_cache.erase(it) : std::next(it);
     }

@@ -169,3 +169,5 @@ extern "C" int pw_prover_specialised(const PwProver* p, size_t* n_kernels, size_
     if (n_chunks) *n_chunks = c;
     return p->jit.state;
 }
+
+extern "C" void pw_jit_cache_stats(uint64_t* units_compiled, uint64_t* units_from_disk) { pw::jit::cache_stats(units_compiled, units_from_disk); }

@@ -16,7 +16,7 @@ class PwStarkConfig(C.Structure):
 
 PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_logup_path", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_lde_fused", "pw_merkle_commit", "pw_poseidon2_permute_host",
-                  "pw_set_poseidon2_constants", "pw_get_poseidon2_constants", "pw_prover_specialise", "pw_prover_specialised", "pw_jit_compile_check",
+                  "pw_set_poseidon2_constants", "pw_get_poseidon2_constants", "pw_prover_specialise", "pw_prover_specialised", "pw_jit_compile_check", "pw_jit_cache_stats",
                   "pw_prove_segments_multi", "pw_multi_last_merge", "pw_assign_units"]
 
 lib.pw_prover_create.restype = C.c_void_p
@@ -263,6 +263,15 @@ def jit_compile_check(width: int, cons_bytecode, cons_spans, interactions=None) 
     else:
         rc = f(width, vp(bc), len(bc), vp(sp), len(sp), None, 0, None, 0, None, 0, C.byref(k), C.byref(b), C.byref(c), err, 4096)
     return dict(rc=int(rc), kernels=k.value, code_bytes=b.value, chunks=c.value, error=err.value.decode(errors="replace"))
+
+
+def jit_cache_stats() -> dict:
+    """pw_jit_cache_stats: translation units this process compiled / loaded from the on-disk code-object cache."""
+    lib.pw_jit_cache_stats.restype = None
+    lib.pw_jit_cache_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    a, b = C.c_uint64(), C.c_uint64()
+    lib.pw_jit_cache_stats(C.byref(a), C.byref(b))
+    return dict(compiled=a.value, from_disk=b.value)
 
 
 _SEGMENT_PROVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_uint32))

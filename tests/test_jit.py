@@ -64,6 +64,41 @@ def test_specialised_kernels_compile_without_a_gpu(shape, logup):
         assert len(prover.logup_group_starts(it)) - 1 < len(it[0]) - 2  # the constant-only interactions share a group
 
 
+def test_code_objects_are_kept_on_disk_across_provers(tmp_path, monkeypatch):
+    """The on-disk cache of compiled units ($POWDR_JIT_CACHE_DIR): the first compilation of an AIR's kernels writes one entry per
+    translation unit, the same AIR again (its programs released in between: the in-process cache only holds live programs) loads
+    them instead of compiling; a truncated or foreign entry is ignored and replaced; POWDR_JIT_CACHE=0 switches the cache off."""
+    from powdr_amd import prover
+
+    monkeypatch.setenv("POWDR_JIT_CACHE_DIR", str(tmp_path / "cache" / "nested"))
+    W, (bc, spans), it = hand_made_air()
+    s0 = prover.jit_cache_stats()
+    r1 = prover.jit_compile_check(W, bc, spans, it)
+    s1 = prover.jit_cache_stats()
+    assert r1["rc"] == 0 and s1["compiled"] - s0["compiled"] == r1["kernels"] and s1["from_disk"] == s0["from_disk"]
+    entries = sorted((tmp_path / "cache" / "nested").glob("*.pwjc"))
+    assert len(entries) == r1["kernels"] and not list((tmp_path / "cache" / "nested").glob("*.tmp*"))
+    r2 = prover.jit_compile_check(W, bc, spans, it)
+    s2 = prover.jit_cache_stats()
+    assert r2 == r1 and s2["compiled"] == s1["compiled"] and s2["from_disk"] - s1["from_disk"] == r1["kernels"]
+    # a damaged entry: ignored, compiled again, rewritten whole
+    whole = entries[0].read_bytes()
+    entries[0].write_bytes(whole[: len(whole) // 2])
+    r3 = prover.jit_compile_check(W, bc, spans, it)
+    s3 = prover.jit_cache_stats()
+    assert r3 == r1 and s3["compiled"] - s2["compiled"] == 1 and s3["from_disk"] - s2["from_disk"] == r1["kernels"] - 1
+    assert entries[0].read_bytes()[:8] == b"PWJC0001" and len(entries[0].read_bytes()) > len(whole) // 2  # (code objects are not byte-reproducible)
+    # an entry whose stored source is another unit's (a file-name collision): not used
+    entries[0].write_bytes(entries[-1].read_bytes() if len(entries) > 1 else whole[:24] + b"x" * (len(whole) - 24))
+    r4 = prover.jit_compile_check(W, bc, spans, it)
+    assert r4 == r1 and prover.jit_cache_stats()["compiled"] - s3["compiled"] == 1
+    monkeypatch.setenv("POWDR_JIT_CACHE", "0")
+    s4 = prover.jit_cache_stats()
+    r5 = prover.jit_compile_check(W, bc, spans, it)
+    s5 = prover.jit_cache_stats()
+    assert r5 == r1 and s5["compiled"] - s4["compiled"] == r1["kernels"] and s5["from_disk"] == s4["from_disk"]
+
+
 def test_jit_is_off_with_POWDR_JIT_0(monkeypatch):
     from powdr_amd import prover
 
