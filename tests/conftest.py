@@ -9,6 +9,13 @@ if str(ROOT) not in sys.path:
 
 REFERENCE = Path("/root/reference")
 
+# the test suite keeps the specialised kernels' code objects under the system temporary directory instead of ~/.cache/powdr_jit
+# (the product's default): nothing outside the repository and /tmp is written by running the tests
+import os  # noqa: E402
+import tempfile  # noqa: E402
+
+os.environ.setdefault("POWDR_JIT_CACHE_DIR", str(Path(tempfile.gettempdir()) / "powdr_jit_cache"))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
