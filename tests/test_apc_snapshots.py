@@ -559,3 +559,46 @@ def test_product_host_orchestration_on_the_golden_machines(name):
     assert sm.verify_logup(proof, W, 6, bc, spans, *it, num_queries=6) == 0
     pr.close()
     h_apc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in sorted(SNAPSHOTS) if n.startswith(("complex/", "superblocks/"))])
+def test_specialised_kernels_on_the_golden_machines(name, monkeypatch):
+    """The run-time specialised (hiprtc) quotient / LogUp kernels on the reference's golden machines — real optimiser output: shared
+    sub-expressions, degree-3 constraints, interactions of every bus — forced on at 2^6 rows (the default policy specialises tall traces
+    only): the proof words equal the interpreter's, both verifiers accept."""
+    import torch
+    from oracle import stark_model as sm
+    from powdr_amd import host, prover, tracegen as tg
+
+    snap, pcs, wires, table, rbs, wpc = block_of(name)
+    calls, H = 48, 64
+    rec, info = vm.execute_block(table, pcs, wpc, calls, seed=len(name) * 7 + len(wires))
+    cols, (src, definitions), cons, _ = apc_trace(snap, table, rec)
+    doc = apc_document(snap, pcs, wires, table, src, definitions, cons)
+    h_apc = host.Apc(doc)
+    W = h_apc.width
+    has = [len(x) > 0 for x in doc["subs"]]
+    lib_table, n_lib, words = h_apc.instruction_table()
+    packed = np.zeros((words, calls), np.uint32)
+    packed[0] = rec[0]
+    for e, full in zip(lib_table, [t_ for t_, h_ in zip(table, has) if h_]):
+        nw = oc.RECORD_WORDS[int(full["kind"])]
+        packed[e.rec_off:e.rec_off + nw] = rec[int(full["rec_off"]):int(full["rec_off"]) + nw]
+    d_rec = torch.from_numpy(packed.view(np.int32).reshape(-1).copy()).cuda()
+    out = tg.DeviceMatrix.zeros(H, W)
+    h_apc.generate_witness_from_records(d_rec.data_ptr(), calls, out.ptr(), None)
+    torch.cuda.synchronize()
+    bc, spans = h_apc.compile_constraints()
+    it = h_apc.compile_bus(1)
+    proofs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("POWDR_JIT", mode)
+        pr = prover.Prover(W, bc, spans, num_queries=6, interactions=it)
+        proofs[mode] = pr.prove(out.ptr(), 6)
+        assert (pr.specialised()["state"] == 1) if mode == "1" else (pr.specialised()["state"] <= 0), (mode, pr.specialised())
+        pr.close()
+    assert (proofs["1"] == proofs["0"]).all()
+    assert prover.verify_logup(proofs["1"], W, 6, bc, spans, it, num_queries=6)[0] == 0
+    assert sm.verify_logup(proofs["1"], W, 6, bc, spans, *it, num_queries=6) == 0
+    h_apc.close()
