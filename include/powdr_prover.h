@@ -211,6 +211,14 @@ int pw_prover_max_constraint_degree(const PwProver* p);
  * kernels, their code-object bytes and the number of code chunks (each NULL = skip). */
 int pw_prover_specialise(PwProver* p);
 int pw_prover_specialised(const PwProver* p, size_t* n_kernels, size_t* code_bytes, size_t* n_chunks);
+/* Test hook: the HIP source the generator emits for translation unit `unit` of an AIR's specialised kernels (which: 0 = quotient
+ * numerator, 1 = LogUp permutation columns; chunk_cost / chunks_per_unit 0 = the defaults), without compiling it: lets a CPU-only
+ * test build the generated code for the HOST and execute it. Returns the source length (0: no such unit). */
+size_t pw_jit_generated_source(uint32_t width, const uint32_t* cons_bytecode, size_t bytecode_len, const uint32_t* cons_spans, size_t n_constraints,
+                               const uint32_t* interactions, size_t n_interactions, const uint32_t* inter_spans, size_t n_inter_spans,
+                               const uint32_t* inter_bytecode, size_t inter_bytecode_len, int which, uint32_t chunk_cost, uint32_t chunks_per_unit,
+                               size_t unit, char* buf, size_t cap, char* kernel_name, size_t name_cap, uint32_t* first_chunk, uint32_t* n_chunks,
+                               uint32_t* total_chunks);
 /* Compiled code objects are kept on disk across processes: $POWDR_JIT_CACHE_DIR, else $XDG_CACHE_HOME/powdr_jit, else
  * $HOME/.cache/powdr_jit (POWDR_JIT_CACHE=0: off); an entry is keyed by the unit's source, the embedded headers and the compile options
  * and confirmed by comparing the stored source. Translation units this process compiled / loaded from disk so far: */

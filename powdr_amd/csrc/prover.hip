@@ -169,6 +169,29 @@ extern "C" int pw_jit_compile_check(uint32_t width, const uint32_t* bc, size_t b
     return rc;
 }
 
+// Test hook: the HIP source the code generator emits for translation unit `unit` of an AIR's specialised kernels (which: 0 quotient
+// numerator, 1 LogUp permutation columns) under explicit chunking parameters, no compilation. Returns the source's length (0: no such
+// unit / the programs did not compile to xbc); buf receives at most cap - 1 characters.
+extern "C" size_t pw_jit_generated_source(uint32_t width, const uint32_t* bc, size_t bc_len, const uint32_t* spans, size_t n_constraints,
+                                          const uint32_t* inter, size_t n_inter, const uint32_t* ispans, size_t n_ispans, const uint32_t* ibc,
+                                          size_t ibc_len, int which, uint32_t chunk_cost, uint32_t chunks_per_unit, size_t unit, char* buf, size_t cap,
+                                          char* kernel_name, size_t name_cap, uint32_t* first_chunk, uint32_t* n_chunks, uint32_t* total_chunks) {
+    const PwStarkConfig cfg{1, 0};
+    PwProver* p = inter ? create_prover_logup(&cfg, width, bc, bc_len, spans, n_constraints, inter, n_inter, ispans, n_ispans, ibc, ibc_len, false)
+                        : create_prover(&cfg, width, bc, bc_len, spans, n_constraints, false);
+    if (!p) return 0;
+    const pw::jit::Generated g = pw::generate_sources(p, which, chunk_cost ? chunk_cost : 8000, chunks_per_unit ? chunks_per_unit : 8);
+    pw_prover_destroy(p);
+    if (total_chunks) *total_chunks = g.n_chunks;
+    if (unit >= g.units.size()) return 0;
+    const pw::jit::Unit& u = g.units[unit];
+    if (buf && cap) { strncpy(buf, u.source.c_str(), cap - 1); buf[cap - 1] = 0; }
+    if (kernel_name && name_cap) { strncpy(kernel_name, u.kernel.c_str(), name_cap - 1); kernel_name[name_cap - 1] = 0; }
+    if (first_chunk) *first_chunk = u.first_chunk;
+    if (n_chunks) *n_chunks = u.n_chunks;
+    return u.source.size();
+}
+
 #define TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
 extern "C" int pw_prover_logup_path(const PwProver* p) { return !p || !p->logup ? 0 : p->d_iforms ? 2 : 1; }

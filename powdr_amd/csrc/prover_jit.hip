@@ -37,6 +37,19 @@ int launch_units(const jit::Generated& g, const std::vector<jit::ProgramPtr>& pr
 
 }  // namespace
 
+// the source generator alone, with explicit chunking parameters (pw_jit_generated_source: a test hook)
+jit::Generated generate_sources(const PwProver* p, int which, uint32_t chunk_cost, uint32_t chunks_per_unit) {
+    if (!p || !p->is_xbc) return {};
+    const jit::XbcView cons{p->h_xcode.data(), p->h_xspans.data(), p->n_constraints};
+    if (which == 0) {
+        if (!p->logup) return jit::gen_quotient(cons, nullptr, chunk_cost, chunks_per_unit);
+        const jit::LogupView lv = logup_view(p);
+        return jit::gen_quotient(cons, &lv, chunk_cost, chunks_per_unit);
+    }
+    if (which == 1 && p->logup) return jit::gen_logup_perm(logup_view(p), chunk_cost, chunks_per_unit);
+    return {};
+}
+
 int specialise_provers(PwProver* const* ps, size_t n, const uint32_t* log_heights, bool force) {
     // POWDR_JIT: 0 = never, 1 = always, unset = for traces of at least 2^POWDR_JIT_MIN_LOG_HEIGHT rows (default 18: compiling
     // costs ~0.3 ms of host time per emitted instruction, paid once per prover and amortised over its segments)

@@ -119,6 +119,7 @@ size_t lde_panel_cols(size_t H, size_t widest);
 // them in ONE concurrent hiprtc batch). force: regardless of the trace height. Returns 0; failures are not errors — the
 // prover keeps using the interpreter and records why (jit.error).
 int specialise_provers(PwProver* const* ps, size_t n, const uint32_t* log_heights, bool force);
+pw::jit::Generated generate_sources(const PwProver* p, int which, uint32_t chunk_cost, uint32_t chunks_per_unit);  // which: 0 quotient, 1 LogUp permutation
 inline bool specialised(const PwProver* p) { return p->jit.state == 1; }
 // the three stages with the specialised kernels; same contracts as quotient_eval / quotient_eval_logup / logup_perm_trace.
 // `perm` / `plde` must have room for 4 extra columns after the committed ones (the per-row sums and their LDE).

@@ -16,7 +16,7 @@ class PwStarkConfig(C.Structure):
 
 PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_logup_path", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_lde_fused", "pw_merkle_commit", "pw_poseidon2_permute_host",
-                  "pw_set_poseidon2_constants", "pw_get_poseidon2_constants", "pw_prover_specialise", "pw_prover_specialised", "pw_jit_compile_check", "pw_jit_cache_stats",
+                  "pw_set_poseidon2_constants", "pw_get_poseidon2_constants", "pw_prover_specialise", "pw_prover_specialised", "pw_jit_compile_check", "pw_jit_cache_stats", "pw_jit_generated_source",
                   "pw_prove_segments_multi", "pw_multi_last_merge", "pw_assign_units"]
 
 lib.pw_prover_create.restype = C.c_void_p
@@ -263,6 +263,36 @@ def jit_compile_check(width: int, cons_bytecode, cons_spans, interactions=None) 
     else:
         rc = f(width, vp(bc), len(bc), vp(sp), len(sp), None, 0, None, 0, None, 0, C.byref(k), C.byref(b), C.byref(c), err, 4096)
     return dict(rc=int(rc), kernels=k.value, code_bytes=b.value, chunks=c.value, error=err.value.decode(errors="replace"))
+
+
+def jit_generated_sources(width: int, cons_bytecode, cons_spans, interactions=None, which: int = 0, chunk_cost: int = 0, chunks_per_unit: int = 0):
+    """pw_jit_generated_source for every translation unit: ([{source, kernel, first_chunk, n_chunks}], total chunks). which: 0 = the
+    quotient numerator, 1 = the LogUp permutation columns. No compilation, no GPU (a test hook)."""
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    bc = np.ascontiguousarray(cons_bytecode, dtype=np.uint32)
+    sp = np.ascontiguousarray(cons_spans, dtype=np.uint32).reshape(-1, 2)
+    f = lib.pw_jit_generated_source
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                  C.c_int, C.c_uint32, C.c_uint32, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32),
+                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    if interactions is not None:
+        it, isp, ibc = (np.ascontiguousarray(a, dtype=np.uint32) for a in interactions)
+        tables = (vp(it), len(it.reshape(-1, 3)), vp(isp), len(isp.reshape(-1, 2)), vp(ibc), len(ibc))
+    else:
+        tables = (None, 0, None, 0, None, 0)
+    units, total = [], C.c_uint32()
+    while True:
+        first, n, name = C.c_uint32(), C.c_uint32(), C.create_string_buffer(64)
+        size = f(width, vp(bc), len(bc), vp(sp), len(sp), *tables, which, chunk_cost, chunks_per_unit, len(units), None, 0, name, 64, C.byref(first), C.byref(n),
+                 C.byref(total))
+        if size == 0:
+            break
+        buf = C.create_string_buffer(size + 1)
+        f(width, vp(bc), len(bc), vp(sp), len(sp), *tables, which, chunk_cost, chunks_per_unit, len(units), buf, size + 1, name, 64, C.byref(first), C.byref(n),
+          C.byref(total))
+        units.append(dict(source=buf.value.decode(), kernel=name.value.decode(), first_chunk=first.value, n_chunks=n.value))
+    return units, total.value
 
 
 def jit_cache_stats() -> dict:

@@ -319,6 +319,11 @@ extern "C" {
                                    prove: PwSegmentProveFn, user: *mut c_void, commitments: *mut u32, worker_of_segment: *mut u32) -> c_int;
     pub fn pw_multi_last_merge() -> c_int;
     pub fn pw_assign_units(cells: *const u64, n_units: usize, n_workers: usize, worker_of_unit: *mut u32) -> usize;
+    pub fn pw_jit_generated_source(width: u32, cons_bytecode: *const u32, bytecode_len: usize, cons_spans: *const u32, n_constraints: usize,
+                                   interactions: *const u32, n_interactions: usize, inter_spans: *const u32, n_inter_spans: usize,
+                                   inter_bytecode: *const u32, inter_bytecode_len: usize, which: c_int, chunk_cost: u32, chunks_per_unit: u32,
+                                   unit: usize, buf: *mut c_char, cap: usize, kernel_name: *mut c_char, name_cap: usize, first_chunk: *mut u32,
+                                   n_chunks: *mut u32, total_chunks: *mut u32) -> usize;
     pub fn pw_jit_cache_stats(units_compiled: *mut u64, units_from_disk: *mut u64);
     pub fn pw_jit_compile_check(width: u32, cons_bytecode: *const u32, bytecode_len: usize, cons_spans: *const u32, n_constraints: usize,
                                 interactions: *const u32, n_interactions: usize, inter_spans: *const u32, n_inter_spans: usize,

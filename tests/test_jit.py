@@ -2,6 +2,8 @@
 constraint / interaction programs emitted as straight-line HIP, compiled with hiprtc and run instead of the interpreter
 kernels. Exact field arithmetic => the proof words must not depend on the path: every test proves with POWDR_JIT=1 and
 POWDR_JIT=0 and compares both with the CPU oracle. CPU part: code generation + hiprtc cross-compilation need no GPU."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -228,3 +230,192 @@ def test_default_policy_specialises_tall_traces_only(gpu, monkeypatch):
     pr2 = prover.Prover(W, bc, spans, num_queries=3)
     assert pr2.specialise() and pr2.specialised()["state"] == 1
     pr2.close()
+
+
+# ---- the generated code executed on the HOST ----------------------------------------------------------------------------------
+_SHIM = """
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(x)
+static struct { unsigned x, y, z; } blockIdx, threadIdx;
+"""
+_W4 = 11  # F_p[X] / (X^4 - 11)
+
+
+def _ext_mul(a, b):
+    c = [0] * 7
+    for i in range(4):
+        for j in range(4):
+            c[i + j] += a[i] * b[j]
+    return [(c[k] + _W4 * (c[k + 4] if k < 3 else 0)) % P for k in range(4)]
+
+
+def _ext_add(a, b):
+    return [(x + y) % P for x, y in zip(a, b)]
+
+
+def _ext_scale(a, s):
+    return [x * s % P for x in a]
+
+
+def _ext_inv(a):
+    r, base, e = [1, 0, 0, 0], list(a), P ** 4 - 2
+    while e:
+        if e & 1:
+            r = _ext_mul(r, base)
+        base = _ext_mul(base, base)
+        e >>= 1
+    return r
+
+
+def _eval_postfix(code, row):
+    st, i = [], 0
+    while i < len(code):
+        op = int(code[i])
+        if op in (PA, PC):
+            st.append(int(row[int(code[i + 1])]) if op == PA else int(code[i + 1]) % P)
+            i += 2
+        elif op == NEG:
+            st.append(-st.pop() % P)
+            i += 1
+        else:
+            y, x = st.pop(), st.pop()
+            st.append((x + y) % P if op == ADD else (x - y) % P if op == SUB else x * y % P)
+            i += 1
+    return st[0]
+
+
+def _run_units_on_the_host(tmp_path, units, which, total_chunks, arrays, n_rows):
+    """Every unit: shim + generated source + a driver that walks (chunk, row) like the grid would; built with the host compiler of the
+    ROCm LLVM (plain C++: the embedded headers have host paths for everything), loaded with ctypes."""
+    import ctypes as C
+    import shutil
+    import subprocess
+
+    cxx = "/opt/rocm/lib/llvm/bin/clang++" if Path("/opt/rocm/lib/llvm/bin/clang++").exists() else shutil.which("g++")
+    csrc = Path(__file__).resolve().parents[1] / "powdr_amd" / "csrc"
+    for k, u in enumerate(units):
+        if which == 0:
+            driver = f"""
+extern "C" void run(const uint32_t* T, const uint32_t* Pm, size_t N, const bb::Ext* apow, const uint32_t* al4, const bb::Ext* blpow, uint32_t* part, uint32_t* unused) {{
+    bb::Ext al; memcpy(&al, al4, 16);
+    for (unsigned y = 0; y < {u['n_chunks']}u; ++y) for (size_t j = 0; j < N; ++j) {{
+        blockIdx.x = (unsigned)(j / 256); blockIdx.y = y; threadIdx.x = (unsigned)(j % 256);
+        {u['kernel']}(T, Pm, N, apow, al, blpow, part);
+    }}
+}}"""
+        else:
+            driver = f"""
+extern "C" void run(const uint32_t* T, const uint32_t* Pm, size_t N, const bb::Ext* apow, const uint32_t* al4, const bb::Ext* blpow, uint32_t* perm, uint32_t* rowsum) {{
+    bb::Ext al; memcpy(&al, al4, 16);
+    for (unsigned y = 0; y < {u['n_chunks']}u; ++y) for (size_t j = 0; j < N; ++j) {{
+        blockIdx.x = (unsigned)(j / 256); blockIdx.y = y; threadIdx.x = (unsigned)(j % 256);
+        {u['kernel']}(T, N, al, blpow, perm, rowsum);
+    }}
+}}"""
+        src = tmp_path / f"unit_{which}_{total_chunks}_{k}.cpp"
+        src.write_text(_SHIM + u["source"] + driver)
+        so = src.with_suffix(".so")
+        subprocess.run([cxx, "-x", "c++", "-std=c++17", "-O1", "-shared", "-fPIC", f"-I{csrc}", str(src), "-o", str(so)], check=True, capture_output=True)
+        fn = C.CDLL(str(so)).run
+        fn.restype = None
+        fn.argtypes = [C.c_void_p] * 2 + [C.c_size_t] + [C.c_void_p] * 5
+        fn(*[a.ctypes.data if isinstance(a, np.ndarray) else a for a in (arrays["T"], arrays["Pm"], n_rows, arrays["apow"], arrays["al"], arrays["blpow"], arrays["out0"],
+                                                                         arrays["out1"])])
+
+
+def _golden_machine_air(name):
+    """(W, (bc, spans), interactions) of one of the reference's golden APC machines (tests/golden/apc_snapshots.json.gz)"""
+    import gzip
+    import json
+
+    from powdr_amd import air_text
+
+    snap = json.loads(gzip.open(Path(__file__).parent / "golden" / "apc_snapshots.json.gz").read())[name]
+    air = air_text.TextAir("apc", snap["columns"], snap["constraints"], [(b, m, a) for b, m, a in snap["interactions"]])
+    bc, spans, it = air.tables()
+    return len(snap["columns"]), (bc, spans), it
+
+
+@pytest.mark.parametrize("air,chunk_cost", [("hand", 200), ("hand", 100000), ("complex/memcpy_block", 400), ("single_instructions/single_div", 100000)])
+def test_generated_code_runs_on_the_host_and_means_what_it_should(tmp_path, air, chunk_cost):
+    """The code generator's output EXECUTED, without a GPU: the generated translation units are plain C++ over the embedded headers,
+    so a shim (`__global__` = nothing, blockIdx / threadIdx = globals) builds them for the host. On random data, for a chunking into
+    several chunks and units and for one big chunk:
+      * the LogUp permutation columns are q_g = sum_{i in g} m_i / (alpha + bus_i + sum_j beta^(j+1) a_ij), the per-chunk row sums add
+        up to sum_g q_g,
+      * the quotient numerator's chunk parts add up to sum_c alpha^c C_c + sum_g alpha^(nc+g) (q_g prod d_i - sum_i m_i prod_{l != i} d_l)
+    in F_p^4, computed here with plain modular arithmetic. (The same kernels on the GPU: the tests below.)"""
+    from powdr_amd import prover
+
+    W, (bc, spans), it = hand_made_air() if air == "hand" else _golden_machine_air(air)
+    inter, ispans, ibc = it
+    starts = prover.logup_group_starts(it)
+    n_groups, n_cons, N = len(starts) - 1, len(spans), 24 if air == "hand" else 6
+    rng = np.random.default_rng(chunk_cost)
+    canon = {"T": rng.integers(0, P, (W, N)), "Pm": rng.integers(0, P, (4 * n_groups + 4, N)), "apow": rng.integers(0, P, (n_cons + n_groups + 2, 4)),
+             "al": rng.integers(0, P, 4), "blpow": rng.integers(0, P, (9, 4))}
+    if air == "hand":
+        canon["T"][3, :5] = 0  # rows whose multiplicities vanish: the zero-multiplicity guard
+        canon["T"][4, :3] = 0
+        canon["T"][5, :3] = 0
+    else:
+        canon["T"][:, 0] = 0   # an all-zero row (a padding row of a real trace): every multiplicity vanishes
+    monty = {k: om.to_monty(np.ascontiguousarray(v, np.uint32)) for k, v in canon.items()}
+    T = canon["T"]
+    # ---- expected values, canonical -----------------------------------------------------------------------------------------
+    al, bl = [int(x) for x in canon["al"]], [[int(x) for x in b] for b in canon["blpow"]]
+    q_want = np.zeros((n_groups, N, 4), np.int64)
+    quot_want = np.zeros((N, 4), np.int64)
+    for r in range(N):
+        row = T[:, r]
+        acc = [0, 0, 0, 0]
+        for c, (off, ln) in enumerate(spans.tolist()):
+            acc = _ext_add(acc, _ext_scale([int(x) for x in canon["apow"][c]], _eval_postfix(bc[off:off + ln], row)))
+        for g in range(n_groups):
+            ms, ds = [], []
+            for i in range(int(starts[g]), int(starts[g + 1])):
+                bus, n_args, s0 = (int(x) for x in inter[i])
+                ev = lambda s: _eval_postfix(ibc[int(ispans[s][0]):int(ispans[s][0]) + int(ispans[s][1])], row)
+                ms.append(ev(s0))
+                d = _ext_add(al, [bus % P, 0, 0, 0])
+                for j in range(n_args):
+                    d = _ext_add(d, _ext_scale(bl[j + 1], ev(s0 + 1 + j)))  # blpow[k] = beta^k: argument j meets beta^(j+1)
+                ds.append(d)
+            q = [0, 0, 0, 0]
+            for m, d in zip(ms, ds):
+                q = _ext_add(q, _ext_scale(_ext_inv(d), m))
+            q_want[g, r] = q
+            pq = [int(canon["Pm"][4 * g + k, r]) for k in range(4)]  # the committed (here: random) q_g the quotient reads
+            prod_all = [1, 0, 0, 0]
+            for d in ds:
+                prod_all = _ext_mul(prod_all, d)
+            term = _ext_mul(pq, prod_all)
+            for i, m in enumerate(ms):
+                rest = [1, 0, 0, 0]
+                for l, d in enumerate(ds):
+                    if l != i:
+                        rest = _ext_mul(rest, d)
+                term = _ext_add(term, _ext_scale(rest, -m % P))
+            acc = _ext_add(acc, _ext_mul([int(x) for x in canon["apow"][n_cons + g]], term))
+        quot_want[r] = acc
+    # ---- the generated code ---------------------------------------------------------------------------------------------------
+    for which in (1, 0):
+        units, total = prover.jit_generated_sources(W, bc, spans, it, which, chunk_cost, 2)
+        assert units and total >= (2 if chunk_cost <= 400 else 1) and sum(u["n_chunks"] for u in units) == total
+        out0 = np.zeros((max(total, n_groups) * 4 + 4, N), np.uint32) if which == 0 else np.zeros((4 * n_groups + 4, N), np.uint32)
+        out1 = np.zeros((total * 4, N), np.uint32)
+        _run_units_on_the_host(tmp_path, units, which, total, dict(monty, out0=out0, out1=out1), N)
+        if which == 1:
+            got_q = om.from_monty(out0[:4 * n_groups]).astype(np.int64).reshape(n_groups, 4, N).transpose(0, 2, 1)
+            assert (got_q == q_want).all()
+            rowsum = om.from_monty(out1).astype(np.int64).reshape(total, 4, N).sum(axis=0) % P
+            assert (rowsum.T == q_want.sum(axis=0) % P).all()
+        else:
+            parts = om.from_monty(out0[:total * 4]).astype(np.int64).reshape(total, 4, N).sum(axis=0) % P
+            assert (parts.T == quot_want).all()
