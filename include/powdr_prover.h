@@ -193,6 +193,18 @@ void pw_commitment_digest(const uint32_t* roots8, size_t n, uint32_t* digest8);
  * pay for the allocation (tens of gigabytes for wide traces). Buffers only grow; calling it is optional. */
 int pw_prover_reserve(PwProver* p, uint32_t log_height);
 
+/* STREAMED proofs. A resident proof keeps the low-degree extension of every committed column in HBM (8 bytes per committed cell
+ * next to the caller's trace); BASELINE configs[2] — the reference's default segment height 2^22
+ * (/root/reference/openvm-riscv/src/lib.rs:366-371) with the bus interactions PowdrAir::eval always pushes
+ * (/root/reference/openvm/src/powdr_extension/chip.rs:117-129) — would need 280 GB for 3 731 + 4 632 columns. When that does not
+ * fit, pw_prover_prove / pw_prover_trace_root / pw_prover_reserve switch to the streamed mode by themselves: the prover keeps the
+ * columns' COEFFICIENT arrays (4 bytes per committed cell) and walks the extended domain as 2^b sub-cosets (rows r + 2^b i),
+ * rebuilding the LDE rows of all columns for one sub-coset at a time — for the leaf hashes of the commitments, for the quotient and
+ * for the query answers. Same proof words as the resident mode. POWDR_STREAM_LOG_BLOCKS=0 forces resident, =b (>= 1) streamed.
+ * pw_prover_stream_log_blocks: the mode a proof of a 2^log_height-row trace would run in with the memory free NOW — 0 resident,
+ * b >= 1 streamed over 2^b sub-cosets, -1 not even that fits. */
+int pw_prover_stream_log_blocks(const PwProver* p, uint32_t log_height);
+
 /* Highest degree (in the trace columns) among the constraint programs the prover was created with; 99 if one of them
  * is malformed or not polynomial. The blow-up-2 quotient carries degree <= 3 — the reference's bound
  * 2 * DEFAULT_APP_LOG_BLOWUP + 1 (openvm/src/lib.rs:97-101); a prover with a higher value produces proofs that do not
@@ -248,6 +260,12 @@ int pw_lde_batch(const uint32_t* d_trace, uint32_t width, uint32_t log_height, u
  * inverse and of the forward transform share one kernel, the coefficient array is never written (d_tmp: width x H words of
  * scratch for the strided stages of traces taller than 2^12 rows; its contents are unspecified afterwards). */
 int pw_lde_fused(const uint32_t* d_trace, uint32_t width, uint32_t log_height, uint32_t* d_tmp, uint32_t* d_lde);
+
+/* One sub-coset of the LDE from coefficient arrays (the stage the streamed mode is built on): d_coeffs as pw_lde_batch leaves them
+ * (width x H, bit-reversed, H-scaled); d_out (width x 2H / 2^log_blocks) receives the rows r + 2^log_blocks * i of the LDE, i.e. the
+ * evaluations on (31 g_(n+1)^r) <g_(n+1)^(2^log_blocks)>; d_scale: H words of scratch. 1 <= log_blocks <= log_height. */
+int pw_lde_subcoset(const uint32_t* d_coeffs, uint32_t width, uint32_t log_height, uint32_t log_blocks, uint32_t r, uint32_t* d_scale,
+                    uint32_t* d_out);
 
 /* Poseidon2 Merkle tree of a column-major matrix; d_digests gets (2*height - 1) * 8 words,
  * leaves first, root last. */

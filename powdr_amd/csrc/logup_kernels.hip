@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* 
                                                                  const uint32_t* __restrict__ spans, uint32_t nc, LogupProgram lp,
                                                                  const Ext* __restrict__ apow, Ext al, const Ext* __restrict__ blpow,
                                                                  Ext S, uint32_t zval_even, uint32_t zval_odd, uint32_t shift,
-                                                                 uint32_t wN, uint32_t ginv, uint32_t* __restrict__ q) {
+                                                                 uint32_t wN, uint32_t ginv, uint32_t* __restrict__ q, int main_only) {
     __shared__ uint32_t stack_lds[kStackCap * kBlock];
     uint32_t* stk = stack_lds + threadIdx.x;
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -176,9 +176,11 @@ __global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* 
     for (uint32_t g = 0; g < lp.n_groups; ++g) {
         const uint32_t* pc = plde + (size_t)(4 * g) * N;
         const Ext qi = {{pc[j], pc[N + j], pc[2 * N + j], pc[3 * N + j]}};
-        const Ext qn = {{pc[jn], pc[N + jn], pc[2 * N + jn], pc[3 * N + jn]}};
-        sumq = bb::ext_add(sumq, qi);
-        sumq_next = bb::ext_add(sumq_next, qn);
+        if (!main_only) {
+            const Ext qn = {{pc[jn], pc[N + jn], pc[2 * N + jn], pc[3 * N + jn]}};
+            sumq = bb::ext_add(sumq, qi);
+            sumq_next = bb::ext_add(sumq_next, qn);
+        }
         const uint32_t i0 = lp.d_gstarts[g], i1 = lp.d_gstarts[g + 1];
         Ext num, den;
         for (uint32_t i = i0; i < i1; ++i) {
@@ -196,6 +198,11 @@ __global__ __launch_bounds__(kBlock) void quotient_logup_kernel(const uint32_t* 
         wide.fma(apow[nc + g], bb::ext_sub(bb::ext_mul(qi, den), num));
     }
     Ext acc = wide.result();
+    if (main_only) {  // the streamed path: `lde` / `plde` hold one sub-coset, the boundary terms are added by quotient_logup_tail_kernel
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[(size_t)k * N + j] = acc.c[k];
+        return;
+    }
     const uint32_t* pp = plde + (size_t)(4 * lp.n_groups) * N;
     const Ext phi = {{pp[j], pp[N + j], pp[2 * N + j], pp[3 * N + j]}};
     const Ext phin = {{pp[jn], pp[N + jn], pp[2 * N + jn], pp[3 * N + jn]}};
@@ -357,13 +364,14 @@ int quotient_logup_tail(const uint32_t* part, uint32_t n_chunks, const uint32_t*
 
 int quotient_eval_logup(const uint32_t* lde, const uint32_t* plde, size_t N, int logN, const ConstraintProgram& prog,
                         const LogupProgram& lp, const bb::Ext* d_apow, bb::Ext al, const bb::Ext* d_blpow, bb::Ext S,
-                        uint32_t zval_even, uint32_t zval_odd, uint32_t* q) {
+                        uint32_t zval_even, uint32_t zval_odd, uint32_t* q, bool main_only) {
     const uint32_t shift = bb::to_monty(field::kCosetShift), wN = field::root_of_unity(logN);
     const uint32_t ginv = bb::inv(field::root_of_unity(logN - 1));
+    const int mo = main_only ? 1 : 0;
     ScopedKernelTimer t("quotient_logup_kernel");
     call_stats()[kStatInterpreterKernelLaunches] += 1;
 #define PW_LAUNCH_QL(X, F) hipLaunchKernelGGL((quotient_logup_kernel<X, F>), dim3(div_up(N, kBlock)), dim3(kBlock), 0, stream(), lde, plde, N, \
-                                            prog.d_bytecode, prog.d_spans, prog.n_constraints, lp, d_apow, al, d_blpow, S, zval_even, zval_odd, shift, wN, ginv, q)
+                                            prog.d_bytecode, prog.d_spans, prog.n_constraints, lp, d_apow, al, d_blpow, S, zval_even, zval_odd, shift, wN, ginv, q, mo)
     if (prog.is_xbc) { if (lp.d_forms) PW_LAUNCH_QL(true, true); else PW_LAUNCH_QL(true, false); }
     else { if (lp.d_forms) PW_LAUNCH_QL(false, true); else PW_LAUNCH_QL(false, false); }
 #undef PW_LAUNCH_QL

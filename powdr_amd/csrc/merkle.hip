@@ -29,7 +29,9 @@ uint64_t g_params_uploaded = 0;  // bit d: the __constant__ table of device d ho
 template <int MINW>
 __global__ __launch_bounds__(kBlock, MINW) void leaf_hash_kernel(const uint32_t* __restrict__ m, size_t height,
                                                             uint32_t width, size_t col_stride,
-                                                            uint32_t* __restrict__ digests) {
+                                                            uint32_t* __restrict__ digests, size_t dstride, size_t doff) {
+    // row j's digest goes to slot j * dstride + doff (1, 0: the matrix is the whole committed matrix; 2^b, r: it holds the rows
+    // r + 2^b i of it — one sub-coset of the streamed prover)
     const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= height) return;
     uint32_t st[16];
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(kBlock, MINW) void leaf_hash_kernel(const uint32_t*
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) st[k] = bb::reduce_2p(st[k]);
-    uint4* out = reinterpret_cast<uint4*>(digests + j * 8);
+    uint4* out = reinterpret_cast<uint4*>(digests + (j * dstride + doff) * 8);
     out[0] = make_uint4(st[0], st[1], st[2], st[3]);
     out[1] = make_uint4(st[4], st[5], st[6], st[7]);
 }
@@ -294,17 +296,25 @@ uint32_t* merkle_root_mailbox(uint32_t** device_ptr) {
     return mb.host;
 }
 
-int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests, uint32_t* root_out) {
+int merkle_leaf_hash(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests, size_t digest_stride,
+                     size_t digest_offset) {
     int rc = poseidon2_upload_params();
     if (rc) return rc;
-    {
-        ScopedKernelTimer t("leaf_hash_kernel");
-        if (hash_min_waves() >= 8)
-            hipLaunchKernelGGL(leaf_hash_kernel<8>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width, col_stride, digests);
-        else
-            hipLaunchKernelGGL(leaf_hash_kernel<6>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width, col_stride, digests);
-    }
-    return build_levels(digests, height, root_out);
+    ScopedKernelTimer t("leaf_hash_kernel");
+    if (hash_min_waves() >= 8)
+        hipLaunchKernelGGL(leaf_hash_kernel<8>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width, col_stride, digests,
+                           digest_stride, digest_offset);
+    else
+        hipLaunchKernelGGL(leaf_hash_kernel<6>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), m, height, width, col_stride, digests,
+                           digest_stride, digest_offset);
+    return (int)hipGetLastError();
+}
+
+int merkle_build_levels(uint32_t* digests, size_t n_leaves, uint32_t* root_out) { return build_levels(digests, n_leaves, root_out); }
+
+int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests, uint32_t* root_out) {
+    const int rc = merkle_leaf_hash(m, height, width, col_stride, digests, 1, 0);
+    return rc ? rc : build_levels(digests, height, root_out);
 }
 
 int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, uint32_t* d_inject) {

@@ -57,6 +57,15 @@ __global__ void bitrev_copy_kernel(const uint32_t* in, uint32_t* out, int n) {
     out[i] = in[k];
 }
 
+// scale[Q] = s^k / 2^n * w^k with k = bitrev_n(Q): the coset scaling of coefficient k on the sub-coset (s w) <g_m> of the LDE domain,
+// in the bit-reversed order the coefficient arrays have (subcoset_lde)
+__global__ void fold_scale_kernel(const uint32_t* __restrict__ shift, int n, uint32_t w, uint32_t* __restrict__ out) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ((size_t)1 << n)) return;
+    const uint32_t k = n ? (__brev((uint32_t)q) >> (32 - n)) : 0u;
+    out[q] = bb::mul(shift[k], bb::pow_u32(w, k));
+}
+
 struct GroupParams {
     int n;        // log2 of the transform size
     int s0;       // first stage of the group
@@ -70,6 +79,7 @@ struct GroupParams {
     unsigned long long n_tiles;  // tiles per column = 2^(n-B)
     int canonical_out;  // forward transform: the last group reduces its [0, 2p) values to [0, p) when it stores
     unsigned twt_off[4];  // per round: offset of its twiddle table (contiguous groups of the fused LDE kernel, see FusedTwiddles)
+    int fold;     // FOLD loads (sub-coset evaluation): element g of the transform's input is the sum of 2^fold scaled coefficients
 };
 
 __device__ __forceinline__ uint32_t lds_phys(uint32_t l) { return l + (l >> 5); }
@@ -160,6 +170,27 @@ __device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t base_top,
     }
 }
 
+// FOLD load (sub-coset evaluation, subcoset_lde below): input element g of a size-2^n' transform is
+//   sum_{t < 2^f} src[(g << f) + t] * scale[(g << f) + t]
+// — the polynomial reduced modulo x^(2^n') - c on the sub-coset, in bit-reversed order: the 2^f coefficients that fold onto one
+// position are contiguous. Canonical result.
+__device__ __forceinline__ uint32_t fold_load(const uint32_t* __restrict__ src, const uint32_t* __restrict__ sc, size_t g, int f) {
+    const size_t q = g << f;
+    if (f == 0) return bb::mul(src[q], sc[q]);
+    if (f == 1) {
+        const uint2 a = *reinterpret_cast<const uint2*>(src + q), s = *reinterpret_cast<const uint2*>(sc + q);
+        return bb::mul2(a.x, s.x, a.y, s.y);
+    }
+    const uint4* pa = reinterpret_cast<const uint4*>(src + q);
+    const uint4* ps = reinterpret_cast<const uint4*>(sc + q);
+    uint32_t acc = 0u;
+    for (int t = 0; t < (1 << (f - 2)); ++t) {
+        const uint4 a = pa[t], s = ps[t];
+        acc = bb::add(acc, bb::add(bb::mul2(a.x, s.x, a.y, s.y), bb::mul2(a.z, s.z, a.w, s.w)));
+    }
+    return acc;
+}
+
 // One round of a group, slot by slot (a slot = the R elements a thread combines). A round is an
 // in-place network: every slot reads and writes the same R tile positions, so slots need no
 // barrier among themselves; barriers separate rounds only. The first round of a group loads from
@@ -167,11 +198,13 @@ __device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t base_top,
 // EXPAND: `src` is the H-sized bit-reversed coefficient array (n = log2(2H)); element g of the
 // 2H-sized vector is src[g >> 1] * scale_br[g >> 1].
 // `tw_base` enters as the twiddle base of this round's slot 0 and leaves as the one of the next round's slot 0.
-template <bool DIF, int LOGR, int EPT, bool EXPAND, bool TWT = false>
+// MODE: 0 = plain loads, 1 = EXPAND, 2 = FOLD (fold_load above; `scale_br` is the sub-coset's scale table).
+template <bool DIF, int LOGR, int EPT, int MODE, bool TWT = false>
 __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, const GroupParams& gp, int round,
                                           const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                           const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid,
                                           uint32_t& tw_base, bool io_first = true, bool io_last = true) {
+    constexpr bool EXPAND = MODE == 1, FOLD = MODE == 2;
     const int rb = gp.rb[round];
     // io_first / io_last = false: the group's first round reads / its last round writes the LDS tile instead of HBM
     // (the fused LDE kernel chains two groups through LDS)
@@ -206,7 +239,17 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
         }
         // ---- load ----
         if (first) {
-            if (EXPAND ? vec_expand : vec_plain) {
+            if (FOLD) {
+                bool valid;
+                const size_t g0 = im.global(l0, valid);
+                if (valid) {
+#pragma unroll
+                    for (int rho = 0; rho < R; ++rho) x[rho] = fold_load(src, scale_br, g0 + ((size_t)rho << gshift), gp.fold);
+                } else {
+#pragma unroll
+                    for (int rho = 0; rho < R; ++rho) x[rho] = 0u;
+                }
+            } else if (EXPAND ? vec_expand : vec_plain) {
                 bool valid;
                 const size_t g0 = im.global(l0, valid);
                 const uint4* pc = reinterpret_cast<const uint4*>(src + (EXPAND ? (g0 >> 1) : g0));
@@ -288,7 +331,7 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
 }
 
 // TWT: `tw` is the group's twiddle TABLE (tile-invariant groups, see group_twiddles) instead of the transform's root table
-template <bool DIF, int LOGT, bool EXPAND, bool TWT = false>
+template <bool DIF, int LOGT, int MODE, bool TWT = false>
 __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                            size_t in_stride, size_t out_stride, GroupParams gp,
                                                            const uint32_t* __restrict__ tw,
@@ -306,10 +349,10 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     uint32_t tw_base = TWT ? 0u : load_twiddle_base<DIF>(im, gp, 0, 0, tid, tw);
     for (int r = 0; r < gp.n_rounds; ++r) {
         switch (gp.logr[r]) {
-            case 1: run_round<DIF, 1, EPT, EXPAND, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
-            case 2: run_round<DIF, 2, EPT, EXPAND, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
-            case 3: run_round<DIF, 3, EPT, EXPAND, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
-            default: run_round<DIF, 4, EPT, EXPAND, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            case 1: run_round<DIF, 1, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            case 2: run_round<DIF, 2, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            case 3: run_round<DIF, 3, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            default: run_round<DIF, 4, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
         }
         if (r + 1 < gp.n_rounds) __syncthreads();  // the next round reads what this round wrote
     }
@@ -322,10 +365,10 @@ __device__ __forceinline__ void run_group(uint32_t* tile, const IndexMap& im, co
     uint32_t tw_base = TWT ? 0u : load_twiddle_base<DIF>(im, gp, 0, 0, tid, tw);
     for (int r = 0; r < gp.n_rounds; ++r) {
         switch (gp.logr[r]) {
-            case 1: run_round<DIF, 1, EPT, false, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
-            case 2: run_round<DIF, 2, EPT, false, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
-            case 3: run_round<DIF, 3, EPT, false, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
-            default: run_round<DIF, 4, EPT, false, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            case 1: run_round<DIF, 1, EPT, 0, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            case 2: run_round<DIF, 2, EPT, 0, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            case 3: run_round<DIF, 3, EPT, 0, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            default: run_round<DIF, 4, EPT, 0, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
         }
         if (r + 1 < gp.n_rounds) __syncthreads();
     }
@@ -530,14 +573,15 @@ const GroupTwiddles* group_twiddles(const GroupParams& gp, bool dif) {
     return &g_group_tw.emplace(key, gt).first->second;
 }
 
+// fold_log >= 0: the first group loads with FOLD (`expand_scale_br` is then the sub-coset's scale table, subcoset_lde)
 template <bool DIF>
 void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n,
-                int first_stage, const uint32_t* tw, const uint32_t* expand_scale_br, const char* name) {
+                int first_stage, const uint32_t* tw, const uint32_t* expand_scale_br, const char* name, int fold_log = -1) {
     int logt = 12;
     auto groups = plan_groups(DIF, n, first_stage, logt);
     const uint32_t* src = in;
     size_t src_stride = in_stride;
-    bool expand = expand_scale_br != nullptr;
+    int mode = fold_log >= 0 ? 2 : expand_scale_br != nullptr ? 1 : 0;
     if (!groups.empty()) groups.back().canonical_out = 1;
     for (auto& g : groups) {
         const size_t tiles = (size_t)1 << (n - g.B);
@@ -545,21 +589,22 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
         const unsigned wgs = (unsigned)((tiles + per_wg - 1) / per_wg);
         const GroupTwiddles* gt = group_twiddles(g, DIF);  // tile-invariant groups read their twiddles from a table
         if (gt) for (int r = 0; r < 4; ++r) g.twt_off[r] = gt->off[r];
+        g.fold = mode == 2 ? fold_log : 0;
         for (uint32_t c0 = 0; c0 < cols; c0 += 65535u) {
             uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;
             ScopedKernelTimer t(name);
             const uint32_t* s_ = src + (size_t)c0 * src_stride;
             uint32_t* d_ = out + (size_t)c0 * out_stride;
             dim3 grid(wgs, cc), block(kBlock);
-#define PW_LAUNCH_NTT(LT, EX) do { if (gt) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, EX, true>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, gt->d, expand_scale_br); \
-                                   else hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, EX, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br); } while (0)
-            if (logt == 13) { if (expand) PW_LAUNCH_NTT(13, true); else PW_LAUNCH_NTT(13, false); }
-            else            { if (expand) PW_LAUNCH_NTT(12, true); else PW_LAUNCH_NTT(12, false); }
+#define PW_LAUNCH_NTT(LT, MD) do { if (gt) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, MD, true>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, gt->d, expand_scale_br); \
+                                   else hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, MD, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br); } while (0)
+            if (logt == 13) { if (mode == 2) PW_LAUNCH_NTT(13, 2); else if (mode == 1) PW_LAUNCH_NTT(13, 1); else PW_LAUNCH_NTT(13, 0); }
+            else            { if (mode == 2) PW_LAUNCH_NTT(12, 2); else if (mode == 1) PW_LAUNCH_NTT(12, 1); else PW_LAUNCH_NTT(12, 0); }
 #undef PW_LAUNCH_NTT
         }
         src = out;
         src_stride = out_stride;
-        expand = false;
+        mode = 0;
         expand_scale_br = nullptr;
     }
     if (groups.empty() && in != out) {
@@ -595,8 +640,8 @@ void launch_groups(std::vector<GroupParams>& groups, int logt, const uint32_t* i
             const uint32_t* s_ = src + (size_t)c0 * src_stride;
             uint32_t* d_ = out + (size_t)c0 * out_stride;
             dim3 grid(wgs, cc), block(kBlock);
-            if (logt == 13) hipLaunchKernelGGL((ntt_group_kernel<DIF, 13, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, (const uint32_t*)nullptr);
-            else hipLaunchKernelGGL((ntt_group_kernel<DIF, 12, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, (const uint32_t*)nullptr);
+            if (logt == 13) hipLaunchKernelGGL((ntt_group_kernel<DIF, 13, 0>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, (const uint32_t*)nullptr);
+            else hipLaunchKernelGGL((ntt_group_kernel<DIF, 12, 0>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, (const uint32_t*)nullptr);
         }
         src = out;
         src_stride = out_stride;
@@ -718,6 +763,31 @@ int coset_lde_from_coeffs(const uint32_t* coeffs, uint32_t* out, size_t in_strid
     }
     // stage 0 of the size-2^(n+1) DIT is the duplication done by the EXPAND load of the first group
     run_groups<false>(coeffs, out, in_stride, out_stride, cols, n + 1, 1, t1->tw_fwd, tn->shift_br, "ntt_group_kernel<dit>");
+    return (int)hipGetLastError();
+}
+
+// ---- sub-coset evaluation (the streamed prover, prover_stream.hip) -------------------------------------------------------
+// The LDE domain s <g_(n+1)> (2^(n+1) points) is the union of 2^b sub-cosets (s g_(n+1)^r) <g_m>, m = 2^(n+1-b), r < 2^b: rows
+// j = r + 2^b i of the LDE. On one of them x^m is the constant c = (s g^r)^m, so a polynomial of degree < 2^n is its remainder
+// modulo x^m - c there: b_i = sum_t a_(i + t m) c^t, 2^(b-1) coefficients per position (contiguous in bit-reversed order), then
+// a size-m transform with the coset scaling folded into the same load. Work: 2^n multiply-adds + (m / 2) log2 m butterflies per
+// column and sub-coset — all 2^b sub-cosets together cost one forward transform plus 2^(b-1) extra passes over the coefficients.
+int subcoset_scale(int n, int b, uint32_t r, uint32_t* scale) {
+    const Tables* tn = tables(n);
+    if (!tn) return (int)hipErrorOutOfMemory;
+    const uint32_t w = bb::pow_u32(field::root_of_unity(n + 1), r);
+    ScopedKernelTimer t("fold_scale_kernel");
+    hipLaunchKernelGGL(fold_scale_kernel, dim3(div_up((size_t)1 << n, 256)), dim3(256), 0, stream(), tn->shift, n, w, scale);
+    return (int)hipGetLastError();
+}
+
+int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b,
+                 const uint32_t* scale) {
+    const int nm = n + 1 - b;  // log2 of the sub-coset's size
+    if (b < 1 || nm < 1) return (int)hipErrorInvalidValue;
+    const Tables* tm = tables(nm);
+    if (!tm) return (int)hipErrorOutOfMemory;
+    run_groups<false>(coeffs, out, in_stride, out_stride, cols, nm, 0, tm->tw_fwd, scale, "ntt_group_kernel<dit>", b - 1);
     return (int)hipGetLastError();
 }
 

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <initializer_list>
 #include <vector>
 
 namespace pw {
@@ -40,6 +41,7 @@ int gather_records(const uint32_t* arena, const uint64_t* d_offsets, uint32_t wo
 using namespace pw;
 
 extern "C" void pw_prover_destroy(PwProver* p);
+extern "C" size_t pw_prover_device_bytes(const PwProver* p);
 extern "C" int pw_prover_specialise(PwProver* p);
 extern "C" int pw_prover_specialised(const PwProver* p, size_t* n_kernels, size_t* code_bytes, size_t* n_chunks);
 
@@ -236,41 +238,33 @@ int lde_matrix(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_
 
 namespace {
 
-// Buffers of the trace commitment, sized as pw_prover_prove needs them (so that a later prove does not reallocate)
-int ensure_commit_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
+// ---- streamed proofs ---------------------------------------------------------------------------------------------------
+// A proof needs the LDE of every committed column three times: to hash its rows, to evaluate the quotient on them and to answer
+// the queries (the DEEP numerator is a polynomial and is extended on its own, see step 4). Resident, that is 8 bytes per committed
+// cell next to the caller's trace: BASELINE configs[2] with its bus interactions (3 731 main + 4 632 permutation columns x 2^22
+// rows) would need 280 GB. In STREAMED mode (b >= 1) the prover keeps the COEFFICIENTS instead — the trace's in `tcoef`, the
+// permutation matrix's in place of the matrix — and walks the extended domain as 2^b sub-cosets (rows r + 2^b i): for each one the
+// LDE rows of all columns are rebuilt from the coefficients (ntt.hip subcoset_lde) into `lde`, consumed (leaf hash / quotient
+// terms / query rows) and dropped. Same field elements everywhere, hence the same proof words as the resident path
+// (tests/test_streamed_prover.py compares both with the oracle).
+// Mode: POWDR_STREAM_LOG_BLOCKS = 0 never, b >= 1 always with 2^b sub-cosets (tests); unset: resident when its buffers fit into
+// what the device has free (plus what the prover already holds), else the smallest b whose buffers do.
+struct BufferPlan {
+    size_t coef = 0, lde = 0, digests = 0, perm = 0, plde = 0, q = 0, qpart = 0, qcoef = 0, qlde = 0, ext_arena = 0, misc = 0,
+           tcoef = 0, fscale = 0, gbuf = 0;
+    size_t commit_total() const { return coef + lde + digests + tcoef + fscale; }
+    size_t total() const { return commit_total() + perm + plde + q + qpart + qcoef + qlde + ext_arena + misc + gbuf; }
+};
+
+void plan_buffers(const PwProver* p, uint32_t log_h, int b, CommitLayout& L, BufferPlan& B) {
     L.H = (size_t)1 << log_h;
     L.N = 2 * L.H;
+    L.b = b;
+    L.m = L.N >> b;
     L.tree_words = merkle_words(L.N);
     L.fri_words = 0;
     for (uint32_t l = 0; l < log_h; ++l) L.fri_words += merkle_words((L.N >> l) / 2);
     L.n_trees = p->logup ? 3 : 2;  // trace | quotient | (perm) | FRI
-    // coefficients exist only per column panel (1 GB by default; larger panels = fewer, larger launches): iNTT -> panel ->
-    // coset NTT into the resident LDE
-    const size_t widest = p->logup ? std::max<size_t>(p->width, 4 * ((size_t)p->n_groups + 1)) : p->width;
-    L.panel_cols = lde_panel_cols(L.H, widest);
-    TRY(p->coef.ensure(L.panel_cols * L.H * 4));
-    TRY(p->lde.ensure((size_t)p->width * L.N * 4));
-    TRY(p->digests.ensure((L.n_trees * L.tree_words + L.fri_words) * 4));
-    return 0;
-}
-
-
-// LDE + Merkle tree of the trace into p->lde / the first tree of p->digests; root (Montgomery) to the host
-int commit_trace(PwProver* p, const CommitLayout& L, const uint32_t* d_trace, uint32_t log_h, uint32_t* root) {
-    hipStream_t st = stream();
-    uint32_t* d_tdig = p->digests.as<uint32_t>();
-    TRY(lde_matrix(p, L, log_h, d_trace, p->width, p->lde.as<uint32_t>()));
-    TRY(merkle_commit_matrix(p->lde.as<uint32_t>(), L.N, p->width, L.N, d_tdig));
-    PW_HIP_TRY(hipMemcpyAsync(root, d_tdig + L.tree_words - 8, 32, hipMemcpyDeviceToHost, st));
-    PW_HIP_TRY(hipStreamSynchronize(st));
-    return 0;
-}
-
-
-// Every device buffer a proof of a 2^log_h-row trace needs (grown on demand; pw_prover_reserve calls this at set-up
-// time so that the first proof does not pay for tens of gigabytes of hipMalloc).
-int ensure_prove_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
-    TRY(ensure_commit_buffers(p, log_h, L));
     const size_t H = L.H, N = L.N;
     const int logN = (int)log_h + 1;
     const bool lg = p->logup;
@@ -279,27 +273,138 @@ int ensure_prove_buffers(PwProver* p, uint32_t log_h, CommitLayout& L) {
     const uint32_t Wp = lg ? 4 * (n_g + 1) : 0;
     const uint32_t K = W + 2 * Wp + 8;
     const uint32_t M = nc + (lg ? n_g + 3 : 0);
-    if (lg) {  // + the uncommitted per-row-sum columns of the specialised path (kJitExtraPermCols)
-        TRY(p->perm.ensure((size_t)(Wp + kJitExtraPermCols) * H * 4));
-        TRY(p->plde.ensure((size_t)(Wp + kJitExtraPermCols) * N * 4));
+    // coefficients exist only per column panel (1 GB by default; larger panels = fewer, larger launches): iNTT -> panel ->
+    // coset NTT into the resident LDE. Streamed: the panel serves the eight phi / row-sum columns only.
+    const size_t widest = b ? 8 : (lg ? std::max<size_t>(W, Wp) : W);
+    L.panel_cols = lde_panel_cols(H, widest);
+    B.coef = L.panel_cols * H * 4;
+    B.lde = b ? (size_t)(W + Wp) * L.m * 4 : (size_t)W * N * 4;
+    B.digests = (L.n_trees * L.tree_words + L.fri_words) * 4;
+    if (b) { B.tcoef = (size_t)W * H * 4; B.fscale = H * 4; B.gbuf = (size_t)24 * H * 4; }
+    if (lg) {  // + the uncommitted per-row-sum columns (kJitExtraPermCols; the streamed path keeps them on every path)
+        B.perm = (size_t)(Wp + kJitExtraPermCols) * H * 4;
+        B.plde = b ? (size_t)8 * N * 4 : (size_t)(Wp + kJitExtraPermCols) * N * 4;
     }
-    TRY(p->q.ensure(4 * N * 4));
+    B.q = 4 * N * 4;
+    const size_t q_rows = b ? L.m : N;
     if (!lg) {
-        const uint32_t chunks = quotient_chunks(N, nc);
-        if (chunks > 1) TRY(p->qpart.ensure((size_t)chunks * 4 * N * 4));
+        const uint32_t chunks = quotient_chunks(q_rows, nc);
+        if (chunks > 1) B.qpart = (size_t)chunks * 4 * q_rows * 4;
     }
-    TRY(p->qcoef.ensure(8 * H * 4));
-    TRY(p->qlde.ensure(8 * N * 4));
+    if (b) B.qpart += 4 * L.m * 4;  // the interpreter kernels' unscaled sums of one sub-coset
+    B.qpart = std::max(B.qpart, jit_part_bytes(p, H, q_rows));
+    B.qcoef = 8 * H * 4;
+    B.qlde = 8 * N * 4;
     // ext arena: FRI layer vectors v_0 (N) .. v_log_h (2): 2N ext; weights (H); LogUp: second weights, row sums
-    TRY(p->ext_arena.ensure((2 * N + (lg ? 3 : 1) * H + H / 4096 + 32) * sizeof(bb::Ext)));
+    B.ext_arena = (2 * N + (lg ? 3 : 1) * H + H / 4096 + 32) * sizeof(bb::Ext);
     const uint32_t n_chunks = div_up(H, 8192);
     const uint32_t dot_cols = std::max({W, Wp, 8u});
     const size_t misc_ext = 2 * (size_t)dot_cols * n_chunks + K + K + M + p->max_args + 64;  // ext_dot_columns2 keeps two sets of partial sums
     const uint32_t nq = p->cfg.num_queries;
     const size_t path_records = (size_t)nq * (L.n_trees * (size_t)logN + (size_t)log_h * logN) + 16;
-    const size_t misc_bytes = misc_ext * sizeof(bb::Ext) + (size_t)nq * 4 + (size_t)nq * (W + Wp + 8) * 4 + path_records * (8 + 32) +
-                              (size_t)nq * log_h * (8 + 16) + 4096;
-    TRY(p->misc.ensure(misc_bytes));
+    B.misc = misc_ext * sizeof(bb::Ext) + (size_t)nq * 8 + (size_t)nq * (W + Wp + 8) * 4 + path_records * (8 + 32) +
+             (size_t)nq * log_h * (8 + 16) + 4096;
+}
+
+// 0 = resident, b >= 1 = streamed over 2^b sub-cosets; < 0: nothing fits
+int stream_log_blocks(const PwProver* p, uint32_t log_h) {
+    const int b_max = (int)log_h - 1;  // sub-cosets of at least 4 rows
+    if (const char* e = getenv("POWDR_STREAM_LOG_BLOCKS")) {
+        const int v = atoi(e);
+        if (v <= 0 || b_max < 1) return 0;
+        return v < b_max ? v : b_max;
+    }
+    if (log_h < 16) return 0;  // (a few MB either way)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    // buffers are grown by free + malloc, so what the prover holds now counts as available; 8 % of head room for the
+    // allocator's granularity, the twiddle tables and the caller's own small allocations during the proof
+    const size_t avail = (size_t)((double)(free_b + pw_prover_device_bytes(p)) * 0.92);
+    for (int b = 0; b <= b_max && b <= 12; ++b) {
+        CommitLayout L;
+        BufferPlan B;
+        plan_buffers(p, log_h, b, L, B);
+        if (B.total() <= avail) return b;
+    }
+    return -1;
+}
+
+int apply_commit_buffers(PwProver* p, const BufferPlan& B) {
+    TRY(p->coef.ensure(B.coef));
+    TRY(p->lde.ensure(B.lde));
+    TRY(p->digests.ensure(B.digests));
+    if (B.tcoef) { TRY(p->tcoef.ensure(B.tcoef)); TRY(p->fscale.ensure(B.fscale)); }
+    return 0;
+}
+
+// Buffers of the trace commitment, sized as pw_prover_prove needs them (so that a later prove does not reallocate)
+int ensure_commit_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L) {
+    BufferPlan B;
+    plan_buffers(p, log_h, b, L, B);
+    return apply_commit_buffers(p, B);
+}
+
+// One pass over the sub-cosets of the extended domain (streamed mode): for every r < 2^b (`wanted`: only those) the rows r + 2^b i
+// of the LDE of the coefficient matrices `mats` (side by side, column stride L.m) are rebuilt in p->lde and handed to body(r).
+struct CoefMatrix { const uint32_t* coef; uint32_t cols; };
+template <class Body>
+int for_each_subcoset(PwProver* p, const CommitLayout& L, uint32_t log_h, std::initializer_list<CoefMatrix> mats, const std::vector<char>* wanted,
+                      Body&& body) {
+    uint32_t* blk = p->lde.as<uint32_t>();
+    uint32_t* fs = p->fscale.as<uint32_t>();
+    for (uint32_t r = 0; r < (1u << L.b); ++r) {
+        if (wanted && !(*wanted)[r]) continue;
+        TRY(subcoset_scale((int)log_h, L.b, r, fs));
+        size_t c0 = 0;
+        for (const CoefMatrix& mt : mats) {
+            if (mt.cols) TRY(subcoset_lde(mt.coef, blk + c0 * L.m, L.H, L.m, mt.cols, (int)log_h, L.b, fs));
+            c0 += mt.cols;
+        }
+        TRY(body(r));
+    }
+    return 0;
+}
+
+// streamed commitment of a matrix given by its coefficient arrays: every sub-coset's rows are hashed into their leaves
+int commit_coefficients(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_t* coef, uint32_t cols, uint32_t* d_tree) {
+    TRY(for_each_subcoset(p, L, log_h, {CoefMatrix{coef, cols}}, nullptr, [&](uint32_t r) {
+        return merkle_leaf_hash(p->lde.as<uint32_t>(), L.m, cols, L.m, d_tree, (size_t)1 << L.b, r);
+    }));
+    return merkle_build_levels(d_tree, L.N);
+}
+
+// LDE + Merkle tree of the trace into p->lde / the first tree of p->digests; root (Montgomery) to the host.
+// Streamed: the trace's coefficients into p->tcoef, the tree from the sub-cosets.
+int commit_trace(PwProver* p, const CommitLayout& L, const uint32_t* d_trace, uint32_t log_h, uint32_t* root) {
+    hipStream_t st = stream();
+    uint32_t* d_tdig = p->digests.as<uint32_t>();
+    if (L.b) {
+        TRY(intt_dif(d_trace, p->tcoef.as<uint32_t>(), L.H, L.H, p->width, (int)log_h));
+        TRY(commit_coefficients(p, L, log_h, p->tcoef.as<uint32_t>(), p->width, d_tdig));
+    } else {
+        TRY(lde_matrix(p, L, log_h, d_trace, p->width, p->lde.as<uint32_t>()));
+        TRY(merkle_commit_matrix(p->lde.as<uint32_t>(), L.N, p->width, L.N, d_tdig));
+    }
+    PW_HIP_TRY(hipMemcpyAsync(root, d_tdig + L.tree_words - 8, 32, hipMemcpyDeviceToHost, st));
+    PW_HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+
+// Every device buffer a proof of a 2^log_h-row trace needs (grown on demand; pw_prover_reserve calls this at set-up
+// time so that the first proof does not pay for tens of gigabytes of hipMalloc).
+int ensure_prove_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L) {
+    BufferPlan B;
+    plan_buffers(p, log_h, b, L, B);
+    TRY(apply_commit_buffers(p, B));
+    if (B.perm) { TRY(p->perm.ensure(B.perm)); TRY(p->plde.ensure(B.plde)); }
+    TRY(p->q.ensure(B.q));
+    if (B.qpart) TRY(p->qpart.ensure(B.qpart));
+    TRY(p->qcoef.ensure(B.qcoef));
+    TRY(p->qlde.ensure(B.qlde));
+    TRY(p->ext_arena.ensure(B.ext_arena));
+    TRY(p->misc.ensure(B.misc));
+    if (B.gbuf) TRY(p->gbuf.ensure(B.gbuf));
     return 0;
 }
 }  // namespace
@@ -311,17 +416,23 @@ extern "C" int pw_prover_trace_root(PwProver* p, const uint32_t* d_trace, uint32
     TRY(poseidon2_upload_params());
     CommitLayout L;
     p->committed_trace = nullptr;
-    TRY(ensure_commit_buffers(p, log_h, L));
+    (void)specialise_provers(&p, 1, &log_h, false);  // before the buffers are sized (the specialised kernels' partial sums)
+    const int sb = stream_log_blocks(p, log_h);
+    if (sb < 0) return (int)hipErrorOutOfMemory;
+    TRY(ensure_commit_buffers(p, log_h, sb, L));
     TRY(commit_trace(p, L, d_trace, log_h, p->committed_root));
     for (int i = 0; i < 8; ++i) root8[i] = bb::from_monty(p->committed_root[i]);
     p->committed_trace = d_trace;
     p->committed_log_h = log_h;
+    p->committed_b = sb;
     return (int)hipGetLastError();
 }
 
 extern "C" void pw_prover_destroy(PwProver* p) {
     if (!p) return;
-    for (DeviceBuf* b : {&p->coef, &p->lde, &p->digests, &p->q, &p->qcoef, &p->qlde, &p->ext_arena, &p->misc, &p->perm, &p->plde, &p->qpart}) b->release();
+    for (DeviceBuf* b : {&p->coef, &p->lde, &p->digests, &p->q, &p->qcoef, &p->qlde, &p->ext_arena, &p->misc, &p->perm, &p->plde, &p->qpart, &p->tcoef,
+                         &p->fscale, &p->gbuf})
+        b->release();
     for (void* q : {(void*)p->d_inter, (void*)p->d_ixspans, (void*)p->d_icode, (void*)p->d_gstarts, (void*)p->d_iforms}) if (q) (void)hipFree(q);
     if (p->d_bytecode) (void)hipFree(p->d_bytecode);
     if (p->d_spans) (void)hipFree(p->d_spans);
@@ -335,12 +446,24 @@ extern "C" int pw_prover_reserve(PwProver* p, uint32_t log_h) {
     if (!p || log_h < 1 || log_h > 26) return (int)hipErrorInvalidValue;
     (void)hipGetLastError();
     CommitLayout L;
-    return ensure_prove_buffers(p, log_h, L);
+    // the kernels are specialised NOW when the height policy will specialise them at the first proof: their partial-sum buffer is
+    // part of the reservation, and the seconds of compilation belong to set-up time as well
+    (void)specialise_provers(&p, 1, &log_h, false);
+    const int sb = stream_log_blocks(p, log_h);
+    if (sb < 0) return (int)hipErrorOutOfMemory;
+    return ensure_prove_buffers(p, log_h, sb, L);
+}
+
+// 0: the last reservation / proof of a 2^log_height-row trace would keep the LDE resident; b >= 1: it is streamed over 2^b sub-cosets
+// (the policy of stream_log_blocks for the CURRENT free memory); -1: not even the streamed buffers fit.
+extern "C" int pw_prover_stream_log_blocks(const PwProver* p, uint32_t log_h) {
+    if (!p || log_h < 1 || log_h > 26) return -1;
+    return stream_log_blocks(p, log_h);
 }
 
 extern "C" size_t pw_prover_device_bytes(const PwProver* p) {
     return p->coef.bytes + p->lde.bytes + p->digests.bytes + p->q.bytes + p->qcoef.bytes + p->qlde.bytes +
-           p->ext_arena.bytes + p->misc.bytes + p->perm.bytes + p->plde.bytes + p->qpart.bytes;
+           p->ext_arena.bytes + p->misc.bytes + p->perm.bytes + p->plde.bytes + p->qpart.bytes + p->tcoef.bytes + p->fscale.bytes + p->gbuf.bytes;
 }
 
 
@@ -367,9 +490,15 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     // digest arena: trace tree | quotient tree | (perm tree) | FRI trees
     const bool have_commitment = p->committed_trace == d_trace && p->committed_log_h == log_h;
     p->committed_trace = nullptr;  // one-shot
+    // resident LDE, or streamed over 2^sb sub-cosets of the extended domain ("streamed proofs" above)
+    const int sb = have_commitment ? p->committed_b : stream_log_blocks(p, log_h);
+    if (sb < 0) return (int)hipErrorOutOfMemory;
     CommitLayout L;
-    TRY(ensure_prove_buffers(p, log_h, L));
+    TRY(ensure_prove_buffers(p, log_h, sb, L));
     const size_t tree_words = L.tree_words, n_trees = L.n_trees;
+    const size_t m_sub = L.m;                                 // streamed: rows of a sub-coset
+    uint32_t* d_tcoef = p->tcoef.as<uint32_t>();              // streamed: the trace's coefficient arrays
+    uint32_t* d_blk = p->lde.as<uint32_t>();                  // streamed: the sub-coset being processed, all committed columns
     const uint32_t n_chunks = div_up(H, 8192);
     const uint32_t dot_cols = std::max({W, Wp, 8u});  // widest matrix ext_dot_columns sees (the quotient has 8 columns)
     const uint32_t nq = p->cfg.num_queries;
@@ -437,12 +566,25 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         PW_HIP_TRY(hipStreamSynchronize(st));
         if (jit) TRY(logup_perm_trace_jit(p, d_trace, H, al, d_blpow, d_perm, d_rowsum, d_rowsum + H));
         else TRY(logup_perm_trace(d_trace, H, lp, al, d_blpow, d_perm, d_rowsum, d_rowsum + H));
-        TRY(lde_matrix(p, L, log_h, d_perm, Wp + (jit ? kJitExtraPermCols : 0u), d_plde));
-        TRY(merkle_commit_matrix(d_plde, N, Wp, N, d_pdig));
+        if (!sb) {
+            TRY(lde_matrix(p, L, log_h, d_perm, Wp + (jit ? kJitExtraPermCols : 0u), d_plde));
+            TRY(merkle_commit_matrix(d_plde, N, Wp, N, d_pdig));
+        } else {
+            // streamed: only phi and the per-row sums (the boundary terms read them at rows j and j + 2) are extended for good
+            if (!jit) TRY(ext_to_cols(d_rowsum, H, d_perm + (size_t)(4 * n_g + 4) * H));
+            TRY(lde_matrix(p, L, log_h, d_perm + (size_t)(4 * n_g) * H, 8, d_plde));
+        }
         uint32_t sw[4];
         PW_HIP_TRY(hipMemcpyAsync(root, d_pdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
         for (int k = 0; k < 4; ++k)  // S = phi(last row)
             PW_HIP_TRY(hipMemcpyAsync(&sw[k], d_perm + ((size_t)(4 * n_g + k) * H + (H - 1)), 4, hipMemcpyDeviceToHost, st));
+        if (sb) {
+            // (S is read from the matrix first:) the permutation matrix becomes its coefficient arrays in place, committed sub-coset by sub-coset
+            PW_HIP_TRY(hipStreamSynchronize(st));
+            TRY(intt_dif(d_perm, d_perm, H, H, Wp, (int)log_h));
+            TRY(commit_coefficients(p, L, log_h, d_perm, Wp, d_pdig));
+            PW_HIP_TRY(hipMemcpyAsync(root, d_pdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
+        }
         PW_HIP_TRY(hipStreamSynchronize(st));
         put_monty(root, 8);
         ch.observe_words(root, 8);
@@ -467,7 +609,27 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const uint32_t zinv_even = bb::inv(bb::sub(sH, one));
     const uint32_t zinv_odd = bb::inv(bb::sub(bb::neg(sH), one));
     ConstraintProgram prog{p->d_bytecode, p->d_spans, nc, p->is_xbc};
-    if (lg && jit)
+    if (sb) {
+        // streamed: the terms that read the current row only, sub-coset by sub-coset (unscaled sums scattered to their rows of d_q), then
+        // the boundary terms / the division by Z_H over all rows
+        uint32_t* d_part = p->qpart.as<uint32_t>();
+        TRY(for_each_subcoset(p, L, log_h, {CoefMatrix{d_tcoef, W}, CoefMatrix{d_perm, Wp}}, nullptr, [&](uint32_t r) -> int {
+            const uint32_t* blk_p = d_blk + (size_t)W * m_sub;
+            uint32_t n_parts = 1;
+            if (jit && (nc || lg)) {
+                TRY(quotient_parts_jit(p, d_blk, lg ? blk_p : nullptr, m_sub, d_apow, al, lg ? d_blpow : nullptr, d_part, &n_parts));
+            } else if (lg) {
+                TRY(quotient_eval_logup(d_blk, blk_p, m_sub, logN, prog, lp, d_apow, al, d_blpow, S, one, one, d_part, true));
+            } else {
+                TRY(quotient_eval(d_blk, m_sub, prog, d_apow, one, one, d_part, d_part + 4 * m_sub, quotient_chunks(m_sub, nc)));
+            }
+            return part_scatter(d_part, n_parts, m_sub, sb, r, N, d_q);
+        }));
+        if (lg)
+            TRY(quotient_logup_tail(d_q, 1, d_plde, d_plde + 4 * N, N, logN, d_apow + nc + n_g, S, bb::sub(sH, one), bb::sub(bb::neg(sH), one), d_q));
+        else
+            TRY(quotient_combine(d_q, 1, N, zinv_even, zinv_odd, d_q));
+    } else if (lg && jit)
         TRY(quotient_eval_logup_jit(p, d_lde, d_plde, N, logN, d_apow, al, d_blpow, S, bb::sub(sH, one), bb::sub(bb::neg(sH), one), d_q));
     else if (lg)
         TRY(quotient_eval_logup(d_lde, d_plde, N, logN, prog, lp, d_apow, al, d_blpow, S, bb::sub(sH, one), bb::sub(bb::neg(sH), one), d_q));
@@ -492,11 +654,15 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     const bb::Ext gzeta = bb::ext_scale(zeta, field::root_of_unity((int)log_h));
     TRY(barycentric_weights(zeta, (int)log_h, d_weights));
     TRY(ext_dot_columns(d_trace, H, W, H, d_weights, d_opened, d_scratch));
-    if (lg) {  // the permutation matrix at zeta and at g zeta: one pass over its columns
+    if (lg && !sb) {  // the permutation matrix at zeta and at g zeta: one pass over its columns
         TRY(barycentric_weights(gzeta, (int)log_h, d_weights2));
         TRY(ext_dot_columns2(d_perm, H, Wp, H, d_weights, d_weights2, d_opened + W, d_opened + K1, d_scratch));
     }
     TRY(zeta_weights(zeta, (int)log_h, d_weights));
+    if (lg && sb) {  // streamed: d_perm holds the matrix's coefficient arrays
+        TRY(zeta_weights(gzeta, (int)log_h, d_weights2));
+        TRY(ext_dot_columns2(d_perm, H, Wp, H, d_weights, d_weights2, d_opened + W, d_opened + K1, d_scratch));
+    }
     TRY(ext_dot_columns(d_qcoef, H, 8, H, d_weights, d_opened + W + Wp, d_scratch));
     std::vector<bb::Ext> opened(K);
     PW_HIP_TRY(hipMemcpyAsync(opened.data(), d_opened, K * sizeof(bb::Ext), hipMemcpyDeviceToHost, st));
@@ -523,7 +689,15 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         PW_HIP_TRY(hipMemcpyAsync(d_gpow, gpow.data(), K * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
         PW_HIP_TRY(hipStreamSynchronize(st));
     }
-    if (lg)
+    if (sb) {
+        // streamed: sum_k gamma^k P_k is a POLYNOMIAL — combined on the coefficient arrays (one pass over them) and extended as 4 (+ 4 for
+        // the second opening point) columns; the eight quotient columns join from their resident LDE
+        uint32_t* d_gcoef = p->gbuf.as<uint32_t>();
+        uint32_t* d_glde = d_gcoef + 8 * H;
+        TRY(ext_lincomb(d_tcoef, W, d_perm, Wp, H, d_gpow, lg ? K1 : 0u, d_gcoef));
+        TRY(coset_lde_from_coeffs(d_gcoef, d_glde, H, N, lg ? 8 : 4, (int)log_h));
+        TRY(deep_from_combo(d_glde, d_qlde, N, logN, d_gpow + W + Wp, opened_sum, opened_sum2, zeta, gzeta, lg ? 1 : 0, d_v));
+    } else if (lg)
         TRY(deep_quotient_logup(d_lde, W, d_plde, Wp, d_qlde, N, logN, d_gpow, opened_sum, opened_sum2, zeta, gzeta, d_v));
     else
         TRY(deep_quotient(d_lde, W, d_qlde, 8, N, logN, d_gpow, opened_sum, zeta, d_v));
@@ -579,10 +753,11 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         for (auto& i : idx) i = ch.sample_bits(logN);
         // layout of the tail buffer
         uint32_t* d_idx = reinterpret_cast<uint32_t*>(d_tail);
-        uint32_t* d_trows = d_idx + nq;
+        uint32_t* d_loc = d_idx + nq;  // streamed: the queries' rows inside their sub-cosets, sorted by sub-coset
+        uint32_t* d_trows = d_loc + nq;
         uint32_t* d_prows = d_trows + (size_t)nq * W;
         uint32_t* d_qrows = d_prows + (size_t)nq * Wp;
-        uint64_t* d_offs = reinterpret_cast<uint64_t*>(d_qrows + (size_t)nq * 8 + (((size_t)nq * (W + Wp + 9)) & 1));
+        uint64_t* d_offs = reinterpret_cast<uint64_t*>(d_qrows + (size_t)nq * 8 + (((size_t)nq * (W + Wp + 10)) & 1));
         // digest records (8 words) then FRI sibling records (4 words)
         std::vector<uint64_t> dig_offs, ext_offs;
         for (uint32_t qi = 0; qi < nq; ++qi) {
@@ -610,8 +785,29 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         PW_HIP_TRY(hipMemcpyAsync(d_idx, idx.data(), nq * 4, hipMemcpyHostToDevice, st));
         PW_HIP_TRY(hipMemcpyAsync(d_dig_offs, dig_offs.data(), n_dig * 8, hipMemcpyHostToDevice, st));
         if (n_ext) PW_HIP_TRY(hipMemcpyAsync(d_ext_offs, ext_offs.data(), n_ext * 8, hipMemcpyHostToDevice, st));
-        TRY(gather_rows(d_lde, N, W, d_idx, nq, d_trows));
-        if (lg) TRY(gather_rows(d_plde, N, Wp, d_idx, nq, d_prows));
+        std::vector<uint32_t> pos(nq);  // pos[qi]: the slot of query qi's rows in d_trows / d_prows
+        if (!sb) {
+            for (uint32_t qi = 0; qi < nq; ++qi) pos[qi] = qi;
+            TRY(gather_rows(d_lde, N, W, d_idx, nq, d_trows));
+            if (lg) TRY(gather_rows(d_plde, N, Wp, d_idx, nq, d_prows));
+        } else {
+            // streamed: one more pass over the sub-cosets that hold a queried row; row idx lives in sub-coset idx mod 2^sb at position idx >> sb
+            const uint32_t nb = 1u << sb;
+            std::vector<uint32_t> order(nq), loc(nq), first(nb + 1, 0);
+            for (uint32_t qi = 0; qi < nq; ++qi) { order[qi] = qi; first[(idx[qi] & (nb - 1)) + 1] += 1; }
+            for (uint32_t r = 0; r < nb; ++r) first[r + 1] += first[r];
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b2) { return (idx[a] & (nb - 1)) < (idx[b2] & (nb - 1)); });
+            std::vector<char> wanted(nb, 0);
+            for (uint32_t k = 0; k < nq; ++k) { loc[k] = idx[order[k]] >> sb; pos[order[k]] = k; wanted[idx[order[k]] & (nb - 1)] = 1; }
+            PW_HIP_TRY(hipMemcpyAsync(d_loc, loc.data(), nq * 4, hipMemcpyHostToDevice, st));
+            PW_HIP_TRY(hipStreamSynchronize(st));  // loc is a local vector
+            TRY(for_each_subcoset(p, L, log_h, {CoefMatrix{d_tcoef, W}, CoefMatrix{d_perm, Wp}}, &wanted, [&](uint32_t r) -> int {
+                const uint32_t k0 = first[r], cnt = first[r + 1] - first[r];
+                TRY(gather_rows(d_blk, m_sub, W, d_loc + k0, cnt, d_trows + (size_t)k0 * W));
+                if (lg) TRY(gather_rows(d_blk + (size_t)W * m_sub, m_sub, Wp, d_loc + k0, cnt, d_prows + (size_t)k0 * Wp));
+                return 0;
+            }));
+        }
         TRY(gather_rows(d_qlde, N, 8, d_idx, nq, d_qrows));
         TRY(gather_records(d_dig, d_dig_offs, 8u, (uint32_t)n_dig, d_dig_out));
         TRY(gather_records(reinterpret_cast<const uint32_t*>(d_v), d_ext_offs, 4u, (uint32_t)n_ext, d_ext_out));
@@ -631,10 +827,10 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         size_t dpos = 0, epos = 0;
         for (uint32_t qi = 0; qi < nq; ++qi) {
             put(idx[qi]);
-            put_raw(&trows[(size_t)qi * W], W);
+            put_raw(&trows[(size_t)pos[qi] * W], W);
             put_raw(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
             if (lg) {
-                put_raw(&prows[(size_t)qi * Wp], Wp);
+                put_raw(&prows[(size_t)pos[qi] * Wp], Wp);
                 put_raw(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
             }
             put_raw(&qrows[(size_t)qi * 8], 8);
@@ -688,6 +884,16 @@ extern "C" int pw_lde_fused(const uint32_t* d_trace, uint32_t width, uint32_t lo
     (void)hipGetLastError();
     const size_t H = (size_t)1 << log_h;
     TRY(lde_fused(d_trace, d_tmp, d_lde, H, H, 2 * H, width, (int)log_h));
+    return (int)hipGetLastError();
+}
+
+extern "C" int pw_lde_subcoset(const uint32_t* d_coeffs, uint32_t width, uint32_t log_h, uint32_t log_blocks, uint32_t r, uint32_t* d_scale,
+                               uint32_t* d_out) {
+    (void)hipGetLastError();
+    if (!d_coeffs || !d_scale || !d_out || !width || log_blocks < 1 || log_blocks > log_h || log_h > 26 || (r >> log_blocks)) return -1;
+    const size_t H = (size_t)1 << log_h, m = (2 * H) >> log_blocks;
+    TRY(subcoset_scale((int)log_h, (int)log_blocks, r, d_scale));
+    TRY(subcoset_lde(d_coeffs, d_out, H, m, width, (int)log_h, (int)log_blocks, d_scale));
     return (int)hipGetLastError();
 }
 

@@ -29,6 +29,11 @@ int coset_lde_from_coeffs(const uint32_t* coeffs, uint32_t* out, size_t in_strid
 // run in one kernel (ntt.hip lde_fused_kernel). tmp: cols x 2^n words of scratch (unused for n <= 12).
 int lde_fused(const uint32_t* in, uint32_t* tmp, uint32_t* out, size_t in_stride, size_t tmp_stride, size_t out_stride, uint32_t cols, int n);
 const uint32_t* shift_table(int n);  // s^k / 2^n (Montgomery), k < 2^n, device
+// Sub-coset evaluation (the streamed prover): the rows j = r + 2^b i, i < 2^(n+1-b), of the LDE of `cols` polynomials given by their
+// coefficient arrays as intt_dif leaves them (2^n words each, bit-reversed, H-scaled): out[c * out_stride + i] = P_c(s g_(n+1)^j).
+// `scale` = subcoset_scale(n, b, r): 2^n words (the coset scaling of every coefficient on that sub-coset), computed once per r.
+int subcoset_scale(int n, int b, uint32_t r, uint32_t* scale);
+int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, const uint32_t* scale);
 
 // ---- merkle.hip ------------------------------------------------------------------------
 // Digest tree layout: level 0 = leaves (n_leaves x 8 words), then n_leaves/2, ... , 1;
@@ -38,6 +43,11 @@ const p2::Params& poseidon2_params_host();
 int poseidon2_set_constants(const uint32_t* ext_rc128, const uint32_t* int_rc13);
 int poseidon2_upload_params();
 int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests, uint32_t* root_out = nullptr);
+// the two halves of merkle_commit_matrix: row digests into the slots j * digest_stride + digest_offset of level 0 (a matrix that holds
+// every 2^b-th row of the committed one fills its share of the leaves), then the inner levels over all n_leaves slots
+int merkle_leaf_hash(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests, size_t digest_stride,
+                     size_t digest_offset);
+int merkle_build_levels(uint32_t* digests, size_t n_leaves, uint32_t* root_out = nullptr);
 // the calling thread's host-mapped landing place for a root (`root_out` above is its device address); nullptr: not available
 uint32_t* merkle_root_mailbox(uint32_t** device_ptr);
 // Mixed-height commitment of a segment (oracle/stark_segment.inc `MixedTree`): by_log[k] = the columns of all matrices of
@@ -129,11 +139,25 @@ int logup_scan(const bb::Ext* d_rowsum, size_t H, bb::Ext* d_block_totals, uint3
 int logup_rowsum_combine(const uint32_t* part, uint32_t n_chunks, size_t H, bb::Ext* d_rowsum, uint32_t* cols4);
 int quotient_logup_tail(const uint32_t* part, uint32_t n_chunks, const uint32_t* plde_phi, const uint32_t* plde_sumq, size_t N, int logN,
                         const bb::Ext* d_apow_tail, bb::Ext S, uint32_t zval_even, uint32_t zval_odd, uint32_t* q);
+// main_only: only sum_k apow[k] C_k + sum_g apow[nc + g] (q_g den_g - num_g), unscaled, on `N` rows of (lde | plde) with column stride N —
+// the part of the quotient that reads the current row only (the streamed path evaluates it sub-coset by sub-coset and adds the
+// boundary terms with quotient_logup_tail)
 int quotient_eval_logup(const uint32_t* lde, const uint32_t* plde, size_t N, int logN, const ConstraintProgram& prog,
                         const LogupProgram& lp, const bb::Ext* d_apow, bb::Ext al, const bb::Ext* d_blpow, bb::Ext S,
-                        uint32_t zval_even, uint32_t zval_odd, uint32_t* q);
+                        uint32_t zval_even, uint32_t zval_odd, uint32_t* q, bool main_only = false);
 int deep_quotient_logup(const uint32_t* lde, uint32_t W, const uint32_t* plde, uint32_t Wp, const uint32_t* qlde, size_t N, int logN,
                         const bb::Ext* d_gpow, bb::Ext sum1, bb::Ext sum2, bb::Ext zeta, bb::Ext gzeta, bb::Ext* v);
+
+// ---- stream_kernels.hip (the streamed proof path) ---------------------------------------------------------------------
+// out[k * N + r + (i << b)] = sum_c part[(c * 4 + k) * m + i]: the partial quotient sums of sub-coset r into their rows of the N-row vector
+int part_scatter(const uint32_t* part, uint32_t n_chunks, size_t m, int b, uint32_t r, size_t N, uint32_t* out);
+// out (4 columns of len, + 4 more when second != 0) = sum_c g[c] ma_c + sum_c g[wa + c] mb_c  |  sum_c g[second + c] mb_c ; g centred
+int ext_lincomb(const uint32_t* ma, uint32_t wa, const uint32_t* mb, uint32_t wb, size_t len, const bb::Ext* d_gpow, uint32_t second,
+                uint32_t* out);
+// v[j] = (G1[j] + sum_k gq[k] qlde_k[j] - sum1) / (x_j - zeta) [+ (G2[j] - sum2) / (x_j - g zeta) when two]; glde = G1 | G2 (8 columns of N)
+int deep_from_combo(const uint32_t* glde, const uint32_t* qlde, size_t N, int logN, const bb::Ext* d_gpow_quotient, bb::Ext sum1, bb::Ext sum2,
+                    bb::Ext zeta, bb::Ext gzeta, int two, bb::Ext* v);
+int ext_to_cols(const bb::Ext* in, size_t len, uint32_t* cols4);
 
 // proof-of-work search: smallest witness w (checked in blocks) such that the transcript state,
 // after observing w, samples a value with `bits` low zero bits. state = 16 words sponge state,

@@ -107,37 +107,40 @@ int specialise_provers(PwProver* const* ps, size_t n, const uint32_t* log_height
     return 0;
 }
 
-int quotient_eval_jit(PwProver* p, const uint32_t* lde, size_t N, const bb::Ext* d_apow, uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q) {
+size_t jit_part_bytes(const PwProver* p, size_t H, size_t q_rows) {
+    if (p->jit.state != 1) return 0;
+    const size_t a = (size_t)(p->jit.perm.n_chunks ? p->jit.perm.n_chunks : (p->logup ? 1 : 0)) * 16 * H;
+    const size_t b = (size_t)(p->jit.quotient.n_chunks ? p->jit.quotient.n_chunks : 1) * 16 * q_rows;
+    return a > b ? a : b;
+}
+
+int quotient_parts_jit(PwProver* p, const uint32_t* T, const uint32_t* Pm, size_t rows, const bb::Ext* d_apow, bb::Ext al, const bb::Ext* d_blpow,
+                       uint32_t* part, uint32_t* n_chunks) {
     const jit::Generated& g = p->jit.quotient;
-    PW_TRY_INT(p->qpart.ensure((size_t)(g.n_chunks ? g.n_chunks : 1) * 4 * N * 4));
+    uint64_t n64 = rows;
+    void* args[] = {(void*)&T, (void*)&Pm, (void*)&n64, (void*)&d_apow, (void*)&al, (void*)&d_blpow, (void*)&part};
+    ScopedKernelTimer t(Pm ? "quotient_logup_jit_kernel" : "quotient_jit_kernel");
+    const int rc = launch_units(g, p->jit.quotient_prog, rows, args);
+    if (n_chunks) *n_chunks = g.n_chunks;
+    return rc;
+}
+
+int quotient_eval_jit(PwProver* p, const uint32_t* lde, size_t N, const bb::Ext* d_apow, uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q) {
+    PW_TRY_INT(p->qpart.ensure(jit_part_bytes(p, N / 2, N)));  // (reserved by ensure_prove_buffers; a no-op then)
     uint32_t* part = p->qpart.as<uint32_t>();
-    const uint32_t* none = nullptr;
-    const bb::Ext* no_ext = nullptr;
-    bb::Ext al = bb::ext_zero();
-    uint64_t n64 = N;
-    void* args[] = {(void*)&lde, (void*)&none, (void*)&n64, (void*)&d_apow, (void*)&al, (void*)&no_ext, (void*)&part};
-    {
-        ScopedKernelTimer t("quotient_jit_kernel");
-        const int rc = launch_units(g, p->jit.quotient_prog, N, args);
-        if (rc) return rc;
-    }
-    return quotient_combine(part, g.n_chunks, N, zinv_even, zinv_odd, q);
+    uint32_t n_chunks = 0;
+    PW_TRY_INT(quotient_parts_jit(p, lde, nullptr, N, d_apow, bb::ext_zero(), nullptr, part, &n_chunks));
+    return quotient_combine(part, n_chunks, N, zinv_even, zinv_odd, q);
 }
 
 int quotient_eval_logup_jit(PwProver* p, const uint32_t* lde, const uint32_t* plde, size_t N, int logN, const bb::Ext* d_apow, bb::Ext al,
                             const bb::Ext* d_blpow, bb::Ext S, uint32_t zval_even, uint32_t zval_odd, uint32_t* q) {
-    const jit::Generated& g = p->jit.quotient;
-    PW_TRY_INT(p->qpart.ensure((size_t)(g.n_chunks ? g.n_chunks : 1) * 4 * N * 4));
+    PW_TRY_INT(p->qpart.ensure(jit_part_bytes(p, N / 2, N)));
     uint32_t* part = p->qpart.as<uint32_t>();
-    uint64_t n64 = N;
-    void* args[] = {(void*)&lde, (void*)&plde, (void*)&n64, (void*)&d_apow, (void*)&al, (void*)&d_blpow, (void*)&part};
-    {
-        ScopedKernelTimer t("quotient_logup_jit_kernel");
-        const int rc = launch_units(g, p->jit.quotient_prog, N, args);
-        if (rc) return rc;
-    }
+    uint32_t n_chunks = 0;
+    PW_TRY_INT(quotient_parts_jit(p, lde, plde, N, d_apow, al, d_blpow, part, &n_chunks));
     const uint32_t G = p->n_groups;
-    return quotient_logup_tail(part, g.n_chunks, plde + (size_t)(4 * G) * N, plde + (size_t)(4 * G + 4) * N, N, logN, d_apow + p->n_constraints + G, S,
+    return quotient_logup_tail(part, n_chunks, plde + (size_t)(4 * G) * N, plde + (size_t)(4 * G + 4) * N, N, logN, d_apow + p->n_constraints + G, S,
                                zval_even, zval_odd, q);
 }
 
@@ -145,7 +148,7 @@ int logup_perm_trace_jit(PwProver* p, const uint32_t* trace, size_t H, bb::Ext a
                          bb::Ext* d_block_totals) {
     const jit::Generated& g = p->jit.perm;
     const uint32_t G = p->n_groups;
-    PW_TRY_INT(p->qpart.ensure((size_t)(g.n_chunks ? g.n_chunks : 1) * 4 * H * 4));
+    PW_TRY_INT(p->qpart.ensure((size_t)(g.n_chunks ? g.n_chunks : 1) * 4 * H * 4));  // (a no-op after ensure_prove_buffers / ensure_air)
     uint32_t* part = p->qpart.as<uint32_t>();
     uint64_t h64 = H;
     void* args[] = {(void*)&trace, (void*)&h64, (void*)&al, (void*)&d_blpow, (void*)&perm, (void*)&part};

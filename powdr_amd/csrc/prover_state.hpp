@@ -90,9 +90,13 @@ struct PwProver {
     const uint32_t* committed_trace = nullptr;
     uint32_t committed_log_h = 0;
     uint32_t committed_root[8] = {0};  // Montgomery
+    int committed_b = 0;               // the mode that commitment was made in (0 resident, b >= 1 streamed over 2^b sub-cosets)
     // device buffers, grown on demand
     pw::DeviceBuf coef, lde, digests, q, qcoef, qlde, ext_arena, misc;
     pw::DeviceBuf qpart;  // partial quotient sums when the constraint list is split over workgroup rows (short traces)
+    // streamed mode (prover.hip "streamed proofs"): the trace's coefficient arrays, the scale table of the sub-coset being evaluated,
+    // the DEEP combinations (8 columns of coefficients + their LDE); `lde` then holds ONE sub-coset of all committed columns
+    pw::DeviceBuf tcoef, fscale, gbuf;
     std::vector<uint32_t> proof;
     // host copies of the plan-compiled (xbc) programs: the source of the run-time specialised kernels (jit_codegen.hpp)
     std::vector<uint32_t> h_xcode, h_xspans, h_icode, h_ixspans, h_gstarts;
@@ -108,6 +112,8 @@ struct PwProver {
 namespace pw {
 struct CommitLayout {
     size_t H, N, tree_words, fri_words, n_trees, panel_cols;
+    int b = 0;     // streamed mode: the extended domain is walked as 2^b sub-cosets (0: the LDE is resident)
+    size_t m = 0;  // rows of a sub-coset, N >> b
 };
 // LDE of a column-major matrix (cols x 2^log_h) through the prover's coefficient panel buffer into `out` (cols x 2^(log_h+1))
 int lde_matrix(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_t* m, uint32_t cols, uint32_t* out);
@@ -124,6 +130,12 @@ inline bool specialised(const PwProver* p) { return p->jit.state == 1; }
 // the three stages with the specialised kernels; same contracts as quotient_eval / quotient_eval_logup / logup_perm_trace.
 // `perm` / `plde` must have room for 4 extra columns after the committed ones (the per-row sums and their LDE).
 int quotient_eval_jit(PwProver* p, const uint32_t* lde, size_t N, const bb::Ext* d_apow, uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q);
+// the chunk kernels of the specialised quotient alone, on `rows` rows of (T | Pm) with column stride `rows`: partial sums
+// part[(c * 4 + k) * rows + j], c < *n_chunks (the streamed path runs them per sub-coset; Pm / d_blpow: nullptr without LogUp)
+int quotient_parts_jit(PwProver* p, const uint32_t* T, const uint32_t* Pm, size_t rows, const bb::Ext* d_apow, bb::Ext al, const bb::Ext* d_blpow,
+                       uint32_t* part, uint32_t* n_chunks);
+// bytes of `qpart` the specialised kernels need for a trace of H rows whose quotient is evaluated `q_rows` rows at a time
+size_t jit_part_bytes(const PwProver* p, size_t H, size_t q_rows);
 int quotient_eval_logup_jit(PwProver* p, const uint32_t* lde, const uint32_t* plde, size_t N, int logN, const bb::Ext* d_apow, bb::Ext al,
                             const bb::Ext* d_blpow, bb::Ext S, uint32_t zval_even, uint32_t zval_odd, uint32_t* q);
 int logup_perm_trace_jit(PwProver* p, const uint32_t* trace, size_t H, bb::Ext al, const bb::Ext* d_blpow, uint32_t* perm, bb::Ext* d_rowsum,

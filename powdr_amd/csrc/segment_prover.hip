@@ -80,6 +80,8 @@ int ensure_air(PwProver* p, const Shape& s, bool logup, CommitLayout& Lc) {
         const uint32_t chunks = quotient_chunks(s.N, s.nc);
         if (chunks > 1) TRY(p->qpart.ensure((size_t)chunks * 4 * s.N * 4));
     }
+    // the specialised kernels' partial sums (not lazily in the middle of the proof, while other AIRs' side streams run)
+    if (specialised(p) && jit_part_bytes(p, s.H, s.N) > p->qpart.bytes) TRY(p->qpart.ensure(jit_part_bytes(p, s.H, s.N)));
     TRY(p->qcoef.ensure(8 * s.H * 4));
     TRY(p->qlde.ensure(8 * s.N * 4));
     TRY(p->ext_arena.ensure((3 * s.H + s.H / 4096 + 32) * sizeof(bb::Ext)));  // weights | weights at g zeta | row sums + block totals

@@ -14,8 +14,8 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_logup_path", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
-                  "pw_lde_batch", "pw_lde_fused", "pw_merkle_commit", "pw_poseidon2_permute_host",
+PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_logup_path", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_stream_log_blocks", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+                  "pw_lde_batch", "pw_lde_fused", "pw_lde_subcoset", "pw_merkle_commit", "pw_poseidon2_permute_host",
                   "pw_set_poseidon2_constants", "pw_get_poseidon2_constants", "pw_prover_specialise", "pw_prover_specialised", "pw_jit_compile_check", "pw_jit_cache_stats", "pw_jit_generated_source",
                   "pw_prove_segments_multi", "pw_multi_last_merge", "pw_assign_units"]
 
@@ -36,6 +36,8 @@ lib.pw_lde_batch.restype = C.c_int
 lib.pw_lde_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
 lib.pw_lde_fused.restype = C.c_int
 lib.pw_lde_fused.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+lib.pw_lde_subcoset.restype = C.c_int
+lib.pw_lde_subcoset.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
 lib.pw_merkle_commit.restype = C.c_int
 lib.pw_merkle_commit.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
 lib.pw_poseidon2_permute_host.argtypes = [C.c_void_p]
@@ -424,6 +426,13 @@ class Prover:
         lib.pw_prover_reserve.restype = C.c_int
         lib.pw_prover_reserve.argtypes = [C.c_void_p, C.c_uint32]
         abi.check(lib.pw_prover_reserve(self._h, log_height), "pw_prover_reserve")
+
+    def stream_log_blocks(self, log_height: int) -> int:
+        """pw_prover_stream_log_blocks: 0 = a proof of this height keeps the LDE resident, b >= 1 = streamed over 2^b sub-cosets of
+        the extended domain (the memory free now decides; POWDR_STREAM_LOG_BLOCKS forces), -1 = does not fit."""
+        lib.pw_prover_stream_log_blocks.restype = C.c_int
+        lib.pw_prover_stream_log_blocks.argtypes = [C.c_void_p, C.c_uint32]
+        return int(lib.pw_prover_stream_log_blocks(self._h, log_height))
 
     def specialise(self) -> bool:
         """pw_prover_specialise: compile the run-time specialised kernels now. True if the prover has them."""

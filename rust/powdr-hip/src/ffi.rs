@@ -307,11 +307,14 @@ extern "C" {
                           check_balance: c_int, total_sum4: *mut u32) -> c_int;
     pub fn pw_commitment_digest(roots8: *const u32, n: usize, digest8: *mut u32);
     pub fn pw_prover_reserve(p: *mut PwProver, log_height: u32) -> c_int;
+    /// 0 = a proof of this height keeps the LDE resident, b >= 1 = streamed over 2^b sub-cosets, -1 = does not fit.
+    pub fn pw_prover_stream_log_blocks(p: *const PwProver, log_height: u32) -> c_int;
     pub fn pw_prover_max_constraint_degree(p: *const PwProver) -> c_int;
     pub fn pw_prover_width(p: *const PwProver) -> u32;
     pub fn pw_prover_device_bytes(p: *const PwProver) -> usize;
     pub fn pw_lde_batch(d_trace: *const u32, width: u32, log_height: u32, d_coeffs: *mut u32, d_lde: *mut u32) -> c_int;
     pub fn pw_lde_fused(d_trace: *const u32, width: u32, log_height: u32, d_tmp: *mut u32, d_lde: *mut u32) -> c_int;
+    pub fn pw_lde_subcoset(d_coeffs: *const u32, width: u32, log_height: u32, log_blocks: u32, r: u32, d_scale: *mut u32, d_out: *mut u32) -> c_int;
     pub fn pw_merkle_commit(d_matrix: *const u32, height: usize, width: u32, d_digests: *mut u32) -> c_int;
     pub fn pw_prover_specialise(p: *mut PwProver) -> c_int;
     pub fn pw_prover_specialised(p: *const PwProver, n_kernels: *mut usize, code_bytes: *mut usize, n_chunks: *mut usize) -> c_int;

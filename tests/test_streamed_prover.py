@@ -1,0 +1,161 @@
+"""The STREAMED proof path (include/powdr_prover.h "STREAMED proofs"; csrc/prover.hip): traces whose low-degree extension does
+not fit in HBM — BASELINE configs[2], 3 731 columns x 2^22 rows with its 2 314 bus interactions — are proven from coefficient
+arrays, one sub-coset of the extended domain at a time. Exact field arithmetic, so the proof WORDS must equal the resident
+path's and the oracle's: these tests force the streamed mode (POWDR_STREAM_LOG_BLOCKS) on traces the oracle can prove in seconds."""
+import numpy as np
+import pytest
+
+from oracle import apc_model as om
+from oracle import stark_model as sm
+from powdr_amd import synth
+
+P = om.P
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from powdr_amd import abi, prover
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch, abi, prover
+
+
+def to_dev(torch, a):
+    return torch.from_numpy(om.to_monty(np.ascontiguousarray(a, dtype=np.uint32)).view(np.int32)).cuda()
+
+
+def from_dev(t):
+    return om.from_monty(t.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("log_h,W,log_blocks", [(3, 2, 1), (3, 2, 2), (3, 1, 3), (6, 3, 1), (6, 3, 4), (10, 2, 3), (12, 3, 1), (12, 2, 2), (13, 2, 3),
+                                                 (14, 2, 5), (16, 3, 3), (18, 2, 2), (20, 2, 3), (20, 1, 1), (21, 1, 4)])
+def test_subcoset_lde_is_the_rows_of_the_lde(gpu, log_h, W, log_blocks):
+    """pw_lde_subcoset: rows r + 2^b i of the oracle's LDE, from the coefficient arrays pw_lde_batch leaves, for every r (small b)
+    or a sample of them."""
+    torch, abi, prover = gpu
+    rng = np.random.default_rng(100 * log_h + log_blocks)
+    H = 1 << log_h
+    t = rng.integers(0, P, W * H, dtype=np.uint32)
+    want = sm.lde(t, W, log_h).reshape(W, 2 * H)
+    d_t = to_dev(torch, t)
+    d_c = torch.empty(W * H, dtype=torch.int32, device="cuda")
+    d_l = torch.empty(W * 2 * H, dtype=torch.int32, device="cuda")
+    abi.check(prover.lib.pw_lde_batch(d_t.data_ptr(), W, log_h, d_c.data_ptr(), d_l.data_ptr()), "pw_lde_batch")
+    B = 1 << log_blocks
+    m = 2 * H // B
+    d_s = torch.empty(H, dtype=torch.int32, device="cuda")
+    d_o = torch.empty(W * m, dtype=torch.int32, device="cuda")
+    rs = range(B) if B <= 8 else sorted({0, 1, B // 2, B - 1, int(rng.integers(0, B))})
+    for r in rs:
+        d_o.zero_()
+        abi.check(prover.lib.pw_lde_subcoset(d_c.data_ptr(), W, log_h, log_blocks, r, d_s.data_ptr(), d_o.data_ptr()), "pw_lde_subcoset")
+        torch.cuda.synchronize()
+        got = from_dev(d_o).reshape(W, m)
+        assert (got == want[:, r::B]).all(), f"sub-coset {r} of {B}"
+
+
+def _synthetic(shape, calls, seed):
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+
+    s = synth.generate(shape, seed=seed)
+    apc, idx, trace, _, _ = run_oracle_gpu_convention(s, calls, seed=seed)
+    W, H = trace.shape
+    bc, spans = sm.compile_constraints(apc, idx)
+    it = sm.compile_interactions(apc, idx)
+    return np.ascontiguousarray(trace).reshape(-1), W, H.bit_length() - 1, bc, spans, it
+
+
+def _prove(prover, monkeypatch, d_t, W, log_h, bc, spans, it, nq, pow_bits, log_blocks, jit):
+    monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", str(log_blocks))
+    monkeypatch.setenv("POWDR_JIT", "1" if jit else "0")
+    pr = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits, interactions=it)
+    assert pr.stream_log_blocks(log_h) == min(log_blocks, max(log_h - 1, 0))
+    got = pr.prove(d_t.data_ptr(), log_h)
+    again = pr.prove(d_t.data_ptr(), log_h)  # buffer reuse
+    assert (got == again).all()
+    state = pr.specialised()["state"]
+    pr.close()
+    return got, state
+
+
+@pytest.mark.parametrize("shape,calls,nq,pow_bits", [("T0", 7, 4, 0), ("T0", 64, 5, 5), ("T1", 100, 6, 0), ("T1", 1000, 8, 3), ("T1", 5000, 10, 0)])
+@pytest.mark.parametrize("logup", [False, True])
+def test_streamed_proof_words_equal_the_oracle(gpu, monkeypatch, shape, calls, nq, pow_bits, logup):
+    """Every stage of the streamed path — commitments from sub-cosets, quotient terms per sub-coset + boundary terms, openings of
+    the permutation matrix from its coefficients, the DEEP numerator as an extended polynomial, query rows from a last pass —
+    against the oracle, for 2, 4 and 8 sub-cosets, with the interpreter and with the run-time specialised kernels."""
+    torch, abi, prover = gpu
+    flat, W, log_h, bc, spans, it = _synthetic(shape, calls, seed=21)
+    want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=nq, pow_bits=pow_bits) if logup else \
+        sm.prove(flat, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits)
+    d_t = to_dev(torch, flat)
+    for log_blocks in (1, 2, 3):
+        for jit in (False, True):
+            got, state = _prove(prover, monkeypatch, d_t, W, log_h, bc, spans, it if logup else None, nq, pow_bits, log_blocks, jit)
+            assert (state == 1) if jit else (state in (0, -1))
+            assert len(got) == len(want) and (got == want).all(), \
+                f"blocks 2^{log_blocks} jit={jit}: first differing word {int(np.argmax(got != want))} of {len(want)}"
+    # the resident path on the same prover inputs (POWDR_STREAM_LOG_BLOCKS=0): same words
+    got, _ = _prove(prover, monkeypatch, d_t, W, log_h, bc, spans, it if logup else None, nq, pow_bits, 0, False)
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("shape,log_h,log_blocks,jit", [("C3", 12, 3, False), ("C3", 12, 2, True), ("C2", 14, 3, True), ("C2", 14, 4, False)])
+def test_baseline_shapes_streamed_with_logup(gpu, monkeypatch, shape, log_h, log_blocks, jit):
+    """the C3 shape (3 731 columns, 3 114 constraints, 2 314 interactions) at 2^12 rows and the C2 shape at 2^14
+    through the streamed path with the LogUp phase: words == sm.prove_logup, both verifiers accept."""
+    torch, abi, prover = gpu
+    flat, W, lh, bc, spans, it = _synthetic(shape, (1 << log_h) - 5, seed=0)
+    assert lh == log_h
+    want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=6, pow_bits=4)
+    d_t = to_dev(torch, flat)
+    got, state = _prove(prover, monkeypatch, d_t, W, log_h, bc, spans, it, 6, 4, log_blocks, jit)
+    assert (state == 1) if jit else (state in (0, -1))
+    assert len(got) == len(want) and (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
+    assert prover.verify_logup(got, W, log_h, bc, spans, it, num_queries=6, pow_bits=4)[0] == 0
+    assert sm.verify_logup(got, W, log_h, bc, spans, *it, num_queries=6, pow_bits=4) == 0
+
+
+def test_trace_root_then_prove_in_streamed_mode(gpu, monkeypatch):
+    """pw_prover_trace_root leaves the streamed commitment (coefficients + tree) for the proof that follows; a shared bus seed
+    works as in the resident mode."""
+    torch, abi, prover = gpu
+    flat, W, log_h, bc, spans, it = _synthetic("T1", 700, seed=5)
+    d_t = to_dev(torch, flat)
+    monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", "0")
+    pr = prover.Prover(W, bc, spans, num_queries=5, interactions=it)
+    root0 = pr.trace_root(d_t.data_ptr(), log_h)
+    pr.set_bus_seed(root0[::-1].copy())
+    want = pr.prove(d_t.data_ptr(), log_h)
+    pr.close()
+    monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", "2")
+    pr = prover.Prover(W, bc, spans, num_queries=5, interactions=it)
+    root = pr.trace_root(d_t.data_ptr(), log_h)
+    assert (root == root0).all()
+    pr.set_bus_seed(root0[::-1].copy())
+    got = pr.prove(d_t.data_ptr(), log_h)
+    assert (got == want).all()
+    pr.close()
+
+
+def test_mode_policy(gpu, monkeypatch):
+    """Unset, the mode follows the free memory: a small trace is resident; a shape that cannot fit resident is streamed with the
+    smallest number of sub-cosets whose buffers fit (here checked through the planner only: nothing is allocated)."""
+    torch, abi, prover = gpu
+    monkeypatch.delenv("POWDR_STREAM_LOG_BLOCKS", raising=False)
+    bc, sp, it = synth.air_programs("apc", 64, 10, 20, seed=1)
+    pr = prover.Prover(64, bc, sp, num_queries=4, interactions=it)
+    assert pr.stream_log_blocks(12) == 0 and pr.stream_log_blocks(18) == 0
+    pr.close()
+    free = torch.cuda.mem_get_info()[0]
+    # a width whose resident LDE alone exceeds the free memory at 2^22 rows
+    W = int(free // (8 << 22)) + 64
+    bc, sp, it = synth.air_programs("apc", W, 4, 8, seed=2)
+    pr = prover.Prover(W, bc, sp, num_queries=4, interactions=None)
+    b = pr.stream_log_blocks(22)
+    assert b >= 1 or b == -1
+    pr.close()
