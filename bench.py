@@ -402,17 +402,20 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
     return rec if rank == 0 else None
 
 
-def c3_leg(queries, pow_bits, steps=2):
-    """BASELINE configs[2] (guest-ecrecover autoprecompile, 2^22 rows, "HBM-roofline report") inside the driver-timed line: the
-    C3 AIR (3 731 columns, 3 114 constraints, 2 314 bus interactions; W * H > 2^32, column-index operands) on dense synthetic
-    sources (`C3p`: the real block's ~600 GB of dummy traces fit no single GPU — SURVEY.md §8 row f-1): one trace generation +
-    1 warm-up proof (allocates ~128 GB) + `steps` timed proofs, host-verified; per-kernel algorithmic GB/s against the 8 TB/s peak
-    and the whole step against 48 B per cell. Needs ~190 GB of free HBM: skipped with the reason otherwise."""
+def c3_leg(queries, pow_bits, steps=2, constraints_only_too=True):
+    """BASELINE configs[2] (guest-ecrecover autoprecompile, 2^22 rows — the reference's default segment height,
+    openvm-riscv/src/lib.rs:366-371 — "HBM-roofline report") inside the driver-timed line, WITH its bus interactions inside the proof
+    (PowdrAir::eval always pushes them, chip.rs:117-129): the C3 AIR (3 731 columns, 3 114 constraints, 2 314 bus interactions = 1 157
+    LogUp groups = 4 632 permutation columns; W * H > 2^32, column-index operands) on dense synthetic sources (`C3p`: the real block's
+    ~600 GB of dummy traces fit no single GPU — SURVEY.md §8 row f-1). The resident LDE of 8 363 committed columns x 2^23 rows would be
+    280 GB, so the prover runs STREAMED (include/powdr_prover.h): coefficient arrays resident, the extended domain walked as 2^b
+    sub-cosets. One trace generation + 1 warm-up proof + `steps` timed proofs, host-verified; per-kernel table; and (sub-record
+    `constraints_only`) the round-3 figure: the resident constraints-only proof of the same trace."""
     from powdr_amd import abi, prover
 
     free = torch.cuda.mem_get_info()[0]
-    if free < 230e9:
-        return dict(skipped=f"needs ~190 GB of HBM for 3 731 x 2^22 (trace 62.6 GB + LDE 125 GB); {free / 1e9:.0f} GB free")
+    if free < 250e9:
+        return dict(skipped=f"needs ~250 GB of HBM for 3 731 x 2^22 with the bus argument (trace 62.6 GB + streamed prover ~185 GB); {free / 1e9:.0f} GB free")
     log_h = 22
     wl = build_workload("C3p", log_h, False, seed=0)
     W, H = wl["W"], wl["H"]
@@ -425,45 +428,82 @@ def c3_leg(queries, pow_bits, steps=2):
     tg_timing = abi.timing_report()
     abi.lib.powdr_gpu_timing_enable(0)
     src_bytes = wl["src_bytes"]
-    wl["dummy"].clear(); wl["tensors"].clear()  # the sources make room for the LDE
+    wl["dummy"].clear(); wl["tensors"].clear()  # the sources make room for the prover
     torch.cuda.empty_cache()
-    pr = prover.Prover(W, *wl["cons"], num_queries=queries, pow_bits=pow_bits)
-    pr.prove(wl["out"].data_ptr(), log_h, copy=False)  # warm-up: allocation of the prover's buffers, specialised kernels
-    torch.cuda.synchronize()
-    abi.lib.powdr_gpu_timing_enable(1)
-    t2 = time.perf_counter()
-    for _ in range(steps):
-        proof = pr.prove(wl["out"].data_ptr(), log_h)
-    torch.cuda.synchronize()
-    t_prove = (time.perf_counter() - t2) / steps
-    timing = abi.timing_report()
-    abi.lib.powdr_gpu_timing_enable(0)
-    rc = prover.verify(proof, W, log_h, *wl["cons"], num_queries=queries, pow_bits=pow_bits)
     cells = W * H
     algo = {"apc_gather_tile_kernel": 8.0, "ntt_group_kernel<dif>": 8.0, "lde_fused_kernel": 12.0, "ntt_group_kernel<dit>": 16.0, "leaf_hash_kernel": 8.0,
-            "deep_kernel": 8.0, "ext_dot_partial_kernel": 4.0}
-    kernels = {}
-    for k, (cnt, ms) in sorted(timing.items(), key=lambda kv: -kv[1][1]):
-        e = dict(launches_per_step=cnt / steps, ms=ms / steps)
-        if k in algo:
-            e["algorithmic_GBps"] = algo[k] * cells / (ms / steps * 1e-3) / 1e9
-            e["frac_of_hbm_peak"] = e["algorithmic_GBps"] / HBM_PEAK_GBS
-        kernels[k] = e
+            "deep_kernel": 8.0, "ext_dot_partial_kernel": 4.0, "ext_lincomb_kernel": 4.0}
+
+    def kernel_table(timing, n, committed_cells):
+        out = {}
+        for k, (cnt, ms) in sorted(timing.items(), key=lambda kv: -kv[1][1]):
+            e = dict(launches_per_step=cnt / n, ms=ms / n)
+            if k in algo:
+                e["algorithmic_GBps"] = algo[k] * committed_cells / (ms / n * 1e-3) / 1e9
+                e["frac_of_hbm_peak"] = e["algorithmic_GBps"] / HBM_PEAK_GBS
+            out[k] = e
+        return out
+
+    def run(pr, n, verify):
+        pr.prove(wl["out"].data_ptr(), log_h, copy=False)  # warm-up: allocation of the prover's buffers
+        torch.cuda.synchronize()
+        abi.lib.powdr_gpu_timing_enable(1)
+        t2 = time.perf_counter()
+        for _ in range(n):
+            proof = pr.prove(wl["out"].data_ptr(), log_h)
+        torch.cuda.synchronize()
+        t_prove = (time.perf_counter() - t2) / n
+        timing = abi.timing_report()
+        abi.lib.powdr_gpu_timing_enable(0)
+        return t_prove, timing, proof, verify(proof)
+
+    # ---- the proof with the bus argument (streamed) ----
+    it = wl["apc"].compile_bus(1)
+    perm_cols = 4 * len(prover.logup_group_starts(it))
+    pr = prover.Prover(W, *wl["cons"], num_queries=queries, pow_bits=pow_bits, interactions=it)
+    t0 = time.perf_counter()
+    pr.specialise()
+    t_spec = time.perf_counter() - t0
+    mode = pr.stream_log_blocks(log_h)
+    t_prove, timing, proof, rc = run(pr, steps, lambda pf: prover.verify_logup(pf, W, log_h, *wl["cons"], it, num_queries=queries, pow_bits=pow_bits)[0])
+    step_s = t_prove + t_gen
+    rho = perm_cols / W
+    bpc = 48.0 + 4.0 + 44.0 * rho
+    rec = dict(workload=f"C3p guest-ecrecover-shaped AIR: {W} cols x 2^{log_h} rows, {len(wl['cons'][1])} constraints, {wl['apc'].n_bus} bus interactions "
+                        f"INSIDE the proof ({perm_cols} permutation columns), dense synthetic sources ({src_bytes / 1e9:.1f} GB, released after trace generation)",
+               logup=True, cells=cells, steps=steps, warmup=1, trace_gen_ms=t_gen * 1e3, prove_ms=t_prove * 1e3, value=cells / step_s, unit="cells/s",
+               cells_per_s_prove_only=cells / t_prove, verify_rc=int(rc), specialised_kernels=pr.specialised(), specialise_s=t_spec,
+               stream_log_blocks=mode,
+               mode=(f"streamed: coefficient arrays resident, extended domain walked as {1 << mode} sub-cosets per pass (commit main, commit perm, quotient, queries)"
+                     if mode > 0 else "resident LDE"),
+               committed_columns=W + perm_cols + 8, trace_bytes=cells * 4, prover_device_bytes=pr.device_bytes(),
+               prover_plus_trace_bytes=pr.device_bytes() + cells * 4,
+               whole_step_hbm=dict(algo_bytes_per_main_cell=bpc, rho=rho, achieved_GBps=cells / step_s * bpc / 1e9, peak_GBps=HBM_PEAK_GBS,
+                                   frac=cells / step_s * bpc / 1e9 / HBM_PEAK_GBS,
+                                   note="SURVEY 8d: 48 + 4 + 44 rho bytes per main cell; the streamed mode re-extends every column for each of its passes, "
+                                        "so the bytes it moves are higher than the resident figure this fraction is priced against"),
+               proof_bytes=int(len(proof) * 4), kernels=kernel_table(timing, steps, (W + perm_cols + 8) * H))
     for k, (cnt, ms) in tg_timing.items():
         e = dict(launches_per_step=cnt, ms=ms)
         if k in algo:
             e["algorithmic_GBps"] = algo[k] * cells / (ms * 1e-3) / 1e9
             e["frac_of_hbm_peak"] = e["algorithmic_GBps"] / HBM_PEAK_GBS
-        kernels[k] = e
-    step_s = t_prove + t_gen
-    rec = dict(workload=f"C3p guest-ecrecover-shaped AIR: {W} cols x 2^{log_h} rows, {len(wl['cons'][1])} constraints, {wl['apc'].n_bus} bus interactions "
-                        f"(replayed into the histograms; constraints-only proof), dense synthetic sources ({src_bytes / 1e9:.1f} GB)",
-               cells=cells, steps=steps, warmup=1, trace_gen_ms=t_gen * 1e3, prove_ms=t_prove * 1e3, value=cells / step_s, unit="cells/s",
-               cells_per_s_prove_only=cells / t_prove, verify_rc=int(rc), specialised_kernels=pr.specialised(),
-               whole_step_hbm=dict(algo_bytes_per_cell=ALGO_BYTES_PER_CELL, achieved_GBps=cells / step_s * ALGO_BYTES_PER_CELL / 1e9, peak_GBps=HBM_PEAK_GBS,
-                                   frac=cells / step_s * ALGO_BYTES_PER_CELL / 1e9 / HBM_PEAK_GBS),
-               prover_device_bytes=pr.device_bytes(), proof_bytes=int(len(proof) * 4), kernels=kernels)
+        rec["kernels"][k] = e
     pr.close()
+    torch.cuda.empty_cache()
+    # ---- the round-3 figure: constraints-only proof of the same trace, resident LDE ----
+    if constraints_only_too:
+        try:
+            pr = prover.Prover(W, *wl["cons"], num_queries=queries, pow_bits=pow_bits)
+            mode0 = pr.stream_log_blocks(log_h)
+            t_p, timing0, proof0, rc0 = run(pr, 1, lambda pf: prover.verify(pf, W, log_h, *wl["cons"], num_queries=queries, pow_bits=pow_bits))
+            rec["constraints_only"] = dict(logup=False, prove_ms=t_p * 1e3, value=cells / (t_p + t_gen), cells_per_s_prove_only=cells / t_p, verify_rc=int(rc0),
+                                           stream_log_blocks=mode0, prover_device_bytes=pr.device_bytes(), proof_bytes=int(len(proof0) * 4),
+                                           kernels=kernel_table(timing0, 1, (W + 8) * H),
+                                           note="a weaker statement than `value`: the bus interactions are replayed into the histograms but not proven")
+            pr.close()
+        except Exception as e:  # an extra
+            rec["constraints_only"] = dict(value=None, error=f"{type(e).__name__}: {e}")
     wl.clear()
     torch.cuda.empty_cache()
     return rec

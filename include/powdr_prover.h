@@ -263,7 +263,7 @@ int pw_lde_fused(const uint32_t* d_trace, uint32_t width, uint32_t log_height, u
 
 /* One sub-coset of the LDE from coefficient arrays (the stage the streamed mode is built on): d_coeffs as pw_lde_batch leaves them
  * (width x H, bit-reversed, H-scaled); d_out (width x 2H / 2^log_blocks) receives the rows r + 2^log_blocks * i of the LDE, i.e. the
- * evaluations on (31 g_(n+1)^r) <g_(n+1)^(2^log_blocks)>; d_scale: H words of scratch. 1 <= log_blocks <= log_height. */
+ * evaluations on (31 g_(n+1)^r) <g_(n+1)^(2^log_blocks)>; d_scale: H words of scratch. 1 <= log_blocks <= min(log_height, 5). */
 int pw_lde_subcoset(const uint32_t* d_coeffs, uint32_t width, uint32_t log_height, uint32_t log_blocks, uint32_t r, uint32_t* d_scale,
                     uint32_t* d_out);
 

@@ -57,15 +57,6 @@ __global__ void bitrev_copy_kernel(const uint32_t* in, uint32_t* out, int n) {
     out[i] = in[k];
 }
 
-// scale[Q] = s^k / 2^n * w^k with k = bitrev_n(Q): the coset scaling of coefficient k on the sub-coset (s w) <g_m> of the LDE domain,
-// in the bit-reversed order the coefficient arrays have (subcoset_lde)
-__global__ void fold_scale_kernel(const uint32_t* __restrict__ shift, int n, uint32_t w, uint32_t* __restrict__ out) {
-    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= ((size_t)1 << n)) return;
-    const uint32_t k = n ? (__brev((uint32_t)q) >> (32 - n)) : 0u;
-    out[q] = bb::mul(shift[k], bb::pow_u32(w, k));
-}
-
 struct GroupParams {
     int n;        // log2 of the transform size
     int s0;       // first stage of the group
@@ -79,7 +70,14 @@ struct GroupParams {
     unsigned long long n_tiles;  // tiles per column = 2^(n-B)
     int canonical_out;  // forward transform: the last group reduces its [0, 2p) values to [0, p) when it stores
     unsigned twt_off[4];  // per round: offset of its twiddle table (contiguous groups of the fused LDE kernel, see FusedTwiddles)
-    int fold;     // FOLD loads (sub-coset evaluation): element g of the transform's input is the sum of 2^fold scaled coefficients
+    // sub-coset evaluation (subcoset_lde): FOLD loads — element g of the transform's input is the sum of 2^fold coefficients times the
+    // wave-uniform constants foldk[] — and a COSET transform: the twiddles of stage s carry the constant c^(2^(n-1-s)). Tile-invariant
+    // groups read them from a table derived for the sub-coset; the others multiply a round's top twiddle base by cst[round] (the lower
+    // stages' constants follow from the squaring chain).
+    int fold;
+    int coset;
+    uint32_t foldk[16];
+    uint32_t cst[4];
 };
 
 __device__ __forceinline__ uint32_t lds_phys(uint32_t l) { return l + (l >> 5); }
@@ -171,22 +169,21 @@ __device__ __forceinline__ void slot_butterflies(uint32_t* v, uint32_t base_top,
 }
 
 // FOLD load (sub-coset evaluation, subcoset_lde below): input element g of a size-2^n' transform is
-//   sum_{t < 2^f} src[(g << f) + t] * scale[(g << f) + t]
-// — the polynomial reduced modulo x^(2^n') - c on the sub-coset, in bit-reversed order: the 2^f coefficients that fold onto one
-// position are contiguous. Canonical result.
-__device__ __forceinline__ uint32_t fold_load(const uint32_t* __restrict__ src, const uint32_t* __restrict__ sc, size_t g, int f) {
+//   sum_{t < 2^f} src[(g << f) + t] * K[t]
+// — the polynomial reduced modulo x^(2^n') - c^(2^n') on the sub-coset, in bit-reversed order: the 2^f coefficients that fold onto one
+// position are contiguous, and their factors (c^(2^n') to the power bitrev(t), over H) are the same for every position. Canonical.
+__device__ __forceinline__ uint32_t fold_load(const uint32_t* __restrict__ src, const uint32_t* K, size_t g, int f) {
     const size_t q = g << f;
-    if (f == 0) return bb::mul(src[q], sc[q]);
+    if (f == 0) return bb::mul(src[q], K[0]);
     if (f == 1) {
-        const uint2 a = *reinterpret_cast<const uint2*>(src + q), s = *reinterpret_cast<const uint2*>(sc + q);
-        return bb::mul2(a.x, s.x, a.y, s.y);
+        const uint2 a = *reinterpret_cast<const uint2*>(src + q);
+        return bb::mul2(a.x, K[0], a.y, K[1]);
     }
     const uint4* pa = reinterpret_cast<const uint4*>(src + q);
-    const uint4* ps = reinterpret_cast<const uint4*>(sc + q);
     uint32_t acc = 0u;
     for (int t = 0; t < (1 << (f - 2)); ++t) {
-        const uint4 a = pa[t], s = ps[t];
-        acc = bb::add(acc, bb::add(bb::mul2(a.x, s.x, a.y, s.y), bb::mul2(a.z, s.z, a.w, s.w)));
+        const uint4 a = pa[t];
+        acc = bb::add(acc, bb::add(bb::mul2(a.x, K[4 * t], a.y, K[4 * t + 1]), bb::mul2(a.z, K[4 * t + 2], a.w, K[4 * t + 3])));
     }
     return acc;
 }
@@ -198,7 +195,7 @@ __device__ __forceinline__ uint32_t fold_load(const uint32_t* __restrict__ src, 
 // EXPAND: `src` is the H-sized bit-reversed coefficient array (n = log2(2H)); element g of the
 // 2H-sized vector is src[g >> 1] * scale_br[g >> 1].
 // `tw_base` enters as the twiddle base of this round's slot 0 and leaves as the one of the next round's slot 0.
-// MODE: 0 = plain loads, 1 = EXPAND, 2 = FOLD (fold_load above; `scale_br` is the sub-coset's scale table).
+// MODE: 0 = plain loads, 1 = EXPAND, 2 = FOLD (fold_load above).
 template <bool DIF, int LOGR, int EPT, int MODE, bool TWT = false>
 __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, const GroupParams& gp, int round,
                                           const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
@@ -227,7 +224,7 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
         const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
         const uint32_t p0 = lds_phys(l0);
         // fetch the next slot's (or the next round's first) twiddle base while this slot computes
-        const uint32_t cur_base = tw_base;
+        const uint32_t cur_base = (!TWT && gp.coset) ? bb::mul(tw_base, gp.cst[round]) : tw_base;
         uint32_t tt[R];  // TWT: the slot's twiddles from the group's table (`tw`), [stage-major index][g], g = the index bits below the window
         if (TWT) {
             const uint32_t* tab = tw + gp.twt_off[round] + (l0 & ((1u << rb) - 1u));
@@ -244,7 +241,7 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
                 const size_t g0 = im.global(l0, valid);
                 if (valid) {
 #pragma unroll
-                    for (int rho = 0; rho < R; ++rho) x[rho] = fold_load(src, scale_br, g0 + ((size_t)rho << gshift), gp.fold);
+                    for (int rho = 0; rho < R; ++rho) x[rho] = fold_load(src, gp.foldk, g0 + ((size_t)rho << gshift), gp.fold);
                 } else {
 #pragma unroll
                     for (int rho = 0; rho < R; ++rho) x[rho] = 0u;
@@ -573,15 +570,34 @@ const GroupTwiddles* group_twiddles(const GroupParams& gp, bool dif) {
     return &g_group_tw.emplace(key, gt).first->second;
 }
 
-// fold_log >= 0: the first group loads with FOLD (`expand_scale_br` is then the sub-coset's scale table, subcoset_lde)
+// A tile-invariant group's twiddle table with a sub-coset's constants folded in: entry (round r, stage q of the round) times cq[r][q]
+struct CosetTableArgs { unsigned off[4]; int rb[4], logr[4]; int n_rounds; uint32_t cq[4][4]; unsigned total; };
+__global__ void coset_table_kernel(const uint32_t* __restrict__ tab, uint32_t* __restrict__ out, CosetTableArgs a) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    int r = 0;
+    while (r + 1 < a.n_rounds && i >= a.off[r + 1]) ++r;
+    const unsigned j = (i - a.off[r]) >> a.rb[r];  // stage-major twiddle index: stage q holds j in [2^q - 1, 2^(q+1) - 1)
+    const int q = 31 - __clz((int)(j + 1));
+    out[i] = bb::mul(tab[i], a.cq[r][q]);
+}
+
+// Sub-coset evaluation (subcoset_lde): the first group loads with FOLD, every stage's twiddles carry the coset constant C[stage]
+struct CosetSpec {
+    int fold_log;
+    uint32_t foldk[16];
+    uint32_t C[32];       // C[s] = c^(2^(n-1-s)), s < n
+    uint32_t* d_scratch;  // room for a group's derived twiddle table (< 2^13 words)
+};
+
 template <bool DIF>
 void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n,
-                int first_stage, const uint32_t* tw, const uint32_t* expand_scale_br, const char* name, int fold_log = -1) {
+                int first_stage, const uint32_t* tw, const uint32_t* expand_scale_br, const char* name, const CosetSpec* cs = nullptr) {
     int logt = 12;
     auto groups = plan_groups(DIF, n, first_stage, logt);
     const uint32_t* src = in;
     size_t src_stride = in_stride;
-    int mode = fold_log >= 0 ? 2 : expand_scale_br != nullptr ? 1 : 0;
+    int mode = cs ? 2 : expand_scale_br != nullptr ? 1 : 0;
     if (!groups.empty()) groups.back().canonical_out = 1;
     for (auto& g : groups) {
         const size_t tiles = (size_t)1 << (n - g.B);
@@ -589,14 +605,32 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
         const unsigned wgs = (unsigned)((tiles + per_wg - 1) / per_wg);
         const GroupTwiddles* gt = group_twiddles(g, DIF);  // tile-invariant groups read their twiddles from a table
         if (gt) for (int r = 0; r < 4; ++r) g.twt_off[r] = gt->off[r];
-        g.fold = mode == 2 ? fold_log : 0;
+        const uint32_t* table = gt ? gt->d : nullptr;
+        if (cs) {
+            g.coset = 1;
+            g.fold = mode == 2 ? cs->fold_log : 0;
+            for (int k = 0; k < 16; ++k) g.foldk[k] = cs->foldk[k];
+            for (int r = 0; r < g.n_rounds; ++r) g.cst[r] = cs->C[g.s0 + g.rb[r] + g.logr[r] - 1 - g.c];
+            if (gt) {
+                CosetTableArgs a{};
+                a.n_rounds = g.n_rounds;
+                for (int r = 0; r < g.n_rounds; ++r) {
+                    a.off[r] = gt->off[r]; a.rb[r] = g.rb[r]; a.logr[r] = g.logr[r];
+                    for (int q = 0; q < g.logr[r]; ++q) a.cq[r][q] = cs->C[g.s0 + g.rb[r] - g.c + q];
+                }
+                const int lr = g.n_rounds - 1;
+                a.total = gt->off[lr] + (((1u << g.logr[lr]) - 1u) << g.rb[lr]);
+                hipLaunchKernelGGL(coset_table_kernel, dim3(div_up(a.total, 256)), dim3(256), 0, stream(), gt->d, cs->d_scratch, a);
+                table = cs->d_scratch;
+            }
+        }
         for (uint32_t c0 = 0; c0 < cols; c0 += 65535u) {
             uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;
             ScopedKernelTimer t(name);
             const uint32_t* s_ = src + (size_t)c0 * src_stride;
             uint32_t* d_ = out + (size_t)c0 * out_stride;
             dim3 grid(wgs, cc), block(kBlock);
-#define PW_LAUNCH_NTT(LT, MD) do { if (gt) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, MD, true>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, gt->d, expand_scale_br); \
+#define PW_LAUNCH_NTT(LT, MD) do { if (gt) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, MD, true>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, table, expand_scale_br); \
                                    else hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, MD, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br); } while (0)
             if (logt == 13) { if (mode == 2) PW_LAUNCH_NTT(13, 2); else if (mode == 1) PW_LAUNCH_NTT(13, 1); else PW_LAUNCH_NTT(13, 0); }
             else            { if (mode == 2) PW_LAUNCH_NTT(12, 2); else if (mode == 1) PW_LAUNCH_NTT(12, 1); else PW_LAUNCH_NTT(12, 0); }
@@ -766,28 +800,35 @@ int coset_lde_from_coeffs(const uint32_t* coeffs, uint32_t* out, size_t in_strid
     return (int)hipGetLastError();
 }
 
-// ---- sub-coset evaluation (the streamed prover, prover_stream.hip) -------------------------------------------------------
-// The LDE domain s <g_(n+1)> (2^(n+1) points) is the union of 2^b sub-cosets (s g_(n+1)^r) <g_m>, m = 2^(n+1-b), r < 2^b: rows
-// j = r + 2^b i of the LDE. On one of them x^m is the constant c = (s g^r)^m, so a polynomial of degree < 2^n is its remainder
-// modulo x^m - c there: b_i = sum_t a_(i + t m) c^t, 2^(b-1) coefficients per position (contiguous in bit-reversed order), then
-// a size-m transform with the coset scaling folded into the same load. Work: 2^n multiply-adds + (m / 2) log2 m butterflies per
-// column and sub-coset — all 2^b sub-cosets together cost one forward transform plus 2^(b-1) extra passes over the coefficients.
-int subcoset_scale(int n, int b, uint32_t r, uint32_t* scale) {
-    const Tables* tn = tables(n);
-    if (!tn) return (int)hipErrorOutOfMemory;
-    const uint32_t w = bb::pow_u32(field::root_of_unity(n + 1), r);
-    ScopedKernelTimer t("fold_scale_kernel");
-    hipLaunchKernelGGL(fold_scale_kernel, dim3(div_up((size_t)1 << n, 256)), dim3(256), 0, stream(), tn->shift, n, w, scale);
-    return (int)hipGetLastError();
-}
-
-int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b,
-                 const uint32_t* scale) {
+// ---- sub-coset evaluation (the streamed prover, prover.hip "streamed proofs") ---------------------------------------------
+// The LDE domain s <g_(n+1)> (2^(n+1) points) is the union of 2^b sub-cosets c <g_m>, c = s g_(n+1)^r, m = 2^(n+1-b), r < 2^b: rows
+// j = r + 2^b i of the LDE. On one of them x^m is the constant c^m, so a polynomial of degree < 2^n is its remainder modulo
+// x^m - c^m there: b_i = sum_t a_(i + t m) c^(t m), 2^(b-1) coefficients per position — contiguous in the bit-reversed order of the
+// coefficient arrays, their factors the same for every position (kernel arguments) — and the remainder is evaluated on c <g_m> by a
+// size-m COSET transform: the DIT network with the twiddles of stage s multiplied by c^(2^(log2 m - 1 - s)) (P(x) = E(x^2) + x O(x^2)
+// level by level), i.e. no scaling pass and no per-element scale table. Work per column and sub-coset: 2^n multiply-adds +
+// (m / 2) log2 m butterflies; all 2^b sub-cosets together read the coefficients 2^(b-1) times for one forward transform's butterflies.
+int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, uint32_t r,
+                 uint32_t* d_scratch) {
     const int nm = n + 1 - b;  // log2 of the sub-coset's size
-    if (b < 1 || nm < 1) return (int)hipErrorInvalidValue;
+    if (b < 1 || b > 5 || nm < 1 || (r >> b)) return (int)hipErrorInvalidValue;
     const Tables* tm = tables(nm);
     if (!tm) return (int)hipErrorOutOfMemory;
-    run_groups<false>(coeffs, out, in_stride, out_stride, cols, nm, 0, tm->tw_fwd, scale, "ntt_group_kernel<dit>", b - 1);
+    CosetSpec cs{};
+    cs.fold_log = b - 1;
+    cs.d_scratch = d_scratch;
+    // c = s g_(n+1)^r; pw[e] = c^(2^e)
+    uint32_t pw[32];
+    pw[0] = bb::mul(bb::to_monty(field::kCosetShift), bb::pow_u32(field::root_of_unity(n + 1), r));
+    for (int e = 1; e <= nm; ++e) pw[e] = bb::sqr(pw[e - 1]);
+    for (int s = 0; s < nm; ++s) cs.C[s] = pw[nm - 1 - s];
+    const uint32_t hinv = bb::inv(bb::to_monty((uint32_t)(((uint64_t)1 << n) % bb::P)));  // the coefficient arrays are H-scaled
+    const int f = b - 1;
+    for (uint32_t tp = 0; tp < (1u << f); ++tp) {
+        const uint32_t t = f ? (__builtin_bitreverse32(tp) >> (32 - f)) : 0u;
+        cs.foldk[tp] = bb::mul(bb::pow_u32(pw[nm], t), hinv);
+    }
+    run_groups<false>(coeffs, out, in_stride, out_stride, cols, nm, 0, tm->tw_fwd, nullptr, "ntt_group_kernel<dit>", &cs);
     return (int)hipGetLastError();
 }
 

@@ -280,7 +280,7 @@ void plan_buffers(const PwProver* p, uint32_t log_h, int b, CommitLayout& L, Buf
     B.coef = L.panel_cols * H * 4;
     B.lde = b ? (size_t)(W + Wp) * L.m * 4 : (size_t)W * N * 4;
     B.digests = (L.n_trees * L.tree_words + L.fri_words) * 4;
-    if (b) { B.tcoef = (size_t)W * H * 4; B.fscale = H * 4; B.gbuf = (size_t)24 * H * 4; }
+    if (b) { B.tcoef = (size_t)W * H * 4; B.fscale = (size_t)1 << 15; B.gbuf = (size_t)24 * H * 4; }
     if (lg) {  // + the uncommitted per-row-sum columns (kJitExtraPermCols; the streamed path keeps them on every path)
         B.perm = (size_t)(Wp + kJitExtraPermCols) * H * 4;
         B.plde = b ? (size_t)8 * N * 4 : (size_t)(Wp + kJitExtraPermCols) * N * 4;
@@ -308,7 +308,7 @@ void plan_buffers(const PwProver* p, uint32_t log_h, int b, CommitLayout& L, Buf
 
 // 0 = resident, b >= 1 = streamed over 2^b sub-cosets; < 0: nothing fits
 int stream_log_blocks(const PwProver* p, uint32_t log_h) {
-    const int b_max = (int)log_h - 1;  // sub-cosets of at least 4 rows
+    const int b_max = std::min((int)log_h - 1, 5);  // sub-cosets of at least 4 rows; at most 32 of them (subcoset_lde)
     if (const char* e = getenv("POWDR_STREAM_LOG_BLOCKS")) {
         const int v = atoi(e);
         if (v <= 0 || b_max < 1) return 0;
@@ -319,8 +319,14 @@ int stream_log_blocks(const PwProver* p, uint32_t log_h) {
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
     // buffers are grown by free + malloc, so what the prover holds now counts as available; 8 % of head room for the
     // allocator's granularity, the twiddle tables and the caller's own small allocations during the proof
-    const size_t avail = (size_t)((double)(free_b + pw_prover_device_bytes(p)) * 0.92);
-    for (int b = 0; b <= b_max && b <= 12; ++b) {
+    const size_t held = pw_prover_device_bytes(p);
+    const size_t others = total_b > free_b + held ? total_b - free_b - held : 0;  // the caller's trace, other provers, the runtime
+    size_t avail = (size_t)((double)(free_b + held) * 0.92);
+    // ... and the device as a whole stays below 90 % (288 GB: 259 GB): a streamed proof trades a few sub-cosets more for room the
+    // caller may need between two proofs
+    const size_t cap = (size_t)((double)total_b * 0.90);
+    avail = std::min(avail, cap > others ? cap - others : (size_t)0);
+    for (int b = 0; b <= b_max; ++b) {
         CommitLayout L;
         BufferPlan B;
         plan_buffers(p, log_h, b, L, B);
@@ -354,10 +360,9 @@ int for_each_subcoset(PwProver* p, const CommitLayout& L, uint32_t log_h, std::i
     uint32_t* fs = p->fscale.as<uint32_t>();
     for (uint32_t r = 0; r < (1u << L.b); ++r) {
         if (wanted && !(*wanted)[r]) continue;
-        TRY(subcoset_scale((int)log_h, L.b, r, fs));
         size_t c0 = 0;
         for (const CoefMatrix& mt : mats) {
-            if (mt.cols) TRY(subcoset_lde(mt.coef, blk + c0 * L.m, L.H, L.m, mt.cols, (int)log_h, L.b, fs));
+            if (mt.cols) TRY(subcoset_lde(mt.coef, blk + c0 * L.m, L.H, L.m, mt.cols, (int)log_h, L.b, r, fs));
             c0 += mt.cols;
         }
         TRY(body(r));
@@ -892,8 +897,7 @@ extern "C" int pw_lde_subcoset(const uint32_t* d_coeffs, uint32_t width, uint32_
     (void)hipGetLastError();
     if (!d_coeffs || !d_scale || !d_out || !width || log_blocks < 1 || log_blocks > log_h || log_h > 26 || (r >> log_blocks)) return -1;
     const size_t H = (size_t)1 << log_h, m = (2 * H) >> log_blocks;
-    TRY(subcoset_scale((int)log_h, (int)log_blocks, r, d_scale));
-    TRY(subcoset_lde(d_coeffs, d_out, H, m, width, (int)log_h, (int)log_blocks, d_scale));
+    TRY(subcoset_lde(d_coeffs, d_out, H, m, width, (int)log_h, (int)log_blocks, r, d_scale));
     return (int)hipGetLastError();
 }
 

@@ -31,9 +31,9 @@ int lde_fused(const uint32_t* in, uint32_t* tmp, uint32_t* out, size_t in_stride
 const uint32_t* shift_table(int n);  // s^k / 2^n (Montgomery), k < 2^n, device
 // Sub-coset evaluation (the streamed prover): the rows j = r + 2^b i, i < 2^(n+1-b), of the LDE of `cols` polynomials given by their
 // coefficient arrays as intt_dif leaves them (2^n words each, bit-reversed, H-scaled): out[c * out_stride + i] = P_c(s g_(n+1)^j).
-// `scale` = subcoset_scale(n, b, r): 2^n words (the coset scaling of every coefficient on that sub-coset), computed once per r.
-int subcoset_scale(int n, int b, uint32_t r, uint32_t* scale);
-int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, const uint32_t* scale);
+// d_scratch: 2^13 words (the sub-coset's twiddle table). 1 <= b <= 5.
+int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, uint32_t r,
+                 uint32_t* d_scratch);
 
 // ---- merkle.hip ------------------------------------------------------------------------
 // Digest tree layout: level 0 = leaves (n_leaves x 8 words), then n_leaves/2, ... , 1;

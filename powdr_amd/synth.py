@@ -96,6 +96,16 @@ def _count(e):
     return 1
 
 
+def _stack_need(e):
+    """Slots the reference's post-fix evaluator needs for `e` as compile_bus_to_gpu / emit_expr emit it (left operand first:
+    cuda/mod.rs:49-98): its stack has 16 (expr_eval.cuh:22) and overflowing it is a device assert."""
+    if not isinstance(e, list):
+        return 1
+    if len(e) == 2:  # unary minus
+        return _stack_need(e[1])
+    return max(_stack_need(e[0]), 1 + _stack_need(e[2]))
+
+
 def generate(shape: Shape | str, seed: int = 0, verbosity: float = 1.0, density_note: str = "uniform") -> SynthApc:
     if isinstance(shape, str):
         shape = SHAPES[shape]
@@ -143,7 +153,10 @@ def generate(shape: Shape | str, seed: int = 0, verbosity: float = 1.0, density_
         while _count(e) < nodes_target:
             r = rng.random()
             if r < 0.4:
-                e = [0, "+", e]
+                # `0 + e` holds the constant while e is evaluated: one stack slot per nesting level. Past 14 the expression would trip
+                # the reference evaluator's own stack (16 slots); it is then padded the other way round — same random stream, so every
+                # shape / seed that never came near the limit is unchanged
+                e = [0, "+", e] if _stack_need(e) < 14 else [e, "*", 1]
             elif r < 0.7:
                 e = [e, "*", 1]
             elif r < 0.85:
