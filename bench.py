@@ -80,6 +80,9 @@ def parse_args():
     ap.add_argument("--inproc", action="store_true",
                     help="--shape C4 / C5 with --gpus N in ONE process: pw_prove_segments_multi (include/powdr_prover.h) — one host thread per "
                          "GPU behind the C ABI, RCCL all-gather of the commitments — instead of one torch.distributed rank per GPU")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks exactly as a real run would (self-launch under torch.distributed.run when --gpus N > 1 and no launcher "
+                         "set WORLD_SIZE), let them meet over gloo on the CPU, print {launch_check, n_gpus, ranks} and exit: no GPU is touched")
     ap.add_argument("--exact-source-heights", action="store_true",
                     help="allocate dummy traces with b*calls rows instead of next_pow2 (less HBM)")
     args = ap.parse_args()
@@ -98,6 +101,48 @@ def emit(line: dict):
         pass
     sys.stdout.flush()
     print(json.dumps(line), flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) as typed, with no launcher around it: become the launcher. Re-runs this command as N ranks
+    under torch.distributed.run — the form the driver uses (`-m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py ...`) — and passes their output and exit code through. A run that was asked for N GPUs never
+    silently measures one (VERDICT r3 #3)."""
+    import socket
+    import subprocess
+
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or args.inproc:
+        return
+    env = dict(os.environ, POWDR_BENCH_LAUNCH="self")
+    if not args.launch_check and env.get("POWDR_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) are visible; an N-GPU line is not produced on fewer "
+              f"GPUs (POWDR_DIST_BACKEND=gloo runs all ranks on GPU 0: the test hook of one-GPU boxes)", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def launch_check():
+    """--launch-check: the ranks meet over gloo on the CPU and rank 0 reports who is there."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    ranks = [0]
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+        ranks = [int(t.item()) for t in got]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        emit(dict(launch_check=True, n_gpus=world, ranks=ranks, launch=os.environ.get("POWDR_BENCH_LAUNCH", "external" if world > 1 else "single process")))
 
 
 def setup_distributed(n):
@@ -264,13 +309,33 @@ def timed_leg(run_steps, steps, warmup, barrier, abi, world):
     timing = abi.timing_report()
     abi.lib.powdr_gpu_timing_enable(0)
     elapsed = t1 - t0
+    LAST_PER_RANK_S[:] = [elapsed]
     if world > 1:
         import torch.distributed as dist
 
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(every, mine)
+        LAST_PER_RANK_S[:] = [float(t.item()) for t in every]
+        elapsed = max(LAST_PER_RANK_S)  # the contract: max over ranks
     return elapsed, timing
+
+
+LAST_PER_RANK_S = [0.0]  # seconds of the last timed_leg on every rank (rank order)
+
+
+def comm_facts(world):
+    """Who took part, as the communicator itself reports it (not as the command line asked)."""
+    if world <= 1:
+        return dict(ranks=1, backend=None, launch=os.environ.get("POWDR_BENCH_LAUNCH", "single process"))
+    import torch.distributed as dist
+
+    backend = dist.get_backend()
+    return dict(ranks=dist.get_world_size(), backend=("RCCL (torch.distributed nccl)" if backend == "nccl" else backend),
+                launch=os.environ.get("POWDR_BENCH_LAUNCH", "external launcher (torch.distributed.run)"),
+                devices_visible=torch.cuda.device_count(),
+                note=None if backend == "nccl" else "POWDR_DIST_BACKEND test hook: every rank on GPU 0, collectives over gloo - not a multi-GPU measurement")
 
 
 def gauges_of(stage_ms):
@@ -381,12 +446,13 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
             last["mine"], last["merged"] = mine, merged
 
     elapsed, timing = timed_leg(run_steps, steps, warmup, barrier, abi, world)
+    per_rank_ms = [t / steps * 1e3 for t in LAST_PER_RANK_S]
     assert (last["merged"] != 0).any(axis=1).all(), "a segment's commitment is missing from the merge"
     total_cells = cells_seg * n_segments * steps
     stage = {k: ms / steps for k, (c, ms) in timing.items()}
     rec = dict(shape=kind, scaling="strong", n_segments=n_segments, segments_on_rank0=len(last["mine"]), airs_per_segment=len(shapes),
                cells_per_segment=cells_seg, value=total_cells / elapsed, unit="cells/s", ms_per_step=elapsed / steps * 1e3, steps=steps,
-               warmup=warmup, logup=bool(logup), proof_bytes_per_segment=int(last["words"]) * 4,
+               warmup=warmup, logup=bool(logup), proof_bytes_per_segment=int(last["words"]) * 4, per_rank_ms=per_rank_ms, ranks=world,
                widths=f"{min(s[1] for s in shapes)}..{max(s[1] for s in shapes)} (sum {sum(s[1] for s in shapes)})",
                log_heights=f"{min(s[2] for s in shapes)}..{max(s[2] for s in shapes)}",
                constraints=sum(s[3] for s in shapes), interactions=sum(s[4] for s in shapes),
@@ -575,6 +641,13 @@ def load_profile_json(name):
 
 def main():
     args = parse_args()
+    self_launch(args)  # --gpus N > 1 without a launcher: re-run as N ranks (does not return)
+    if args.launch_check:
+        launch_check()
+        return
+    if int(os.environ.get("WORLD_SIZE", "1")) != max(1, args.gpus) and not args.inproc:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {os.environ.get('WORLD_SIZE', '1')} rank(s)", file=sys.stderr)
+        sys.exit(2)
     rank, local, world = setup_distributed(args.gpus)
     from powdr_amd import abi, prover, synth
 
@@ -611,6 +684,7 @@ def main():
                                + (" [with the bus argument]" if args.logup else " [constraints-only proofs]"),
                         value=rec["value"], unit="cells/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=rec["ms_per_step"],
                         higher_is_better=True, scaling="strong", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
+                        rccl_ranks=comm_facts(world)["ranks"], comm=comm_facts(world), per_rank_ms=rec.get("per_rank_ms"),
                         config=dict(workload=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs ({rec['cells_per_segment']} cells each, "
                                              f"heights 2^{rec['log_heights']}, widths {rec['widths']}), one proof per segment, segments sharded over "
                                              f"{world} GPU(s) by cells, main commitments all-gathered",
@@ -697,6 +771,7 @@ def main():
         [t.join() for t in th]
 
     elapsed, timing = timed_leg(run_steps, args.steps, max(args.warmup, len(workers) if args.warmup else 0), barrier, abi, world)
+    per_rank_ms = [t / args.steps * 1e3 for t in LAST_PER_RANK_S]
     cells_per_step = wl["W"] * wl["H"]
     total_cells = cells_per_step * args.steps * world
     value = total_cells / elapsed
@@ -892,12 +967,59 @@ def main():
                                reference_flow_expand_ms=expand_ms, reference_flow_gather_ms=timing.get("apc_gather_tile_kernel", (0, 0.0))[1] / args.steps,
                                reference_flow_dummy_trace_bytes=wl["src_bytes"],
                                step_ms_with_trace_from_records=elapsed / args.steps * 1e3 - timing.get("apc_gather_tile_kernel", (0, 0.0))[1] / args.steps + fused_ms,
-                               step_note="derived, not timed: the headline step with its gather kernel replaced by the fused kernel's time (the headline itself "
-                                         "keeps _apc_tracegen, the entry point cuda_abi.rs binds); powdr_apc_generate_witness_from_records is the one-call form",
+                               step_note="derived: the headline step with its gather kernel replaced by the fused kernel's time (the headline itself "
+                                         "keeps _apc_tracegen, the entry point cuda_abi.rs binds); the MEASURED step from records is `timed_step`",
                                note="powdr_apc_tracegen_records: the original chips (all thirteen RV32IM instruction AIRs; every constraint and lookup of the "
                                     "reference's openvm_constraints.txt holds on their rows; this block uses BaseAlu, Shift, LoadStore, BranchEqual, JalLui) expand "
                                     "their records inside the gather; only the cells the APC keeps are written, straight into their columns. The reference flow materialises the full dummy traces first (reference_flow_expand_ms on the same "
                                     "records, strided writes like a chip's) and gathers them (reference_flow_gather_ms)")
+            # ---- the step FROM RECORDS, timed: powdr_apc_generate_witness_from_records (a1-a3 in one call: fused chip
+            # expansion + gather, derived columns, bus replay) + the same proof as the headline, `--logup-steps` steps after one warm-up,
+            # between barrier + synchronize like every timed leg. The 150 GB of dummy traces are released first: this flow has none.
+            try:
+                from powdr_amd import host as host_
+
+                for k in ("tensors", "dummy"):
+                    wl[k].clear()
+                del bufs
+                torch.cuda.empty_cache()
+                doc_r = dict(doc)
+                blk_r = dict(doc["block"]["blocks"][0])
+                blk_r["instructions"] = ins
+                doc_r["block"] = dict(doc["block"], blocks=[blk_r])
+                apc_r = host_.Apc(doc_r)
+                cons_r = apc_r.compile_constraints()
+                pr_r = prover.Prover(wl["W"], *cons_r, num_queries=args.queries, pow_bits=args.pow_bits, interactions=apc_r.compile_bus(1) if args.logup else None)
+                if log_h >= 18:
+                    pr_r.specialise()
+                r_last = {}
+
+                def run_r(n):
+                    for _ in range(n):
+                        for t_ in (wl["per"].var_hist, wl["per"].tuple_hist, wl["per"].bitwise_hist):
+                            t_.zero_()
+                        apc_r.generate_witness_from_records(rec.data_ptr(), calls, out2.data_ptr(), wl["per"])
+                        r_last["proof"] = pr_r.prove(out2.data_ptr(), log_h, copy=False)
+                        if world > 1:
+                            o = 7 if args.logup else 6
+                            sharding.merge_commitments([rank], r_last["proof"][o:o + 8].reshape(1, 8), world)
+
+                r_elapsed, r_timing = timed_leg(run_r, args.logup_steps, 1, barrier, abi, world)
+                r_stage = {k: ms / args.logup_steps for k, (c, ms) in r_timing.items()}
+                tg_names = ("apc_tracegen_records_kernel", "apc_apply_derived_expr_kernel", "apc_apply_bus_kernel", "bus_histogram_kernel")
+                records_leg["timed_step"] = dict(
+                    ms_per_step=r_elapsed / args.logup_steps * 1e3, value=cells_per_step * args.logup_steps * world / r_elapsed, unit="main cells/s",
+                    steps=args.logup_steps, warmup=1, logup=bool(args.logup), trace_gen_ms=sum(r_stage.get(k, 0.0) for k in tg_names),
+                    stage_ms=r_stage, proof_bytes=int(len(r_last["proof"]) * 4), record_bytes=int(rec.numel() * 4),
+                    prover_mode=pr_r.stream_log_blocks(log_h),
+                    note="TIMED: powdr_apc_generate_witness_from_records (the original chips' expansion fused into the gather + derived columns + bus "
+                         "replay) + pw_prover_prove, records resident in HBM, no dummy traces anywhere; the bus arguments are evaluated on the chips' real "
+                         "cell values (the synthetic APC's lookups then fall outside their tables more often than with the bounded dummy cells of the "
+                         "headline: a different histogram mix, same work per lookup)")
+                pr_r.close()
+                apc_r.close()
+            except Exception as e:
+                records_leg["timed_step"] = dict(ms_per_step=None, error=f"{type(e).__name__}: {e}")
             del out2, rec
             torch.cuda.empty_cache()
         except Exception as e:
@@ -1048,6 +1170,10 @@ def main():
             value=value, unit="cells/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
+            rccl_ranks=comm_facts(world)["ranks"], comm=comm_facts(world), per_rank_ms=per_rank_ms,
+            strong_scaling_value=(segment_leg or {}).get("value"),
+            strong_scaling_note="`value` = weak scaling (one C2 segment per rank per step); `multi_segment.value` (= strong_scaling_value) = strong scaling: "
+                                "a fixed number of C4 segments placed on the ranks by cells — the >= 6x at 8 GPUs target of north_star is read off that one",
             config=dict(workload=f"{args.shape} {shape.name} autoprecompile AIR: {wl['W']} cols x 2^{log_h} rows, "
                                  f"{len(wl['cons'][1])} constraints, {wl['apc'].n_bus} bus interactions; trace generation + "
                                  f"pw-stark v0 proof (blow-up 2, {args.queries} queries, {args.pow_bits} PoW bits)"

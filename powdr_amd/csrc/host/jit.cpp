@@ -36,6 +36,7 @@ struct Rtc {
     int (*GetCodeSize)(hiprtcProgram, size_t*) = nullptr;
     int (*GetCode)(hiprtcProgram, char*) = nullptr;
     int (*DestroyProgram)(hiprtcProgram*) = nullptr;
+    int (*Version)(int*, int*) = nullptr;
     bool ok = false;
 };
 
@@ -59,6 +60,7 @@ const Rtc& rtc() {
         r.GetCodeSize = (decltype(r.GetCodeSize))sym("hiprtcGetCodeSize");
         r.GetCode = (decltype(r.GetCode))sym("hiprtcGetCode");
         r.DestroyProgram = (decltype(r.DestroyProgram))sym("hiprtcDestroyProgram");
+        r.Version = (decltype(r.Version))sym("hiprtcVersion");
         r.ok = r.CreateProgram && r.CompileProgram && r.GetProgramLogSize && r.GetProgramLog && r.GetCodeSize && r.GetCode && r.DestroyProgram;
     });
     return r;
@@ -219,6 +221,11 @@ std::atomic<uint64_t> g_units_compiled{0}, g_units_from_disk{0};  // process-wid
 uint64_t environment_hash() {
     static const uint64_t h = [] {
         std::string all = "--offload-arch=gfx950 -O3 -std=c++17";
+        // the compiler's own version: a code object built by another ROCm release is not reused after an upgrade
+        int major = 0, minor = 0, runtime = 0;
+        if (rtc().ok && rtc().Version) (void)rtc().Version(&major, &minor);
+        if (hipRuntimeGetVersion(&runtime) != hipSuccess) { runtime = 0; (void)hipGetLastError(); }
+        all += " hiprtc=" + std::to_string(major) + "." + std::to_string(minor) + " hip=" + std::to_string(runtime);
         for (int i = 0; i < kNumEmbeddedHeaders; ++i) { all += '\0'; all += kEmbeddedHeaders[i].name; all += '\0'; all += kEmbeddedHeaders[i].text; }
         return hash64(all);
     }();
@@ -232,8 +239,12 @@ std::string disk_cache_dir() {
     else if (const char* x = getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/powdr_jit";
     else if (const char* h = getenv("HOME")) dir = std::string(h) + "/.cache/powdr_jit";
     if (dir.empty()) return "";
-    for (size_t i = 1; i <= dir.size(); ++i)  // mkdir -p
-        if (i == dir.size() || dir[i] == '/') { const std::string part = dir.substr(0, i); if (mkdir(part.c_str(), 0755) != 0 && errno != EEXIST) return ""; }
+    for (size_t i = 1; i <= dir.size(); ++i)  // mkdir -p; the cache directory itself is private
+        if (i == dir.size() || dir[i] == '/') { const std::string part = dir.substr(0, i); if (mkdir(part.c_str(), i == dir.size() ? 0700 : 0755) != 0 && errno != EEXIST) return ""; }
+    // code objects are LOADED from here: only a directory that belongs to the caller and that nobody else can write to is trusted
+    // (a predictable path under a world-writable parent could otherwise be prepared by another local user)
+    struct stat sb;
+    if (lstat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != geteuid() || (sb.st_mode & (S_IWGRP | S_IWOTH))) return "";
     return dir;
 }
 

@@ -548,7 +548,8 @@ extern "C" int powdr_apc_tracegen_records(PowdrFp* d_output, size_t output_heigh
     if ((H & (H - 1)) != 0) return (int)hipErrorInvalidValue;
     if (H == 0 || n_subs == 0) return (int)hipGetLastError();
     if (!d_output || !h_instrs || !h_subs || (num_apc_calls && !d_records)) return (int)hipErrorInvalidValue;
-    if (num_apc_calls > H) num_apc_calls = H;
+    // the records are word-major with stride num_apc_calls: clamping the count would read them with the wrong stride
+    if (num_apc_calls > H) return (int)hipErrorInvalidValue;
     if (int rc = check_instrs(h_instrs, n_instrs)) return rc;
     for (size_t i = 0; i < n_subs; ++i)
         if (h_subs[i].instr < 0 || (size_t)h_subs[i].instr >= n_instrs || h_subs[i].col < 0 || h_subs[i].col >= kWidths[h_instrs[h_subs[i].instr].kind] ||

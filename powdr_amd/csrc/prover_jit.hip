@@ -93,6 +93,14 @@ int specialise_provers(PwProver* const* ps, size_t n, const uint32_t* log_height
     }
     std::string err;
     std::vector<jit::ProgramPtr> progs = jit::compile_all(sources, &err);
+    if (progs.empty() && todo.size() > 1) {
+        // one AIR's unit did not compile: the others must not lose their kernels with it — every prover on its own
+        for (PwProver* p : todo) { PwProver* one[1] = {p}; uint32_t lh = 40; p->jit.state = 0; p->jit.quotient = {}; p->jit.perm = {}; (void)specialise_provers(one, 1, &lh, true); }
+        return 0;
+    }
+    int n_dev = 0;
+    const bool have_device = hipGetDeviceCount(&n_dev) == hipSuccess && n_dev > 0;  // (pw_jit_compile_check cross-compiles without a GPU)
+    if (!have_device) (void)hipGetLastError();
     size_t k = 0;
     for (PwProver* p : todo) {
         if (progs.empty()) { p->jit.state = -1; p->jit.error = err; p->jit.quotient = {}; p->jit.perm = {}; continue; }
@@ -103,6 +111,20 @@ int specialise_provers(PwProver* const* ps, size_t n, const uint32_t* log_height
         for (auto& u : p->jit.quotient.units) { u.source.clear(); u.source.shrink_to_fit(); }  // the programs keep their text
         for (auto& u : p->jit.perm.units) { u.source.clear(); u.source.shrink_to_fit(); }
         p->jit.state = 1;
+        if (have_device) {
+            // load the modules and resolve every kernel NOW: a code object this device cannot run (a stale cache entry after a ROCm
+            // upgrade, a device that is not gfx950) must leave the prover with the interpreter, not fail its first tall proof
+            std::string e2;
+            bool ok = true;
+            for (size_t u = 0; u < p->jit.quotient.units.size() && ok; ++u) ok = jit::kernel(*p->jit.quotient_prog[u], p->jit.quotient.units[u].kernel.c_str(), &e2) != nullptr;
+            for (size_t u = 0; u < p->jit.perm.units.size() && ok; ++u) ok = jit::kernel(*p->jit.perm_prog[u], p->jit.perm.units[u].kernel.c_str(), &e2) != nullptr;
+            if (!ok) {
+                (void)hipGetLastError();
+                p->jit.state = -1;
+                p->jit.error = "the compiled kernels do not load on this device: " + e2;
+                p->jit.quotient_prog.clear(); p->jit.perm_prog.clear(); p->jit.quotient = {}; p->jit.perm = {};
+            }
+        }
     }
     return 0;
 }

@@ -14,7 +14,13 @@ REFERENCE = Path("/root/reference")
 import os  # noqa: E402
 import tempfile  # noqa: E402
 
-os.environ.setdefault("POWDR_JIT_CACHE_DIR", str(Path(tempfile.gettempdir()) / "powdr_jit_cache"))
+# ... in a per-user directory that only this user can write to (the library refuses any other kind: code objects are loaded from it)
+_jit_cache = Path(tempfile.gettempdir()) / f"powdr_jit_cache_{os.getuid()}"
+try:
+    _jit_cache.mkdir(mode=0o700, exist_ok=True)
+except OSError:
+    pass
+os.environ.setdefault("POWDR_JIT_CACHE_DIR", str(_jit_cache))
 
 
 def pytest_configure(config):

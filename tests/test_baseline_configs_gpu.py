@@ -27,7 +27,8 @@ def gpu():
     import torch
     from powdr_amd import abi, host, prover, tracegen
 
-    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU (run with -m gpu on the GPU box)")
     return torch, abi, tracegen, host, prover
 
 

@@ -117,3 +117,24 @@ def test_two_ranks_on_one_gpu_weak_and_strong_legs():
     ms = d["multi_segment"]
     assert ms["scaling"] == "strong" and ms["n_segments"] == 8 and ms["segments_on_rank0"] == 4 and ms["value"] > 0
     assert d["constraints_only"]["value"] > 0
+
+
+def test_plain_command_with_gpus_2_produces_a_two_rank_line():
+    """`python bench.py --gpus 2 ...` as a plain subprocess — no torch.distributed.run around it — launches its two ranks
+    itself (here both on GPU 0 over gloo, the one-GPU test hook) and the line says so: n_gpus, the communicator's rank count, per-rank
+    times, the weak C2 value AND the strong multi-segment value in one record."""
+    import os
+
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--log-height", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, POWDR_DIST_BACKEND="gloo"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["comm"]["launch"] == "self" and d["comm"]["backend"] == "gloo"
+    assert len(d["per_rank_ms"]) == 2 and abs(max(d["per_rank_ms"]) - d["ms_per_step"]) < 1e-6 * d["ms_per_step"]
+    assert d["scaling"] == "weak" and d["strong_scaling_value"] == d["multi_segment"]["value"] > 0
+    assert d["multi_segment"]["ranks"] == 2 and len(d["multi_segment"]["per_rank_ms"]) == 2
+    # asked for more GPUs than the box has, without the hook: refused, not relabelled
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "64", "--log-height", "12"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 2 and "only" in out.stderr
