@@ -167,43 +167,10 @@ def setup_distributed(n):
 
 
 def build_workload(shape_name, log_h, exact_heights, seed, calls_fraction=1.0):
-    from powdr_amd import host, synth, tracegen as tg
+    """One APC AIR's trace-generation inputs, resident in HBM (powdr_amd/segment_workload.py build_apc_workload)."""
+    from powdr_amd import segment_workload as sw
 
-    s = synth.generate(shape_name, seed=seed)
-    apc = host.Apc(s.doc)
-    H = 1 << log_h
-    calls = max(1, int(H * calls_fraction))
-    # AIR ids by first appearance among instructions with substitutions
-    order, instr_air = [], []
-    for n in s.instr_air:
-        if n and n not in order:
-            order.append(n)
-        instr_air.append(order.index(n) if n else -1)
-    dims = {n: (w, b) for n, w, b in s.airs}
-    dummy, tensors, src_bytes = [], {}, 0
-    for n in order:
-        w, b = dims[n]
-        rows = b * calls
-        h = max(4, (rows + 3) // 4 * 4 if exact_heights else synth.next_pow2_or_zero(rows))
-        t = torch.empty(w * h, dtype=torch.int32, device="cuda")
-        t.random_(0, P)
-        tensors[n] = (t, w, h, b)
-        dummy.append((t.data_ptr(), w, h))
-        src_bytes += t.numel() * 4
-    # cells that feed bounded column kinds (bytes, range-checked limbs, flags): Montgomery form
-    g = torch.Generator(device="cuda").manual_seed(seed + 1)
-    for pid, (name, row, col) in s.source_of.items():
-        kind, bound = s.kinds[pid]
-        if bound >= P:
-            continue
-        t, w, h, b = tensors[name]
-        v = torch.randint(0, bound, (calls,), dtype=torch.int64, device="cuda", generator=g)
-        t[col * h + row: col * h + row + b * calls: b] = ((v << 32) % P).to(torch.int32)
-    out = torch.empty(apc.width * H, dtype=torch.int32, device="cuda")
-    per = tg.Periphery.fresh()
-    cons_bc, cons_spans = apc.compile_constraints()
-    return dict(synth=s, apc=apc, instr_air=instr_air, air_names=order, dummy=dummy, tensors=tensors, out=out, per=per,
-                calls=calls, log_h=log_h, H=H, W=apc.width, cons=(cons_bc, cons_spans), src_bytes=src_bytes)
+    return sw.build_apc_workload(shape_name, log_h, exact_heights, seed, calls_fraction)
 
 
 def cpu_baseline(shape_name, log_h, queries, pow_bits, seed, logup=False):
@@ -353,37 +320,57 @@ def gauges_of(stage_ms):
              "stark_prove_excluding_trace_time_ms = ms_per_step - trace_gen_time_ms")
 
 
+def _segment_checks(seg, proof, rec):
+    """After the timed region: the proof against the product's host verifier, the device's mock prover on the traces it was made
+    from, and the lookup buses' balance (segment_workload.HonestSegment.balance_witness). Results into `rec`."""
+    t0 = time.perf_counter()
+    rec["verify_rc"] = seg.verify(proof)
+    rec["verify_s"] = time.perf_counter() - t0
+    rec["constraint_violations"] = int(seg.check_constraints())
+    prev = os.environ.get("POWDR_JIT")
+    try:
+        os.environ["POWDR_JIT"] = "0"  # the witness is proven once: not worth compiling 26 more sets of kernels
+        seg.release_provers()
+        rc, total = seg.balance_witness()
+        rec["lookup_balance"] = dict(verify_rc=rc, total_sum=[int(x) for x in total], buses=[3, 6, 7],
+                                     note="the same traces, every AIR restricted to the lookup buses (var-range 3, bitwise 6, tuple 7), one segment proof, "
+                                          "pw_verify_segment with check_balance: the APC and instruction AIRs' sends and the periphery AIRs' receives cancel. "
+                                          "Memory / execution-bridge / program buses: send side only (their receivers are external chips)")
+    except Exception as e:
+        rec["lookup_balance"] = dict(verify_rc=None, error=f"{type(e).__name__}: {e}")
+    finally:
+        if prev is None:
+            os.environ.pop("POWDR_JIT", None)
+        else:
+            os.environ["POWDR_JIT"] = prev
+
+
 def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup, queries, pow_bits, n_workers, abi):
     """The same strong-scaling workload as segment_bench, driven from ONE process through the C ABI's multi-device entry
     pw_prove_segments_multi: one host thread per worker (worker w on GPU w mod #GPUs) with its own launch stream and its own
-    replica of the segment's provers and traces; placement by cells; the only exchange is the RCCL all-gather of the 8-word
-    commitments at the end of every step."""
-    from powdr_amd import prover, synth
+    replica of the segment (trace generators, provers, buffers); placement by cells; the only exchange is the RCCL all-gather of
+    the 8-word commitments at the end of every step."""
+    from powdr_amd import prover, segment_workload as sw
 
-    shapes = synth.segment_shape(kind, seed=0, max_log_height=max_log_height)
-    cells_seg = sum(w << lh for _, w, lh, _, _ in shapes)
     n_dev = torch.cuda.device_count()
     devices = [w % n_dev for w in range(n_workers)]
     workers = []
     for w in range(n_workers):
         with torch.cuda.device(devices[w]):
-            provers, traces = [], []
-            for k, (name, wd, lh, nc, ni) in enumerate(shapes):
-                bc, sp, it = synth.air_programs(name, wd, nc, ni, seed=k)
-                provers.append(prover.Prover(wd, bc, sp, num_queries=queries, pow_bits=pow_bits, interactions=it if logup else None))
-                t = torch.empty(wd << lh, dtype=torch.int32, device="cuda")
-                t.random_(0, P)
-                traces.append(t)
-            workers.append(dict(provers=provers, traces=traces,
-                                seg=[(pr, t.data_ptr(), lh) for pr, t, (_, _, lh, _, _) in zip(provers, traces, shapes)]))
+            workers.append(sw.HonestSegment(kind, max_log_height=max_log_height, seed=0, queries=queries, pow_bits=pow_bits, logup=logup))
     for d in set(devices):
         torch.cuda.synchronize(d)
-    hdr = 5 + 4 * len(shapes)
+    seg0 = workers[0]
+    cells_seg = seg0.cells
+    hdr = 5 + 4 * len(seg0.airs)
     last = {}
 
     def prove_one(segment, worker, device):
-        pf = prover.prove_segment(workers[worker]["seg"], logup=logup, copy=False)
+        workers[worker].generate_traces()
+        pf = workers[worker].prove()
         last["words"] = len(pf)
+        if worker == 0:
+            last["proof"] = pf.copy()
         return pf[hdr:hdr + 8].copy()
 
     def run_steps(n):
@@ -401,43 +388,47 @@ def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup,
     barrier()
     elapsed = time.perf_counter() - t0
     assert (last["merged"] != 0).any(axis=1).all(), "a segment's commitment is missing from the merge"
-    rec = dict(shape=kind, scaling="strong", n_segments=n_segments, workers=n_workers, devices=devices, airs_per_segment=len(shapes),
+    rec = dict(shape=kind, scaling="strong", n_segments=n_segments, workers=n_workers, devices=devices, airs_per_segment=len(seg0.airs),
                cells_per_segment=cells_seg, value=cells_seg * n_segments * steps / elapsed, unit="cells/s", ms_per_step=elapsed / steps * 1e3,
                steps=steps, warmup=warmup, logup=bool(logup), proof_bytes_per_segment=int(last["words"]) * 4,
                segments_per_worker=[int((last["owner"] == w).sum()) for w in range(n_workers)],
                commitment_merge={1: "RCCL all-gather (one communicator per device set, ncclCommInitAll at first use)", 2: "host (RCCL not available)"}[last["merge"]],
-               note="pw_prove_segments_multi: one process, one host thread + launch stream per worker, one pw-stark v1 proof per segment")
+               note="pw_prove_segments_multi: one process, one host thread + launch stream per worker; per segment: trace generation of every AIR + one "
+                    "pw-stark v1 proof (segment_workload.HonestSegment: one resident segment per worker, regenerated and proven for every unit)")
+    with torch.cuda.device(devices[0]):
+        _segment_checks(seg0, last["proof"], rec)
     for wk in workers:
-        for pr in wk["provers"]:
-            pr.close()
+        wk.close()
     return rec
 
 
 def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, queries, pow_bits, rank, world, abi, barrier):
     """Multi-AIR segments, STRONG scaling: a fixed number of independent segments is placed on the
-    ranks by cell count; every rank proves its segments one after the other — ONE pw-stark v1 proof per segment
-    (pw_prove_segment: all AIRs of a phase in one mixed-height commitment, one FRI) — and the main commitments are
-    all-gathered (32 B per segment) inside the timed region. Traces are resident random matrices of the segment's
-    shapes (trace generation is measured on the single-AIR configs; a proof's cost does not depend on the values);
-    all segments of a rank share one set of device buffers. Returns the record (rank 0) or None."""
-    from powdr_amd import prover, sharding, synth
+    ranks by cell count; every rank handles its segments one after the other — trace generation of EVERY AIR of the segment (APC
+    AIRs: gather + derived columns + bus replay; instruction AIRs: record expansion + replay of their lookups; periphery AIRs from
+    the histograms) and ONE pw-stark v1 proof (pw_prove_segment: all AIRs of a phase in one mixed-height commitment, one FRI), both
+    inside the timed region — and the main commitments are all-gathered (32 B per segment). Every rank keeps ONE resident segment
+    (powdr_amd/segment_workload.py) that is regenerated and proven once per unit placed on it: the segments of a run are copies of
+    each other (a real execution's segments differ in values, not in shape). After the timed region: host verification of the last
+    proof, the device's mock prover on its traces, the lookup buses' balance. Returns the record (rank 0) or None."""
+    from powdr_amd import segment_workload as sw, sharding
 
-    shapes = synth.segment_shape(kind, seed=0, max_log_height=max_log_height)
-    cells_seg = sum(w << lh for _, w, lh, _, _ in shapes)
-    provers, traces = [], []
-    for k, (name, w, lh, nc, ni) in enumerate(shapes):
-        bc, sp, it = synth.air_programs(name, w, nc, ni, seed=k)
-        provers.append(prover.Prover(w, bc, sp, num_queries=queries, pow_bits=pow_bits, interactions=it if logup else None))
-        t = torch.empty(w << lh, dtype=torch.int32, device="cuda")
-        t.random_(0, P)
-        traces.append(t)
-    seg = [(pr, t.data_ptr(), lh) for pr, t, (_, _, lh, _, _) in zip(provers, traces, shapes)]
-    hdr = 5 + 4 * len(shapes)  # proof words before the main commitment
-    last = {}
+    seg = sw.HonestSegment(kind, max_log_height=max_log_height, seed=0, queries=queries, pow_bits=pow_bits, logup=logup)
+    cells_seg = seg.cells
+    hdr = 5 + 4 * len(seg.airs)  # proof words before the main commitment
+    last = dict(gen_s=0.0, prove_s=0.0, units=0)
 
     def prove_one(u):
-        pf = prover.prove_segment(seg, logup=logup, copy=False)
-        last["words"] = len(pf)
+        t0 = time.perf_counter()
+        seg.generate_traces()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pf = seg.prove()
+        t2 = time.perf_counter()
+        last["gen_s"] += t1 - t0
+        last["prove_s"] += t2 - t1
+        last["units"] += 1
+        last["words"], last["proof"] = len(pf), pf
         return pf[hdr:hdr + 8].copy()
 
     def run_steps(n):
@@ -445,25 +436,39 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
             mine, merged = sharding.prove_segments_sharded([cells_seg] * n_segments, prove_one, rank, world)
             last["mine"], last["merged"] = mine, merged
 
-    elapsed, timing = timed_leg(run_steps, steps, warmup, barrier, abi, world)
+    run_steps(warmup)
+    last.update(gen_s=0.0, prove_s=0.0, units=0)
+    elapsed, timing = timed_leg(run_steps, steps, 0, barrier, abi, world)
     per_rank_ms = [t / steps * 1e3 for t in LAST_PER_RANK_S]
     assert (last["merged"] != 0).any(axis=1).all(), "a segment's commitment is missing from the merge"
     total_cells = cells_seg * n_segments * steps
     stage = {k: ms / steps for k, (c, ms) in timing.items()}
+    units = max(1, last["units"])
+    shapes = [(a["name"], a["width"], a["log_h"], len(a["cons"][1]), len(a["inter"][0])) for a in seg.airs]
     rec = dict(shape=kind, scaling="strong", n_segments=n_segments, segments_on_rank0=len(last["mine"]), airs_per_segment=len(shapes),
+               airs_by_role={r: sum(1 for a in seg.airs if a["role"] == r) for r in ("apc", "instruction", "periphery")}, cells_by_role=seg.cells_by_role,
                cells_per_segment=cells_seg, value=total_cells / elapsed, unit="cells/s", ms_per_step=elapsed / steps * 1e3, steps=steps,
+               trace_gen_ms_per_segment=last["gen_s"] / units * 1e3, prove_ms_per_segment=last["prove_s"] / units * 1e3,
+               cells_per_s_prove_only=cells_seg / (last["prove_s"] / units) if last["prove_s"] else None,
                warmup=warmup, logup=bool(logup), proof_bytes_per_segment=int(last["words"]) * 4, per_rank_ms=per_rank_ms, ranks=world,
                widths=f"{min(s[1] for s in shapes)}..{max(s[1] for s in shapes)} (sum {sum(s[1] for s in shapes)})",
                log_heights=f"{min(s[2] for s in shapes)}..{max(s[2] for s in shapes)}",
-               constraints=sum(s[3] for s in shapes), interactions=sum(s[4] for s in shapes),
-               prover_device_bytes=sum(pr.device_bytes() for pr in provers), stage_ms_rank0=stage,
+               constraints=sum(s[3] for s in shapes), interactions=sum(s[4] for s in shapes), source_bytes=seg.source_bytes,
+               prover_device_bytes=seg.device_bytes(), stage_ms_rank0=stage,
                stage_ms_note="per-kernel elapsed times; the per-AIR stages of a segment run on side streams (POWDR_SEGMENT_STREAMS, default 4) and "
                              "overlap, so the sum exceeds the wall time of the step",
-               note="one pw-stark v1 proof per segment (pw_prove_segment); proof only, traces resident; value = all segments of all ranks / "
-                    "max-over-ranks time; the 19 system AIRs have the reference's pinned totals (819 columns, 643 constraints, 253 interactions)")
-    for pr in provers:
-        pr.close()
-    del traces
+               note="per unit: trace generation of every AIR + one pw-stark v1 proof, both timed; ONE resident segment per rank regenerated for every "
+                    "unit placed on it (the run's segments are copies); value = all segments of all ranks / max-over-ranks time. AIRs: synthetic APCs with "
+                    "generated traces, the 13 RV32IM instruction AIRs with the reference's real constraints / interactions on traces expanded from "
+                    "records, the 3 lookup periphery AIRs from the histograms; the other 5 system AIRs of the reference's 19 (connector, program, "
+                    "memory boundary, Merkle, Poseidon2: 357 of 819 columns) are external chips and are left out")
+    if rank == 0:
+        _segment_checks(seg, np.array(last["proof"], copy=True), rec)
+    seg.close()
+    import gc
+
+    del seg
+    gc.collect()
     torch.cuda.empty_cache()
     return rec if rank == 0 else None
 

@@ -54,6 +54,7 @@ class Shape:
     airs: list  # [(air name, width, instructions per call)]
     n_quotient: int = 4
     config_id: int = 0
+    honest_bitwise: bool = False  # bitwise-bus interactions are range pairs (x, y, 0, 0) only (segment_workload.py: a synthetic APC has no x ^ y column)
 
 
 SHAPES = {
@@ -283,8 +284,11 @@ def generate(shape: Shape | str, seed: int = 0, verbosity: float = 1.0, density_
             x, y = _ref(pick("byte")), _ref(pick("byte"))
             if rng.random() < 0.3:
                 x = [[255, "-", _ref(pick("byte"))], "*", 1]
-            buses.append({"id": BUS_BITWISE, "mult": mult_expr(),
-                          "args": [pad(x, nodes()), pad(y, nodes()), _ref(pick("byte")), sel]})
+            mult = mult_expr()
+            args = [pad(x, nodes()), pad(y, nodes()), _ref(pick("byte")), sel]
+            if shape.honest_bitwise:  # (drawn all the same: the random stream does not depend on the flag)
+                args[2], args[3] = 0, 0
+            buses.append({"id": BUS_BITWISE, "mult": mult, "args": args})
 
     # ---- constraints (vanish on valid rows and on all-zero rows) ---------------------------
     cons = [[_ref(valid_pid), "*", [_ref(valid_pid), "-", 1]]]

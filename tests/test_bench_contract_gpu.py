@@ -44,8 +44,12 @@ def test_default_line_has_the_contract_fields():
     assert co["proof_bytes"] < d["config"]["proof_bytes"] and "CONSTRAINTS-ONLY" in co["note"]
     # the third leg: multi-AIR segments (C4 shape), one proof per segment, strong scaling over a fixed number of segments
     ms = d["multi_segment"]
-    assert ms["shape"] == "C4" and ms["scaling"] == "strong" and ms["n_segments"] == 8 and ms["airs_per_segment"] == 29
+    assert ms["shape"] == "C4" and ms["scaling"] == "strong" and ms["n_segments"] == 8 and ms["airs_per_segment"] == 26
+    assert ms["airs_by_role"] == {"apc": 10, "instruction": 13, "periphery": 3}
     assert ms["value"] > 0 and ms["proof_bytes_per_segment"] > 0 and ms["segments_on_rank0"] == 8
+    # an honest workload: traces generated inside the timed region, the proof verifies, the constraints hold, the lookup buses balance
+    assert ms["verify_rc"] == 0 and ms["constraint_violations"] == 0 and ms["lookup_balance"]["verify_rc"] == 0
+    assert ms["trace_gen_ms_per_segment"] > 0 and ms["prove_ms_per_segment"] > 0
     # the dominant kernel's HBM bytes and VALU instructions are measured in the run itself (two rocprofv3 --pmc passes)
     if r["kernel"] == "leaf_hash_kernel":
         import shutil
@@ -80,7 +84,7 @@ def test_segment_shapes_run_as_the_main_workload():
     assert d["scaling"] == "strong" and "multi-segment" in d["metric"] and d["multi_segment"]["n_segments"] == 3
     assert d["value"] > 0 and abs(d["value"] - 3 * d["multi_segment"]["cells_per_segment"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     d = run_bench("--shape", "C5", "--segments", "2", "--segment-log-height", "12", "--logup")
-    assert d["multi_segment"]["logup"] is True and d["multi_segment"]["airs_per_segment"] >= 25
+    assert d["multi_segment"]["logup"] is True and d["multi_segment"]["airs_per_segment"] >= 25 and d["multi_segment"]["verify_rc"] == 0
 
 
 def test_inproc_multi_device_form():
