@@ -249,6 +249,11 @@ namespace {
 // (tests/test_streamed_prover.py compares both with the oracle).
 // Mode: POWDR_STREAM_LOG_BLOCKS = 0 never, b >= 1 always with 2^b sub-cosets (tests); unset: resident when its buffers fit into
 // what the device has free (plus what the prover already holds), else the smallest b whose buffers do.
+// The DEEP numerator sum_k gamma^k P_k is a polynomial: from 2^16 rows on it is combined on the UN-extended matrices (half the bytes
+// the LDE holds) and extended as 4 + 4 columns instead of being accumulated over the LDE of every column (deep_kernel); shorter traces
+// keep the one-kernel form (the extra launches cost more than the bytes they save).
+constexpr uint32_t kDeepComboMinLogHeight = 16;
+
 struct BufferPlan {
     size_t coef = 0, lde = 0, digests = 0, perm = 0, plde = 0, q = 0, qpart = 0, qcoef = 0, qlde = 0, ext_arena = 0, misc = 0,
            tcoef = 0, fscale = 0, gbuf = 0;
@@ -280,7 +285,8 @@ void plan_buffers(const PwProver* p, uint32_t log_h, int b, CommitLayout& L, Buf
     B.coef = L.panel_cols * H * 4;
     B.lde = b ? (size_t)(W + Wp) * L.m * 4 : (size_t)W * N * 4;
     B.digests = (L.n_trees * L.tree_words + L.fri_words) * 4;
-    if (b) { B.tcoef = (size_t)W * H * 4; B.fscale = (size_t)1 << 15; B.gbuf = (size_t)24 * H * 4; }
+    if (b) { B.tcoef = (size_t)W * H * 4; B.fscale = (size_t)1 << 15; }
+    if (b || log_h >= kDeepComboMinLogHeight) B.gbuf = (size_t)24 * H * 4;
     if (lg) {  // + the uncommitted per-row-sum columns (kJitExtraPermCols; the streamed path keeps them on every path)
         B.perm = (size_t)(Wp + kJitExtraPermCols) * H * 4;
         B.plde = b ? (size_t)8 * N * 4 : (size_t)(Wp + kJitExtraPermCols) * N * 4;
@@ -701,6 +707,14 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         uint32_t* d_glde = d_gcoef + 8 * H;
         TRY(ext_lincomb(d_tcoef, W, d_perm, Wp, H, d_gpow, lg ? K1 : 0u, d_gcoef));
         TRY(coset_lde_from_coeffs(d_gcoef, d_glde, H, N, lg ? 8 : 4, (int)log_h));
+        TRY(deep_from_combo(d_glde, d_qlde, N, logN, d_gpow + W + Wp, opened_sum, opened_sum2, zeta, gzeta, lg ? 1 : 0, d_v));
+    } else if (log_h >= kDeepComboMinLogHeight && !getenv("POWDR_DEEP_DIRECT")) {
+        // resident: the same combination on the evaluations over <g_n> (the caller's trace, the permutation matrix), extended like any column
+        uint32_t* d_gev = p->gbuf.as<uint32_t>();
+        uint32_t* d_glde = d_gev + 8 * H;
+        const uint32_t gc = lg ? 8u : 4u;
+        TRY(ext_lincomb(d_trace, W, d_perm, Wp, H, d_gpow, lg ? K1 : 0u, d_gev));
+        TRY(lde_matrix(p, L, log_h, d_gev, gc, d_glde));
         TRY(deep_from_combo(d_glde, d_qlde, N, logN, d_gpow + W + Wp, opened_sum, opened_sum2, zeta, gzeta, lg ? 1 : 0, d_v));
     } else if (lg)
         TRY(deep_quotient_logup(d_lde, W, d_plde, Wp, d_qlde, N, logN, d_gpow, opened_sum, opened_sum2, zeta, gzeta, d_v));

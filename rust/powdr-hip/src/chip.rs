@@ -5,7 +5,7 @@
 //! rebuilt and re-uploaded per segment (cuda/mod.rs:272-398) — the C++ host mirror behind `powdr_apc_generate_witness_gpu`
 //! (include/powdr_host.h) compiles them once per APC and keeps them on the device; the chip hands over only what changes
 //! per segment: the dummy traces' device pointers and the call count.
-use crate::device::{DeviceBuffer, DeviceMatrix, HipError};
+use crate::device::{DeviceBuffer, DeviceMatrix, HipError, MemCopyH2D};
 use crate::ffi;
 use std::cell::RefCell;
 use std::collections::HashMap;
@@ -15,6 +15,8 @@ use openvm_circuit::arch::DenseRecordArena;
 use openvm_stark_backend::prover::{AirProvingContext, ProverBackend};
 use openvm_stark_backend::Chip;
 use openvm_stark_sdk::p3_baby_bear::BabyBear;
+use crate::isa_hip::OpenVmIsaHip;
+use crate::records_from_arena::{records_from_arenas, BridgeError};
 use powdr_openvm::isa::{IsaApc, OpenVmISA};
 use powdr_openvm::powdr_extension::executor::OriginalArenas;
 use powdr_openvm::powdr_extension::PowdrPrecompile;
@@ -37,7 +39,7 @@ impl Drop for ApcHandle {
     }
 }
 
-pub struct PowdrTraceGeneratorHip<ISA: OpenVmISA> {
+pub struct PowdrTraceGeneratorHip<ISA: OpenVmIsaHip> {
     pub apc: IsaApc<BabyBear, ISA>,
     pub original_airs: OriginalAirs<BabyBear, ISA>,
     pub config: OriginalVmConfig<ISA>,
@@ -50,7 +52,7 @@ pub struct PowdrTraceGeneratorHip<ISA: OpenVmISA> {
     instr_air: Vec<i32>,
 }
 
-impl<ISA: OpenVmISA> PowdrTraceGeneratorHip<ISA> {
+impl<ISA: OpenVmIsaHip> PowdrTraceGeneratorHip<ISA> {
     pub fn new(
         apc: IsaApc<BabyBear, ISA>,
         original_airs: OriginalAirs<BabyBear, ISA>,
@@ -88,11 +90,12 @@ impl<ISA: OpenVmISA> PowdrTraceGeneratorHip<ISA> {
         };
         let num_apc_calls = original_arenas.number_of_calls;
 
-        // the original chips expand their records into "dummy" traces (cuda/mod.rs:215-253); their tracegen is the
-        // instruction set's own (ISA::create_dummy_chip_complex_hip, the HIP twin of isa.rs:47-120's GpuBuilder hooks)
-        let chip_inventory = ISA::create_dummy_chip_complex_hip(
+        // the original chips expand their records into "dummy" traces (cuda/mod.rs:215-253); their tracegen is the instruction
+        // set's own: `OpenVmIsaHip::create_dummy_chip_complex_hip` (src/isa_hip.rs — an extension trait of this crate, the twin
+        // of isa.rs:94-99's `create_dummy_chip_complex_gpu`; `create_dummy_airs` is isa.rs:83-86)
+        let chip_inventory = <ISA as OpenVmIsaHip>::create_dummy_chip_complex_hip(
             self.config.config(),
-            ISA::create_dummy_airs(self.config.config(), self.periphery.dummy.clone()).expect("dummy airs"),
+            <ISA as OpenVmISA>::create_dummy_airs(self.config.config(), self.periphery.dummy.clone()).expect("dummy airs"),
             self.periphery.dummy.clone(),
         )
         .expect("dummy chip complex")
@@ -161,6 +164,32 @@ impl<ISA: OpenVmISA> PowdrTraceGeneratorHip<ISA> {
         Some(output)
     }
 
+    /// The record flow end to end: the arenas `PowdrExecutor::execute` filled (executor/mod.rs:531-600) -> word-major call records
+    /// (src/records_from_arena.rs) -> device -> `powdr_apc_generate_witness_from_records`. `Err`: the block uses a chip the bridge
+    /// does not cover yet — the caller falls back to `try_generate_witness` (dummy chips).
+    pub fn try_generate_witness_from_arenas(
+        &self,
+        mut original_arenas: OriginalArenas<DenseRecordArena>,
+    ) -> Result<Option<DeviceMatrix<BabyBear>>, BridgeError> {
+        let num_apc_calls = match &original_arenas {
+            OriginalArenas::Initialized(arenas) => arenas.number_of_calls,
+            OriginalArenas::Uninitialized => return Ok(None),
+        };
+        let (table, words) = self.record_layout();
+        let name_of_kind = |kind: u32| -> String { self.air_name_of_kind(kind) };
+        let host = records_from_arenas(&table, words, num_apc_calls, &mut original_arenas, &name_of_kind)?;
+        let records: DeviceBuffer<u32> = host.as_slice().to_device().expect("records to device");
+        Ok(self.try_generate_witness_from_records(&records, num_apc_calls))
+    }
+
+    /// AIR name of a chip kind (`POWDR_ORIG_*`): the name `original_airs.opcode_to_air` gives the first opcode of the kind's range
+    /// (powdr_amd/original_chips.py OPCODE_RANGES = include/powdr_gpu.h)
+    fn air_name_of_kind(&self, kind: u32) -> String {
+        const FIRST_OPCODE: [usize; 13] = [512, 517, 528, 544, 560, 520, 549, 565, 534, 596, 593, 592, 576];
+        let opcode = openvm_instructions::VmOpcode::from_usize(FIRST_OPCODE[kind as usize]);
+        self.original_airs.opcode_to_air[&opcode].clone()
+    }
+
     /// (instruction table of the block, u32 words of one call's record): which instruction keeps a cell, its pc, timestamp offset, row
     /// inside its AIR's block and first record word.
     pub fn record_layout(&self) -> (Vec<ffi::PowdrOrigInstr>, usize) {
@@ -173,13 +202,13 @@ impl<ISA: OpenVmISA> PowdrTraceGeneratorHip<ISA> {
     }
 }
 
-pub struct PowdrChipHip<ISA: OpenVmISA> {
+pub struct PowdrChipHip<ISA: OpenVmIsaHip> {
     pub name: String,
     pub record_arena_by_air_name: Rc<RefCell<OriginalArenas<DenseRecordArena>>>,
     pub trace_generator: PowdrTraceGeneratorHip<ISA>,
 }
 
-impl<ISA: OpenVmISA> PowdrChipHip<ISA> {
+impl<ISA: OpenVmIsaHip> PowdrChipHip<ISA> {
     /// chip.rs:153-175 (`PowdrChipGpu::new`)
     pub fn new(
         precompile: PowdrPrecompile<BabyBear, ISA>,
@@ -197,9 +226,11 @@ impl<ISA: OpenVmISA> PowdrChipHip<ISA> {
 }
 
 /// cuda/mod.rs:404-421, with the HIP matrix type
-impl<R, PB: ProverBackend<Matrix = DeviceMatrix<BabyBear>>, ISA: OpenVmISA> Chip<R, PB> for PowdrChipHip<ISA> {
+impl<R, PB: ProverBackend<Matrix = DeviceMatrix<BabyBear>>, ISA: OpenVmIsaHip> Chip<R, PB> for PowdrChipHip<ISA> {
     fn generate_proving_ctx(&self, _: R) -> AirProvingContext<PB> {
         tracing::trace!("Generating air proof input for PowdrChip {}", self.name);
+        // reference flow (dummy chips -> dummy traces -> gather). The record flow is `try_generate_witness_from_arenas`: a maintainer
+        // switches to it once src/records_from_arena.rs has been compiled against the pinned openvm-rv32im-circuit.
         let trace = self
             .trace_generator
             .try_generate_witness(self.record_arena_by_air_name.take())

@@ -17,6 +17,7 @@ use openvm_circuit::arch::{
 use openvm_stark_backend::prover::{AirProvingContext, ProverBackend, ProvingContext};
 use openvm_stark_backend::{keygen::types::MultiStarkProvingKey, StarkEngine};
 use openvm_stark_sdk::p3_baby_bear::BabyBear;
+use crate::isa_hip::OpenVmIsaHip;
 use powdr_openvm::isa::OpenVmISA;
 use powdr_openvm::powdr_extension::{chip::PowdrAir, PowdrExtension};
 use powdr_openvm::{BabyBearSC, PeripheryBusIds, SpecializedConfig};
@@ -174,9 +175,9 @@ pub struct SpecializedConfigHipBuilder<ISA> {
     _marker: PhantomData<ISA>,
 }
 
-impl<ISA: OpenVmISA> VmBuilder<HipEngine> for SpecializedConfigHipBuilder<ISA> {
+impl<ISA: OpenVmIsaHip> VmBuilder<HipEngine> for SpecializedConfigHipBuilder<ISA> {
     type VmConfig = SpecializedConfig<ISA>;
-    type SystemChipInventory = <ISA::HipBuilder as VmBuilder<HipEngine>>::SystemChipInventory;
+    type SystemChipInventory = <<ISA as OpenVmIsaHip>::HipBuilder as VmBuilder<HipEngine>>::SystemChipInventory;
     type RecordArena = DenseRecordArena;
 
     fn create_chip_complex(
@@ -184,10 +185,10 @@ impl<ISA: OpenVmISA> VmBuilder<HipEngine> for SpecializedConfigHipBuilder<ISA> {
         config: &SpecializedConfig<ISA>,
         circuit: AirInventory<BabyBearSC>,
     ) -> Result<VmChipComplex<BabyBearSC, Self::RecordArena, HipBackend, Self::SystemChipInventory>, ChipInventoryError> {
-        // `ISA::HipBuilder`: the instruction set's builder for this engine, the third associated type beside
-        // `CpuBuilder` / `GpuBuilder` of `OpenVmISA` (isa.rs:47-120)
+        // `OpenVmIsaHip::HipBuilder` (src/isa_hip.rs): the instruction set's builder for this engine — the third one beside
+        // `CpuBuilder` / `GpuBuilder` of `OpenVmISA` (isa.rs:63-81), which upstream does not have
         let mut chip_complex =
-            VmBuilder::<HipEngine>::create_chip_complex(&<ISA as OpenVmISA>::HipBuilder::default(), &config.original.config, circuit)?;
+            VmBuilder::<HipEngine>::create_chip_complex(&<ISA as OpenVmIsaHip>::HipBuilder::default(), &config.original.config, circuit)?;
         let inventory = &mut chip_complex.inventory;
         VmProverExtension::<HipEngine, _, _>::extend_prover(&PowdrHipProverExt::<ISA>::default(), &config.powdr, inventory)?;
         Ok(chip_complex)
@@ -200,7 +201,7 @@ pub struct PowdrHipProverExt<ISA> {
     _marker: PhantomData<ISA>,
 }
 
-impl<ISA: OpenVmISA> VmProverExtension<HipEngine, DenseRecordArena, PowdrExtension<BabyBear, ISA>> for PowdrHipProverExt<ISA> {
+impl<ISA: OpenVmIsaHip> VmProverExtension<HipEngine, DenseRecordArena, PowdrExtension<BabyBear, ISA>> for PowdrHipProverExt<ISA> {
     fn extend_prover(
         &self,
         extension: &PowdrExtension<BabyBear, ISA>,

@@ -5,6 +5,10 @@
 //! * [`device`] — `DeviceBuffer` / `DeviceMatrix` over hipMalloc (stand-ins for openvm-cuda-common / -backend types)
 //! * [`chip`]   — `PowdrChipHip`: `Chip::generate_proving_ctx` -> `powdr_apc_generate_witness_gpu`; from call records without dummy
 //!                chips: `PowdrTraceGeneratorHip::try_generate_witness_from_records` -> `powdr_apc_generate_witness_from_records`
+//! * [`isa_hip`] — `OpenVmIsaHip`: the builder type and dummy-chip-complex constructor `OpenVmISA` (isa.rs:47-120) has for the CPU and
+//!                CUDA engines but not for a third one (an extension trait; the upstream patch is INTEGRATION.md §3c)
+//! * [`records_from_arena`] — the per-AIR `DenseRecordArena`s of `PowdrExecutor::execute` -> the word-major call records of
+//!                `powdr_apc_generate_witness_from_records` (keccak-block chips)
 //! * [`engine`] — `HipEngine` (one `pw_prove_segment` call per segment), `SpecializedConfigHipBuilder`,
 //!                `PowdrHipProverExt`
 //! * [`multi`]  — the reference's sequential segment loop (trace_generation.rs:111-141) on N GPUs at once:
@@ -20,9 +24,12 @@ pub mod chip;
 pub mod device;
 pub mod engine;
 pub mod ffi;
+pub mod isa_hip;
 pub mod multi;
+pub mod records_from_arena;
 
 pub use chip::{PowdrChipHip, PowdrPeripheryInstancesHip, PowdrTraceGeneratorHip};
+pub use isa_hip::{OpenVmIsaHip, OriginalHipChipComplex};
 pub use device::{DeviceBuffer, DeviceMatrix, HipError, MemCopyH2D};
 pub use engine::{AirProgram, HipAirProver, HipBackend, HipEngine, HipSegmentProof, PowdrHipProverExt, SpecializedConfigHipBuilder};
 

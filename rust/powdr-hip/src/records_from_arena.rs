@@ -1,0 +1,220 @@
+//! Arena -> record bridge: what `PowdrExecutor::execute` leaves in the per-AIR `DenseRecordArena`s
+//! (openvm/src/powdr_extension/executor/mod.rs:531-600: every original instruction of an APC call is executed by its own
+//! executor "in the context of the relevant original table", i.e. appends ONE record to that AIR's arena) rewritten into the
+//! word-major call records `powdr_apc_generate_witness_from_records` consumes (include/powdr_gpu.h; INTEGRATION.md §3b lists word
+//! by word what goes where). With it `PowdrChipHip::generate_proving_ctx` needs neither dummy chips nor dummy traces.
+//!
+//! Covered: the five chips a keccak block uses — BaseAlu, Shift, LoadStore, BranchEqual, JalLui (`POWDR_ORIG_*` 0..4) — plus
+//! LessThan, which shares BaseAlu's adapter. The remaining seven chips follow the same three adapter shapes (ALU adapter:
+//! Multiplication, MulH, DivRem; load/store adapter: LoadSignExtend; branch adapter: BranchLessThan; rd-write adapter: Auipc;
+//! jalr adapter: Jalr) and are left as `Unsupported` until someone compiles this against openvm-rv32im-circuit.
+//!
+//! The record structs themselves are EXTERNAL (openvm-rv32im-circuit / openvm-circuit at the tag of /root/reference/Cargo.toml:
+//! 51-86); the field names below are the ones of that crate's `*AdapterRecord` / `*CoreRecord` types as of its "new execution"
+//! layout. They cannot be checked in this repository (no Rust toolchain, crate not vendored): the accessors are therefore kept
+//! in ONE place (`RecordView`) — a maintainer who compiles this fixes at most those few lines.
+use crate::ffi;
+
+use openvm_circuit::arch::{DenseRecordArena, RecordSeeker};
+use openvm_rv32im_circuit::adapters::{
+    Rv32BaseAluAdapterRecord, Rv32BranchAdapterRecord, Rv32CondRdWriteAdapterRecord, Rv32LoadStoreAdapterRecord,
+};
+use openvm_rv32im_circuit::{BaseAluCoreRecord, BranchEqualCoreRecord, LessThanCoreRecord, LoadStoreCoreRecord, Rv32JalLuiCoreRecord, ShiftCoreRecord};
+use powdr_openvm::powdr_extension::executor::OriginalArenas;
+
+/// chip kinds of include/powdr_gpu.h (`POWDR_ORIG_*`)
+pub const BASE_ALU: u32 = 0;
+pub const SHIFT: u32 = 1;
+pub const LOAD_STORE: u32 = 2;
+pub const BRANCH_EQ: u32 = 3;
+pub const JAL_LUI: u32 = 4;
+pub const LESS_THAN: u32 = 5;
+
+#[derive(Debug)]
+pub enum BridgeError {
+    /// the block uses a chip this bridge has no record accessor for yet (kind = POWDR_ORIG_*)
+    Unsupported(u32),
+    /// an AIR's arena holds fewer records than `rows of that AIR per call x calls`
+    ShortArena { air: String, have: usize, want: usize },
+}
+
+#[inline]
+fn word(limbs: [u8; 4]) -> u32 {
+    u32::from_le_bytes(limbs)
+}
+
+/// The words one instruction owns in a call record: up to three data words, then the previous timestamps
+/// of its accesses in access order.
+pub struct RecordWords {
+    pub data: [u32; 3],
+    pub n_data: usize,
+    pub prev_ts: [u32; 3],
+    pub n_prev: usize,
+    pub from_timestamp: u32,
+}
+
+/// The ONLY place that touches the external record structs.
+pub trait RecordView {
+    fn words(&self) -> RecordWords;
+}
+
+impl RecordView for (&Rv32BaseAluAdapterRecord, &BaseAluCoreRecord<4>) {
+    /// BaseAlu / Shift / LessThan (and Multiplication, MulH, DivRem): `b`, `c`, `writes_aux.prev_data`; reads_aux[0], reads_aux[1], writes_aux
+    fn words(&self) -> RecordWords {
+        let (a, c) = *self;
+        RecordWords {
+            data: [word(c.b), word(c.c), word(a.writes_aux.prev_data)],
+            n_data: 3,
+            prev_ts: [a.reads_aux[0].prev_timestamp, a.reads_aux[1].prev_timestamp, a.writes_aux.prev_timestamp],
+            n_prev: 3,
+            from_timestamp: a.from_timestamp,
+        }
+    }
+}
+impl RecordView for (&Rv32BaseAluAdapterRecord, &ShiftCoreRecord<4, 8>) {
+    fn words(&self) -> RecordWords {
+        let (a, c) = *self;
+        RecordWords {
+            data: [word(c.b), word(c.c), word(a.writes_aux.prev_data)],
+            n_data: 3,
+            prev_ts: [a.reads_aux[0].prev_timestamp, a.reads_aux[1].prev_timestamp, a.writes_aux.prev_timestamp],
+            n_prev: 3,
+            from_timestamp: a.from_timestamp,
+        }
+    }
+}
+impl RecordView for (&Rv32BaseAluAdapterRecord, &LessThanCoreRecord<4, 8>) {
+    fn words(&self) -> RecordWords {
+        let (a, c) = *self;
+        RecordWords {
+            data: [word(c.b), word(c.c), word(a.writes_aux.prev_data)],
+            n_data: 3,
+            prev_ts: [a.reads_aux[0].prev_timestamp, a.reads_aux[1].prev_timestamp, a.writes_aux.prev_timestamp],
+            n_prev: 3,
+            from_timestamp: a.from_timestamp,
+        }
+    }
+}
+impl RecordView for (&Rv32LoadStoreAdapterRecord, &LoadStoreCoreRecord<4>) {
+    /// `rs1_data`, the ALIGNED word that is read, `prev_data`; rs1_aux, read_data_aux, write_base_aux
+    fn words(&self) -> RecordWords {
+        let (a, c) = *self;
+        RecordWords {
+            data: [a.rs1_val, word(c.read_data), word(c.prev_data.map(|x| x as u8))],
+            n_data: 3,
+            prev_ts: [a.rs1_aux_record.prev_timestamp, a.read_data_aux.prev_timestamp, a.write_prev_timestamp],
+            n_prev: 3,
+            from_timestamp: a.from_timestamp,
+        }
+    }
+}
+impl RecordView for (&Rv32BranchAdapterRecord, &BranchEqualCoreRecord<4>) {
+    /// `a` (rs1), `b` (rs2); reads_aux[0], reads_aux[1]
+    fn words(&self) -> RecordWords {
+        let (a, c) = *self;
+        RecordWords {
+            data: [word(c.a), word(c.b), 0],
+            n_data: 2,
+            prev_ts: [a.reads_aux[0].prev_timestamp, a.reads_aux[1].prev_timestamp, 0],
+            n_prev: 2,
+            from_timestamp: a.from_timestamp,
+        }
+    }
+}
+impl RecordView for (&Rv32CondRdWriteAdapterRecord, &Rv32JalLuiCoreRecord) {
+    /// `rd_aux_cols.prev_data`; rd_aux_cols
+    fn words(&self) -> RecordWords {
+        let (a, _c) = *self;
+        RecordWords {
+            data: [word(a.inner.rd_aux_record.prev_data), 0, 0],
+            n_data: 1,
+            prev_ts: [a.inner.rd_aux_record.prev_timestamp, 0, 0],
+            n_prev: 1,
+            from_timestamp: a.inner.from_timestamp,
+        }
+    }
+}
+
+/// (data words, previous timestamps) of a chip kind = `RECORD_WORDS` / `N_PREV_TS` of powdr_amd/original_chips.py
+fn shape_of(kind: u32) -> Result<(usize, usize), BridgeError> {
+    match kind {
+        BASE_ALU | SHIFT | LOAD_STORE | LESS_THAN => Ok((3, 3)),
+        BRANCH_EQ => Ok((2, 2)),
+        JAL_LUI => Ok((1, 1)),
+        k => Err(BridgeError::Unsupported(k)),
+    }
+}
+
+/// Word-major call records (`records[word * num_calls + call]`, the layout of include/powdr_gpu.h) from the arenas of one APC.
+///
+/// * `table` / `words_per_call`: `PowdrTraceGeneratorHip::record_layout()` (= `powdr_apc_instruction_table`): per instruction that
+///   keeps a cell its chip kind, its row inside that chip's per-call block (`air_row`) and its first record word (`rec_off`);
+/// * `air_name_of_kind`: chip kind -> the AIR name the arenas are keyed by (`OriginalArenas::take_real_arena`);
+/// * the arena of an AIR holds its records in execution order: call after call, inside a call the AIR's instructions in block
+///   order — record `call * rows_per_call + air_row` is the one of (call, instruction).
+pub fn records_from_arenas(
+    table: &[ffi::PowdrOrigInstr],
+    words_per_call: usize,
+    num_calls: usize,
+    arenas: &mut OriginalArenas<DenseRecordArena>,
+    air_name_of_kind: &dyn Fn(u32) -> String,
+) -> Result<Vec<u32>, BridgeError> {
+    let mut out = vec![0u32; words_per_call * num_calls];
+    let mut rows_per_call = [0usize; 13];
+    for e in table {
+        rows_per_call[e.kind as usize] = rows_per_call[e.kind as usize].max(e.air_row as usize + 1);
+    }
+    // word 0 of a call = `from_state.timestamp` of its first instruction = from_timestamp of the table's first entry minus its offset
+    for kind in 0..13u32 {
+        let per_call = rows_per_call[kind as usize];
+        if per_call == 0 {
+            continue;
+        }
+        let (n_data, n_prev) = shape_of(kind)?;
+        let name = air_name_of_kind(kind);
+        let Some(mut arena) = arenas.take_real_arena(&name) else { continue };
+        let want = per_call * num_calls;
+        macro_rules! walk {
+            ($adapter:ty, $core:ty) => {{
+                let records: Vec<(&$adapter, &$core)> = RecordSeeker::<DenseRecordArena, ($adapter, $core), _>::get_records(&mut arena);
+                if records.len() < want {
+                    return Err(BridgeError::ShortArena { air: name, have: records.len(), want });
+                }
+                for e in table.iter().filter(|e| e.kind == kind) {
+                    for call in 0..num_calls {
+                        let r = &records[call * per_call + e.air_row as usize];
+                        let w = (r.0, r.1).words();
+                        debug_assert!(w.n_data == n_data && w.n_prev == n_prev);
+                        let base = e.rec_off as usize;
+                        for k in 0..n_data {
+                            out[(base + k) * num_calls + call] = w.data[k];
+                        }
+                        for k in 0..n_prev {
+                            out[(base + n_data + k) * num_calls + call] = w.prev_ts[k];
+                        }
+                        if e.ts_delta == 0 && e.rec_off == 1 {
+                            out[call] = w.from_timestamp; // the call's first instruction
+                        }
+                    }
+                }
+            }};
+        }
+        match kind {
+            BASE_ALU => walk!(Rv32BaseAluAdapterRecord, BaseAluCoreRecord<4>),
+            SHIFT => walk!(Rv32BaseAluAdapterRecord, ShiftCoreRecord<4, 8>),
+            LESS_THAN => walk!(Rv32BaseAluAdapterRecord, LessThanCoreRecord<4, 8>),
+            LOAD_STORE => walk!(Rv32LoadStoreAdapterRecord, LoadStoreCoreRecord<4>),
+            BRANCH_EQ => walk!(Rv32BranchAdapterRecord, BranchEqualCoreRecord<4>),
+            JAL_LUI => walk!(Rv32CondRdWriteAdapterRecord, Rv32JalLuiCoreRecord),
+            k => return Err(BridgeError::Unsupported(k)),
+        }
+    }
+    // (a block whose FIRST instruction keeps no cell has nobody to read the call's first timestamp from: set_call_timestamps below)
+    Ok(out)
+}
+
+/// word 0 of every call = `from_state.timestamp` at the start of `PowdrExecutor::execute` (executor/mod.rs:533-541), for blocks
+/// whose first instruction keeps no cell (the bridge cannot read it from a record then)
+pub fn set_call_timestamps(records: &mut [u32], num_calls: usize, first_timestamps: &[u32]) {
+    records[..num_calls].copy_from_slice(&first_timestamps[..num_calls]);
+}

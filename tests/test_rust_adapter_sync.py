@@ -80,3 +80,61 @@ def test_reference_ffi_names_are_unchanged(reference_dir):
         my_params = re.search(r"pub fn " + name + r"\s*\((.*?)\)\s*->", FFI, flags=re.S).group(1)
         assert re.findall(r"(\w+)\s*:", my_params) == ref_names, name
         assert mine[name] == len(ref_names)
+
+
+def _rust_sources():
+    return {p.name: p.read_text() for p in sorted((ROOT / "rust" / "powdr-hip" / "src").glob("*.rs"))}
+
+
+def test_every_ffi_name_the_crate_uses_is_declared():
+    """`ffi::name` anywhere in the crate -> a function, struct or constant of ffi.rs (whose functions the first test ties to include/*.h)."""
+    declared = set(re.findall(r"pub (?:fn|struct|const|type|static) (\w+)", FFI))
+    for name, text in _rust_sources().items():
+        code = re.sub(r"//[^\n]*", "", text)
+        for used in set(re.findall(r"(?<!core::)(?<!std::)\bffi::(\w+)", code)):
+            assert used in declared, f"{name} uses ffi::{used}, which ffi.rs does not declare"
+
+
+def test_every_isa_member_the_crate_uses_exists(reference_dir):
+    """round 3 called `ISA::create_dummy_chip_complex_hip`, which `OpenVmISA` does not have. Every member taken from
+    `OpenVmISA` must exist in the reference's isa.rs; every member taken from the crate's own extension trait `OpenVmIsaHip` must be
+    declared in src/isa_hip.rs; a bare `ISA::member` is not allowed (it would not say which trait it means)."""
+    isa_rs = (reference_dir / "openvm" / "src" / "isa.rs").read_text()
+    trait = isa_rs[isa_rs.index("pub trait OpenVmISA"):]
+    upstream = set(re.findall(r"\bfn (\w+)", trait)) | set(re.findall(r"\btype (\w+)", trait))
+    src = _rust_sources()
+    ext = src["isa_hip.rs"]
+    ext_trait = ext[ext.index("pub trait OpenVmIsaHip"):]
+    own = set(re.findall(r"\bfn (\w+)", ext_trait)) | set(re.findall(r"\btype (\w+)", ext_trait))
+    assert own == {"HipBuilder", "create_dummy_chip_complex_hip"} and not (own & upstream)
+    n_up = n_own = 0
+    for name, text in src.items():
+        code = re.sub(r"//[^\n]*", "", text)
+        assert not re.search(r"\bISA::\w+\s*\(", code), f"{name}: bare ISA::method(...) — say which trait"
+        for m in re.findall(r"<ISA as OpenVmISA>::(\w+)", code):
+            assert m in upstream, f"{name}: OpenVmISA has no `{m}` (openvm/src/isa.rs)"
+            n_up += 1
+        for m in re.findall(r"<ISA as OpenVmIsaHip>::(\w+)", code):
+            assert m in own, f"{name}: OpenVmIsaHip has no `{m}`"
+            n_own += 1
+        for m in re.findall(r"\bISA::(\w+)", code):  # associated types written `ISA::Config` etc.
+            assert m in upstream or m in own, f"{name}: ISA::{m} exists in neither trait"
+    assert n_up >= 1 and n_own >= 2
+
+
+def test_record_bridge_matches_the_record_layout_tables():
+    """records_from_arena.rs restates RECORD_WORDS / N_PREV_TS (powdr_amd/original_chips.py = include/powdr_gpu.h) for the chips it
+    covers, and its kind constants are the POWDR_ORIG_* numbers."""
+    from powdr_amd import original_chips as oc
+
+    text = _rust_sources()["records_from_arena.rs"]
+    for name, kind in (("BASE_ALU", oc.BASE_ALU), ("SHIFT", oc.SHIFT), ("LOAD_STORE", oc.LOAD_STORE), ("BRANCH_EQ", oc.BRANCH_EQ),
+                       ("JAL_LUI", oc.JAL_LUI), ("LESS_THAN", oc.LESS_THAN)):
+        assert re.search(rf"pub const {name}: u32 = {kind};", text), name
+    shapes = {k: (oc.RECORD_WORDS[k] - oc.N_PREV_TS[k], oc.N_PREV_TS[k]) for k in range(oc.N_KINDS)}
+    assert shapes[oc.BASE_ALU] == shapes[oc.SHIFT] == shapes[oc.LOAD_STORE] == shapes[oc.LESS_THAN] == (3, 3)
+    assert shapes[oc.BRANCH_EQ] == (2, 2) and shapes[oc.JAL_LUI] == (1, 1)
+    assert "BASE_ALU | SHIFT | LOAD_STORE | LESS_THAN => Ok((3, 3))" in text and "BRANCH_EQ => Ok((2, 2))" in text and "JAL_LUI => Ok((1, 1))" in text
+    first = [lo for lo, hi, k in sorted(oc.OPCODE_RANGES, key=lambda t: t[2])]
+    chip = _rust_sources()["chip.rs"]
+    assert "[" + ", ".join(str(x) for x in first) + "]" in chip  # FIRST_OPCODE of air_name_of_kind
