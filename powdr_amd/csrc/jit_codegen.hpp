@@ -31,6 +31,8 @@ struct Unit {
     std::string kernel;     // name of the __global__ function
     uint32_t first_chunk;   // chunks [first_chunk, first_chunk + n_chunks) of the program: gridDim.y = n_chunks
     uint32_t n_chunks;
+    uint32_t g0 = 0, g1 = 0;  // the LogUp groups [g0, g1) this unit's chunks cover (g0 == g1: constraint chunks only): the only
+                              // permutation columns the unit reads are 4 g0 .. 4 g1 - 1 (the streamed prover extends just those)
 };
 struct Generated {
     std::vector<Unit> units;

@@ -592,13 +592,18 @@ struct CosetSpec {
 
 template <bool DIF>
 void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n,
-                int first_stage, const uint32_t* tw, const uint32_t* expand_scale_br, const char* name, const CosetSpec* cs = nullptr) {
+                int first_stage, const uint32_t* tw, const uint32_t* expand_scale_br, const char* name, const CosetSpec* cs = nullptr,
+                int max_groups = -1, int* stages_done = nullptr) {
     int logt = 12;
     auto groups = plan_groups(DIF, n, first_stage, logt);
+    // max_groups: only the first groups of the plan (subcoset_lde_first_group: the rest is evaluated for a few outputs only)
+    if (max_groups >= 0 && (size_t)max_groups < groups.size()) groups.resize((size_t)max_groups);
+    if (stages_done) { *stages_done = first_stage; for (auto& g : groups) *stages_done += g.k; }
+    const bool complete = !stages_done || *stages_done == n;
     const uint32_t* src = in;
     size_t src_stride = in_stride;
     int mode = cs ? 2 : expand_scale_br != nullptr ? 1 : 0;
-    if (!groups.empty()) groups.back().canonical_out = 1;
+    if (!groups.empty() && complete) groups.back().canonical_out = 1;
     for (auto& g : groups) {
         const size_t tiles = (size_t)1 << (n - g.B);
         const size_t per_wg = (size_t)1 << (logt - g.B);
@@ -808,16 +813,14 @@ int coset_lde_from_coeffs(const uint32_t* coeffs, uint32_t* out, size_t in_strid
 // size-m COSET transform: the DIT network with the twiddles of stage s multiplied by c^(2^(log2 m - 1 - s)) (P(x) = E(x^2) + x O(x^2)
 // level by level), i.e. no scaling pass and no per-element scale table. Work per column and sub-coset: 2^n multiply-adds +
 // (m / 2) log2 m butterflies; all 2^b sub-cosets together read the coefficients 2^(b-1) times for one forward transform's butterflies.
-int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, uint32_t r,
-                 uint32_t* d_scratch) {
-    const int nm = n + 1 - b;  // log2 of the sub-coset's size
-    if (b < 1 || b > 5 || nm < 1 || (r >> b)) return (int)hipErrorInvalidValue;
-    const Tables* tm = tables(nm);
-    if (!tm) return (int)hipErrorOutOfMemory;
-    CosetSpec cs{};
+namespace {
+// the sub-coset's constants: c = s g_(n+1)^r; C[s] = c^(2^(nm-1-s)); fold factors (c^m)^bitrev(t) / H
+bool subcoset_spec(int n, int b, uint32_t r, uint32_t* d_scratch, CosetSpec& cs) {
+    const int nm = n + 1 - b;
+    if (b < 1 || b > 5 || nm < 1 || (r >> b)) return false;
+    cs = CosetSpec{};
     cs.fold_log = b - 1;
     cs.d_scratch = d_scratch;
-    // c = s g_(n+1)^r; pw[e] = c^(2^e)
     uint32_t pw[32];
     pw[0] = bb::mul(bb::to_monty(field::kCosetShift), bb::pow_u32(field::root_of_unity(n + 1), r));
     for (int e = 1; e <= nm; ++e) pw[e] = bb::sqr(pw[e - 1]);
@@ -828,7 +831,65 @@ int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t
         const uint32_t t = f ? (__builtin_bitreverse32(tp) >> (32 - f)) : 0u;
         cs.foldk[tp] = bb::mul(bb::pow_u32(pw[nm], t), hinv);
     }
+    return true;
+}
+
+// After the first `k1` DIT stages block t of 2^k1 contiguous elements holds P_u(y), u = bitrev(t), on the points y = x^(2^k2) of its
+// own coset, where P(x) = sum_u x^u P_u(x^(2^k2)), k2 = nm - k1. Output i of the whole transform is then a 2^k2-term sum:
+//   out[i] = sum_u x_i^u part[bitrev_k2(u) * 2^k1 + (i mod 2^k1)],  x_i = c w_m^i
+// — what the remaining (strided) stages compute for EVERY i; the query phase needs ~a hundred of them. One thread per (row, column).
+// The partial values are the forward network's [0, 2p) representatives.
+__global__ __launch_bounds__(256) void subcoset_rows_kernel(const uint32_t* __restrict__ part, size_t stride, uint32_t cols, int k1, int k2, uint32_t c0,
+                                                            uint32_t wm, const uint32_t* __restrict__ idx, uint32_t* __restrict__ out) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= cols) return;
+    const uint32_t i = idx[blockIdx.y];
+    const uint32_t x = bb::mul(c0, bb::pow_u32(wm, i));
+    const uint32_t* col = part + (size_t)c * stride + (i & ((1u << k1) - 1u));
+    uint32_t acc = 0u, xp = bb::R_MOD_P;
+    for (uint32_t u = 0; u < (1u << k2); ++u) {
+        const uint32_t t = k2 ? (__brev(u) >> (32 - k2)) : 0u;
+        acc = bb::add(acc, bb::mul(bb::reduce_2p(col[(size_t)t << k1]), xp));
+        xp = bb::mul(xp, x);
+    }
+    out[(size_t)blockIdx.y * cols + c] = acc;
+}
+}  // namespace
+
+int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, uint32_t r,
+                 uint32_t* d_scratch) {
+    const int nm = n + 1 - b;  // log2 of the sub-coset's size
+    CosetSpec cs;
+    if (!subcoset_spec(n, b, r, d_scratch, cs)) return (int)hipErrorInvalidValue;
+    const Tables* tm = tables(nm);
+    if (!tm) return (int)hipErrorOutOfMemory;
     run_groups<false>(coeffs, out, in_stride, out_stride, cols, nm, 0, tm->tw_fwd, nullptr, "ntt_group_kernel<dit>", &cs);
+    return (int)hipGetLastError();
+}
+
+// Only the first stage group of subcoset_lde (the contiguous stages, with the FOLD loads): `out` holds the PARTIAL transform,
+// *stages_done stages of log2 m. subcoset_rows finishes it for chosen rows.
+int subcoset_lde_first_group(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, uint32_t r,
+                             uint32_t* d_scratch, int* stages_done) {
+    const int nm = n + 1 - b;
+    CosetSpec cs;
+    if (!subcoset_spec(n, b, r, d_scratch, cs) || !stages_done) return (int)hipErrorInvalidValue;
+    const Tables* tm = tables(nm);
+    if (!tm) return (int)hipErrorOutOfMemory;
+    run_groups<false>(coeffs, out, in_stride, out_stride, cols, nm, 0, tm->tw_fwd, nullptr, "ntt_group_kernel<dit>", &cs, 1, stages_done);
+    return (int)hipGetLastError();
+}
+
+// out[q * cols + c] = row d_local_idx[q] of the sub-coset's LDE (canonical Montgomery words), from the partial transform
+int subcoset_rows(const uint32_t* part, size_t stride, uint32_t cols, int n, int b, uint32_t r, int stages_done, const uint32_t* d_local_idx,
+                  uint32_t n_idx, uint32_t* out) {
+    const int nm = n + 1 - b;
+    if (!n_idx || !cols) return 0;
+    if (stages_done < 0 || stages_done > nm) return (int)hipErrorInvalidValue;
+    const uint32_t c0 = bb::mul(bb::to_monty(field::kCosetShift), bb::pow_u32(field::root_of_unity(n + 1), r));
+    ScopedKernelTimer t("subcoset_rows_kernel");
+    hipLaunchKernelGGL(subcoset_rows_kernel, dim3(div_up(cols, 256), n_idx), dim3(256), 0, stream(), part, stride, cols, stages_done, nm - stages_done, c0,
+                       field::root_of_unity(nm), d_local_idx, out);
     return (int)hipGetLastError();
 }
 

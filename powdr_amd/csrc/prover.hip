@@ -283,7 +283,14 @@ void plan_buffers(const PwProver* p, uint32_t log_h, int b, CommitLayout& L, Buf
     const size_t widest = b ? 8 : (lg ? std::max<size_t>(W, Wp) : W);
     L.panel_cols = lde_panel_cols(H, widest);
     B.coef = L.panel_cols * H * 4;
-    B.lde = b ? (size_t)(W + Wp) * L.m * 4 : (size_t)W * N * 4;
+    // streamed: `lde` holds one sub-coset. The commitments and the query rows take the two matrices one after the other (max(W, Wp)
+    // columns); the quotient needs main AND permutation columns of the same rows — all of them for the interpreter, but a unit of the
+    // specialised LogUp kernels reads only the columns of its own groups: the main block + one unit's panel. That is what lets
+    // configs[2] run with 4 sub-cosets instead of 8 (half the coefficient re-reads, the transforms' first stage group is bound by them).
+    L.perm_panels = b && lg && p->jit.state == 1 && !getenv("POWDR_STREAM_NO_PANELS");
+    if (!b) B.lde = (size_t)W * N * 4;
+    else if (L.perm_panels) B.lde = std::max<size_t>(std::max(W, Wp), (size_t)W + quotient_max_unit_perm_cols(p)) * L.m * 4;
+    else B.lde = (size_t)(W + Wp) * L.m * 4;
     B.digests = (L.n_trees * L.tree_words + L.fri_words) * 4;
     if (b) { B.tcoef = (size_t)W * H * 4; B.fscale = (size_t)1 << 15; }
     if (b || log_h >= kDeepComboMinLogHeight) B.gbuf = (size_t)24 * H * 4;
@@ -624,6 +631,23 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         // streamed: the terms that read the current row only, sub-coset by sub-coset (unscaled sums scattered to their rows of d_q), then
         // the boundary terms / the division by Z_H over all rows
         uint32_t* d_part = p->qpart.as<uint32_t>();
+        if (L.perm_panels) {
+            // main columns of the sub-coset once; the permutation columns unit by unit into the panel behind them
+            uint32_t* d_panel = d_blk + (size_t)W * m_sub;
+            uint32_t* fs = p->fscale.as<uint32_t>();
+            TRY(for_each_subcoset(p, L, log_h, {CoefMatrix{d_tcoef, W}}, nullptr, [&](uint32_t r) -> int {
+                const uint32_t n_units = quotient_units_jit(p);
+                for (uint32_t u = 0; u < n_units; ++u) {
+                    uint32_t g0 = 0, g1 = 0;
+                    quotient_unit_groups(p, u, &g0, &g1);
+                    if (g1 > g0) TRY(subcoset_lde(d_perm + (size_t)(4 * g0) * H, d_panel, H, m_sub, 4 * (g1 - g0), (int)log_h, sb, r, fs));
+                    // Pm = where permutation column 0 would be: the panel holds columns 4 g0 .. 4 g1 - 1
+                    const uint32_t* Pm = d_panel - (size_t)(4 * g0) * m_sub;
+                    TRY(quotient_unit_jit(p, u, d_blk, Pm, m_sub, d_apow, al, d_blpow, d_part));
+                }
+                return part_scatter(d_part, p->jit.quotient.n_chunks, m_sub, sb, r, N, d_q);
+            }));
+        } else
         TRY(for_each_subcoset(p, L, log_h, {CoefMatrix{d_tcoef, W}, CoefMatrix{d_perm, Wp}}, nullptr, [&](uint32_t r) -> int {
             const uint32_t* blk_p = d_blk + (size_t)W * m_sub;
             uint32_t n_parts = 1;
@@ -820,12 +844,19 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
             for (uint32_t k = 0; k < nq; ++k) { loc[k] = idx[order[k]] >> sb; pos[order[k]] = k; wanted[idx[order[k]] & (nb - 1)] = 1; }
             PW_HIP_TRY(hipMemcpyAsync(d_loc, loc.data(), nq * 4, hipMemcpyHostToDevice, st));
             PW_HIP_TRY(hipStreamSynchronize(st));  // loc is a local vector
-            TRY(for_each_subcoset(p, L, log_h, {CoefMatrix{d_tcoef, W}, CoefMatrix{d_perm, Wp}}, &wanted, [&](uint32_t r) -> int {
+            // ... of which only the contiguous stage group runs over every row: the strided stages are finished for the queried rows alone
+            uint32_t* fs = p->fscale.as<uint32_t>();
+            for (uint32_t r = 0; r < nb; ++r) {
+                if (!wanted[r]) continue;
                 const uint32_t k0 = first[r], cnt = first[r + 1] - first[r];
-                TRY(gather_rows(d_blk, m_sub, W, d_loc + k0, cnt, d_trows + (size_t)k0 * W));
-                if (lg) TRY(gather_rows(d_blk + (size_t)W * m_sub, m_sub, Wp, d_loc + k0, cnt, d_prows + (size_t)k0 * Wp));
-                return 0;
-            }));
+                int done = 0;
+                TRY(subcoset_lde_first_group(d_tcoef, d_blk, H, m_sub, W, (int)log_h, sb, r, fs, &done));
+                TRY(subcoset_rows(d_blk, m_sub, W, (int)log_h, sb, r, done, d_loc + k0, cnt, d_trows + (size_t)k0 * W));
+                if (lg) {
+                    TRY(subcoset_lde_first_group(d_perm, d_blk, H, m_sub, Wp, (int)log_h, sb, r, fs, &done));
+                    TRY(subcoset_rows(d_blk, m_sub, Wp, (int)log_h, sb, r, done, d_loc + k0, cnt, d_prows + (size_t)k0 * Wp));
+                }
+            }
         }
         TRY(gather_rows(d_qlde, N, 8, d_idx, nq, d_qrows));
         TRY(gather_records(d_dig, d_dig_offs, 8u, (uint32_t)n_dig, d_dig_out));

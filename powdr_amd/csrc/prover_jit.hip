@@ -4,6 +4,7 @@
 // canonical words; POWDR_JIT=0 / 1 forces either path, the tests compare proofs made with both.
 #include "prover_state.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <thread>
 
@@ -23,14 +24,19 @@ jit::LogupView logup_view(const PwProver* p) {
                           p->h_gstarts.data(), p->n_groups};
 }
 
+int launch_unit(const jit::Generated& g, const std::vector<jit::ProgramPtr>& progs, size_t u, size_t rows, void** args) {
+    std::string err;
+    hipFunction_t f = jit::kernel(*progs[u], g.units[u].kernel.c_str(), &err);
+    if (!f) return (int)hipErrorSharedObjectInitFailed;
+    const int rc = jit::launch(f, dim3(div_up(rows, 256), g.units[u].n_chunks), dim3(256), args, stream());
+    if (rc) return rc;
+    call_stats()[kStatJitKernelLaunches] += 1;
+    return 0;
+}
 int launch_units(const jit::Generated& g, const std::vector<jit::ProgramPtr>& progs, size_t rows, void** args) {
     for (size_t u = 0; u < g.units.size(); ++u) {
-        std::string err;
-        hipFunction_t f = jit::kernel(*progs[u], g.units[u].kernel.c_str(), &err);
-        if (!f) return (int)hipErrorSharedObjectInitFailed;
-        const int rc = jit::launch(f, dim3(div_up(rows, 256), g.units[u].n_chunks), dim3(256), args, stream());
+        const int rc = launch_unit(g, progs, u, rows, args);
         if (rc) return rc;
-        call_stats()[kStatJitKernelLaunches] += 1;
     }
     return 0;
 }
@@ -145,6 +151,27 @@ int quotient_parts_jit(PwProver* p, const uint32_t* T, const uint32_t* Pm, size_
     const int rc = launch_units(g, p->jit.quotient_prog, rows, args);
     if (n_chunks) *n_chunks = g.n_chunks;
     return rc;
+}
+
+uint32_t quotient_units_jit(const PwProver* p) { return (uint32_t)p->jit.quotient.units.size(); }
+void quotient_unit_groups(const PwProver* p, uint32_t u, uint32_t* g0, uint32_t* g1) {
+    *g0 = p->jit.quotient.units[u].g0;
+    *g1 = p->jit.quotient.units[u].g1;
+}
+uint32_t quotient_max_unit_perm_cols(const PwProver* p) {
+    uint32_t w = 0;
+    for (const auto& u : p->jit.quotient.units) w = std::max(w, 4 * (u.g1 - u.g0));
+    return w;
+}
+int quotient_unit_jit(PwProver* p, uint32_t u, const uint32_t* T, const uint32_t* Pm, size_t rows, const bb::Ext* d_apow, bb::Ext al,
+                      const bb::Ext* d_blpow, uint32_t* part) {
+    const jit::Generated& g = p->jit.quotient;
+    // (a chunk stores to part + <its program-wide chunk id> * 4 * rows — the id is a literal in the generated code — so every unit
+    // takes the same base pointer)
+    uint64_t n64 = rows;
+    void* args[] = {(void*)&T, (void*)&Pm, (void*)&n64, (void*)&d_apow, (void*)&al, (void*)&d_blpow, (void*)&part};
+    ScopedKernelTimer t(Pm ? "quotient_logup_jit_kernel" : "quotient_jit_kernel");
+    return launch_unit(g, p->jit.quotient_prog, u, rows, args);
 }
 
 int quotient_eval_jit(PwProver* p, const uint32_t* lde, size_t N, const bb::Ext* d_apow, uint32_t zinv_even, uint32_t zinv_odd, uint32_t* q) {

@@ -114,6 +114,7 @@ struct CommitLayout {
     size_t H, N, tree_words, fri_words, n_trees, panel_cols;
     int b = 0;     // streamed mode: the extended domain is walked as 2^b sub-cosets (0: the LDE is resident)
     size_t m = 0;  // rows of a sub-coset, N >> b
+    bool perm_panels = false;  // streamed quotient: the permutation columns come in unit by unit (specialised LogUp kernels) instead of all at once
 };
 // LDE of a column-major matrix (cols x 2^log_h) through the prover's coefficient panel buffer into `out` (cols x 2^(log_h+1))
 int lde_matrix(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_t* m, uint32_t cols, uint32_t* out);
@@ -134,6 +135,16 @@ int quotient_eval_jit(PwProver* p, const uint32_t* lde, size_t N, const bb::Ext*
 // part[(c * 4 + k) * rows + j], c < *n_chunks (the streamed path runs them per sub-coset; Pm / d_blpow: nullptr without LogUp)
 int quotient_parts_jit(PwProver* p, const uint32_t* T, const uint32_t* Pm, size_t rows, const bb::Ext* d_apow, bb::Ext al, const bb::Ext* d_blpow,
                        uint32_t* part, uint32_t* n_chunks);
+// The same unit by unit (the streamed prover extends only the permutation columns a unit reads): quotient_units_jit = number of units;
+// quotient_unit_groups: the LogUp groups [*g0, *g1) unit u covers (equal: none); quotient_unit_jit launches unit u — Pm is the address
+// permutation column 0 WOULD have (the caller's panel holds columns 4 g0 .. 4 g1 - 1 at Pm + 4 g0 * rows), every chunk of the unit
+// writes part[(chunk * 4 + k) * rows + j] at its own chunk index, as quotient_parts_jit does.
+uint32_t quotient_units_jit(const PwProver* p);
+void quotient_unit_groups(const PwProver* p, uint32_t u, uint32_t* g0, uint32_t* g1);
+int quotient_unit_jit(PwProver* p, uint32_t u, const uint32_t* T, const uint32_t* Pm, size_t rows, const bb::Ext* d_apow, bb::Ext al,
+                      const bb::Ext* d_blpow, uint32_t* part);
+// widest permutation-column range (in columns) any unit of the specialised quotient reads
+uint32_t quotient_max_unit_perm_cols(const PwProver* p);
 // bytes of `qpart` the specialised kernels need for a trace of H rows whose quotient is evaluated `q_rows` rows at a time
 size_t jit_part_bytes(const PwProver* p, size_t H, size_t q_rows);
 int quotient_eval_logup_jit(PwProver* p, const uint32_t* lde, const uint32_t* plde, size_t N, int logN, const bb::Ext* d_apow, bb::Ext al,

@@ -99,6 +99,11 @@ def test_streamed_proof_words_equal_the_oracle(gpu, monkeypatch, shape, calls, n
             assert (state == 1) if jit else (state in (0, -1))
             assert len(got) == len(want) and (got == want).all(), \
                 f"blocks 2^{log_blocks} jit={jit}: first differing word {int(np.argmax(got != want))} of {len(want)}"
+    # the specialised quotient without permutation panels (all permutation columns of a sub-coset at once): same words
+    monkeypatch.setenv("POWDR_STREAM_NO_PANELS", "1")
+    got, state = _prove(prover, monkeypatch, d_t, W, log_h, bc, spans, it if logup else None, nq, pow_bits, 2, True)
+    monkeypatch.delenv("POWDR_STREAM_NO_PANELS")
+    assert state == 1 and (got == want).all()
     # the resident path on the same prover inputs (POWDR_STREAM_LOG_BLOCKS=0): same words
     got, _ = _prove(prover, monkeypatch, d_t, W, log_h, bc, spans, it if logup else None, nq, pow_bits, 0, False)
     assert (got == want).all()
@@ -118,6 +123,19 @@ def test_baseline_shapes_streamed_with_logup(gpu, monkeypatch, shape, log_h, log
     assert len(got) == len(want) and (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
     assert prover.verify_logup(got, W, log_h, bc, spans, it, num_queries=6, pow_bits=4)[0] == 0
     assert sm.verify_logup(got, W, log_h, bc, spans, *it, num_queries=6, pow_bits=4) == 0
+
+
+@pytest.mark.parametrize("log_blocks,jit", [(1, False), (2, True)])
+def test_tall_trace_query_rows_from_the_partial_transform(gpu, monkeypatch, log_blocks, jit):
+    """From 2^14-point sub-cosets on, the transform has strided stage groups and the query phase finishes them for the queried rows
+    only (subcoset_lde_first_group + subcoset_rows): 2^16 rows, sub-cosets of 2^16 and 2^15 points."""
+    torch, abi, prover = gpu
+    flat, W, log_h, bc, spans, it = _synthetic("T1", 40000, seed=3)
+    assert log_h == 16
+    want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=12, pow_bits=0)
+    d_t = to_dev(torch, flat)
+    got, _ = _prove(prover, monkeypatch, d_t, W, log_h, bc, spans, it, 12, 0, log_blocks, jit)
+    assert len(got) == len(want) and (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
 
 
 def test_trace_root_then_prove_in_streamed_mode(gpu, monkeypatch):
