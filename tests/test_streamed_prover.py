@@ -138,6 +138,33 @@ def test_tall_trace_query_rows_from_the_partial_transform(gpu, monkeypatch, log_
     assert len(got) == len(want) and (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
 
 
+def test_streamed_equals_resident_at_2_to_18_rows(gpu, monkeypatch):
+    """Beyond what the oracle proves in seconds: the C2 AIR (2 022 columns, 187 constraints, 1 734 interactions) on a 2^18-row trace,
+    specialised kernels, 4 and 8 sub-cosets (three stage groups per sub-coset transform, permutation panels by unit) against the
+    resident path — the same words, which the product's verifier accepts or rejects alike (the trace is random: code 2)."""
+    torch, abi, prover = gpu
+    from powdr_amd import host
+
+    s = synth.generate("C2", seed=0)
+    apc = host.Apc(s.doc)
+    bc, spans = apc.compile_constraints()
+    it = apc.compile_bus(1)
+    W, log_h = apc.width, 18
+    d_t = torch.empty(W << log_h, dtype=torch.int32, device="cuda")
+    d_t.random_(0, P)
+    monkeypatch.setenv("POWDR_JIT", "1")
+    proofs = {}
+    for b in (0, 2, 3):
+        monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", str(b))
+        pr = prover.Prover(W, bc, spans, num_queries=20, pow_bits=8, interactions=it)
+        proofs[b] = pr.prove(d_t.data_ptr(), log_h)
+        assert pr.specialised()["state"] == 1
+        pr.close()
+    assert (proofs[2] == proofs[0]).all() and (proofs[3] == proofs[0]).all()
+    assert prover.verify_logup(proofs[2], W, log_h, bc, spans, it, num_queries=20, pow_bits=8)[0] == 2
+    apc.close()
+
+
 def test_trace_root_then_prove_in_streamed_mode(gpu, monkeypatch):
     """pw_prover_trace_root leaves the streamed commitment (coefficients + tree) for the proof that follows; a shared bus seed
     works as in the resident mode."""
