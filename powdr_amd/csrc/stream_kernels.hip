@@ -33,44 +33,56 @@ __global__ __launch_bounds__(kBlock) void part_scatter_kernel(const uint32_t* __
 // out[(4 + k) * len + q]   = coordinate k of sum_{c < wb} g[second + c] mb_c[q]                          (second != 0 only)
 // g: CENTRED gamma powers (the host centres them for the DEEP kernels); cells are Montgomery words, centred here; signed 64-bit
 // accumulators folded every fourth column (bb::ExtCentredAcc) — the inner loops of deep_logup_kernel over `len` rows of
-// arbitrary matrices.
+// arbitrary matrices. A lane owns TWO neighbouring rows (one 8-byte load per column: half the load instructions, 512 contiguous
+// bytes per wave and column); len is even (a power of two >= 2).
 __global__ __launch_bounds__(kBlock) void ext_lincomb_kernel(const uint32_t* __restrict__ ma, uint32_t wa, const uint32_t* __restrict__ mb,
                                                               uint32_t wb, size_t len, const Ext* __restrict__ gpow, uint32_t second,
                                                               uint32_t* __restrict__ out) {
-    const size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t q = 2 * ((size_t)blockIdx.x * kBlock + threadIdx.x);
     if (q >= len) return;
-    bb::ExtCentredAcc w1, w2;
+    bb::ExtCentredAcc w1[2], w2[2];
     const int32_t (*g)[4] = reinterpret_cast<const int32_t (*)[4]>(gpow);
+    auto ld2 = [&](const uint32_t* m, uint32_t c) {  // (one 8-byte, non-temporal load: the matrices are read once)
+        const unsigned long long w = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(m + (size_t)c * len + q));
+        return make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+    };
     uint32_t k = 0;
     for (; k + 4 <= wa; k += 4) {
+        uint2 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w1.fma_uniform(g[k + u], bb::centred(__builtin_nontemporal_load(ma + (size_t)(k + u) * len + q)));
-        w1.fold();
+        for (int u = 0; u < 4; ++u) v[u] = ld2(ma, k + u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { w1[0].fma_uniform(g[k + u], bb::centred(v[u].x)); w1[1].fma_uniform(g[k + u], bb::centred(v[u].y)); }
+        w1[0].fold(); w1[1].fold();
     }
-    for (; k < wa; ++k) w1.fma_uniform(g[k], bb::centred(ma[(size_t)k * len + q]));
-    w1.fold();
+    for (; k < wa; ++k) { const uint2 v = ld2(ma, k); w1[0].fma_uniform(g[k], bb::centred(v.x)); w1[1].fma_uniform(g[k], bb::centred(v.y)); }
+    w1[0].fold(); w1[1].fold();
     for (k = 0; k + 4 <= wb; k += 4) {
+        uint2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld2(mb, k + u);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int32_t x = bb::centred(__builtin_nontemporal_load(mb + (size_t)(k + u) * len + q));
-            w1.fma_uniform(g[wa + k + u], x);
-            if (second) w2.fma_uniform(g[second + k + u], x);
+            const int32_t x0 = bb::centred(v[u].x), x1 = bb::centred(v[u].y);
+            w1[0].fma_uniform(g[wa + k + u], x0); w1[1].fma_uniform(g[wa + k + u], x1);
+            if (second) { w2[0].fma_uniform(g[second + k + u], x0); w2[1].fma_uniform(g[second + k + u], x1); }
         }
-        w1.fold();
-        w2.fold();
+        w1[0].fold(); w1[1].fold();
+        w2[0].fold(); w2[1].fold();
     }
     for (; k < wb; ++k) {
-        const int32_t x = bb::centred(mb[(size_t)k * len + q]);
-        w1.fma_uniform(g[wa + k], x);
-        if (second) w2.fma_uniform(g[second + k], x);
+        const uint2 v = ld2(mb, k);
+        const int32_t x0 = bb::centred(v.x), x1 = bb::centred(v.y);
+        w1[0].fma_uniform(g[wa + k], x0); w1[1].fma_uniform(g[wa + k], x1);
+        if (second) { w2[0].fma_uniform(g[second + k], x0); w2[1].fma_uniform(g[second + k], x1); }
     }
-    const Ext a1 = w1.result();
+    const Ext a10 = w1[0].result(), a11 = w1[1].result();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) out[(size_t)c * len + q] = a1.c[c];
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<uint2*>(out + (size_t)c * len + q) = make_uint2(a10.c[c], a11.c[c]);
     if (second) {
-        const Ext a2 = w2.result();
+        const Ext a20 = w2[0].result(), a21 = w2[1].result();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) out[(size_t)(4 + c) * len + q] = a2.c[c];
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<uint2*>(out + (size_t)(4 + c) * len + q) = make_uint2(a20.c[c], a21.c[c]);
     }
 }
 
@@ -119,7 +131,8 @@ int part_scatter(const uint32_t* part, uint32_t n_chunks, size_t m, int b, uint3
 int ext_lincomb(const uint32_t* ma, uint32_t wa, const uint32_t* mb, uint32_t wb, size_t len, const bb::Ext* d_gpow, uint32_t second,
                 uint32_t* out) {
     ScopedKernelTimer t("ext_lincomb_kernel");
-    hipLaunchKernelGGL(ext_lincomb_kernel, dim3(div_up(len, kBlock)), dim3(kBlock), 0, stream(), ma, wa, mb, wb, len, d_gpow, second, out);
+    if (len & 1) return (int)hipErrorInvalidValue;  // (traces have at least two rows)
+    hipLaunchKernelGGL(ext_lincomb_kernel, dim3(div_up(len / 2, kBlock)), dim3(kBlock), 0, stream(), ma, wa, mb, wb, len, d_gpow, second, out);
     return (int)hipGetLastError();
 }
 
