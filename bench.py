@@ -1096,7 +1096,7 @@ def main():
             del a_, b_
         # PMC profiles of THIS round's code (separate rocprofv3 --pmc passes of this command, tools/pmc_traffic_json.py and
         # tools/pmc_valu_json.py): HBM traffic per kernel and step; VALU instructions per Poseidon2 permutation
-        tprof_name = "r03_pmc_traffic_c2.json" if args.logup else "r02_pmc_traffic_c2.json"  # per-kernel PMC traffic of the committed profile of this proof kind
+        tprof_name = "r04_pmc_traffic_c2.json" if args.logup else "r02_pmc_traffic_c2.json"  # per-kernel PMC traffic of the committed profile of this proof kind
         tprof = load_profile_json(tprof_name) if (args.shape == "C2" and log_h == 20) else None
         traffic_db = {}
         if tprof:
