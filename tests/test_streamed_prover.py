@@ -204,3 +204,43 @@ def test_mode_policy(gpu, monkeypatch):
     b = pr.stream_log_blocks(22)
     assert b >= 1 or b == -1
     pr.close()
+
+
+@pytest.mark.parametrize("workers", [1, 3])
+def test_streamed_airs_of_a_segment_share_a_bus_seed_and_balance(gpu, monkeypatch, workers):
+    """A segment whose AIRs are proven independently (pw_prove_airs: two phases, shared bus seed — the flow that also shards AIRs over
+    GPUs) works unchanged when its proofs are streamed: the phase-1 commitment (pw_prover_trace_root) leaves coefficients + tree for
+    phase 2, the proofs equal the resident ones, the APC's lookups and the periphery AIRs' receives cancel."""
+    torch, abi, prover = gpu
+    from powdr_amd import periphery, tracegen as tg
+    from tests.test_oracle_apc import run_oracle_gpu_convention
+    from tests.test_tracegen_gpu import run_gpu
+
+    no_cons = (np.zeros(0, np.uint32), np.zeros((0, 2), np.uint32))
+    s = synth.generate("T1", seed=6)
+    apc, idx, want, hist, (bufs, dims, gt, order) = run_oracle_gpu_convention(s, 3000, seed=6)
+    W, H = want.shape
+    log_h = H.bit_length() - 1
+    out, per = run_gpu((torch, None, tg), W, H, 3000, bufs, dims, gt.air_names, gt.row_block_size, gt.subs,
+                       om.compile_derived(apc, idx, H), om.compile_bus(apc, idx, H))
+    cons = sm.compile_constraints(apc, idx)
+    sends = periphery.select_buses(sm.compile_interactions(apc, idx), {per.var_bus, per.tuple_bus})
+    airs = [(out.buf, W, cons, sends, log_h),
+            (periphery.var_range_trace(per.var_hist), 3, no_cons, periphery.var_range_interactions(per.var_bus), per.var_hist.numel().bit_length() - 1),
+            (periphery.tuple2_trace(per.tuple_hist, per.tuple_sizes), 3, no_cons, periphery.tuple2_interactions(per.tuple_bus),
+             per.tuple_hist.numel().bit_length() - 1)]
+    proofs = {}
+    for b in (0, 2):
+        monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", str(b))
+        provers = [prover.Prover(w, *c, num_queries=7, interactions=it) for (_, w, c, it, _) in airs]
+        assert [pr.stream_log_blocks(lh) for pr, (*_, lh) in zip(provers, airs)] == [b] * 3
+        proofs[b], seed = prover.prove_airs([(pr, t.data_ptr(), lh) for pr, (t, _, _, _, lh) in zip(provers, airs)], shared_bus_seed=True,
+                                            n_workers=workers)
+        proofs[b] = [np.array(x, copy=True) for x in proofs[b]]
+        for pr in provers:
+            pr.close()
+    for a, c in zip(proofs[0], proofs[2]):
+        assert len(a) == len(c) and (a == c).all()
+    descs = [(w, lh, *c, it) for (_, w, c, it, lh) in airs]
+    rc, total = prover.verify_airs(descs, proofs[2], num_queries=7, shared_bus_seed=True, check_balance=True)
+    assert rc == 0 and (total == 0).all()
