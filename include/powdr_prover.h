@@ -189,8 +189,11 @@ size_t pw_assign_units(const uint64_t* cells, size_t n_units, size_t n_workers, 
 /* Digest over an ordered list of 8-word commitments (binary Poseidon2 tree; canonical words). */
 void pw_commitment_digest(const uint32_t* roots8, size_t n, uint32_t* digest8);
 
-/* Allocates every device buffer a proof of a 2^log_height-row trace needs, so that the first pw_prover_prove does not
- * pay for the allocation (tens of gigabytes for wide traces). Buffers only grow; calling it is optional. */
+/* Set-up for proofs of 2^log_height-row traces, so that the first pw_prover_prove pays for neither: (1) the run-time specialised
+ * kernels are compiled now if the height policy would compile them at the first proof (seconds of host time for a keccak-sized AIR;
+ * their partial-sum buffer is part of the reservation), (2) every device buffer such a proof needs is allocated (tens of gigabytes
+ * for wide traces) — in the mode the memory free NOW allows (resident, or streamed: see below). Buffers only grow; calling it is
+ * optional. Returns hipErrorOutOfMemory when not even the streamed buffers fit. */
 int pw_prover_reserve(PwProver* p, uint32_t log_height);
 
 /* STREAMED proofs. A resident proof keeps the low-degree extension of every committed column in HBM (8 bytes per committed cell
