@@ -473,7 +473,7 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
     return rec if rank == 0 else None
 
 
-def c3_leg(queries, pow_bits, steps=2, constraints_only_too=True):
+def c3_leg(queries, pow_bits, steps=2, constraints_only_too=True, segment_too=True):
     """BASELINE configs[2] (guest-ecrecover autoprecompile, 2^22 rows — the reference's default segment height,
     openvm-riscv/src/lib.rs:366-371 — "HBM-roofline report") inside the driver-timed line, WITH its bus interactions inside the proof
     (PowdrAir::eval always pushes them, chip.rs:117-129): the C3 AIR (3 731 columns, 3 114 constraints, 2 314 bus interactions = 1 157
@@ -562,6 +562,39 @@ def c3_leg(queries, pow_bits, steps=2, constraints_only_too=True):
         rec["kernels"][k] = e
     pr.close()
     torch.cuda.empty_cache()
+    # ---- the same AIR inside ONE SEGMENT PROOF with the periphery AIRs its lookups go to (pw_prove_segment, pw-stark v1): the shape of
+    # the reference's per-segment engine call. The APC AIR is the only one of its height and is streamed inside the segment proof.
+    if segment_too:
+        try:
+            from powdr_amd import periphery as per_
+
+            p_ = wl["per"]
+            empty = (np.zeros(0, np.uint32), np.zeros((0, 2), np.uint32))
+            traces = [wl["out"], per_.var_range_trace(p_.var_hist), per_.tuple2_trace(p_.tuple_hist, p_.tuple_sizes), per_.bitwise_trace(p_.bitwise_hist)]
+            descs = [(W, log_h, wl["cons"][0], wl["cons"][1], it),
+                     (3, p_.var_hist.numel().bit_length() - 1, *empty, per_.var_range_interactions(p_.var_bus)),
+                     (3, p_.tuple_hist.numel().bit_length() - 1, *empty, per_.tuple2_interactions(p_.tuple_bus)),
+                     (5, 16, *empty, per_.bitwise_interactions(p_.bitwise_bus))]
+            provers = [prover.Prover(w, bc, sp, num_queries=queries, pow_bits=pow_bits, interactions=ia) for (w, lh, bc, sp, ia) in descs]
+            seg = [(pr_, t.data_ptr(), d[1]) for pr_, t, d in zip(provers, traces, descs)]
+            prover.prove_segment(seg, logup=True, copy=False)  # warm-up: buffers, kernels
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            pf = prover.prove_segment(seg, logup=True, copy=True)
+            t_seg = time.perf_counter() - t3
+            seg_cells = sum(d[0] << d[1] for d in descs)
+            rec["segment"] = dict(airs=len(descs), cells=seg_cells, prove_ms=t_seg * 1e3, cells_per_s_prove_only=seg_cells / t_seg,
+                                  verify_rc=int(prover.verify_segment(descs, pf, queries, pow_bits, True)[0]), proof_bytes=int(len(pf) * 4),
+                                  apc_air_stream_log_blocks=provers[0].stream_log_blocks(log_h), prover_device_bytes=sum(x.device_bytes() for x in provers),
+                                  note="ONE pw-stark v1 proof for {the C3 APC AIR with all its interactions, var-range, tuple and bitwise periphery AIRs from "
+                                       "the histograms trace generation filled}; the APC AIR is streamed inside the segment proof (the only AIR of its height)")
+            for x in provers:
+                x.close()
+            del traces, seg
+            torch.cuda.empty_cache()
+        except Exception as e:  # an extra
+            rec["segment"] = dict(verify_rc=None, error=f"{type(e).__name__}: {e}")
+            torch.cuda.empty_cache()
     # ---- the round-3 figure: constraints-only proof of the same trace, resident LDE ----
     if constraints_only_too:
         try:

@@ -320,7 +320,7 @@ int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_
 int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, uint32_t* d_inject) {
     int rc = poseidon2_upload_params();
     if (rc) return rc;
-    if (L < 0 || L > 27 || !by_log[L].n_cols) return (int)hipErrorInvalidValue;
+    if (L < 0 || L > 27 || (!by_log[L].n_cols && !by_log[L].external)) return (int)hipErrorInvalidValue;
     const size_t N = (size_t)1 << L;
     // row digests of every height in one launch: level L into the tree's leaves, smaller heights into their slice of
     // d_inject (offset 2^lg * 8 words: the slices of all heights below L fit in 2^L * 8 words)
@@ -328,14 +328,14 @@ int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, 
     LeafLevel* h_levels = levels.lv;
     int n_levels = 0;
     for (int lg = L; lg >= 0; --lg)
-        if (by_log[lg].n_cols)
+        if (by_log[lg].n_cols && !by_log[lg].external)
             h_levels[n_levels++] = LeafLevel{by_log[lg].d_cols, by_log[lg].n_cols, 0u, (uint64_t)1 << lg,
                                              lg == L ? digests : d_inject + ((size_t)1 << lg) * 8};
     std::stable_sort(h_levels, h_levels + n_levels, [](const LeafLevel& a, const LeafLevel& b) { return a.n_cols > b.n_cols; });
     uint32_t blocks = 0;
     for (int k = 0; k < n_levels; ++k) { h_levels[k].first_block = blocks; blocks += div_up((size_t)h_levels[k].height, kBlock); }
     levels.n = n_levels;
-    {
+    if (n_levels) {
         ScopedKernelTimer t("leaf_hash_kernel");
         if (hash_min_waves() >= 8) hipLaunchKernelGGL(leaf_hash_levels_kernel<8>, dim3(blocks), dim3(kBlock), 0, stream(), levels);
         else hipLaunchKernelGGL(leaf_hash_levels_kernel<6>, dim3(blocks), dim3(kBlock), 0, stream(), levels);
@@ -343,7 +343,7 @@ int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, 
     size_t off = 0;
     for (int lg = L - 1; lg >= 0; --lg) {
         const size_t n = (size_t)1 << lg;
-        const uint32_t* inj = by_log[lg].n_cols ? d_inject + n * 8 : nullptr;
+        const uint32_t* inj = (by_log[lg].n_cols || by_log[lg].external) ? d_inject + n * 8 : nullptr;
         ScopedKernelTimer t("compress_kernel");
         hipLaunchKernelGGL(compress_strided_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, stream(), digests + off, n, inj, digests + off + 2 * n * 8);
         off += 2 * n * 8;

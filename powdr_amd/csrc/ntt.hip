@@ -840,7 +840,8 @@ bool subcoset_spec(int n, int b, uint32_t r, uint32_t* d_scratch, CosetSpec& cs)
 // — what the remaining (strided) stages compute for EVERY i; the query phase needs ~a hundred of them. One thread per (row, column).
 // The partial values are the forward network's [0, 2p) representatives.
 __global__ __launch_bounds__(256) void subcoset_rows_kernel(const uint32_t* __restrict__ part, size_t stride, uint32_t cols, int k1, int k2, uint32_t c0,
-                                                            uint32_t wm, const uint32_t* __restrict__ idx, uint32_t* __restrict__ out) {
+                                                            uint32_t wm, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ slot,
+                                                            uint32_t* __restrict__ out) {
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     if (c >= cols) return;
     const uint32_t i = idx[blockIdx.y];
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(256) void subcoset_rows_kernel(const uint32_t* __re
         acc = bb::add(acc, bb::mul(bb::reduce_2p(col[(size_t)t << k1]), xp));
         xp = bb::mul(xp, x);
     }
-    out[(size_t)blockIdx.y * cols + c] = acc;
+    out[(size_t)(slot ? slot[blockIdx.y] : blockIdx.y) * cols + c] = acc;
 }
 }  // namespace
 
@@ -880,16 +881,17 @@ int subcoset_lde_first_group(const uint32_t* coeffs, uint32_t* out, size_t in_st
     return (int)hipGetLastError();
 }
 
-// out[q * cols + c] = row d_local_idx[q] of the sub-coset's LDE (canonical Montgomery words), from the partial transform
+// out[slot(q) * cols + c] = row d_local_idx[q] of the sub-coset's LDE (canonical Montgomery words), from the partial transform;
+// slot(q) = d_slot[q], or q when d_slot is null
 int subcoset_rows(const uint32_t* part, size_t stride, uint32_t cols, int n, int b, uint32_t r, int stages_done, const uint32_t* d_local_idx,
-                  uint32_t n_idx, uint32_t* out) {
+                  uint32_t n_idx, const uint32_t* d_slot, uint32_t* out) {
     const int nm = n + 1 - b;
     if (!n_idx || !cols) return 0;
     if (stages_done < 0 || stages_done > nm) return (int)hipErrorInvalidValue;
     const uint32_t c0 = bb::mul(bb::to_monty(field::kCosetShift), bb::pow_u32(field::root_of_unity(n + 1), r));
     ScopedKernelTimer t("subcoset_rows_kernel");
     hipLaunchKernelGGL(subcoset_rows_kernel, dim3(div_up(cols, 256), n_idx), dim3(256), 0, stream(), part, stride, cols, stages_done, nm - stages_done, c0,
-                       field::root_of_unity(nm), d_local_idx, out);
+                       field::root_of_unity(nm), d_local_idx, d_slot, out);
     return (int)hipGetLastError();
 }
 

@@ -6,6 +6,7 @@
 // 32-byte roots, the W+8 opened values and the query answers (a few hundred KB), which is
 // what it needs to run the transcript.
 #include "prover_state.hpp"
+#include "prover_stream.hpp"
 #include "logup_groups.hpp"
 #include "xbc_compile.hpp"
 
@@ -363,31 +364,14 @@ int ensure_commit_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L) {
     return apply_commit_buffers(p, B);
 }
 
-// One pass over the sub-cosets of the extended domain (streamed mode): for every r < 2^b (`wanted`: only those) the rows r + 2^b i
-// of the LDE of the coefficient matrices `mats` (side by side, column stride L.m) are rebuilt in p->lde and handed to body(r).
-struct CoefMatrix { const uint32_t* coef; uint32_t cols; };
-template <class Body>
-int for_each_subcoset(PwProver* p, const CommitLayout& L, uint32_t log_h, std::initializer_list<CoefMatrix> mats, const std::vector<char>* wanted,
-                      Body&& body) {
-    uint32_t* blk = p->lde.as<uint32_t>();
-    uint32_t* fs = p->fscale.as<uint32_t>();
-    for (uint32_t r = 0; r < (1u << L.b); ++r) {
-        if (wanted && !(*wanted)[r]) continue;
-        size_t c0 = 0;
-        for (const CoefMatrix& mt : mats) {
-            if (mt.cols) TRY(subcoset_lde(mt.coef, blk + c0 * L.m, L.H, L.m, mt.cols, (int)log_h, L.b, r, fs));
-            c0 += mt.cols;
-        }
-        TRY(body(r));
-    }
-    return 0;
+streamed::Ctx stream_ctx(PwProver* p, const CommitLayout& L, uint32_t log_h) {
+    const uint32_t Wp = p->logup ? 4 * (p->n_groups + 1) : 0;
+    return streamed::Ctx{p, log_h, L.b, L.perm_panels, L.H, L.N, L.m, p->width, Wp};
 }
 
 // streamed commitment of a matrix given by its coefficient arrays: every sub-coset's rows are hashed into their leaves
 int commit_coefficients(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_t* coef, uint32_t cols, uint32_t* d_tree) {
-    TRY(for_each_subcoset(p, L, log_h, {CoefMatrix{coef, cols}}, nullptr, [&](uint32_t r) {
-        return merkle_leaf_hash(p->lde.as<uint32_t>(), L.m, cols, L.m, d_tree, (size_t)1 << L.b, r);
-    }));
+    TRY(streamed::leaf_hashes(stream_ctx(p, L, log_h), coef, cols, d_tree));
     return merkle_build_levels(d_tree, L.N);
 }
 
@@ -426,6 +410,16 @@ int ensure_prove_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L) {
     return 0;
 }
 }  // namespace
+
+namespace pw {
+size_t proof_plan_bytes(const PwProver* p, uint32_t log_h, int b) {
+    CommitLayout L;
+    BufferPlan B;
+    plan_buffers(p, log_h, b, L, B);
+    return B.total();
+}
+int ensure_proof_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L) { return ensure_prove_buffers(p, log_h, b, L); }
+}  // namespace pw
 
 // Trace commitment only (LDE + Merkle root): what a segment's AIRs exchange before the bus seed can be formed.
 extern "C" int pw_prover_trace_root(PwProver* p, const uint32_t* d_trace, uint32_t log_h, uint32_t* root8) {
@@ -514,9 +508,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     CommitLayout L;
     TRY(ensure_prove_buffers(p, log_h, sb, L));
     const size_t tree_words = L.tree_words, n_trees = L.n_trees;
-    const size_t m_sub = L.m;                                 // streamed: rows of a sub-coset
     uint32_t* d_tcoef = p->tcoef.as<uint32_t>();              // streamed: the trace's coefficient arrays
-    uint32_t* d_blk = p->lde.as<uint32_t>();                  // streamed: the sub-coset being processed, all committed columns
     const uint32_t n_chunks = div_up(H, 8192);
     const uint32_t dot_cols = std::max({W, Wp, 8u});  // widest matrix ext_dot_columns sees (the quotient has 8 columns)
     const uint32_t nq = p->cfg.num_queries;
@@ -630,36 +622,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     if (sb) {
         // streamed: the terms that read the current row only, sub-coset by sub-coset (unscaled sums scattered to their rows of d_q), then
         // the boundary terms / the division by Z_H over all rows
-        uint32_t* d_part = p->qpart.as<uint32_t>();
-        if (L.perm_panels) {
-            // main columns of the sub-coset once; the permutation columns unit by unit into the panel behind them
-            uint32_t* d_panel = d_blk + (size_t)W * m_sub;
-            uint32_t* fs = p->fscale.as<uint32_t>();
-            TRY(for_each_subcoset(p, L, log_h, {CoefMatrix{d_tcoef, W}}, nullptr, [&](uint32_t r) -> int {
-                const uint32_t n_units = quotient_units_jit(p);
-                for (uint32_t u = 0; u < n_units; ++u) {
-                    uint32_t g0 = 0, g1 = 0;
-                    quotient_unit_groups(p, u, &g0, &g1);
-                    if (g1 > g0) TRY(subcoset_lde(d_perm + (size_t)(4 * g0) * H, d_panel, H, m_sub, 4 * (g1 - g0), (int)log_h, sb, r, fs));
-                    // Pm = where permutation column 0 would be: the panel holds columns 4 g0 .. 4 g1 - 1
-                    const uint32_t* Pm = d_panel - (size_t)(4 * g0) * m_sub;
-                    TRY(quotient_unit_jit(p, u, d_blk, Pm, m_sub, d_apow, al, d_blpow, d_part));
-                }
-                return part_scatter(d_part, p->jit.quotient.n_chunks, m_sub, sb, r, N, d_q);
-            }));
-        } else
-        TRY(for_each_subcoset(p, L, log_h, {CoefMatrix{d_tcoef, W}, CoefMatrix{d_perm, Wp}}, nullptr, [&](uint32_t r) -> int {
-            const uint32_t* blk_p = d_blk + (size_t)W * m_sub;
-            uint32_t n_parts = 1;
-            if (jit && (nc || lg)) {
-                TRY(quotient_parts_jit(p, d_blk, lg ? blk_p : nullptr, m_sub, d_apow, al, lg ? d_blpow : nullptr, d_part, &n_parts));
-            } else if (lg) {
-                TRY(quotient_eval_logup(d_blk, blk_p, m_sub, logN, prog, lp, d_apow, al, d_blpow, S, one, one, d_part, true));
-            } else {
-                TRY(quotient_eval(d_blk, m_sub, prog, d_apow, one, one, d_part, d_part + 4 * m_sub, quotient_chunks(m_sub, nc)));
-            }
-            return part_scatter(d_part, n_parts, m_sub, sb, r, N, d_q);
-        }));
+        TRY(streamed::quotient_sums(stream_ctx(p, L, log_h), jit, lg, nc, prog, lp, d_tcoef, d_perm, d_apow, al, d_blpow, S, logN, d_q));
         if (lg)
             TRY(quotient_logup_tail(d_q, 1, d_plde, d_plde + 4 * N, N, logN, d_apow + nc + n_g, S, bb::sub(sH, one), bb::sub(bb::neg(sH), one), d_q));
         else
@@ -727,11 +690,7 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     if (sb) {
         // streamed: sum_k gamma^k P_k is a POLYNOMIAL — combined on the coefficient arrays (one pass over them) and extended as 4 (+ 4 for
         // the second opening point) columns; the eight quotient columns join from their resident LDE
-        uint32_t* d_gcoef = p->gbuf.as<uint32_t>();
-        uint32_t* d_glde = d_gcoef + 8 * H;
-        TRY(ext_lincomb(d_tcoef, W, d_perm, Wp, H, d_gpow, lg ? K1 : 0u, d_gcoef));
-        TRY(coset_lde_from_coeffs(d_gcoef, d_glde, H, N, lg ? 8 : 4, (int)log_h));
-        TRY(deep_from_combo(d_glde, d_qlde, N, logN, d_gpow + W + Wp, opened_sum, opened_sum2, zeta, gzeta, lg ? 1 : 0, d_v));
+        TRY(streamed::deep_from_coefficients(stream_ctx(p, L, log_h), lg, d_tcoef, d_perm, d_qlde, logN, d_gpow, opened_sum, opened_sum2, zeta, gzeta, d_v));
     } else if (log_h >= kDeepComboMinLogHeight && !getenv("POWDR_DEEP_DIRECT")) {
         // resident: the same combination on the evaluations over <g_n> (the caller's trace, the permutation matrix), extended like any column
         uint32_t* d_gev = p->gbuf.as<uint32_t>();
@@ -828,35 +787,15 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         PW_HIP_TRY(hipMemcpyAsync(d_idx, idx.data(), nq * 4, hipMemcpyHostToDevice, st));
         PW_HIP_TRY(hipMemcpyAsync(d_dig_offs, dig_offs.data(), n_dig * 8, hipMemcpyHostToDevice, st));
         if (n_ext) PW_HIP_TRY(hipMemcpyAsync(d_ext_offs, ext_offs.data(), n_ext * 8, hipMemcpyHostToDevice, st));
-        std::vector<uint32_t> pos(nq);  // pos[qi]: the slot of query qi's rows in d_trows / d_prows
         if (!sb) {
-            for (uint32_t qi = 0; qi < nq; ++qi) pos[qi] = qi;
             TRY(gather_rows(d_lde, N, W, d_idx, nq, d_trows));
             if (lg) TRY(gather_rows(d_plde, N, Wp, d_idx, nq, d_prows));
         } else {
-            // streamed: one more pass over the sub-cosets that hold a queried row; row idx lives in sub-coset idx mod 2^sb at position idx >> sb
-            const uint32_t nb = 1u << sb;
-            std::vector<uint32_t> order(nq), loc(nq), first(nb + 1, 0);
-            for (uint32_t qi = 0; qi < nq; ++qi) { order[qi] = qi; first[(idx[qi] & (nb - 1)) + 1] += 1; }
-            for (uint32_t r = 0; r < nb; ++r) first[r + 1] += first[r];
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b2) { return (idx[a] & (nb - 1)) < (idx[b2] & (nb - 1)); });
-            std::vector<char> wanted(nb, 0);
-            for (uint32_t k = 0; k < nq; ++k) { loc[k] = idx[order[k]] >> sb; pos[order[k]] = k; wanted[idx[order[k]] & (nb - 1)] = 1; }
-            PW_HIP_TRY(hipMemcpyAsync(d_loc, loc.data(), nq * 4, hipMemcpyHostToDevice, st));
-            PW_HIP_TRY(hipStreamSynchronize(st));  // loc is a local vector
-            // ... of which only the contiguous stage group runs over every row: the strided stages are finished for the queried rows alone
-            uint32_t* fs = p->fscale.as<uint32_t>();
-            for (uint32_t r = 0; r < nb; ++r) {
-                if (!wanted[r]) continue;
-                const uint32_t k0 = first[r], cnt = first[r + 1] - first[r];
-                int done = 0;
-                TRY(subcoset_lde_first_group(d_tcoef, d_blk, H, m_sub, W, (int)log_h, sb, r, fs, &done));
-                TRY(subcoset_rows(d_blk, m_sub, W, (int)log_h, sb, r, done, d_loc + k0, cnt, d_trows + (size_t)k0 * W));
-                if (lg) {
-                    TRY(subcoset_lde_first_group(d_perm, d_blk, H, m_sub, Wp, (int)log_h, sb, r, fs, &done));
-                    TRY(subcoset_rows(d_blk, m_sub, Wp, (int)log_h, sb, r, done, d_loc + k0, cnt, d_prows + (size_t)k0 * Wp));
-                }
-            }
+            // streamed: one more pass over the sub-cosets that hold a queried row (prover_stream.hpp query_rows); d_loc and the first nq
+            // words of d_qrows (filled afterwards) are its index scratch
+            const streamed::Ctx sc = stream_ctx(p, L, log_h);
+            TRY(streamed::query_rows(sc, d_tcoef, W, idx.data(), nq, d_loc, d_qrows, d_trows));
+            if (lg) TRY(streamed::query_rows(sc, d_perm, Wp, idx.data(), nq, d_loc, d_qrows, d_prows));
         }
         TRY(gather_rows(d_qlde, N, 8, d_idx, nq, d_qrows));
         TRY(gather_records(d_dig, d_dig_offs, 8u, (uint32_t)n_dig, d_dig_out));
@@ -877,10 +816,10 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         size_t dpos = 0, epos = 0;
         for (uint32_t qi = 0; qi < nq; ++qi) {
             put(idx[qi]);
-            put_raw(&trows[(size_t)pos[qi] * W], W);
+            put_raw(&trows[(size_t)qi * W], W);
             put_raw(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
             if (lg) {
-                put_raw(&prows[(size_t)pos[qi] * Wp], Wp);
+                put_raw(&prows[(size_t)qi * Wp], Wp);
                 put_raw(&dig[dpos * 8], (size_t)logN * 8); dpos += logN;
             }
             put_raw(&qrows[(size_t)qi * 8], 8);

@@ -40,7 +40,7 @@ int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t
 int subcoset_lde_first_group(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, uint32_t r,
                              uint32_t* d_scratch, int* stages_done);
 int subcoset_rows(const uint32_t* part, size_t stride, uint32_t cols, int n, int b, uint32_t r, int stages_done, const uint32_t* d_local_idx,
-                  uint32_t n_idx, uint32_t* rows_out);
+                  uint32_t n_idx, const uint32_t* d_slot, uint32_t* rows_out);  // row q goes to slot d_slot[q] (null: q)
 
 // ---- merkle.hip ------------------------------------------------------------------------
 // Digest tree layout: level 0 = leaves (n_leaves x 8 words), then n_leaves/2, ... , 1;
@@ -62,7 +62,13 @@ uint32_t* merkle_root_mailbox(uint32_t** device_ptr);
 // digests: levels of 2^L, 2^(L-1), ..., 1 nodes concatenated ((2^(L+1) - 1) * 8 words), level of n nodes:
 // node j = compress(child j, child j + n) [then compress(node, H(rows j of the height-n matrices))]. d_inject: 2^(L-1) * 8 words
 // of scratch. NOTE the same scratch is reused level after level on the launch stream.
-struct MixedLevelCols { const uint32_t* const* d_cols; uint32_t n_cols; };
+struct MixedLevelCols {
+    const uint32_t* const* d_cols;
+    uint32_t n_cols;
+    // non-zero: the level's row digests are ALREADY in place (level L: in `digests`; level k < L: in d_inject + 2^k * 8) — a streamed AIR
+    // hashed them sub-coset by sub-coset (prover_stream.hpp leaf_hashes); d_cols / n_cols are ignored
+    uint32_t external = 0;
+};
 // d_inject: 2^L * 8 words (row digests of the smaller heights, the slice of height 2^k at offset 2^k * 8). All heights are hashed
 // by ONE launch (widest level first); L <= 27.
 int merkle_commit_mixed(const MixedLevelCols* by_log, int L, uint32_t* digests, uint32_t* d_inject);

@@ -121,6 +121,12 @@ int lde_matrix(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_
 // columns per LDE panel for a 2^log_h-row matrix of `widest` columns (POWDR_PANEL_LOG_WORDS, read per call)
 size_t lde_panel_cols(size_t H, size_t widest);
 
+// ---- streamed proofs: what the segment prover needs from prover.hip ("streamed proofs") ---------------------------------
+// device bytes a proof of a 2^log_h-row trace of this AIR needs with the LDE resident (b = 0) or streamed over 2^b sub-cosets
+size_t proof_plan_bytes(const PwProver* p, uint32_t log_h, int b);
+// every buffer of such a proof (grown on demand), the layout in L (b, m, perm_panels, panel_cols)
+int ensure_proof_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L);
+
 // ---- run-time specialised expression kernels (prover_jit.hip) ---------------------------------------------------------
 // Compile the specialised kernels of every prover in `ps` that qualifies and has none yet (all translation units of all of
 // them in ONE concurrent hiprtc batch). force: regardless of the trace height. Returns 0; failures are not errors — the

@@ -12,7 +12,14 @@
 //   phase 4   openings at zeta / g_a zeta, all AIRs' values fetched with one copy
 //   phase 5   reduced openings per height; FRI over the tallest domain with the smaller heights rolled in; one query phase
 // Host round trips per segment: 3 roots + 1 (sums) + 1 (openings) + L FRI roots + queries, instead of that per AIR.
+//
+// STREAMED AIRs (round 4): an AIR whose LDE does not fit beside the others — BASELINE configs[2]'s 3 731 + 4 632 committed
+// columns x 2^23 rows — is proven from coefficient arrays inside the same segment proof: its row digests are hashed sub-coset by
+// sub-coset into its level of the mixed trees (merkle.hip `external` levels), its quotient, DEEP numerator and query rows come from
+// prover_stream.hpp. Condition: it is the only AIR of its height (a level's row digest is a sponge over the CONCATENATED rows of all
+// matrices of that height; a streamed matrix in the middle of one would need the sponge state handed over between matrices).
 #include "prover_state.hpp"
+#include "prover_stream.hpp"
 #include "logup_groups.hpp"
 
 #include <algorithm>
@@ -213,8 +220,54 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     uint32_t* d_ext_out = reinterpret_cast<uint32_t*>(mp); mp += (size_t)nq * rounds * 16;
     uint32_t* d_small = reinterpret_cast<uint32_t*>(mp);  // 4 A words (cumulative sums), PoW scratch
 
+    // ---- which AIRs are streamed (sbv[a] = log2 of the number of sub-cosets, 0 = LDE resident) ------------------------------
+    std::vector<int> sbv(A, 0);
+    {
+        std::vector<int> at_height(L + 1, 0);
+        for (size_t a = 0; a < A; ++a) at_height[sh[a].logN] += 1;
+        auto may_stream = [&](size_t a) { return at_height[sh[a].logN] == 1 && sh[a].log_h >= 3; };
+        auto b_max = [&](size_t a) { return std::min((int)sh[a].log_h - 1, 5); };
+        if (const char* e = getenv("POWDR_STREAM_LOG_BLOCKS")) {  // forced (tests): every AIR that may be streamed is
+            const int v = atoi(e);
+            for (size_t a = 0; a < A && v > 0; ++a) if (may_stream(a)) sbv[a] = std::min(v, b_max(a));
+        } else {
+            size_t free_b = 0, total_b = 0, held = cx.dig.bytes + cx.inject.bytes + cx.ext.bytes + cx.misc.bytes;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                for (size_t a = 0; a < A; ++a) held += pw_prover_device_bytes(airs[a].prover);
+                const size_t others = total_b > free_b + held ? total_b - free_b - held : 0;
+                size_t avail = (size_t)((double)(free_b + held) * 0.92);
+                const size_t cap = (size_t)((double)total_b * 0.90);
+                avail = std::min(avail, cap > others ? cap - others : (size_t)0);
+                const size_t own = (n_trees * tree_words + fri_words) * 4 + (Nmax + 1) * 32 + ext_words * sizeof(bb::Ext);
+                size_t need = own;
+                std::vector<size_t> bytes(A);
+                for (size_t a = 0; a < A; ++a) { bytes[a] = proof_plan_bytes(airs[a].prover, sh[a].log_h, 0); need += bytes[a]; }
+                // the largest AIRs first, each with the fewest sub-cosets that make the whole segment fit
+                std::vector<size_t> order(A);
+                for (size_t a = 0; a < A; ++a) order[a] = a;
+                std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return bytes[x] > bytes[y]; });
+                for (size_t k = 0; k < A && need > avail; ++k) {
+                    const size_t a = order[k];
+                    if (!may_stream(a) || sh[a].log_h < 16) continue;
+                    for (int b = 1; b <= b_max(a); ++b) {
+                        const size_t nb = proof_plan_bytes(airs[a].prover, sh[a].log_h, b);
+                        if (nb >= bytes[a]) continue;
+                        if (need - bytes[a] + nb <= avail || b == b_max(a)) { need = need - bytes[a] + nb; bytes[a] = nb; sbv[a] = b; break; }
+                    }
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
     std::vector<CommitLayout> Lc(A);
-    for (size_t a = 0; a < A; ++a) TRY(ensure_air(airs[a].prover, sh[a], lg, Lc[a]));
+    for (size_t a = 0; a < A; ++a) {
+        if (sbv[a]) TRY(ensure_proof_buffers(airs[a].prover, sh[a].log_h, sbv[a], Lc[a]));
+        else TRY(ensure_air(airs[a].prover, sh[a], lg, Lc[a]));
+    }
+    auto sctx = [&](size_t a) {
+        return streamed::Ctx{airs[a].prover, sh[a].log_h, sbv[a], Lc[a].perm_panels, sh[a].H, sh[a].N, Lc[a].m, sh[a].W, sh[a].Wp};
+    };
 
     std::vector<uint32_t>& pf = cx.proof;
     pf.clear();
@@ -229,19 +282,25 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     std::vector<const uint32_t*> h_cols;
     auto commit_mixed = [&](auto matrix_of, int tree, uint32_t* root_monty) -> int {
         h_cols.clear();
+        uint32_t* dg = d_dig + (size_t)tree * tree_words;
         std::vector<MixedLevelCols> by_log(L + 1, MixedLevelCols{nullptr, 0});
         for (int k = L; k >= 0; --k) {
             const size_t first = h_cols.size();
             for (size_t a = 0; a < A; ++a) {
                 if (sh[a].logN != k) continue;
                 const uint32_t* m; uint32_t w;
-                matrix_of(a, m, w);
+                matrix_of(a, m, w);  // a streamed AIR hands over the matrix's COEFFICIENT arrays (column stride H)
+                if (sbv[a] && tree != 1) {
+                    // the only AIR of its height: its row digests go straight into the level's slots, sub-coset by sub-coset
+                    TRY(streamed::leaf_hashes(sctx(a), m, w, k == L ? dg : cx.inject.as<uint32_t>() + ((size_t)1 << k) * 8));
+                    by_log[k].external = 1;
+                    continue;
+                }
                 for (uint32_t c = 0; c < w; ++c) h_cols.push_back(m + (size_t)c * sh[a].N);
             }
-            by_log[k] = MixedLevelCols{d_cols + first, (uint32_t)(h_cols.size() - first)};
+            if (!by_log[k].external) by_log[k] = MixedLevelCols{d_cols + first, (uint32_t)(h_cols.size() - first)};
         }
         PW_HIP_TRY(hipMemcpyAsync(d_cols, h_cols.data(), h_cols.size() * 8, hipMemcpyHostToDevice, st));
-        uint32_t* dg = d_dig + (size_t)tree * tree_words;
         TRY(merkle_commit_mixed(by_log.data(), L, dg, cx.inject.as<uint32_t>()));
         PW_HIP_TRY(hipMemcpyAsync(root_monty, dg + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
         return 0;
@@ -254,10 +313,17 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         PwProver* p = airs[a].prover;
         p->committed_trace = nullptr;
         on_air(a);
-        TRY(lde_matrix(p, Lc[a], sh[a].log_h, airs[a].d_trace, sh[a].W, p->lde.as<uint32_t>()));
+        if (sbv[a]) {  // streamed: the trace's coefficient arrays; its LDE rows exist one sub-coset at a time from here on
+            TRY(intt_dif(airs[a].d_trace, p->tcoef.as<uint32_t>(), sh[a].H, sh[a].H, sh[a].W, (int)sh[a].log_h));
+        } else {
+            TRY(lde_matrix(p, Lc[a], sh[a].log_h, airs[a].d_trace, sh[a].W, p->lde.as<uint32_t>()));
+        }
     }
     TRY(join());
-    TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) { m = airs[a].prover->lde.as<uint32_t>(); w = sh[a].W; }, 0, root));
+    TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) {
+        m = sbv[a] ? airs[a].prover->tcoef.as<uint32_t>() : airs[a].prover->lde.as<uint32_t>();
+        w = sh[a].W;
+    }, 0, root));
     PW_HIP_TRY(hipStreamSynchronize(st));
     put_monty(root, 8);
     ch.observe_words(root, 8);
@@ -290,11 +356,28 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             bb::Ext* rowsum = weights_of(a) + 2 * sh[a].H;
             if (specialised(p)) TRY(logup_perm_trace_jit(p, airs[a].d_trace, sh[a].H, al, blpow_of(a), p->perm.as<uint32_t>(), rowsum, rowsum + sh[a].H));
             else TRY(logup_perm_trace(airs[a].d_trace, sh[a].H, logup_program(a), al, blpow_of(a), p->perm.as<uint32_t>(), rowsum, rowsum + sh[a].H));
+            if (sbv[a]) {
+                // streamed: only phi and the per-row sums are extended for good (the boundary terms read them at rows j and j + 2); S is
+                // saved before the matrix becomes its coefficient arrays in place
+                uint32_t* d_perm_a = p->perm.as<uint32_t>();
+                if (!specialised(p)) TRY(ext_to_cols(rowsum, sh[a].H, d_perm_a + (size_t)(4 * sh[a].n_g + 4) * sh[a].H));
+                TRY(lde_matrix(p, Lc[a], sh[a].log_h, d_perm_a + (size_t)(4 * sh[a].n_g) * sh[a].H, 8, p->plde.as<uint32_t>()));
+                uint32_t* d_save = p->gbuf.as<uint32_t>();
+                for (int k = 0; k < 4; ++k) {
+                    PW_HIP_TRY(hipMemcpyAsync(d_save + k, d_perm_a + ((size_t)(4 * sh[a].n_g + k) * sh[a].H + (sh[a].H - 1)), 4, hipMemcpyDeviceToDevice, stream()));
+                    sp.push_back(d_save + k);
+                }
+                TRY(intt_dif(d_perm_a, d_perm_a, sh[a].H, sh[a].H, sh[a].Wp, (int)sh[a].log_h));
+                continue;
+            }
             TRY(lde_matrix(p, Lc[a], sh[a].log_h, p->perm.as<uint32_t>(), sh[a].Wp + (specialised(p) ? kJitExtraPermCols : 0u), p->plde.as<uint32_t>()));
             for (int k = 0; k < 4; ++k) sp.push_back(p->perm.as<uint32_t>() + ((size_t)(4 * sh[a].n_g + k) * sh[a].H + (sh[a].H - 1)));  // S = phi(last row)
         }
         TRY(join());
-        TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) { m = airs[a].prover->plde.as<uint32_t>(); w = sh[a].Wp; }, 2, root));
+        TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) {
+            m = sbv[a] ? airs[a].prover->perm.as<uint32_t>() : airs[a].prover->plde.as<uint32_t>();  // (streamed: the coefficient arrays)
+            w = sh[a].Wp;
+        }, 2, root));
         PW_HIP_TRY(hipMemcpyAsync(d_sptrs, sp.data(), sp.size() * 8, hipMemcpyHostToDevice, st));
         TRY(gather_words(d_sptrs, (uint32_t)sp.size(), d_small));
         std::vector<uint32_t> sw(4 * A);
@@ -329,7 +412,16 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             const uint32_t zv_even = bb::sub(sH, one), zv_odd = bb::sub(bb::neg(sH), one);
             ConstraintProgram prog{p->d_bytecode, p->d_spans, s.nc, p->is_xbc};
             uint32_t* d_q = p->q.as<uint32_t>();
-            if (lg && specialised(p))
+            if (sbv[a]) {
+                // streamed: the current-row terms sub-coset by sub-coset, then the boundary terms / the division by Z_H over all rows
+                TRY(streamed::quotient_sums(sctx(a), specialised(p), lg, s.nc, prog, lg ? logup_program(a) : LogupProgram{}, p->tcoef.as<uint32_t>(),
+                                            p->perm.as<uint32_t>(), apow_of(a), al, blpow_of(a), S[a], s.logN, d_q));
+                if (lg)
+                    TRY(quotient_logup_tail(d_q, 1, p->plde.as<uint32_t>(), p->plde.as<uint32_t>() + 4 * s.N, s.N, s.logN, apow_of(a) + s.nc + s.n_g, S[a],
+                                            zv_even, zv_odd, d_q));
+                else
+                    TRY(quotient_combine(d_q, 1, s.N, bb::inv(zv_even), bb::inv(zv_odd), d_q));
+            } else if (lg && specialised(p))
                 TRY(quotient_eval_logup_jit(p, p->lde.as<uint32_t>(), p->plde.as<uint32_t>(), s.N, s.logN, apow_of(a), al, blpow_of(a), S[a], zv_even,
                                             zv_odd, d_q));
             else if (lg)
@@ -367,11 +459,15 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         // trace columns: barycentric evaluation straight from the caller's trace; quotient chunks from their coefficients
         TRY(barycentric_weights(zeta, (int)s.log_h, w1));
         TRY(ext_dot_columns(airs[a].d_trace, s.H, s.W, s.H, w1, o, scratch_of(a)));
-        if (lg) {  // the permutation matrix at zeta and at g zeta: one pass over its columns
+        if (lg && !sbv[a]) {  // the permutation matrix at zeta and at g zeta: one pass over its columns
             TRY(barycentric_weights(gzeta[a], (int)s.log_h, w2));
             TRY(ext_dot_columns2(p->perm.as<uint32_t>(), s.H, s.Wp, s.H, w1, w2, o + s.W, o + s.W + s.Wp + 8, scratch_of(a)));
         }
         TRY(zeta_weights(zeta, (int)s.log_h, w1));
+        if (lg && sbv[a]) {  // streamed: p->perm holds the matrix's coefficient arrays
+            TRY(zeta_weights(gzeta[a], (int)s.log_h, w2));
+            TRY(ext_dot_columns2(p->perm.as<uint32_t>(), s.H, s.Wp, s.H, w1, w2, o + s.W, o + s.W + s.Wp + 8, scratch_of(a)));
+        }
         TRY(ext_dot_columns(p->qcoef.as<uint32_t>(), s.H, 8, s.H, w1, o + s.W + s.Wp, scratch_of(a)));
     }
     TRY(join());
@@ -400,7 +496,10 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             for (size_t k = K1; k < s.K; ++k) sum2 = bb::ext_add(sum2, bb::ext_mul(gpow[s.koff + k], opened[s.koff + k]));
             bb::Ext* target = s.logN == L ? d_v : d_v + ro_off[s.logN];
             bb::Ext* out = started[s.logN] ? d_v + tmp_off : target;
-            if (lg)
+            if (sbv[a])
+                TRY(streamed::deep_from_coefficients(sctx(a), lg, p->tcoef.as<uint32_t>(), p->perm.as<uint32_t>(), p->qlde.as<uint32_t>(), s.logN,
+                                                     d_gpow + s.koff, sum1, sum2, zeta, gzeta[a], out));
+            else if (lg)
                 TRY(deep_quotient_logup(p->lde.as<uint32_t>(), s.W, p->plde.as<uint32_t>(), s.Wp, p->qlde.as<uint32_t>(), s.N, s.logN,
                                         d_gpow + s.koff, sum1, sum2, zeta, gzeta[a], out));
             else
@@ -475,7 +574,14 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
                 const uint32_t w = ph == 0 ? sh[a].W : ph == 1 ? sh[a].Wp : 8u;
                 row_off[ph][a] = ro;
                 on_air(a);
-                TRY(gather_rows(m, sh[a].N, w, d_idx + a * nq, nq, d_rows + ro));
+                if (sbv[a] && ph != 2) {
+                    // streamed: the rows are rebuilt from the coefficient arrays (index scratch: the AIR's own gbuf, free by now)
+                    uint32_t* d_scr = p->gbuf.as<uint32_t>();
+                    TRY(streamed::query_rows(sctx(a), ph == 0 ? p->tcoef.as<uint32_t>() : p->perm.as<uint32_t>(), w, idx.data() + a * nq, nq, d_scr,
+                                             d_scr + nq, d_rows + ro));
+                } else {
+                    TRY(gather_rows(m, sh[a].N, w, d_idx + a * nq, nq, d_rows + ro));
+                }
                 ro += (size_t)nq * w;
             }
         }

@@ -174,6 +174,31 @@ def test_hip_segment_proof_bytes_match_oracle(gpu, spec, nq, pow_bits, logup):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spec,nq,pow_bits", [
+    ([("T1", 1000), ("T0", 40), ("T1", 100)], 6, 3),                                # three heights, each AIR alone at its own: all streamed
+    ([("C1", 600), ("T1", 5000), ("T0", 40), ("T1", 1000), ("T0", 33)], 8, 0),      # two pairs of AIRs share a height (resident); only the 2^13-row AIR is streamed
+    ([("T1", 40000), ("T0", 64)], 5, 0),                                            # 2^16 rows: strided stage groups, query rows from the partial transform
+])
+@pytest.mark.parametrize("logup", [False, True])
+@pytest.mark.parametrize("log_blocks,jit", [(1, "0"), (2, "1"), (3, "1")])
+def test_hip_segment_proof_with_streamed_airs(gpu, monkeypatch, spec, nq, pow_bits, logup, log_blocks, jit):
+    """Streamed AIRs INSIDE a segment proof: every AIR that is alone at its height is proven from coefficient arrays —
+    row digests hashed sub-coset by sub-coset into its level of the mixed trees, quotient / DEEP / query rows from prover_stream.hpp —
+    and the words still equal the oracle's."""
+    torch, abi, prover = gpu
+    if len(spec) == 2 and (log_blocks == 1 or not logup):
+        pytest.skip("the tall case runs once per kernel kind")
+    airs = synthetic_airs(spec, seed0=11)
+    want = sm.prove_segment(airs, num_queries=nq, pow_bits=pow_bits, logup=logup)
+    monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", str(log_blocks))
+    monkeypatch.setenv("POWDR_JIT", jit)
+    got = hip_segment(gpu, airs, nq, pow_bits, logup)
+    assert len(got) == len(want)
+    assert (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
+    assert prover.verify_segment(descs_of(airs), got, nq, pow_bits, logup)[0] == 0
+
+
+@pytest.mark.gpu
 def test_hip_segment_golden_and_panels(gpu, monkeypatch):
     """The HIP prover reproduces the pinned golden segment digests, also with the LDE forced through many small panels."""
     g = json.loads(GOLDEN.read_text())
