@@ -344,12 +344,25 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     const uint32_t* src = in + (size_t)blockIdx.y * in_stride;
     uint32_t* dst = out + (size_t)blockIdx.y * out_stride;
     uint32_t tw_base = TWT ? 0u : load_twiddle_base<DIF>(im, gp, 0, 0, tid, tw);
+    // FOLD (sub-coset evaluation): the folded inputs of the workgroup's tile(s) are staged through LDS first — lane = output, so a wave
+    // reads 2^fold * 256 CONTIGUOUS bytes per instruction. (Loaded slot by slot like the other modes, a lane would read the 16 neighbouring
+    // outputs of its slot: 64 lanes x 16 instructions walking 64 cache lines side by side, which L1 does not hold for a CU's worth of waves.)
+    constexpr bool kStageFold = MODE == 2;
+    if (kStageFold) {
+#pragma unroll 4
+        for (uint32_t l = (uint32_t)tid; l < (1u << LOGT); l += kBlock) {
+            bool valid;
+            const size_t g = im.global(l, valid);
+            tile[lds_phys(l)] = valid ? fold_load(src, gp.foldk, g, gp.fold) : 0u;
+        }
+        __syncthreads();
+    }
     for (int r = 0; r < gp.n_rounds; ++r) {
         switch (gp.logr[r]) {
-            case 1: run_round<DIF, 1, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
-            case 2: run_round<DIF, 2, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
-            case 3: run_round<DIF, 3, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
-            default: run_round<DIF, 4, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base); break;
+            case 1: run_round<DIF, 1, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold); break;
+            case 2: run_round<DIF, 2, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold); break;
+            case 3: run_round<DIF, 3, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold); break;
+            default: run_round<DIF, 4, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold); break;
         }
         if (r + 1 < gp.n_rounds) __syncthreads();  // the next round reads what this round wrote
     }
