@@ -1234,6 +1234,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        barrier()  # rank 0 ran the single-GPU extras (C3, checks) alone: everybody leaves together
         dist.destroy_process_group()
 
 
