@@ -96,6 +96,67 @@ __global__ __launch_bounds__(kBlock, MINW) void leaf_hash_levels_kernel(const Le
     out[1] = make_uint4(st[4], st[5], st[6], st[7]);
 }
 
+// The general form of a level's row digest: the hashed row is the CONCATENATION of the rows of several matrices, of which some exist
+// only one sub-coset at a time (streamed AIRs, prover_stream.hpp). The concatenation is absorbed run by run — a run = consecutive
+// resident matrices (column-pointer table) or one streamed matrix (one launch per sub-coset) — with the rows' sponge states parked
+// in a buffer between the runs: a run continues the rate block the previous one left open at position pos0, and only the last run
+// closes a partial block and writes digests. Same words as one sponge over the whole row (leaf_hash_levels_kernel).
+struct AbsorbArgs {
+    const uint32_t* m;            // a matrix (column stride col_stride) when cols == nullptr
+    size_t col_stride;
+    const uint32_t* const* cols;  // or a column-pointer table
+    uint32_t n_cols, pos0;
+    size_t height;                // rows of this launch; its row j is row j * rstride + roff of the level
+    size_t rstride, roff;
+    uint32_t* state;              // 16 words per row of the level: read unless `first`, written unless `last`
+    uint32_t* digests;            // 8 words per row of the level: written when `last`
+    int first, last;
+};
+template <int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void leaf_absorb_kernel(const AbsorbArgs a) {
+    const size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= a.height) return;
+    const size_t row = j * a.rstride + a.roff;
+    uint32_t st[16];
+    if (a.first) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = 0u;
+    } else {
+        const uint4* in = reinterpret_cast<const uint4*>(a.state + row * 16);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const uint4 x = in[v]; st[4 * v] = x.x; st[4 * v + 1] = x.y; st[4 * v + 2] = x.z; st[4 * v + 3] = x.w; }
+    }
+    auto cell = [&](uint32_t c) -> uint32_t { return a.cols ? a.cols[c][j] : a.m[(size_t)c * a.col_stride + j]; };
+    uint32_t c = 0, pos = a.pos0;  // wave-uniform
+    if (pos) {  // complete the rate block the previous run left open
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if ((uint32_t)k >= pos && (uint32_t)k - pos < a.n_cols) st[k] = cell((uint32_t)k - pos);
+        const uint32_t take = 8u - pos < a.n_cols ? 8u - pos : a.n_cols;
+        c = take;
+        pos += take;
+        if (pos == 8u) { p2::permute<true>(st, c_params); pos = 0; }
+    }
+#pragma unroll 1
+    for (; c < a.n_cols; c += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (c + k < a.n_cols) st[k] = cell(c + k);
+        if (c + 8 <= a.n_cols) p2::permute<true>(st, c_params);
+        else pos = a.n_cols - c;  // an open block: the next run continues it, the last run closes it below
+    }
+    if (a.last) {
+        if (pos) p2::permute<true>(st, c_params);
+        uint4* out = reinterpret_cast<uint4*>(a.digests + row * 8);
+        out[0] = make_uint4(bb::reduce_2p(st[0]), bb::reduce_2p(st[1]), bb::reduce_2p(st[2]), bb::reduce_2p(st[3]));
+        out[1] = make_uint4(bb::reduce_2p(st[4]), bb::reduce_2p(st[5]), bb::reduce_2p(st[6]), bb::reduce_2p(st[7]));
+    } else {
+        uint4* out = reinterpret_cast<uint4*>(a.state + row * 16);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) out[v] = make_uint4(st[4 * v], st[4 * v + 1], st[4 * v + 2], st[4 * v + 3]);
+    }
+}
+
 // One level of the mixed-height tree: parent j = compress(child j, child j + n) — the sibling pairing of the FRI fold, so
 // that the ancestor of leaf q on the level of n nodes is q mod n — and, where matrices of height n exist, the digest of
 // their rows is injected: parent = compress(parent, inject[j]).
@@ -311,6 +372,18 @@ int merkle_leaf_hash(const uint32_t* m, size_t height, uint32_t width, size_t co
 }
 
 int merkle_build_levels(uint32_t* digests, size_t n_leaves, uint32_t* root_out) { return build_levels(digests, n_leaves, root_out); }
+
+int merkle_leaf_absorb(const uint32_t* m, size_t col_stride, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t pos0, size_t height, size_t rstride,
+                       size_t roff, uint32_t* state, uint32_t* digests, bool first, bool last) {
+    int rc = poseidon2_upload_params();
+    if (rc) return rc;
+    if (!height) return 0;
+    const AbsorbArgs a{m, col_stride, d_cols, n_cols, pos0, height, rstride, roff, state, digests, first ? 1 : 0, last ? 1 : 0};
+    ScopedKernelTimer t("leaf_hash_kernel");
+    if (hash_min_waves() >= 8) hipLaunchKernelGGL(leaf_absorb_kernel<8>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), a);
+    else hipLaunchKernelGGL(leaf_absorb_kernel<6>, dim3(div_up(height, kBlock)), dim3(kBlock), 0, stream(), a);
+    return (int)hipGetLastError();
+}
 
 int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests, uint32_t* root_out) {
     const int rc = merkle_leaf_hash(m, height, width, col_stride, digests, 1, 0);

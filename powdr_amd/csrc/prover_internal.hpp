@@ -55,6 +55,12 @@ int merkle_commit_matrix(const uint32_t* m, size_t height, uint32_t width, size_
 int merkle_leaf_hash(const uint32_t* m, size_t height, uint32_t width, size_t col_stride, uint32_t* digests, size_t digest_stride,
                      size_t digest_offset);
 int merkle_build_levels(uint32_t* digests, size_t n_leaves, uint32_t* root_out = nullptr);
+// One RUN of a level's row digest (the hashed row = the concatenation of several matrices' rows, absorbed run by run with the sponge
+// states parked in `state`, 16 words per row of the level): the columns of a matrix (m, col_stride) or of a column-pointer table
+// (d_cols) continue the rate block at position pos0 (= columns absorbed so far mod 8) for the rows j * rstride + roff, j < height;
+// `first`: the states start at zero; `last`: a partial block is closed and the digests are written (8 words per row of the level).
+int merkle_leaf_absorb(const uint32_t* m, size_t col_stride, const uint32_t* const* d_cols, uint32_t n_cols, uint32_t pos0, size_t height, size_t rstride,
+                       size_t roff, uint32_t* state, uint32_t* digests, bool first, bool last);
 // the calling thread's host-mapped landing place for a root (`root_out` above is its device address); nullptr: not available
 uint32_t* merkle_root_mailbox(uint32_t** device_ptr);
 // Mixed-height commitment of a segment (oracle/stark_segment.inc `MixedTree`): by_log[k] = the columns of all matrices of

@@ -16,8 +16,8 @@
 // STREAMED AIRs (round 4): an AIR whose LDE does not fit beside the others — BASELINE configs[2]'s 3 731 + 4 632 committed
 // columns x 2^23 rows — is proven from coefficient arrays inside the same segment proof: its row digests are hashed sub-coset by
 // sub-coset into its level of the mixed trees (merkle.hip `external` levels), its quotient, DEEP numerator and query rows come from
-// prover_stream.hpp. Condition: it is the only AIR of its height (a level's row digest is a sponge over the CONCATENATED rows of all
-// matrices of that height; a streamed matrix in the middle of one would need the sponge state handed over between matrices).
+// prover_stream.hpp. A level's row digest is a sponge over the CONCATENATED rows of all matrices of that height: a level that holds a
+// streamed matrix is absorbed run by run with the rows' sponge states parked in between (merkle.hip leaf_absorb_kernel).
 #include "prover_state.hpp"
 #include "prover_stream.hpp"
 #include "logup_groups.hpp"
@@ -39,6 +39,7 @@ struct SegCtx {
     DeviceBuf inject;  // row digests of the smaller heights (one level at a time)
     DeviceBuf ext;     // FRI layers (2 N) | reduced openings of the smaller heights (N) | scratch vector (N)
     DeviceBuf misc;    // column-pointer tables, opened values, gamma powers, query indices / answers
+    DeviceBuf state;   // streamed AIRs: the rows' sponge states of the level being hashed run by run (16 words per row)
     std::vector<uint32_t> proof;
     // side streams for the per-AIR stages of a segment with many AIRs (fork from / join into the caller's stream by events)
     hipStream_t side[kMaxSide] = {};
@@ -223,9 +224,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     // ---- which AIRs are streamed (sbv[a] = log2 of the number of sub-cosets, 0 = LDE resident) ------------------------------
     std::vector<int> sbv(A, 0);
     {
-        std::vector<int> at_height(L + 1, 0);
-        for (size_t a = 0; a < A; ++a) at_height[sh[a].logN] += 1;
-        auto may_stream = [&](size_t a) { return at_height[sh[a].logN] == 1 && sh[a].log_h >= 3; };
+        auto may_stream = [&](size_t a) { return sh[a].log_h >= 3; };  // (AIRs that share a height: their level is hashed run by run)
         auto b_max = [&](size_t a) { return std::min((int)sh[a].log_h - 1, 5); };
         if (const char* e = getenv("POWDR_STREAM_LOG_BLOCKS")) {  // forced (tests): every AIR that may be streamed is
             const int v = atoi(e);
@@ -284,23 +283,53 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         h_cols.clear();
         uint32_t* dg = d_dig + (size_t)tree * tree_words;
         std::vector<MixedLevelCols> by_log(L + 1, MixedLevelCols{nullptr, 0});
+        // a level that holds a streamed matrix is hashed RUN BY RUN (merkle.hip leaf_absorb_kernel): consecutive resident matrices
+        // through their slice of the column-pointer table, a streamed matrix sub-coset by sub-coset, the rows' sponge states parked
+        // in cx.state in between; the level is then `external` for merkle_commit_mixed (which only injects / compresses)
+        struct Run { size_t first_col; uint32_t n_cols; size_t air; bool streamed; };
+        std::vector<std::vector<Run>> runs(L + 1);
         for (int k = L; k >= 0; --k) {
             const size_t first = h_cols.size();
+            bool any_streamed = false;
+            for (size_t a = 0; a < A; ++a) any_streamed = any_streamed || (sh[a].logN == k && sbv[a] && tree != 1);
             for (size_t a = 0; a < A; ++a) {
                 if (sh[a].logN != k) continue;
                 const uint32_t* m; uint32_t w;
                 matrix_of(a, m, w);  // a streamed AIR hands over the matrix's COEFFICIENT arrays (column stride H)
-                if (sbv[a] && tree != 1) {
-                    // the only AIR of its height: its row digests go straight into the level's slots, sub-coset by sub-coset
-                    TRY(streamed::leaf_hashes(sctx(a), m, w, k == L ? dg : cx.inject.as<uint32_t>() + ((size_t)1 << k) * 8));
-                    by_log[k].external = 1;
-                    continue;
+                if (sbv[a] && tree != 1) { runs[k].push_back(Run{0, w, a, true}); continue; }
+                if (any_streamed) {
+                    if (runs[k].empty() || runs[k].back().streamed) runs[k].push_back(Run{h_cols.size(), 0, a, false});
+                    runs[k].back().n_cols += w;
                 }
                 for (uint32_t c = 0; c < w; ++c) h_cols.push_back(m + (size_t)c * sh[a].N);
             }
-            if (!by_log[k].external) by_log[k] = MixedLevelCols{d_cols + first, (uint32_t)(h_cols.size() - first)};
+            by_log[k] = MixedLevelCols{d_cols + first, (uint32_t)(h_cols.size() - first)};
+            by_log[k].external = any_streamed ? 1u : 0u;
         }
         PW_HIP_TRY(hipMemcpyAsync(d_cols, h_cols.data(), h_cols.size() * 8, hipMemcpyHostToDevice, st));
+        for (int k = L; k >= 0; --k) {
+            if (runs[k].empty()) continue;
+            const size_t rows = (size_t)1 << k;
+            TRY(cx.state.ensure(rows * 16 * 4));
+            uint32_t* level_digests = k == L ? dg : cx.inject.as<uint32_t>() + rows * 8;
+            uint32_t pos = 0;
+            for (size_t i = 0; i < runs[k].size(); ++i) {
+                const Run& r = runs[k][i];
+                const bool first_run = i == 0, last_run = i + 1 == runs[k].size();
+                if (!r.streamed) {
+                    TRY(merkle_leaf_absorb(nullptr, 0, d_cols + r.first_col, r.n_cols, pos, rows, 1, 0, cx.state.as<uint32_t>(), level_digests, first_run, last_run));
+                } else {
+                    const uint32_t* coef; uint32_t w;
+                    matrix_of(r.air, coef, w);
+                    const streamed::Ctx c = sctx(r.air);
+                    TRY(streamed::for_each_subcoset(c, {streamed::CoefMatrix{coef, w}}, nullptr, [&](uint32_t sub) {
+                        return merkle_leaf_absorb(c.p->lde.as<uint32_t>(), c.m, nullptr, w, pos, c.m, (size_t)1 << c.b, sub, cx.state.as<uint32_t>(), level_digests,
+                                                  first_run, last_run);
+                    }));
+                }
+                pos = (pos + r.n_cols) & 7u;
+            }
+        }
         TRY(merkle_commit_mixed(by_log.data(), L, dg, cx.inject.as<uint32_t>()));
         PW_HIP_TRY(hipMemcpyAsync(root_monty, dg + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
         return 0;
