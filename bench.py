@@ -1025,6 +1025,10 @@ def main():
                 blk_r = dict(doc["block"]["blocks"][0])
                 blk_r["instructions"] = ins
                 doc_r["block"] = dict(doc["block"], blocks=[blk_r])
+                # the synthetic APC draws its substitutions uniformly over the original rows' cells; from RECORDS the cells hold the chips'
+                # real values, so every bounded APC column (bit, byte, k-bit range) is re-targeted to a cell of its own row whose real
+                # values respect the bound (original_chips.typed_substitutions) — as in a real APC, whose lookups are in range by construction
+                doc_r["subs"], untyped = oc_.typed_substitutions(ins, doc["subs"], wl["synth"].kinds, int(blk_r["start_pc"]))
                 apc_r = host_.Apc(doc_r)
                 cons_r = apc_r.compile_constraints()
                 pr_r = prover.Prover(wl["W"], *cons_r, num_queries=args.queries, pow_bits=args.pow_bits, interactions=apc_r.compile_bus(1) if args.logup else None)
@@ -1049,11 +1053,13 @@ def main():
                     ms_per_step=r_elapsed / args.logup_steps * 1e3, value=cells_per_step * args.logup_steps * world / r_elapsed, unit="main cells/s",
                     steps=args.logup_steps, warmup=1, logup=bool(args.logup), trace_gen_ms=sum(r_stage.get(k, 0.0) for k in tg_names),
                     stage_ms=r_stage, proof_bytes=int(len(r_last["proof"]) * 4), record_bytes=int(rec.numel() * 4),
-                    prover_mode=pr_r.stream_log_blocks(log_h),
+                    prover_mode=pr_r.stream_log_blocks(log_h), typed_substitutions=True, bounded_columns_left_untyped=int(untyped),
                     note="TIMED: powdr_apc_generate_witness_from_records (the original chips' expansion fused into the gather + derived columns + bus "
-                         "replay) + pw_prover_prove, records resident in HBM, no dummy traces anywhere; the bus arguments are evaluated on the chips' real "
-                         "cell values (the synthetic APC's lookups then fall outside their tables more often than with the bounded dummy cells of the "
-                         "headline: a different histogram mix, same work per lookup)")
+                         "replay) + pw_prover_prove, records resident in HBM, no dummy traces anywhere; same instructions, constraints and "
+                         "interactions as the headline, every bounded APC column fed from a cell of its instruction's row whose real values respect "
+                         "the bound (typed_substitutions), so that the lookups are in range as a real APC's are (with the headline's uniformly drawn "
+                         "cells the chips' operand words land in byte columns, 50 lookups per row leave the binned path and the replay takes 28 ms "
+                         "instead of 5: profiles/r04_bench_c2.json of the untyped run)")
                 pr_r.close()
                 apc_r.close()
             except Exception as e:

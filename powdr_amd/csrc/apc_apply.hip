@@ -304,10 +304,20 @@ __global__ __launch_bounds__(kHistBlock) void bus_histogram_kernel(
         for (size_t q = (r0 >> 2) + threadIdx.x; q < (r1 >> 2); q += kHistBlock) {
             const uint4 v = it[q];
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            // lanes of this iteration (the last one of a chunk may be partial) and the first of them
+            const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+            const bool leader = (unsigned)__lane_id() == (unsigned)__builtin_ctzll(active);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t b = (w[k] & ((1u << kItemBinBits) - 1u)) - bin0;
-                if (w[k] != kItemNone && b < kPartBins) atomicAdd(&lh[b], w[k] >> kItemBinBits);
+                const bool hit = w[k] != kItemNone && b < kPartBins;
+                // a slot fed from a cell that does not change from row to row sends ONE item 64 times: one LDS atomic for the wave
+                // instead of 64 that conflict (same-address LDS atomics of one instruction are serialised)
+                if (__builtin_amdgcn_ballot_w64(w[k] != (uint32_t)__builtin_amdgcn_readfirstlane((int)w[k])) == 0ull) {
+                    if (hit && leader) atomicAdd(&lh[b], (w[k] >> kItemBinBits) * (uint32_t)__builtin_popcountll(active));
+                } else if (hit) {
+                    atomicAdd(&lh[b], w[k] >> kItemBinBits);
+                }
             }
         }
     }

@@ -253,7 +253,7 @@ namespace {
 // The DEEP numerator sum_k gamma^k P_k is a polynomial: from 2^16 rows on it is combined on the UN-extended matrices (half the bytes
 // the LDE holds) and extended as 4 + 4 columns instead of being accumulated over the LDE of every column (deep_kernel); shorter traces
 // keep the one-kernel form (the extra launches cost more than the bytes they save).
-constexpr uint32_t kDeepComboMinLogHeight = 16;
+// (kDeepComboMinLogHeight: prover_state.hpp — the segment prover follows the same rule)
 
 struct BufferPlan {
     size_t coef = 0, lde = 0, digests = 0, perm = 0, plde = 0, q = 0, qpart = 0, qcoef = 0, qlde = 0, ext_arena = 0, misc = 0,
@@ -440,6 +440,43 @@ extern "C" int pw_prover_trace_root(PwProver* p, const uint32_t* d_trace, uint32
     return (int)hipGetLastError();
 }
 
+// The prover's host-mapped landing place for K opened values (PwProver::OpenedMailbox) on the current device, or nullptr (no pinned
+// memory to be had, POWDR_OPENINGS_OVERLAP=0): the caller then copies the values after the fact.
+static void release_opened_mailbox(PwProver* p) {
+    PwProver::OpenedMailbox& mb = p->opened_mb;
+    for (int i = 0; i < mb.n_events; ++i) (void)hipEventDestroy(mb.ev[i]);
+    mb.n_events = 0;
+    if (mb.host) (void)hipHostFree(mb.host);
+    mb.host = mb.dev = nullptr;
+    mb.cap = 0;
+    mb.device = -1;
+}
+
+static PwProver::OpenedMailbox* opened_mailbox(PwProver* p, size_t K) {
+    const char* env = getenv("POWDR_OPENINGS_OVERLAP");
+    if (env && atoi(env) == 0) return nullptr;
+    PwProver::OpenedMailbox& mb = p->opened_mb;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (mb.host && (mb.device != device || mb.cap < K)) release_opened_mailbox(p);
+    if (!mb.host) {
+        void *h = nullptr, *d = nullptr;
+        const size_t cap = std::max<size_t>(K, 64);
+        if (hipHostMalloc(&h, cap * sizeof(bb::Ext), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return nullptr; }
+        mb.host = (bb::Ext*)h; mb.dev = (bb::Ext*)d; mb.cap = cap; mb.device = device;
+        while (mb.n_events < PwProver::OpenedMailbox::kEvents) {
+            if (hipEventCreateWithFlags(&mb.ev[mb.n_events], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                release_opened_mailbox(p);
+                return nullptr;
+            }
+            ++mb.n_events;
+        }
+    }
+    return &mb;
+}
+
 extern "C" void pw_prover_destroy(PwProver* p) {
     if (!p) return;
     for (DeviceBuf* b : {&p->coef, &p->lde, &p->digests, &p->q, &p->qcoef, &p->qlde, &p->ext_arena, &p->misc, &p->perm, &p->plde, &p->qpart, &p->tcoef,
@@ -448,6 +485,7 @@ extern "C" void pw_prover_destroy(PwProver* p) {
     for (void* q : {(void*)p->d_inter, (void*)p->d_ixspans, (void*)p->d_icode, (void*)p->d_gstarts, (void*)p->d_iforms}) if (q) (void)hipFree(q);
     if (p->d_bytecode) (void)hipFree(p->d_bytecode);
     if (p->d_spans) (void)hipFree(p->d_spans);
+    release_opened_mailbox(p);
     delete p;
 }
 
@@ -650,47 +688,87 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     // quotient chunks: from their (small) coefficient arrays
     // internal order of `opened` (= order of the gamma powers): main | perm@zeta | quotient | perm@g*zeta
     const bb::Ext gzeta = bb::ext_scale(zeta, field::root_of_unity((int)log_h));
+    // Every matrix's values go straight into host-mapped memory when the prover has it (opened_mailbox), the permutation matrix's in
+    // four column slices, with an event after each piece: the host absorbs a piece into the transcript — a sequential sponge, two
+    // opened values per permutation — while the device computes the next.
+    PwProver::OpenedMailbox* mb = opened_mailbox(p, K);
+    bb::Ext* d_open = mb ? mb->dev : d_opened;
+    int n_marks = 0;
+    auto mark = [&]() -> int {
+        if (mb) PW_HIP_TRY(hipEventRecord(mb->ev[n_marks], st));
+        ++n_marks;
+        return 0;
+    };
+    const uint32_t n_slices = (mb && Wp >= 1024) ? 4u : 1u;
+    uint32_t slice_at[5];
+    for (uint32_t i = 0; i <= n_slices; ++i) slice_at[i] = i == n_slices ? Wp : (uint32_t)((uint64_t)Wp * i / n_slices) & ~7u;
+    auto open_perm = [&]() -> int {  // at zeta and at g zeta: one pass over the columns of a slice
+        for (uint32_t i = 0; i < n_slices; ++i) {
+            const uint32_t c0 = slice_at[i], c1 = slice_at[i + 1];
+            if (c1 > c0) TRY(ext_dot_columns2(d_perm + (size_t)c0 * H, H, c1 - c0, H, d_weights, d_weights2, d_open + W + c0, d_open + K1 + c0, d_scratch));
+            TRY(mark());
+        }
+        return 0;
+    };
     TRY(barycentric_weights(zeta, (int)log_h, d_weights));
-    TRY(ext_dot_columns(d_trace, H, W, H, d_weights, d_opened, d_scratch));
-    if (lg && !sb) {  // the permutation matrix at zeta and at g zeta: one pass over its columns
+    TRY(ext_dot_columns(d_trace, H, W, H, d_weights, d_open, d_scratch));
+    TRY(mark());
+    if (lg && !sb) {
         TRY(barycentric_weights(gzeta, (int)log_h, d_weights2));
-        TRY(ext_dot_columns2(d_perm, H, Wp, H, d_weights, d_weights2, d_opened + W, d_opened + K1, d_scratch));
+        TRY(open_perm());
     }
     TRY(zeta_weights(zeta, (int)log_h, d_weights));
     if (lg && sb) {  // streamed: d_perm holds the matrix's coefficient arrays
         TRY(zeta_weights(gzeta, (int)log_h, d_weights2));
-        TRY(ext_dot_columns2(d_perm, H, Wp, H, d_weights, d_weights2, d_opened + W, d_opened + K1, d_scratch));
+        TRY(open_perm());
     }
-    TRY(ext_dot_columns(d_qcoef, H, 8, H, d_weights, d_opened + W + Wp, d_scratch));
-    std::vector<bb::Ext> opened(K);
-    PW_HIP_TRY(hipMemcpyAsync(opened.data(), d_opened, K * sizeof(bb::Ext), hipMemcpyDeviceToHost, st));
-    PW_HIP_TRY(hipStreamSynchronize(st));
+    TRY(ext_dot_columns(d_qcoef, H, 8, H, d_weights, d_open + W + Wp, d_scratch));
+    TRY(mark());
+    std::vector<bb::Ext> opened_copy;
+    const bb::Ext* opened = mb ? mb->host : nullptr;
+    if (!mb) {
+        opened_copy.resize(K);
+        PW_HIP_TRY(hipMemcpyAsync(opened_copy.data(), d_opened, K * sizeof(bb::Ext), hipMemcpyDeviceToHost, st));
+        PW_HIP_TRY(hipStreamSynchronize(st));
+        opened = opened_copy.data();
+    }
     {
         // proof / transcript order: main, perm@zeta, perm@g*zeta, quotient
+        int waited = 0;
+        auto wait = [&]() -> int {
+            if (mb) PW_HIP_TRY(hipEventSynchronize(mb->ev[waited]));
+            ++waited;
+            return 0;
+        };
         auto emit = [&](size_t a, size_t b) { for (size_t k = a; k < b; ++k) { put_monty(opened[k].c, 4); ch.observe_ext(opened[k]); } };
-        emit(0, (size_t)W + Wp);
+        TRY(wait());
+        emit(0, W);
+        if (lg)
+            for (uint32_t i = 0; i < n_slices; ++i) {
+                TRY(wait());
+                emit((size_t)W + slice_at[i], (size_t)W + slice_at[i + 1]);
+            }
+        TRY(wait());  // the quotient's values: everything is there
         emit(K1, K);
         emit((size_t)W + Wp, K1);
     }
 
     // ---- 4. reduced-opening vector -------------------------------------------------------------
     const bb::Ext gamma = ch.sample_ext();
+    // the powers of gamma are computed where they are used (CENTRED, the form the DEEP kernels take); the host only needs
+    // sum_k gamma^k opened[k] — by Horner's rule, and where the DEEP numerator is combined first (below) while those kernels run
+    TRY(gamma_powers(gamma, K, d_gpow));
     bb::Ext opened_sum = bb::ext_zero(), opened_sum2 = bb::ext_zero();
-    {
-        std::vector<bb::Ext> gpow(K);
-        bb::Ext g = bb::ext_one();
-        for (uint32_t k = 0; k < K; ++k) { gpow[k] = g; g = bb::ext_mul(g, gamma); }
-        for (uint32_t k = 0; k < K1; ++k) opened_sum = bb::ext_add(opened_sum, bb::ext_mul(gpow[k], opened[k]));
-        for (uint32_t k = K1; k < K; ++k) opened_sum2 = bb::ext_add(opened_sum2, bb::ext_mul(gpow[k], opened[k]));
-        // the DEEP kernels take the powers as CENTRED representatives (signed 64-bit accumulation, bb::ExtCentredAcc)
-        for (auto& e : gpow) for (auto& c : e.c) c = (uint32_t)bb::centred(c);
-        PW_HIP_TRY(hipMemcpyAsync(d_gpow, gpow.data(), K * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
-        PW_HIP_TRY(hipStreamSynchronize(st));
-    }
+    auto opened_sums = [&]() {
+        for (uint32_t k = K1; k-- > 0;) opened_sum = bb::ext_add(bb::ext_mul(opened_sum, gamma), opened[k]);
+        for (uint32_t k = K; k-- > K1;) opened_sum2 = bb::ext_add(bb::ext_mul(opened_sum2, gamma), opened[k]);
+        opened_sum2 = bb::ext_mul(opened_sum2, bb::ext_pow(gamma, K1));
+    };
     if (sb) {
         // streamed: sum_k gamma^k P_k is a POLYNOMIAL — combined on the coefficient arrays (one pass over them) and extended as 4 (+ 4 for
         // the second opening point) columns; the eight quotient columns join from their resident LDE
-        TRY(streamed::deep_from_coefficients(stream_ctx(p, L, log_h), lg, d_tcoef, d_perm, d_qlde, logN, d_gpow, opened_sum, opened_sum2, zeta, gzeta, d_v));
+        TRY(streamed::deep_from_coefficients(stream_ctx(p, L, log_h), lg, d_tcoef, d_perm, d_qlde, logN, d_gpow, opened_sums, opened_sum, opened_sum2, zeta,
+                                             gzeta, d_v));
     } else if (log_h >= kDeepComboMinLogHeight && !getenv("POWDR_DEEP_DIRECT")) {
         // resident: the same combination on the evaluations over <g_n> (the caller's trace, the permutation matrix), extended like any column
         uint32_t* d_gev = p->gbuf.as<uint32_t>();
@@ -698,11 +776,15 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         const uint32_t gc = lg ? 8u : 4u;
         TRY(ext_lincomb(d_trace, W, d_perm, Wp, H, d_gpow, lg ? K1 : 0u, d_gev));
         TRY(lde_matrix(p, L, log_h, d_gev, gc, d_glde));
+        opened_sums();  // (the device is busy with the two launches above)
         TRY(deep_from_combo(d_glde, d_qlde, N, logN, d_gpow + W + Wp, opened_sum, opened_sum2, zeta, gzeta, lg ? 1 : 0, d_v));
-    } else if (lg)
+    } else if (lg) {
+        opened_sums();
         TRY(deep_quotient_logup(d_lde, W, d_plde, Wp, d_qlde, N, logN, d_gpow, opened_sum, opened_sum2, zeta, gzeta, d_v));
-    else
+    } else {
+        opened_sums();
         TRY(deep_quotient(d_lde, W, d_qlde, 8, N, logN, d_gpow, opened_sum, zeta, d_v));
+    }
 
     // ---- 5. FRI commit phase --------------------------------------------------------------------
     std::vector<size_t> layer_off(log_h + 1), tree_off(log_h);  // offsets in Ext / in words

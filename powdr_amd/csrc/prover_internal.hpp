@@ -124,6 +124,8 @@ int ext_dot_columns2(const uint32_t* cols, size_t stride, uint32_t n_cols, size_
 int deep_quotient(const uint32_t* lde_a, uint32_t wa, const uint32_t* lde_b, uint32_t wb, size_t N, int logN,
                   const bb::Ext* d_gpow, bb::Ext opened_sum, bb::Ext zeta, bb::Ext* v);
 // out[i] = (a+b)/2 + beta (a-b)/(2 x_i), a = v[i], b = v[i+half], x_i = shift * w^i
+// d_gpow[k] = gamma^k, k < K <= 2^24, as CENTRED words (the form the DEEP kernels and ext_lincomb take), computed on the device
+int gamma_powers(bb::Ext gamma, uint32_t K, bb::Ext* d_gpow);
 int fri_fold(const bb::Ext* v, size_t half, int log_size, uint32_t shift, bb::Ext beta, bb::Ext* out);
 // y[i] += a * x[i] (a == nullptr: a = 1), Ext vectors of length n
 int ext_axpy(bb::Ext* y, const bb::Ext* a_or_null, const bb::Ext* x, size_t n);

@@ -97,6 +97,18 @@ struct PwProver {
     // streamed mode (prover.hip "streamed proofs"): the trace's coefficient arrays, the scale table of the sub-coset being evaluated,
     // the DEEP combinations (8 columns of coefficients + their LDE); `lde` then holds ONE sub-coset of all committed columns
     pw::DeviceBuf tcoef, fscale, gbuf;
+    // pw_prover_prove step 3: host-mapped landing place of the opened values — the dot-product kernels write them straight into
+    // host memory, slice by slice with an event after each, and the host absorbs a slice into the transcript while the device
+    // computes the next (4 487 sequential transcript permutations at BASELINE configs[1]); host == nullptr: plain copy afterwards
+    struct OpenedMailbox {
+        static constexpr int kEvents = 8;
+        bb::Ext* host = nullptr;
+        bb::Ext* dev = nullptr;
+        size_t cap = 0;
+        int device = -1;
+        hipEvent_t ev[kEvents] = {};
+        int n_events = 0;
+    } opened_mb;
     std::vector<uint32_t> proof;
     // host copies of the plan-compiled (xbc) programs: the source of the run-time specialised kernels (jit_codegen.hpp)
     std::vector<uint32_t> h_xcode, h_xspans, h_icode, h_ixspans, h_gstarts;
@@ -116,6 +128,9 @@ struct CommitLayout {
     size_t m = 0;  // rows of a sub-coset, N >> b
     bool perm_panels = false;  // streamed quotient: the permutation columns come in unit by unit (specialised LogUp kernels) instead of all at once
 };
+// traces of at least 2^this rows: the DEEP numerator is combined on the un-extended matrices and extended as 4 (+ 4) columns through
+// PwProver::gbuf (24 words per row); shorter ones accumulate it over the LDE (prover.hip "streamed proofs")
+constexpr uint32_t kDeepComboMinLogHeight = 16;
 // LDE of a column-major matrix (cols x 2^log_h) through the prover's coefficient panel buffer into `out` (cols x 2^(log_h+1))
 int lde_matrix(PwProver* p, const CommitLayout& L, uint32_t log_h, const uint32_t* m, uint32_t cols, uint32_t* out);
 // columns per LDE panel for a 2^log_h-row matrix of `widest` columns (POWDR_PANEL_LOG_WORDS, read per call)

@@ -121,14 +121,18 @@ inline int query_rows(const Ctx& c, const uint32_t* coef, uint32_t cols, const u
 
 // v[j] = (sum_k g^k P_k(x_j) - sum1) / (x_j - zeta) [+ (sum_k g^(K1+k) perm_k(x_j) - sum2) / (x_j - g zeta)] from the coefficient arrays:
 // the numerator is a polynomial — combined on the arrays, extended as 4 (+ 4) columns through p->gbuf. d_gpow: the AIR's centred gamma
-// powers in the order main | perm | quotient (8) | perm at g zeta.
+// powers in the order main | perm | quotient (8) | perm at g zeta. sum1 / sum2 are read AFTER host_work() has run: the caller's host
+// work (the sums themselves, in the one-AIR prover) that the combination and its extension hide.
+template <class HostWork>
 inline int deep_from_coefficients(const Ctx& c, bool lg, const uint32_t* d_tcoef, const uint32_t* d_pcoef, const uint32_t* d_qlde, int logN,
-                                  const bb::Ext* d_gpow, bb::Ext sum1, bb::Ext sum2, bb::Ext zeta, bb::Ext gzeta, bb::Ext* d_v) {
+                                  const bb::Ext* d_gpow, HostWork&& host_work, const bb::Ext& sum1, const bb::Ext& sum2, bb::Ext zeta, bb::Ext gzeta,
+                                  bb::Ext* d_v) {
     uint32_t* d_gcoef = c.p->gbuf.as<uint32_t>();
     uint32_t* d_glde = d_gcoef + 8 * c.H;
     const uint32_t K1 = c.W + c.Wp + 8;
     PW_STRY(ext_lincomb(d_tcoef, c.W, d_pcoef, c.Wp, c.H, d_gpow, lg ? K1 : 0u, d_gcoef));
     PW_STRY(coset_lde_from_coeffs(d_gcoef, d_glde, c.H, c.N, lg ? 8 : 4, (int)c.log_h));
+    host_work();
     return deep_from_combo(d_glde, d_qlde, c.N, logN, d_gpow + c.W + c.Wp, sum1, sum2, zeta, gzeta, lg ? 1 : 0, d_v);
 }
 

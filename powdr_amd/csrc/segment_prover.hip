@@ -96,6 +96,7 @@ int ensure_air(PwProver* p, const Shape& s, bool logup, CommitLayout& Lc) {
     const uint32_t n_chunks = div_up(s.H, 8192);
     const uint32_t dot_cols = std::max({s.W, s.Wp, 8u});
     TRY(p->misc.ensure((2 * (size_t)dot_cols * n_chunks + s.M + p->max_args + 64) * sizeof(bb::Ext) + 4096));  // ext_dot_columns2: two sets of partial sums
+    if (s.log_h >= kDeepComboMinLogHeight) TRY(p->gbuf.ensure((size_t)24 * s.H * 4));  // the DEEP combinations and their LDE
     return 0;
 }
 
@@ -527,8 +528,16 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             bb::Ext* out = started[s.logN] ? d_v + tmp_off : target;
             if (sbv[a])
                 TRY(streamed::deep_from_coefficients(sctx(a), lg, p->tcoef.as<uint32_t>(), p->perm.as<uint32_t>(), p->qlde.as<uint32_t>(), s.logN,
-                                                     d_gpow + s.koff, sum1, sum2, zeta, gzeta[a], out));
-            else if (lg)
+                                                     d_gpow + s.koff, [] {}, sum1, sum2, zeta, gzeta[a], out));
+            else if (s.log_h >= kDeepComboMinLogHeight && !getenv("POWDR_DEEP_DIRECT")) {
+                // resident and tall: the numerator is combined on the evaluations over <g_n> — the caller's trace, the permutation
+                // matrix: half the bytes their LDE holds — and extended as 4 (+ 4) columns, like the one-AIR prover does
+                uint32_t* d_gev = p->gbuf.as<uint32_t>();
+                uint32_t* d_glde = d_gev + 8 * s.H;
+                TRY(ext_lincomb(airs[a].d_trace, s.W, p->perm.as<uint32_t>(), s.Wp, s.H, d_gpow + s.koff, lg ? (uint32_t)K1 : 0u, d_gev));
+                TRY(lde_matrix(p, Lc[a], s.log_h, d_gev, lg ? 8u : 4u, d_glde));
+                TRY(deep_from_combo(d_glde, p->qlde.as<uint32_t>(), s.N, s.logN, d_gpow + s.koff + s.W + s.Wp, sum1, sum2, zeta, gzeta[a], lg ? 1 : 0, out));
+            } else if (lg)
                 TRY(deep_quotient_logup(p->lde.as<uint32_t>(), s.W, p->plde.as<uint32_t>(), s.Wp, p->qlde.as<uint32_t>(), s.N, s.logN,
                                         d_gpow + s.koff, sum1, sum2, zeta, gzeta[a], out));
             else

@@ -247,6 +247,22 @@ __global__ void ext_dot_final_kernel(const bb::Ext* __restrict__ partial, uint32
     out[c] = acc;
 }
 
+// out[k] = gamma^k (k < K), coordinates as CENTRED words — what the DEEP kernels take (deep_kernel below): lane k multiplies the
+// squares gamma^(2^i) its bits select (wave-uniform kernel arguments); field arithmetic is exact, so the words equal those of K - 1
+// successive multiplications on the host
+struct GammaSquares { bb::Ext s[24]; };
+__global__ __launch_bounds__(kBlock) void gamma_powers_kernel(GammaSquares g, uint32_t K, bb::Ext* __restrict__ out) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= K) return;
+    bb::Ext r = bb::ext_one();
+#pragma unroll 1
+    for (int i = 0; i < 24; ++i)
+        if ((k >> i) & 1u) r = bb::ext_mul(r, g.s[i]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r.c[c] = (uint32_t)bb::centred(r.c[c]);
+    out[k] = r;
+}
+
 // ---- DEEP / reduced opening ----------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void deep_kernel(const uint32_t* __restrict__ ma, uint32_t wa,
                                                        const uint32_t* __restrict__ mb, uint32_t wb, size_t N,
@@ -421,6 +437,16 @@ int ext_dot_columns2(const uint32_t* cols, size_t stride, uint32_t n_cols, size_
     }
     hipLaunchKernelGGL(ext_dot_final_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, stream(), scratch, n_cols, n_chunks, out);
     hipLaunchKernelGGL(ext_dot_final_kernel, dim3(div_up(n_cols, 256)), dim3(256), 0, stream(), scratch + second, n_cols, n_chunks, out2);
+    return (int)hipGetLastError();
+}
+
+int gamma_powers(bb::Ext gamma, uint32_t K, bb::Ext* d_gpow) {
+    if (!K) return 0;
+    if (K > (1u << 24)) return (int)hipErrorInvalidValue;
+    GammaSquares g;
+    g.s[0] = gamma;
+    for (int i = 1; i < 24; ++i) g.s[i] = bb::ext_sqr(g.s[i - 1]);
+    hipLaunchKernelGGL(gamma_powers_kernel, dim3(div_up(K, kBlock)), dim3(kBlock), 0, stream(), g, K, d_gpow);
     return (int)hipGetLastError();
 }
 

@@ -172,3 +172,67 @@ def random_records_device(table: InstructionTable, num_calls: int, seed: int = 0
         gap = torch.randint(1, 1 << 20, (n_prev, num_calls), dtype=torch.int32, device="cuda", generator=g)
         rec[first:first + n_prev] = torch.clamp(base[None, :] + e.ts_delta - gap, min=0)
     return rec.reshape(-1)
+
+
+def typed_substitutions(instructions, subs_json, kinds, start_pc: int, n_samples: int = 96, seed: int = 0):
+    """The substitutions of a SYNTHETIC APC (synth.py draws them uniformly over the original rows' cells) re-targeted so that the flow
+    from records feeds every bounded APC column from a cell whose REAL values respect the bound: `kinds[poly_id] = (kind, bound)`
+    (synth.SynthApc.kinds: bit < 2, tri < 3, byte < 256, range < 2^k, field: anything). A cell's type is what the library's own
+    expander (powdr_original_row_expand_host) produces for `n_samples` random records of that instruction (operand words over all
+    32 bits, equal / nearly equal / extreme operands among them, timestamps and access gaps over all 29 bits) — flags, byte limbs, timestamp limbs are bounded by construction, operand words
+    are not. Same instructions, the same APC columns per instruction, distinct
+    cells per instruction; an APC column for which the row has no free cell of its type keeps its cell.
+    Why: a real APC's lookups are in range by construction (the optimiser keeps a cell WITH the range checks the chip proved about it);
+    a synthetic one that reads a random operand word as a `byte` sends most of its lookups outside their tables, which is a different
+    histogram workload (bench.py tracegen_from_records.timed_step).
+    Returns (subs_json', number of bounded columns left untyped)."""
+    has = [len(x) > 0 for x in subs_json]
+    table = InstructionTable(instructions, has, start_pc)
+    rng = np.random.default_rng(seed)
+    out, untyped = [], 0
+    for i, subs in enumerate(subs_json):
+        if not subs:
+            out.append([])
+            continue
+        e = table.entries[table.index_of[i]]
+        n_words, n_prev = RECORD_WORDS[e.kind], N_PREV_TS[e.kind]
+        mx = np.zeros(WIDTHS[e.kind], np.uint64)
+        for _ in range(n_samples):
+            rec = rng.integers(0, 1 << 32, size=n_words, dtype=np.uint64).astype(np.uint32)
+            n_data = n_words - n_prev
+            for w in range(n_data):  # operand words at their extremes now and then
+                if rng.random() < 0.125:
+                    rec[w] = (0, 0xFFFFFFFF, 0x80000000, int(rng.integers(0, 256)))[int(rng.integers(4))]
+            if n_data >= 2:  # equal operands, operands that differ in one limb only (comparison markers, division corner cases)
+                u = rng.random()
+                if u < 0.25:
+                    rec[1] = rec[0]
+                elif u < 0.5:
+                    rec[1] = int(rec[0]) ^ (int(rng.integers(1, 256)) << (8 * int(rng.integers(4))))
+            ts = int(rng.integers(1 << 10, (1 << 29) - (1 << 12))) + e.ts_delta  # (timestamps are 29-bit: the full range of the gap limbs)
+            for j in range(n_prev):
+                rec[n_words - n_prev + j] = ts + j - int(rng.integers(1, ts + j + 1))
+            mx = np.maximum(mx, expand_row_host(e, rec, ts).astype(np.uint64))
+        pairs = [(int(s["original_poly_index"]), int(s["apc_poly_id"])) for s in subs]
+        bound_of = {pid: int(kinds[pid][1]) for _, pid in pairs}
+        taken, chosen = set(), {}
+        for col, pid in sorted(pairs, key=lambda cp: bound_of[cp[1]]):  # tightest bounds choose first
+            b = bound_of[pid]
+            if b >= P:
+                continue
+            free = [c for c in range(len(mx)) if c not in taken and int(mx[c]) < b]
+            if free:
+                chosen[pid] = free[int(rng.integers(len(free)))]
+                taken.add(chosen[pid])
+            else:
+                untyped += 1
+        for col, pid in pairs:  # unbounded columns (and the untyped ones): their own cell when it is still free, else any free one
+            if pid in chosen:
+                continue
+            if col in taken:
+                free = [c for c in range(len(mx)) if c not in taken]
+                col = free[int(rng.integers(len(free)))]
+            chosen[pid] = col
+            taken.add(col)
+        out.append(sorted(({"original_poly_index": c, "apc_poly_id": p} for p, c in chosen.items()), key=lambda s: s["original_poly_index"]))
+    return out, untyped

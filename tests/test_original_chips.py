@@ -168,6 +168,47 @@ def test_library_expanders_on_the_host_equal_the_restatement():
         pc.expand_row_host(bad, [0] * 6, 0)
 
 
+@pytest.mark.parametrize("shape", ["T1", "C2"])
+def test_typed_substitutions_feed_bounded_columns_from_bounded_cells(shape):
+    """original_chips.typed_substitutions: the synthetic APC keeps the same columns per instruction, every instruction's cells stay
+    distinct, and on FRESH records the restatement's rows (oracle/original_chips.py expand_rows) hold a value below the bound in
+    every cell that feeds a bounded column (bit, tri, byte, k-bit range) — what makes the flow from records look up in range."""
+    from powdr_amd import original_chips as pc
+
+    s = synth.generate(shape, seed=0)
+    blk = s.doc["block"]["blocks"][0]
+    ins = oc.sanitise_instructions(blk["instructions"])
+    typed, untyped = pc.typed_substitutions(ins, s.doc["subs"], s.kinds, int(blk["start_pc"]), seed=1)
+    assert untyped == 0
+    again, _ = pc.typed_substitutions(ins, s.doc["subs"], s.kinds, int(blk["start_pc"]), seed=1)
+    assert again == typed
+    moved = 0
+    for before, after in zip(s.doc["subs"], typed):
+        assert sorted(x["apc_poly_id"] for x in before) == sorted(x["apc_poly_id"] for x in after)
+        cols = [x["original_poly_index"] for x in after]
+        assert len(set(cols)) == len(cols) and cols == sorted(cols)
+        was = {x["apc_poly_id"]: x["original_poly_index"] for x in before}
+        moved += sum(was[x["apc_poly_id"]] != x["original_poly_index"] for x in after)
+        for x in after:  # an unbounded column keeps its cell unless a bounded one needed it
+            if s.kinds[x["apc_poly_id"]][1] >= P and was[x["apc_poly_id"]] != x["original_poly_index"]:
+                assert was[x["apc_poly_id"]] in cols
+    assert moved > 0
+    has = [len(x) > 0 for x in typed]
+    table, index, rbs, wpc = oc.build_instruction_table(ins, has, int(blk["start_pc"]))
+    calls = 24
+    rec = oc.random_records(table, wpc, calls, seed=77)
+    checked = 0
+    for row, i in zip(table, index):
+        cells = oc.expand_rows(row, rec, rec[0])
+        for x in typed[int(i)]:
+            bound = s.kinds[x["apc_poly_id"]][1]
+            if bound < P:
+                v = np.broadcast_to(np.asarray(cells[x["original_poly_index"]]) % P, (calls,))
+                assert int(v.max()) < bound, (oc.KIND_NAMES[int(row["kind"])], x, int(v.max()), bound)
+                checked += 1
+    assert checked == sum(1 for r in typed for x in r if s.kinds[x["apc_poly_id"]][1] < P) > 0
+
+
 def test_library_instruction_table_equals_the_restatement():
     """powdr_apc_instruction_table (C++ host library, from the APC's own block and substitutions) == the Python mirror == the
     restatement, for the synthetic C2 APC (instructions without a surviving cell have no entry but still advance the timestamp)."""
@@ -356,11 +397,13 @@ def test_one_segment_proof_of_all_thirteen_chips_from_records_verifies(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("calls", [100, 1024])
-def test_generate_witness_from_records_equals_the_reference_flow(gpu, calls):
+@pytest.mark.parametrize("calls,typed", [(100, False), (1024, False), (1024, True), (20000, True)])
+def test_generate_witness_from_records_equals_the_reference_flow(gpu, calls, typed):
     """powdr_apc_generate_witness_from_records (a1-a3 from call records, one host call) == powdr_original_airs_expand on the same
     records followed by powdr_apc_generate_witness_gpu (the reference flow: dummy traces -> gather -> derived -> bus): the same trace
-    in every column and the same three periphery histograms."""
+    in every column and the same three periphery histograms. typed: with the substitutions of the bench's timed step from records
+    (original_chips.typed_substitutions) — every bounded column of the generated trace then stays below its bound; 20 000 calls take
+    the binned histogram path."""
     from powdr_amd import host
 
     torch, abi, pc, prover, tg = gpu
@@ -369,6 +412,9 @@ def test_generate_witness_from_records_equals_the_reference_flow(gpu, calls):
     blk = dict(doc["block"]["blocks"][0])
     blk["instructions"] = oc.sanitise_instructions(blk["instructions"])
     doc["block"] = dict(doc["block"], blocks=[blk])
+    if typed:
+        doc["subs"], untyped = pc.typed_substitutions(blk["instructions"], doc["subs"], s.kinds, int(blk["start_pc"]))
+        assert untyped == 0
     h_apc = host.Apc(doc)
     has = [len(x) > 0 for x in doc["subs"]]
     t = pc.InstructionTable(blk["instructions"], has, int(blk["start_pc"]))
@@ -395,4 +441,10 @@ def test_generate_witness_from_records_equals_the_reference_flow(gpu, calls):
     for a, b in ((per1.var_hist, per2.var_hist), (per1.tuple_hist, per2.tuple_hist), (per1.bitwise_hist, per2.bitwise_hist)):
         assert torch.equal(a, b)
     assert int(per2.var_hist.sum()) > 0
+    if typed:
+        index = apc.poly_id_to_index()
+        bounded = [(index[pid], b) for pid, (_, b) in s.kinds.items() if b < P and pid in s.source_of]
+        view = out2.buf.view(W, H)[:, :calls]
+        for c, b in bounded[:: max(1, len(bounded) // 200)]:
+            assert int(om.from_monty(view[c].cpu().numpy().astype(np.uint32)).max()) < b, (c, b)
     h_apc.close()

@@ -186,7 +186,7 @@ def test_hip_segment_proof_with_streamed_airs(gpu, monkeypatch, spec, nq, pow_bi
     row digests hashed sub-coset by sub-coset into its level of the mixed trees, quotient / DEEP / query rows from prover_stream.hpp —
     and the words still equal the oracle's."""
     torch, abi, prover = gpu
-    if len(spec) == 2 and (log_blocks == 1 or not logup):
+    if len(spec) == 2 and (log_blocks == 1 or (not logup and log_blocks != 2)):
         pytest.skip("the tall case runs once per kernel kind")
     airs = synthetic_airs(spec, seed0=11)
     want = sm.prove_segment(airs, num_queries=nq, pow_bits=pow_bits, logup=logup)
@@ -196,6 +196,13 @@ def test_hip_segment_proof_with_streamed_airs(gpu, monkeypatch, spec, nq, pow_bi
     assert len(got) == len(want)
     assert (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
     assert prover.verify_segment(descs_of(airs), got, nq, pow_bits, logup)[0] == 0
+    if len(spec) == 2 and log_blocks == 2:
+        # the same segment with every LDE resident: from 2^16 rows on an AIR's DEEP numerator is combined on the un-extended matrices
+        # and extended as 4 (+ 4) columns (segment_prover.hip, like the one-AIR prover) — and accumulated over the LDE when told to
+        monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", "0")
+        assert (hip_segment(gpu, airs, nq, pow_bits, logup) == want).all()
+        monkeypatch.setenv("POWDR_DEEP_DIRECT", "1")
+        assert (hip_segment(gpu, airs, nq, pow_bits, logup) == want).all()
 
 
 @pytest.mark.gpu
