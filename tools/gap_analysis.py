@@ -29,6 +29,18 @@ for s, e, n in rows:
             total_gap += g
     busy += (e - s) / 1000.0
     end = e if end is None else max(end, e)
-print(f"{len(rows)} dispatches, kernel time {busy / 1000:.1f} ms, idle (gaps <= {max_gap:.0f} us) {total_gap / 1000:.1f} ms")
+# wall time covered by at least one kernel (kernels of different streams overlap in the segment prover) and by at least two
+cover = over = 0.0
+ev = sorted([(s, 1) for s, e, n in rows] + [(e, -1) for s, e, n in rows])
+depth, last = 0, None
+for t, dlt in ev:
+    if last is not None and depth >= 1:
+        cover += (t - last) / 1000.0
+    if last is not None and depth >= 2:
+        over += (t - last) / 1000.0
+    depth += dlt
+    last = t
+print(f"{len(rows)} dispatches, kernel time {busy / 1000:.1f} ms, idle (gaps <= {max_gap:.0f} us) {total_gap / 1000:.1f} ms; "
+      f"wall with a kernel running {cover / 1000:.1f} ms, with two or more {over / 1000:.1f} ms")
 for name, (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f"  {t / 1000:8.2f} ms in {c:6d} gaps (avg {t / c:7.1f} us) before {name[:90]}")
