@@ -124,8 +124,13 @@ int ext_dot_columns2(const uint32_t* cols, size_t stride, uint32_t n_cols, size_
 int deep_quotient(const uint32_t* lde_a, uint32_t wa, const uint32_t* lde_b, uint32_t wb, size_t N, int logN,
                   const bb::Ext* d_gpow, bb::Ext opened_sum, bb::Ext zeta, bb::Ext* v);
 // out[i] = (a+b)/2 + beta (a-b)/(2 x_i), a = v[i], b = v[i+half], x_i = shift * w^i
-// d_gpow[k] = gamma^k, k < K <= 2^24, as CENTRED words (the form the DEEP kernels and ext_lincomb take), computed on the device
+// d_out[k] = base^k (reversed: base^(n - 1 - k)), k < n <= 2^24, computed on the device; centred: as CENTRED words (the form the DEEP
+// kernels and ext_lincomb take). gamma_powers = plain order, centred.
+int ext_powers(bb::Ext base, uint32_t n, bool reversed, bool centred, bb::Ext* d_out);
 int gamma_powers(bb::Ext gamma, uint32_t K, bb::Ext* d_gpow);
+// rows d_indices[idx_off + q] (q < n_idx) of n_jobs column-major matrices into out + out_off (row-major, q-th row at q * width): ONE launch
+struct GatherRowsJob { const uint32_t* m; uint64_t height; uint32_t width; uint32_t idx_off; uint64_t out_off; };
+int gather_rows_multi(const GatherRowsJob* d_jobs, uint32_t n_jobs, uint32_t max_width, const uint32_t* d_indices, uint32_t n_idx, uint32_t* out);
 int fri_fold(const bb::Ext* v, size_t half, int log_size, uint32_t shift, bb::Ext beta, bb::Ext* out);
 // y[i] += a * x[i] (a == nullptr: a = 1), Ext vectors of length n
 int ext_axpy(bb::Ext* y, const bb::Ext* a_or_null, const bb::Ext* x, size_t n);

@@ -162,7 +162,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
 
     // ---- shapes -----------------------------------------------------------------------------------------------
     std::vector<Shape> sh(A);
-    size_t K_total = 0, M_max = 0;
+    size_t K_total = 0;
     int L = 0;
     for (size_t a = 0; a < A; ++a) {
         const PwProver* p = airs[a].prover;
@@ -175,7 +175,6 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         s.koff = K_total;
         K_total += s.K;
         if (s.logN > L) L = s.logN;
-        if (s.M > M_max) M_max = s.M;
     }
     const size_t Nmax = (size_t)1 << L;
     const size_t tree_words = merkle_words(Nmax);
@@ -204,7 +203,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     for (size_t a = 0; a < A; ++a) row_words += (size_t)nq * (sh[a].W + sh[a].Wp + 8);
     const size_t n_dig = (size_t)nq * ((size_t)n_trees * L + (size_t)rounds * L) + 16;  // upper bound of digest records
     const size_t misc_bytes = cols_total * 8 + 4 * A * 8 + 2 * K_total * sizeof(bb::Ext) + (size_t)A * nq * 4 + row_words * 4 + n_dig * (8 + 32) +
-                              (size_t)nq * rounds * (8 + 16) + 4 * A * 4 + 8192;
+                              (size_t)nq * rounds * (8 + 16) + 4 * A * 4 + 3 * A * sizeof(GatherRowsJob) + 8192;
     TRY(cx.misc.ensure(misc_bytes));
     uint32_t* d_dig = cx.dig.as<uint32_t>();
     uint32_t* d_fdig = d_dig + n_trees * tree_words;
@@ -213,6 +212,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     uint8_t* mp = cx.misc.as<uint8_t>();
     const uint32_t** d_cols = reinterpret_cast<const uint32_t**>(mp); mp += cols_total * 8;
     const uint32_t** d_sptrs = reinterpret_cast<const uint32_t**>(mp); mp += 4 * A * 8;
+    GatherRowsJob* d_jobs = reinterpret_cast<GatherRowsJob*>(mp); mp += 3 * A * sizeof(GatherRowsJob);  // query phase: one per AIR and tree
     uint64_t* d_offs = reinterpret_cast<uint64_t*>(mp); mp += n_dig * 8 + (size_t)nq * rounds * 8;
     bb::Ext* d_opened = reinterpret_cast<bb::Ext*>(mp); mp += K_total * sizeof(bb::Ext);
     bb::Ext* d_gpow = reinterpret_cast<bb::Ext*>(mp); mp += K_total * sizeof(bb::Ext);
@@ -371,7 +371,6 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     // ---- 2. LogUp ---------------------------------------------------------------------------------------------
     bb::Ext al = bb::ext_zero(), bl = bb::ext_zero();
     std::vector<bb::Ext> S(A, bb::ext_zero());
-    std::vector<std::vector<bb::Ext>> keep;  // host sources of asynchronous uploads, alive until the next synchronisation
     if (lg) {
         al = ch.sample_ext();
         bl = ch.sample_ext();
@@ -379,10 +378,8 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         TRY(fork());
         for (size_t a = 0; a < A; ++a) {
             PwProver* p = airs[a].prover;
-            keep.emplace_back(p->max_args + 2);
-            { bb::Ext b = bb::ext_one(); for (auto& x : keep.back()) { x = b; b = bb::ext_mul(b, bl); } }
             on_air(a);
-            PW_HIP_TRY(hipMemcpyAsync(blpow_of(a), keep.back().data(), keep.back().size() * sizeof(bb::Ext), hipMemcpyHostToDevice, stream()));
+            TRY(ext_powers(bl, p->max_args + 2, false, false, blpow_of(a)));  // beta^0 .. (computed where they are used: no upload per AIR)
             bb::Ext* rowsum = weights_of(a) + 2 * sh[a].H;
             if (specialised(p)) TRY(logup_perm_trace_jit(p, airs[a].d_trace, sh[a].H, al, blpow_of(a), p->perm.as<uint32_t>(), rowsum, rowsum + sh[a].H));
             else TRY(logup_perm_trace(airs[a].d_trace, sh[a].H, logup_program(a), al, blpow_of(a), p->perm.as<uint32_t>(), rowsum, rowsum + sh[a].H));
@@ -413,7 +410,6 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         std::vector<uint32_t> sw(4 * A);
         PW_HIP_TRY(hipMemcpyAsync(sw.data(), d_small, sw.size() * 4, hipMemcpyDeviceToHost, st));
         PW_HIP_TRY(hipStreamSynchronize(st));
-        keep.clear();
         put_monty(root, 8);
         ch.observe_words(root, 8);
         for (size_t a = 0; a < A; ++a) {
@@ -426,17 +422,13 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     // ---- 3. quotients -----------------------------------------------------------------------------------------
     const bb::Ext alpha = ch.sample_ext();
     {
-        std::vector<bb::Ext> apow_all(M_max ? M_max : 1);  // alpha^0 .. alpha^(M_max - 1)
-        { bb::Ext x = bb::ext_one(); for (auto& v : apow_all) { v = x; x = bb::ext_mul(x, alpha); } }
         const uint32_t s_m = bb::to_monty(field::kCosetShift), one = bb::R_MOD_P;
         TRY(fork());
         for (size_t a = 0; a < A; ++a) {
             PwProver* p = airs[a].prover;
             const Shape& s = sh[a];
-            keep.emplace_back(s.M ? s.M : 1);
-            for (size_t j = 0; j < s.M; ++j) keep.back()[j] = apow_all[s.M - 1 - j];
             on_air(a);
-            if (s.M) PW_HIP_TRY(hipMemcpyAsync(apow_of(a), keep.back().data(), s.M * sizeof(bb::Ext), hipMemcpyHostToDevice, stream()));
+            TRY(ext_powers(alpha, s.M, true, false, apow_of(a)));  // alpha^(M - 1) .. alpha^0
             uint32_t sH = s_m;
             for (uint32_t i = 0; i < s.log_h; ++i) sH = bb::sqr(sH);
             const uint32_t zv_even = bb::sub(sH, one), zv_odd = bb::sub(bb::neg(sH), one);
@@ -469,7 +461,6 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         TRY(join());
         TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) { m = airs[a].prover->qlde.as<uint32_t>(); w = 8; }, 1, root));
         PW_HIP_TRY(hipStreamSynchronize(st));
-        keep.clear();
     }
     put_monty(root, 8);
     ch.observe_words(root, 8);
@@ -601,6 +592,8 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         // rows: tree by tree (proof order main, perm, quotient), AIR by AIR, nq rows each
         const int tree_of_phase[3] = {0, 2, 1};  // digest arena order: main | quotient | perm
         std::vector<size_t> row_off[3];
+        std::vector<GatherRowsJob> jobs;  // (alive until the synchronisation below)
+        uint32_t max_w = 0;
         size_t ro = 0;
         TRY(fork());  // after the index upload
         for (int ph = 0; ph < 3; ++ph) {
@@ -618,12 +611,17 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
                     TRY(streamed::query_rows(sctx(a), ph == 0 ? p->tcoef.as<uint32_t>() : p->perm.as<uint32_t>(), w, idx.data() + a * nq, nq, d_scr,
                                              d_scr + nq, d_rows + ro));
                 } else {
-                    TRY(gather_rows(m, sh[a].N, w, d_idx + a * nq, nq, d_rows + ro));
+                    jobs.push_back(GatherRowsJob{m, (uint64_t)sh[a].N, w, (uint32_t)(a * nq), (uint64_t)ro});
+                    max_w = std::max(max_w, w);
                 }
                 ro += (size_t)nq * w;
             }
         }
         TRY(join());
+        if (!jobs.empty()) {  // the resident matrices' rows: one launch for all AIRs and trees
+            PW_HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(GatherRowsJob), hipMemcpyHostToDevice, st));
+            TRY(gather_rows_multi(d_jobs, (uint32_t)jobs.size(), max_w, d_idx, nq, d_rows));
+        }
         std::vector<uint64_t> dig_offs, ext_offs;
         for (uint32_t qi = 0; qi < nq; ++qi) {
             const size_t q = qs[qi];

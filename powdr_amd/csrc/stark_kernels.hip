@@ -8,6 +8,8 @@
 #include "expr_eval.hpp"
 #include "xbc.hpp"
 
+#include <algorithm>
+
 namespace pw {
 
 namespace {
@@ -247,20 +249,33 @@ __global__ void ext_dot_final_kernel(const bb::Ext* __restrict__ partial, uint32
     out[c] = acc;
 }
 
-// out[k] = gamma^k (k < K), coordinates as CENTRED words — what the DEEP kernels take (deep_kernel below): lane k multiplies the
-// squares gamma^(2^i) its bits select (wave-uniform kernel arguments); field arithmetic is exact, so the words equal those of K - 1
-// successive multiplications on the host
-struct GammaSquares { bb::Ext s[24]; };
-__global__ __launch_bounds__(kBlock) void gamma_powers_kernel(GammaSquares g, uint32_t K, bb::Ext* __restrict__ out) {
+// out[k] = base^k (reversed: base^(n - 1 - k)), k < n; centre: coordinates as CENTRED words — what the DEEP kernels take (deep_kernel
+// below). Lane k multiplies the squares base^(2^i) its bits select (wave-uniform kernel arguments); field arithmetic is exact, so the
+// words equal those of n - 1 successive multiplications on the host.
+struct ExtSquares { bb::Ext s[24]; };
+__global__ __launch_bounds__(kBlock) void ext_powers_kernel(ExtSquares g, uint32_t n, int reversed, int centre, bb::Ext* __restrict__ out) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= K) return;
+    if (k >= n) return;
+    const uint32_t e = reversed ? n - 1u - k : k;
     bb::Ext r = bb::ext_one();
 #pragma unroll 1
     for (int i = 0; i < 24; ++i)
-        if ((k >> i) & 1u) r = bb::ext_mul(r, g.s[i]);
+        if ((e >> i) & 1u) r = bb::ext_mul(r, g.s[i]);
+    if (centre) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r.c[c] = (uint32_t)bb::centred(r.c[c]);
+        for (int c = 0; c < 4; ++c) r.c[c] = (uint32_t)bb::centred(r.c[c]);
+    }
     out[k] = r;
+}
+
+// out[j.out_off + q * j.width + c] = j.m[c * j.height + idx[j.idx_off + q]]: the queried rows of MANY matrices in one launch (a
+// segment's query phase: one job per AIR and tree, each far shorter than a launch takes to issue)
+__global__ __launch_bounds__(kBlock) void gather_rows_multi_kernel(const GatherRowsJob* __restrict__ jobs, const uint32_t* __restrict__ idx,
+                                                                    uint32_t* __restrict__ out) {
+    const GatherRowsJob j = jobs[blockIdx.z];
+    const size_t row = idx[j.idx_off + blockIdx.y];
+    uint32_t* o = out + j.out_off + (size_t)blockIdx.y * j.width;
+    for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < j.width; c += gridDim.x * kBlock) o[c] = j.m[(size_t)c * j.height + row];
 }
 
 // ---- DEEP / reduced opening ----------------------------------------------------------------
@@ -440,13 +455,24 @@ int ext_dot_columns2(const uint32_t* cols, size_t stride, uint32_t n_cols, size_
     return (int)hipGetLastError();
 }
 
-int gamma_powers(bb::Ext gamma, uint32_t K, bb::Ext* d_gpow) {
-    if (!K) return 0;
-    if (K > (1u << 24)) return (int)hipErrorInvalidValue;
-    GammaSquares g;
-    g.s[0] = gamma;
+int ext_powers(bb::Ext base, uint32_t n, bool reversed, bool centred, bb::Ext* d_out) {
+    if (!n) return 0;
+    if (n > (1u << 24)) return (int)hipErrorInvalidValue;
+    ExtSquares g;
+    g.s[0] = base;
     for (int i = 1; i < 24; ++i) g.s[i] = bb::ext_sqr(g.s[i - 1]);
-    hipLaunchKernelGGL(gamma_powers_kernel, dim3(div_up(K, kBlock)), dim3(kBlock), 0, stream(), g, K, d_gpow);
+    hipLaunchKernelGGL(ext_powers_kernel, dim3(div_up(n, kBlock)), dim3(kBlock), 0, stream(), g, n, reversed ? 1 : 0, centred ? 1 : 0, d_out);
+    return (int)hipGetLastError();
+}
+
+int gamma_powers(bb::Ext gamma, uint32_t K, bb::Ext* d_gpow) { return ext_powers(gamma, K, false, true, d_gpow); }
+
+int gather_rows_multi(const GatherRowsJob* d_jobs, uint32_t n_jobs, uint32_t max_width, const uint32_t* d_indices, uint32_t n_idx, uint32_t* out) {
+    if (!n_jobs || !n_idx || !max_width) return 0;
+    if (n_jobs > 65535u || n_idx > 65535u) return (int)hipErrorInvalidValue;
+    ScopedKernelTimer t("gather_rows_kernel");
+    const uint32_t gx = std::min<uint32_t>(div_up(max_width, kBlock), 8u);
+    hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(gx, n_idx, n_jobs), dim3(kBlock), 0, stream(), d_jobs, d_indices, out);
     return (int)hipGetLastError();
 }
 
