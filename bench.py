@@ -85,22 +85,137 @@ def parse_args():
                          "set WORLD_SIZE), let them meet over gloo on the CPU, print {launch_check, n_gpus, ranks} and exit: no GPU is touched")
     ap.add_argument("--exact-source-heights", action="store_true",
                     help="allocate dummy traces with b*calls rows instead of next_pow2 (less HBM)")
+    ap.add_argument("--full-out", default=None,
+                    help="where the full record of the run is written (default: bench_full.json next to this script; also POWDR_BENCH_FULL). "
+                         "stdout carries the compact line only")
     args = ap.parse_args()
     args.logup = not args.constraints_only
+    global FULL_OUT
+    FULL_OUT = args.full_out
     return args
+
+
+LINE_LIMIT = 6000  # bytes; BENCH_r04.json.parsed was null on a 23 KB line
+FULL_OUT = None    # --full-out / POWDR_BENCH_FULL; default <repo>/bench_full.json
+
+
+def _clean(x, sig=6, strlen=None):
+    """Strict-JSON value: non-finite floats -> None, floats to `sig` significant digits, numpy scalars -> python, strings cut to `strlen`."""
+    import math
+
+    if isinstance(x, dict):
+        return {str(k): _clean(v, sig, strlen) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_clean(v, sig, strlen) for v in x]
+    if isinstance(x, (bool, type(None))):
+        return x
+    if isinstance(x, (np.bool_,)):
+        return bool(x)
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if not math.isfinite(x):
+            return None
+        return float(f"{x:.{sig}g}") if sig else x
+    if isinstance(x, str):
+        return x if strlen is None or len(x) <= strlen else x[:strlen - 1] + "~"
+    return str(x)
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d} if isinstance(d, dict) else None
+
+
+def compact_line(full: dict) -> dict:
+    """The line the driver reads: the contract's fields plus ONE number (or a handful) per sub-benchmark; every string under 120 characters.
+    Everything else — kernel tables, notes, per-kernel rooflines, the trace-generation variants — lives in bench_full.json."""
+    if full.get("launch_check"):
+        return _clean(full)
+    out = _pick(full, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "rccl_ranks", "per_rank_ms", "strong_scaling_value")
+    out["metric"] = full.get("metric_short") or out.get("metric")
+    cfg = full.get("config") or {}
+    out["config"] = _pick(cfg, "rows", "cols", "perm_cols", "proof_bytes", "parallelism")
+    out["config"] = dict(workload=cfg.get("workload_short") or cfg.get("workload"), **out["config"])
+    r = full.get("roofline")
+    if r:
+        rr = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_step", "avg_launch_ms", "launches_per_step")
+        if r.get("whole_step"):
+            rr["whole_step"] = _pick(r["whole_step"], "frac", "achieved_GBps", "algo_bytes_per_cell")
+        if r.get("valu"):
+            rr["valu"] = _pick(r["valu"], "frac", "valu_instr_per_perm")
+        out["roofline"] = rr
+    else:
+        out["roofline"] = None
+    c = full.get("cpu_baseline")
+    if c:
+        cc = _pick(c, "value", "unit", "cores", "kind", "sample")
+        cc["sample"] = c.get("sample_short") or cc.get("sample")
+        if c.get("tuned"):
+            cc["tuned"] = _pick(c["tuned"], "value", "upper_bound_commit_stages_only")
+        out["cpu_baseline"] = cc
+    else:
+        out["cpu_baseline"] = None
+    for key in ("constraints_only", "logup"):
+        if full.get(key):
+            out[key] = _pick(full[key], "value", "ms_per_step", "error")
+    c3 = full.get("c3")
+    if c3:
+        out["c3"] = _pick(c3, "value", "prove_ms", "trace_gen_ms", "verify_rc", "logup", "cells", "committed_columns", "stream_log_blocks", "skipped", "error")
+    ms = full.get("multi_segment")
+    if ms:
+        m = _pick(ms, "value", "ms_per_step", "verify_rc", "n_segments", "distinct_segments", "constraint_violations", "error")
+        if isinstance(ms.get("lookup_balance"), dict):
+            m["lookup_balance_rc"] = ms["lookup_balance"].get("verify_rc")
+        out["multi_segment"] = m
+    tr = (full.get("tracegen_from_records") or {}).get("timed_step")
+    if tr:
+        out["tracegen_from_records"] = dict(timed_step=_pick(tr, "ms_per_step", "value", "error"))
+    if full.get("stage_ms"):
+        out["stage_ms"] = {k: v for k, v in full["stage_ms"].items()}
+    if full.get("gauges"):
+        out["gauges"] = {k: v for k, v in full["gauges"].items() if k != "note"}
+    if full.get("comm"):
+        out["comm"] = _pick(full["comm"], "backend", "launch", "ranks")
+    out["hbm_copy_GBps_measured"] = full.get("hbm_copy_GBps_measured")
+    out["full_record"] = full.get("full_record")
+    out = _clean(out, sig=6, strlen=119)
+    # belt and braces: never above the limit, whatever a future sub-record adds
+    for victim in ("gauges", "stage_ms", "tracegen_from_records", "comm", "per_rank_ms"):
+        if len(json.dumps(out, allow_nan=False, separators=(", ", ": "))) <= LINE_LIMIT:
+            break
+        if victim == "stage_ms" and isinstance(out.get("stage_ms"), dict):  # keep the five largest first
+            top = sorted(out["stage_ms"].items(), key=lambda kv: -(kv[1] or 0))[:5]
+            out["stage_ms"] = dict(top)
+            continue
+        out.pop(victim, None)
+    return out
 
 
 def emit(line: dict):
     """The ONE JSON line, as the last thing on stdout: RCCL writes a version banner through C stdio when a communicator is created
-    (torch.distributed's nccl backend, pw_prove_segments_multi) and a pipe buffers it until exit, i.e. until after our line."""
+    (torch.distributed's nccl backend, pw_prove_segments_multi) and a pipe buffers it until exit, i.e. until after our line.
+    The line is the COMPACT record (compact_line: <= LINE_LIMIT bytes, strict JSON); the full record of the run goes to bench_full.json
+    next to this script (--full-out / POWDR_BENCH_FULL name another place). Nothing large goes to stderr: the driver's tail holds both."""
     import ctypes
 
+    full_path = Path(FULL_OUT or os.environ.get("POWDR_BENCH_FULL") or ROOT / "bench_full.json")
+    if not line.get("launch_check"):
+        try:
+            full_path.parent.mkdir(parents=True, exist_ok=True)
+            full_path.write_text(json.dumps(_clean(line, sig=0), allow_nan=False, indent=1) + "\n")
+            line = dict(line, full_record=str(full_path.relative_to(ROOT)) if full_path.is_relative_to(ROOT) else str(full_path))
+        except OSError as e:
+            print(f"bench.py: could not write {full_path}: {e}", file=sys.stderr)
+    text = json.dumps(compact_line(line), allow_nan=False)
+    assert len(text) <= LINE_LIMIT, len(text)
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
     sys.stdout.flush()
-    print(json.dumps(line), flush=True)
+    print(text, flush=True)
 
 
 def self_launch(args):
@@ -218,6 +333,8 @@ def cpu_baseline(shape_name, log_h, queries, pow_bits, seed, logup=False):
                 sample=f"{shape_name} AIR W={len(idx)} at 2^{log_h} rows ({cells} cells): oracle trace generation "
                        f"(single thread, like the reference's row loop) {t1 - t0:.2f}s + oracle prover{' with the LogUp phase' if logup else ''} "
                        f"(OpenMP, {cores} threads) {t2 - t1:.2f}s",
+                sample_short=f"{shape_name} W={len(idx)} at 2^{log_h} rows ({cells / 1e6:.1f} M cells): oracle tracegen 1 thread {t1 - t0:.1f} s + oracle "
+                             f"prover{' +LogUp' if logup else ''} OpenMP x{cores} {t2 - t1:.1f} s",
                 trace_gen_s=t1 - t0, prove_s=t2 - t1)
 
 
@@ -705,7 +822,9 @@ def main():
                    + (" [with the bus argument]" if args.logup else " [constraints-only proofs]"),
             value=rec["value"], unit="cells/s", n_gpus=max(1, args.gpus), steps=args.steps, warmup=args.warmup, ms_per_step=rec["ms_per_step"],
             higher_is_better=True, scaling="strong", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
-            config=dict(workload=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs ({rec['cells_per_segment']} cells each), one proof "
+            metric_short=f"STARK cells/sec (trace rows x cols), multi-segment {args.shape}" + (" [with the bus argument]" if args.logup else " [constraints-only]"),
+            config=dict(workload_short=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs, one proof per segment, {rec['workers']} in-process workers",
+                        workload=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs ({rec['cells_per_segment']} cells each), one proof "
                                  f"per segment, {rec['workers']} in-process workers on devices {rec['devices']} (pw_prove_segments_multi)",
                         parallelism=f"segments over {rec['workers']} host threads in one process (strong)", proof_bytes=rec["proof_bytes_per_segment"]),
             roofline=dict(bound="hbm", kernel="whole step", achieved=whole, peak=HBM_PEAK_GBS, unit="GB/s", frac=whole / HBM_PEAK_GBS, traffic=None,
@@ -723,7 +842,9 @@ def main():
                         value=rec["value"], unit="cells/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=rec["ms_per_step"],
                         higher_is_better=True, scaling="strong", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
                         rccl_ranks=comm_facts(world)["ranks"], comm=comm_facts(world), per_rank_ms=rec.get("per_rank_ms"),
-                        config=dict(workload=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs ({rec['cells_per_segment']} cells each, "
+                        metric_short=f"STARK cells/sec (trace rows x cols), multi-segment {args.shape}" + (" [with the bus argument]" if args.logup else " [constraints-only]"),
+                        config=dict(workload_short=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs, one proof per segment, sharded over {world} GPU(s) by cells",
+                                    workload=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs ({rec['cells_per_segment']} cells each, "
                                              f"heights 2^{rec['log_heights']}, widths {rec['widths']}), one proof per segment, segments sharded over "
                                              f"{world} GPU(s) by cells, main commitments all-gathered",
                                     parallelism=f"segments over {world} ranks (strong)", proof_bytes=rec["proof_bytes_per_segment"]),
@@ -764,8 +885,7 @@ def main():
         pr.specialise()
 
     def run_segment(w, with_logup):
-        for t in (w["per"].var_hist, w["per"].tuple_hist, w["per"].bitwise_hist):
-            t.zero_()
+        w["per"].zero()
         w["apc"].generate_witness_gpu(wl["instr_air"], wl["dummy"], wl["calls"], w["out"].data_ptr(), w["per"])
         proof = w["pr"].prove(w["out"].data_ptr(), log_h, copy=False)
         if world > 1:
@@ -1038,8 +1158,7 @@ def main():
 
                 def run_r(n):
                     for _ in range(n):
-                        for t_ in (wl["per"].var_hist, wl["per"].tuple_hist, wl["per"].bitwise_hist):
-                            t_.zero_()
+                        wl["per"].zero()
                         apc_r.generate_witness_from_records(rec.data_ptr(), calls, out2.data_ptr(), wl["per"])
                         r_last["proof"] = pr_r.prove(out2.data_ptr(), log_h, copy=False)
                         if world > 1:
@@ -1211,6 +1330,7 @@ def main():
         line = dict(
             metric="STARK cells/sec (trace rows x cols) proving guest-keccak" + (" [proof includes the AIR's bus interactions (LogUp); `constraints_only` = without them]"
                                                                                      if args.logup else " [constraints-only proof; `logup` = with the bus argument]"),
+            metric_short="STARK cells/sec (trace rows x cols) proving guest-keccak" + (" [bus interactions (LogUp) inside the proof]" if args.logup else " [constraints-only proof]"),
             value=value, unit="cells/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
@@ -1229,6 +1349,8 @@ def main():
                                  + (f"; {wl['calls']} APC calls, the remaining rows are zero padding" if wl["calls"] != wl["H"] else "")
                                  + "; one segment per step per GPU"
                                  + ("; source heights b*calls (not padded to a power of two)" if args.exact_source_heights else ""),
+                        workload_short=f"{args.shape} {shape.name} APC AIR {wl['W']} cols x 2^{log_h} rows, {len(wl['cons'][1])} constraints, {wl['apc'].n_bus} bus "
+                                       f"interactions; tracegen + proof" + (f" +LogUp ({perm_cols} perm cols)" if args.logup else " (constraints only)"),
                         rows=wl["H"], cols=wl["W"], perm_cols=perm_cols, parallelism=f"segments x{world}" + (f", {args.pipeline} streams per GPU" if args.pipeline > 1 else ""),
                         source_bytes=wl["src_bytes"], proof_bytes=proof_bytes, prover_device_bytes=prover_bytes,
                         caveat="proof system pw-stark v0 is this repository's own (oracle/stark_oracle.cpp); its Poseidon2 round constants are a "

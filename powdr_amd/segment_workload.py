@@ -219,8 +219,7 @@ class HonestSegment:
         """Trace generation of the whole segment: APC AIRs (gather + derived columns + bus replay), instruction AIRs (record
         expansion + replay of their lookups), periphery AIRs from the histograms every other AIR filled."""
         p = self.per
-        for t in (p.var_hist, p.tuple_hist, p.bitwise_hist):
-            t.zero_()
+        p.zero()  # on the library's launch stream: this runs on worker threads' streams too (pw_prove_segments_multi)
         for wl in self.apcs:
             wl["apc"].generate_witness_gpu(wl["instr_air"], wl["dummy"], wl["calls"], wl["out"].data_ptr(), p)
         oc.expand(self.records.data_ptr(), self.calls, self.table, self.instr_bufs)

@@ -11,6 +11,8 @@ from __future__ import annotations
 import ctypes as C
 from dataclasses import dataclass
 
+import contextlib
+
 import numpy as np
 import torch
 
@@ -58,6 +60,16 @@ class Periphery:
         z = lambda n: torch.zeros(n, dtype=torch.int32, device=device)
         return Periphery(var_bus, z(1 << (max_bits + 1)), tuple_bus, z(tuple_sizes[0] * tuple_sizes[1]),
                          tuple_sizes, bitwise_bus, z(2 * 65536))
+
+    def zero(self):
+        """Clear the three histograms ON THE LIBRARY'S LAUNCH STREAM of the calling thread (powdr_gpu_get_stream): the kernels that
+        accumulate into them are launched there, and a worker thread's stream (pw_prove_segments_multi: hipStreamNonBlocking) does not
+        synchronise with torch's current stream — a zero_() issued on torch's stream could land after multiplicities were added."""
+        s = abi.lib.powdr_gpu_get_stream()
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(int(s))) if s else contextlib.nullcontext()
+        with ctx:
+            for t in (self.var_hist, self.tuple_hist, self.bitwise_hist):
+                t.zero_()
 
 
 def apc_tracegen(output: DeviceMatrix, airs: list, subs: np.ndarray, num_calls: int):

@@ -10,14 +10,68 @@ ROOT = Path(__file__).resolve().parents[1]
 pytestmark = pytest.mark.gpu
 
 
-def run_bench(*extra):
-    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--log-height", "12", "--steps", "2", "--warmup", "1",
-                          "--cpu-log-height", "8", *extra], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    # ONE JSON line, and it is the last line (RCCL prints a version banner through C stdio when a communicator is created)
+LINE_LIMIT = 6000
+
+
+def _no_constants(name):
+    raise AssertionError(f"non-strict JSON constant {name} on the bench line")
+
+
+def check_line(stdout, full_path):
+    """The stdout contract: ONE JSON line, the last one (RCCL prints a version banner through C stdio when a communicator
+    is created), under LINE_LIMIT bytes, strict JSON (no NaN / Infinity), every string under 120 characters, the contract's fields
+    present — and equal (to the 6 digits the line keeps) to the full record written next to it, which is what the tests below read."""
+    lines = [l for l in stdout.splitlines() if l.strip()]
     assert len([l for l in lines if l.lstrip().startswith("{")]) == 1 and lines[-1].lstrip().startswith("{"), lines
-    return json.loads(lines[-1])
+    line = lines[-1]
+    assert len(line.encode()) < LINE_LIMIT, len(line)
+    c = json.loads(line, parse_constant=_no_constants)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+
+    def strings(x):
+        if isinstance(x, dict):
+            for v in x.values():
+                yield from strings(v)
+        elif isinstance(x, list):
+            for v in x:
+                yield from strings(v)
+        elif isinstance(x, str):
+            yield x
+
+    assert max(len(s_) for s_ in strings(c)) < 120
+    assert "workload" in c["config"] and "model" not in c["config"]
+    full = json.loads(Path(full_path).read_text(), parse_constant=_no_constants)
+    assert c["full_record"] and Path(c["full_record"]).name == Path(full_path).name
+    for k in ("value", "ms_per_step"):
+        assert abs(c[k] - full[k]) <= 1e-5 * abs(full[k])
+    for k in ("unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "data"):
+        assert c[k] == full[k]
+    if full.get("roofline"):
+        for k in ("bound", "kernel", "unit", "peak"):
+            assert c["roofline"][k] == full["roofline"][k]
+        assert abs(c["roofline"]["frac"] - full["roofline"]["frac"]) <= 1e-5 * full["roofline"]["frac"]
+        assert "traffic" in c["roofline"]
+    if full.get("cpu_baseline"):
+        assert c["cpu_baseline"]["kind"] == full["cpu_baseline"]["kind"] and c["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"]
+        assert c["cpu_baseline"]["sample"]
+    return c, full
+
+
+def run_bench(*extra, env=None, argv_prefix=None, base=("--log-height", "12", "--steps", "2", "--warmup", "1", "--cpu-log-height", "8"), timeout=900):
+    """Runs bench.py, checks the stdout line (check_line) and returns the FULL record of the run (bench_full.json, --full-out)."""
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        fp = Path(td) / "bench_full.json"
+        cmd = (argv_prefix or [sys.executable]) + [str(ROOT / "bench.py"), *base, "--full-out", str(fp), *extra]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        assert len(out.stderr) < 4000, out.stderr[-1000:]  # the driver's tail holds stdout AND stderr: nothing large may follow the line
+        c, full = check_line(out.stdout, fp)
+        full["_compact"] = c
+        return full
 
 
 def test_default_line_has_the_contract_fields():
@@ -109,13 +163,9 @@ def test_two_ranks_on_one_gpu_weak_and_strong_legs():
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
     env = dict(os.environ, POWDR_DIST_BACKEND="gloo")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--log-height", "12", "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    d = run_bench("--gpus", "2", "--no-cpu-baseline", env=env, base=("--log-height", "12", "--steps", "2", "--warmup", "1"),
+                  argv_prefix=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                               "--master-port", str(port)])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * d["config"]["rows"] * d["config"]["cols"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     ms = d["multi_segment"]
@@ -129,12 +179,9 @@ def test_plain_command_with_gpus_2_produces_a_two_rank_line():
     times, the weak C2 value AND the strong multi-segment value in one record."""
     import os
 
-    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--log-height", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, POWDR_DIST_BACKEND="gloo"))
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    d = run_bench("--gpus", "2", "--no-cpu-baseline", env=dict(os.environ, POWDR_DIST_BACKEND="gloo"), base=("--log-height", "12", "--steps", "2", "--warmup", "1"))
+    c = d["_compact"]
+    assert c["n_gpus"] == 2 and c["rccl_ranks"] == 2 and len(c["per_rank_ms"]) == 2 and c["strong_scaling_value"] > 0 and c["multi_segment"]["value"] > 0
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["comm"]["launch"] == "self" and d["comm"]["backend"] == "gloo"
     assert len(d["per_rank_ms"]) == 2 and abs(max(d["per_rank_ms"]) - d["ms_per_step"]) < 1e-6 * d["ms_per_step"]
     assert d["scaling"] == "weak" and d["strong_scaling_value"] == d["multi_segment"]["value"] > 0
