@@ -881,6 +881,21 @@ int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t
     return (int)hipGetLastError();
 }
 
+// Coefficient arrays as intt_dif leaves them (bit-reversed, H-scaled) back to the values on <g_n>, natural order, canonical words: the
+// forward network of subcoset_lde with the trivial coset (every stage constant 1) and the single "fold" factor 1/H. In place or not.
+int values_from_coefficients(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, uint32_t* d_scratch) {
+    if (n < 1 || n > 26) return (int)hipErrorInvalidValue;
+    CosetSpec cs{};
+    cs.fold_log = 0;
+    cs.d_scratch = d_scratch;
+    for (int s = 0; s < 32; ++s) cs.C[s] = bb::R_MOD_P;
+    cs.foldk[0] = bb::inv(bb::to_monty((uint32_t)(((uint64_t)1 << n) % bb::P)));
+    const Tables* tn = tables(n);
+    if (!tn) return (int)hipErrorOutOfMemory;
+    run_groups<false>(coeffs, out, in_stride, out_stride, cols, n, 0, tn->tw_fwd, nullptr, "ntt_group_kernel<dit>", &cs);
+    return (int)hipGetLastError();
+}
+
 // Only the first stage group of subcoset_lde (the contiguous stages, with the FOLD loads): `out` holds the PARTIAL transform,
 // *stages_done stages of log2 m. subcoset_rows finishes it for chosen rows.
 int subcoset_lde_first_group(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, uint32_t r,

@@ -262,7 +262,10 @@ struct BufferPlan {
     size_t total() const { return commit_total() + perm + plde + q + qpart + qcoef + qlde + ext_arena + misc + gbuf; }
 };
 
-void plan_buffers(const PwProver* p, uint32_t log_h, int b, CommitLayout& L, BufferPlan& B) {
+// consume: the caller hands its trace over (pw_prover_prove_consuming) — a streamed proof then keeps the trace's coefficient arrays IN
+// the caller's buffer (no tcoef); with LogUp the permutation matrix is computed into `lde` first (its evaluations are only needed until
+// its coefficients exist), while `perm` lends its room to the trace's coefficients until the trace itself is dead.
+void plan_buffers(const PwProver* p, uint32_t log_h, int b, CommitLayout& L, BufferPlan& B, bool consume = false) {
     L.H = (size_t)1 << log_h;
     L.N = 2 * L.H;
     L.b = b;
@@ -307,6 +310,13 @@ void plan_buffers(const PwProver* p, uint32_t log_h, int b, CommitLayout& L, Buf
     }
     if (b) B.qpart += 4 * L.m * 4;  // the interpreter kernels' unscaled sums of one sub-coset
     B.qpart = std::max(B.qpart, jit_part_bytes(p, H, q_rows));
+    if (b && consume) {
+        B.tcoef = 0;
+        if (lg) {
+            B.perm = std::max(B.perm, (size_t)W * H * 4);
+            B.lde = std::max(B.lde, (size_t)(Wp + kJitExtraPermCols) * H * 4);
+        }
+    }
     B.qcoef = 8 * H * 4;
     B.qlde = 8 * N * 4;
     // ext arena: FRI layer vectors v_0 (N) .. v_log_h (2): 2N ext; weights (H); LogUp: second weights, row sums
@@ -321,7 +331,7 @@ void plan_buffers(const PwProver* p, uint32_t log_h, int b, CommitLayout& L, Buf
 }
 
 // 0 = resident, b >= 1 = streamed over 2^b sub-cosets; < 0: nothing fits
-int stream_log_blocks(const PwProver* p, uint32_t log_h) {
+int stream_log_blocks(const PwProver* p, uint32_t log_h, bool consume = false) {
     const int b_max = std::min((int)log_h - 1, 5);  // sub-cosets of at least 4 rows; at most 32 of them (subcoset_lde)
     if (const char* e = getenv("POWDR_STREAM_LOG_BLOCKS")) {
         const int v = atoi(e);
@@ -343,7 +353,7 @@ int stream_log_blocks(const PwProver* p, uint32_t log_h) {
     for (int b = 0; b <= b_max; ++b) {
         CommitLayout L;
         BufferPlan B;
-        plan_buffers(p, log_h, b, L, B);
+        plan_buffers(p, log_h, b, L, B, consume);
         if (B.total() <= avail) return b;
     }
     return -1;
@@ -353,7 +363,9 @@ int apply_commit_buffers(PwProver* p, const BufferPlan& B) {
     TRY(p->coef.ensure(B.coef));
     TRY(p->lde.ensure(B.lde));
     TRY(p->digests.ensure(B.digests));
-    if (B.tcoef) { TRY(p->tcoef.ensure(B.tcoef)); TRY(p->fscale.ensure(B.fscale)); }
+    if (B.tcoef) TRY(p->tcoef.ensure(B.tcoef));
+    else p->tcoef.release();  // (a consuming proof after a plain one: the room is needed)
+    if (B.fscale) TRY(p->fscale.ensure(B.fscale));
     return 0;
 }
 
@@ -395,9 +407,9 @@ int commit_trace(PwProver* p, const CommitLayout& L, const uint32_t* d_trace, ui
 
 // Every device buffer a proof of a 2^log_h-row trace needs (grown on demand; pw_prover_reserve calls this at set-up
 // time so that the first proof does not pay for tens of gigabytes of hipMalloc).
-int ensure_prove_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L) {
+int ensure_prove_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L, bool consume = false) {
     BufferPlan B;
-    plan_buffers(p, log_h, b, L, B);
+    plan_buffers(p, log_h, b, L, B, consume);
     TRY(apply_commit_buffers(p, B));
     if (B.perm) { TRY(p->perm.ensure(B.perm)); TRY(p->plde.ensure(B.plde)); }
     TRY(p->q.ensure(B.q));
@@ -517,8 +529,10 @@ extern "C" size_t pw_prover_device_bytes(const PwProver* p) {
 }
 
 
-extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t log_h, const uint32_t** proof_words,
-                               size_t* n_words) {
+namespace {
+// consume: pw_prover_prove_consuming — d_trace is the caller's to give away. Only a STREAMED proof uses that: the coefficient arrays
+// of the trace end up in d_trace itself (no tcoef buffer: 62.6 GB at configs[2], which is what lets it run on 2 sub-cosets instead of 4).
+int prove_impl(PwProver* p, const uint32_t* d_trace, uint32_t log_h, const uint32_t** proof_words, size_t* n_words, bool consume) {
     if (!p || !d_trace || log_h < 1 || log_h > 26) return -1;
     (void)hipGetLastError();
     const uint32_t W = p->width, nc = p->n_constraints;
@@ -538,15 +552,18 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
 
     // ---- buffers --------------------------------------------------------------------------
     // digest arena: trace tree | quotient tree | (perm tree) | FRI trees
-    const bool have_commitment = p->committed_trace == d_trace && p->committed_log_h == log_h;
+    // (a consuming proof commits in its own way: a pw_prover_trace_root before it is not reused)
+    const bool have_commitment = !consume && p->committed_trace == d_trace && p->committed_log_h == log_h;
     p->committed_trace = nullptr;  // one-shot
     // resident LDE, or streamed over 2^sb sub-cosets of the extended domain ("streamed proofs" above)
-    const int sb = have_commitment ? p->committed_b : stream_log_blocks(p, log_h);
+    const int sb = have_commitment ? p->committed_b : stream_log_blocks(p, log_h, consume);
     if (sb < 0) return (int)hipErrorOutOfMemory;
+    const bool eat = consume && sb > 0;  // the trace is overwritten by its coefficient arrays
     CommitLayout L;
-    TRY(ensure_prove_buffers(p, log_h, sb, L));
+    TRY(ensure_prove_buffers(p, log_h, sb, L, eat));
     const size_t tree_words = L.tree_words, n_trees = L.n_trees;
-    uint32_t* d_tcoef = p->tcoef.as<uint32_t>();              // streamed: the trace's coefficient arrays
+    // streamed: the trace's coefficient arrays — in tcoef, or (eat) in the caller's buffer, from the moment nothing reads the trace any more
+    uint32_t* d_tcoef = eat ? const_cast<uint32_t*>(d_trace) : p->tcoef.as<uint32_t>();
     const uint32_t n_chunks = div_up(H, 8192);
     const uint32_t dot_cols = std::max({W, Wp, 8u});  // widest matrix ext_dot_columns sees (the quotient has 8 columns)
     const uint32_t nq = p->cfg.num_queries;
@@ -588,8 +605,16 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
 
     // ---- 1. trace: coefficients, LDE, commitment ---------------------------------------------
     uint32_t root[8];
+    // eat + LogUp: the permutation columns are computed from the trace's VALUES after this commitment, so the coefficients go to the
+    // (still empty) permutation buffer first; eat without LogUp: nothing reads the values again — in place.
+    uint32_t* d_coef_tmp = eat ? (lg ? p->perm.as<uint32_t>() : d_tcoef) : nullptr;
     if (have_commitment) memcpy(root, p->committed_root, 32);  // pw_prover_trace_root already did this step
-    else TRY(commit_trace(p, L, d_trace, log_h, root));
+    else if (eat) {
+        TRY(intt_dif(d_trace, d_coef_tmp, H, H, W, (int)log_h));
+        TRY(commit_coefficients(p, L, log_h, d_coef_tmp, W, p->digests.as<uint32_t>()));
+        PW_HIP_TRY(hipMemcpyAsync(root, p->digests.as<uint32_t>() + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
+        PW_HIP_TRY(hipStreamSynchronize(st));
+    } else TRY(commit_trace(p, L, d_trace, log_h, root));
     put_monty(root, 8);
     ch.observe_words(root, 8);
 
@@ -612,24 +637,30 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         { bb::Ext b = bb::ext_one(); for (auto& x : blpow) { x = b; b = bb::ext_mul(b, bl); } }
         PW_HIP_TRY(hipMemcpyAsync(d_blpow, blpow.data(), blpow.size() * sizeof(bb::Ext), hipMemcpyHostToDevice, st));
         PW_HIP_TRY(hipStreamSynchronize(st));
-        if (jit) TRY(logup_perm_trace_jit(p, d_trace, H, al, d_blpow, d_perm, d_rowsum, d_rowsum + H));
-        else TRY(logup_perm_trace(d_trace, H, lp, al, d_blpow, d_perm, d_rowsum, d_rowsum + H));
+        // eat: the matrix's VALUES live in the sub-coset buffer (idle between two passes) until its coefficient arrays exist
+        uint32_t* d_pval = eat ? d_lde : d_perm;
+        if (jit) TRY(logup_perm_trace_jit(p, d_trace, H, al, d_blpow, d_pval, d_rowsum, d_rowsum + H));
+        else TRY(logup_perm_trace(d_trace, H, lp, al, d_blpow, d_pval, d_rowsum, d_rowsum + H));
         if (!sb) {
             TRY(lde_matrix(p, L, log_h, d_perm, Wp + (jit ? kJitExtraPermCols : 0u), d_plde));
             TRY(merkle_commit_matrix(d_plde, N, Wp, N, d_pdig));
         } else {
             // streamed: only phi and the per-row sums (the boundary terms read them at rows j and j + 2) are extended for good
-            if (!jit) TRY(ext_to_cols(d_rowsum, H, d_perm + (size_t)(4 * n_g + 4) * H));
-            TRY(lde_matrix(p, L, log_h, d_perm + (size_t)(4 * n_g) * H, 8, d_plde));
+            if (!jit) TRY(ext_to_cols(d_rowsum, H, d_pval + (size_t)(4 * n_g + 4) * H));
+            TRY(lde_matrix(p, L, log_h, d_pval + (size_t)(4 * n_g) * H, 8, d_plde));
         }
         uint32_t sw[4];
         PW_HIP_TRY(hipMemcpyAsync(root, d_pdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
         for (int k = 0; k < 4; ++k)  // S = phi(last row)
-            PW_HIP_TRY(hipMemcpyAsync(&sw[k], d_perm + ((size_t)(4 * n_g + k) * H + (H - 1)), 4, hipMemcpyDeviceToHost, st));
+            PW_HIP_TRY(hipMemcpyAsync(&sw[k], d_pval + ((size_t)(4 * n_g + k) * H + (H - 1)), 4, hipMemcpyDeviceToHost, st));
         if (sb) {
             // (S is read from the matrix first:) the permutation matrix becomes its coefficient arrays in place, committed sub-coset by sub-coset
             PW_HIP_TRY(hipStreamSynchronize(st));
-            TRY(intt_dif(d_perm, d_perm, H, H, Wp, (int)log_h));
+            if (eat) {
+                // the trace's values are dead now: its coefficient arrays move into its place, the permutation buffer takes the matrix's
+                PW_HIP_TRY(hipMemcpyAsync(d_tcoef, d_coef_tmp, (size_t)W * H * 4, hipMemcpyDeviceToDevice, st));
+                TRY(intt_dif(d_pval, d_perm, H, H, Wp, (int)log_h));
+            } else TRY(intt_dif(d_perm, d_perm, H, H, Wp, (int)log_h));
             TRY(commit_coefficients(p, L, log_h, d_perm, Wp, d_pdig));
             PW_HIP_TRY(hipMemcpyAsync(root, d_pdig + tree_words - 8, 32, hipMemcpyDeviceToHost, st));
         }
@@ -710,14 +741,20 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
         }
         return 0;
     };
-    TRY(barycentric_weights(zeta, (int)log_h, d_weights));
-    TRY(ext_dot_columns(d_trace, H, W, H, d_weights, d_open, d_scratch));
-    TRY(mark());
+    if (!eat) {
+        TRY(barycentric_weights(zeta, (int)log_h, d_weights));
+        TRY(ext_dot_columns(d_trace, H, W, H, d_weights, d_open, d_scratch));
+        TRY(mark());
+    }
     if (lg && !sb) {
         TRY(barycentric_weights(gzeta, (int)log_h, d_weights2));
         TRY(open_perm());
     }
     TRY(zeta_weights(zeta, (int)log_h, d_weights));
+    if (eat) {  // the trace is its coefficient arrays by now: opened like the permutation matrix below
+        TRY(ext_dot_columns(d_tcoef, H, W, H, d_weights, d_open, d_scratch));
+        TRY(mark());
+    }
     if (lg && sb) {  // streamed: d_perm holds the matrix's coefficient arrays
         TRY(zeta_weights(gzeta, (int)log_h, d_weights2));
         TRY(open_perm());
@@ -915,6 +952,31 @@ extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t lo
     }
     *proof_words = pf.data();
     *n_words = pf.size();
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t log_h, const uint32_t** proof_words, size_t* n_words) {
+    return prove_impl(p, d_trace, log_h, proof_words, n_words, false);
+}
+
+// The caller hands the trace over (the reference moves `common_main` into the engine: openvm/src/powdr_extension/trace_generator/
+// cuda/mod.rs:415-419). Same proof words. A resident proof leaves the trace as it was; a streamed one leaves its H-scaled coefficient
+// arrays in bit-reversed order there (pw_trace_from_coefficients turns them back into the trace).
+extern "C" int pw_prover_prove_consuming(PwProver* p, uint32_t* d_trace, uint32_t log_h, const uint32_t** proof_words, size_t* n_words) {
+    return prove_impl(p, d_trace, log_h, proof_words, n_words, true);
+}
+
+extern "C" int pw_prover_stream_log_blocks_consuming(const PwProver* p, uint32_t log_h) {
+    if (!p || log_h < 1 || log_h > 26) return -1;
+    return stream_log_blocks(p, log_h, true);
+}
+
+// the inverse of what a streamed consuming proof did to the caller's buffer: coefficient arrays (H-scaled, bit-reversed) -> values on <g_n>
+extern "C" int pw_trace_from_coefficients(uint32_t* d_coeffs, uint32_t width, uint32_t log_h, uint32_t* d_scratch8k) {
+    (void)hipGetLastError();
+    if (!d_coeffs || !d_scratch8k || !width || log_h < 1 || log_h > 26) return -1;
+    TRY(values_from_coefficients(d_coeffs, d_coeffs, (size_t)1 << log_h, (size_t)1 << log_h, width, (int)log_h, d_scratch8k));
     return (int)hipGetLastError();
 }
 

@@ -37,6 +37,8 @@ int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t
 // A FEW rows of a sub-coset (the query phase): only the first stage group of the transform (the contiguous stages; *stages_done of
 // log2 m) into `out`, then subcoset_rows finishes the remaining stages for the rows d_local_idx[q] alone — a 2^(log2 m - stages_done)-term
 // sum per (row, column) instead of the strided stage groups over every row. rows_out[q * cols + c], canonical Montgomery words.
+// the values on <g_n> (natural order, canonical) from coefficient arrays as intt_dif leaves them; d_scratch: >= 2^13 words
+int values_from_coefficients(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, uint32_t* d_scratch);
 int subcoset_lde_first_group(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, uint32_t r,
                              uint32_t* d_scratch, int* stages_done);
 int subcoset_rows(const uint32_t* part, size_t stride, uint32_t cols, int n, int b, uint32_t r, int stages_done, const uint32_t* d_local_idx,
