@@ -162,7 +162,7 @@ def compact_line(full: dict) -> dict:
             out[key] = _pick(full[key], "value", "ms_per_step", "error")
     c3 = full.get("c3")
     if c3:
-        out["c3"] = _pick(c3, "value", "prove_ms", "trace_gen_ms", "verify_rc", "logup", "cells", "committed_columns", "stream_log_blocks", "skipped", "error")
+        out["c3"] = _pick(c3, "value", "prove_ms", "trace_gen_ms", "verify_rc", "logup", "cells", "committed_columns", "stream_log_blocks", "trace_handed_over", "skipped", "error")
     ms = full.get("multi_segment")
     if ms:
         m = _pick(ms, "value", "ms_per_step", "verify_rc", "n_segments", "distinct_segments", "constraint_violations", "error")
@@ -632,18 +632,34 @@ def c3_leg(queries, pow_bits, steps=2, constraints_only_too=True, segment_too=Tr
             out[k] = e
         return out
 
-    def run(pr, n, verify):
-        pr.prove(wl["out"].data_ptr(), log_h, copy=False)  # warm-up: allocation of the prover's buffers
+    def run(pr, n, verify, consume=False):
+        """1 warm-up + n timed proofs. consume: pw_prover_prove_consuming — the trace is handed over, as the reference hands `common_main`
+        to its engine (cuda/mod.rs:415-419); a streamed proof leaves the trace's coefficient arrays in its place, and the trace is
+        restored from them (pw_trace_from_coefficients, exact) OUTSIDE the timed region before the next proof."""
+        ptr = wl["out"].data_ptr()
+        eaten = consume and pr.stream_log_blocks_consuming(log_h) > 0
+
+        def restore():
+            if eaten:
+                prover.trace_from_coefficients(ptr, W, log_h)
+
+        pr.prove(ptr, log_h, copy=False, consume=consume)  # warm-up: allocation of the prover's buffers
         torch.cuda.synchronize()
-        abi.lib.powdr_gpu_timing_enable(1)
-        t2 = time.perf_counter()
+        restore()
+        timing, t_total, proof = {}, 0.0, None
         for _ in range(n):
-            proof = pr.prove(wl["out"].data_ptr(), log_h)
-        torch.cuda.synchronize()
-        t_prove = (time.perf_counter() - t2) / n
-        timing = abi.timing_report()
-        abi.lib.powdr_gpu_timing_enable(0)
-        return t_prove, timing, proof, verify(proof)
+            torch.cuda.synchronize()
+            abi.lib.powdr_gpu_timing_enable(1)
+            t2 = time.perf_counter()
+            proof = pr.prove(ptr, log_h, consume=consume)
+            torch.cuda.synchronize()
+            t_total += time.perf_counter() - t2
+            for k, (cnt, ms) in abi.timing_report().items():
+                c0, m0 = timing.get(k, (0, 0.0))
+                timing[k] = (c0 + cnt, m0 + ms)
+            abi.lib.powdr_gpu_timing_enable(0)
+            restore()
+        return t_total / n, timing, proof, verify(proof)
 
     # ---- the proof with the bus argument (streamed) ----
     it = wl["apc"].compile_bus(1)
@@ -652,8 +668,12 @@ def c3_leg(queries, pow_bits, steps=2, constraints_only_too=True, segment_too=Tr
     t0 = time.perf_counter()
     pr.specialise()
     t_spec = time.perf_counter() - t0
-    mode = pr.stream_log_blocks(log_h)
-    t_prove, timing, proof, rc = run(pr, steps, lambda pf: prover.verify_logup(pf, W, log_h, *wl["cons"], it, num_queries=queries, pow_bits=pow_bits)[0])
+    consume = not os.environ.get("POWDR_BENCH_C3_KEEP_TRACE")
+    checksum0 = int(wl["out"].view(torch.int64).sum().item())
+    t_prove, timing, proof, rc = run(pr, steps, lambda pf: prover.verify_logup(pf, W, log_h, *wl["cons"], it, num_queries=queries, pow_bits=pow_bits)[0],
+                                     consume=consume)
+    mode = pr.stream_log_blocks_consuming(log_h) if consume else pr.stream_log_blocks(log_h)
+    trace_restored = int(wl["out"].view(torch.int64).sum().item()) == checksum0
     step_s = t_prove + t_gen
     rho = perm_cols / W
     bpc = 48.0 + 4.0 + 44.0 * rho
@@ -661,7 +681,7 @@ def c3_leg(queries, pow_bits, steps=2, constraints_only_too=True, segment_too=Tr
                         f"INSIDE the proof ({perm_cols} permutation columns), dense synthetic sources ({src_bytes / 1e9:.1f} GB, released after trace generation)",
                logup=True, cells=cells, steps=steps, warmup=1, trace_gen_ms=t_gen * 1e3, prove_ms=t_prove * 1e3, value=cells / step_s, unit="cells/s",
                cells_per_s_prove_only=cells / t_prove, verify_rc=int(rc), specialised_kernels=pr.specialised(), specialise_s=t_spec,
-               stream_log_blocks=mode,
+               stream_log_blocks=mode, trace_handed_over=bool(consume), trace_restored_between_proofs=bool(trace_restored),
                mode=(f"streamed: coefficient arrays resident, extended domain walked as {1 << mode} sub-cosets per pass (commit main, commit perm, quotient, queries)"
                      if mode > 0 else "resident LDE"),
                committed_columns=W + perm_cols + 8, trace_bytes=cells * 4, prover_device_bytes=pr.device_bytes(),

@@ -71,6 +71,22 @@ void pw_prover_destroy(PwProver* p);
 int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t log_height, const uint32_t** proof_words,
                     size_t* n_words);
 
+/* The same proof (the same words) of a trace the caller HANDS OVER — what the reference does with `common_main`: the
+ * trace generator moves the matrix into the AirProvingContext and the engine owns it from there
+ * (/root/reference/openvm/src/powdr_extension/trace_generator/cuda/mod.rs:404-421). The prover may then overwrite
+ * d_trace: when the low-degree extension is resident it does not; when the proof is STREAMED (pw_prover_stream_log_blocks)
+ * the trace's coefficient arrays replace the trace in place instead of living in a buffer of their own — at BASELINE
+ * configs[2] (3 731 x 2^22 + 4 632 permutation columns) that is 62.6 GB, the difference between walking the extended
+ * domain as 4 sub-cosets and as 2 (half the coefficient re-reads of every pass). Afterwards d_trace holds, per column,
+ * H * (the coefficients) in bit-reversed order; pw_trace_from_coefficients turns that back into the trace (exact).
+ * pw_prover_stream_log_blocks_consuming: the mode such a proof would run in with the memory free now. */
+int pw_prover_prove_consuming(PwProver* p, uint32_t* d_trace, uint32_t log_height, const uint32_t** proof_words,
+                              size_t* n_words);
+int pw_prover_stream_log_blocks_consuming(const PwProver* p, uint32_t log_height);
+/* In place: width columns of 2^log_height H-scaled bit-reversed coefficients (what a streamed pw_prover_prove_consuming
+ * leaves) -> the values on the trace domain, natural row order, canonical Montgomery words. d_scratch: 2^13 words. */
+int pw_trace_from_coefficients(uint32_t* d_coeffs, uint32_t width, uint32_t log_height, uint32_t* d_scratch);
+
 /* "Mock prover": evaluate every constraint on every row of the trace on the device and report violations —
  * the counterpart of the reference's `debug_proving_ctx` used by its `prove_mock` tests
  * (openvm-riscv/src/lib.rs:288-294). *n_violations = number of (row, constraint) pairs that are non-zero;

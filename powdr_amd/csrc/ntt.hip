@@ -644,7 +644,8 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
         }
         for (uint32_t c0 = 0; c0 < cols; c0 += 65535u) {
             uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;
-            ScopedKernelTimer t(name);
+            // (the sub-coset transforms' first group — FOLD loads, the sub-coset's own twiddle table — has a timer of its own)
+            ScopedKernelTimer t(mode == 2 ? "ntt_subcoset_first_group_kernel" : name);
             const uint32_t* s_ = src + (size_t)c0 * src_stride;
             uint32_t* d_ = out + (size_t)c0 * out_stride;
             dim3 grid(wgs, cc), block(kBlock);

@@ -14,7 +14,7 @@ class PwStarkConfig(C.Structure):
     _fields_ = [("num_queries", C.c_uint32), ("pow_bits", C.c_uint32)]
 
 
-PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_logup_path", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_stream_log_blocks", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_device_bytes",
+PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_logup_path", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_stream_log_blocks", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_prove_consuming", "pw_prover_stream_log_blocks_consuming", "pw_trace_from_coefficients", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_lde_fused", "pw_lde_subcoset", "pw_merkle_commit", "pw_poseidon2_permute_host",
                   "pw_set_poseidon2_constants", "pw_get_poseidon2_constants", "pw_prover_specialise", "pw_prover_specialised", "pw_jit_compile_check", "pw_jit_cache_stats", "pw_jit_generated_source",
                   "pw_prove_segments_multi", "pw_multi_last_merge", "pw_assign_units"]
@@ -36,6 +36,12 @@ lib.pw_lde_batch.restype = C.c_int
 lib.pw_lde_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
 lib.pw_lde_fused.restype = C.c_int
 lib.pw_lde_fused.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+lib.pw_prover_prove_consuming.restype = C.c_int
+lib.pw_prover_prove_consuming.argtypes = lib.pw_prover_prove.argtypes
+lib.pw_prover_stream_log_blocks_consuming.restype = C.c_int
+lib.pw_prover_stream_log_blocks_consuming.argtypes = [C.c_void_p, C.c_uint32]
+lib.pw_trace_from_coefficients.restype = C.c_int
+lib.pw_trace_from_coefficients.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
 lib.pw_lde_subcoset.restype = C.c_int
 lib.pw_lde_subcoset.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
 lib.pw_merkle_commit.restype = C.c_int
@@ -395,11 +401,14 @@ class Prover:
         if not self._h:
             raise RuntimeError("pw_prover_create failed")
 
-    def prove(self, d_trace_ptr: int, log_height: int, copy: bool = True) -> np.ndarray:
+    def prove(self, d_trace_ptr: int, log_height: int, copy: bool = True, consume: bool = False) -> np.ndarray:
+        """pw_prover_prove; consume=True: pw_prover_prove_consuming — the trace is handed over (a streamed proof leaves its
+        coefficient arrays there: trace_from_coefficients restores it)."""
         words = C.POINTER(C.c_uint32)()
         n = C.c_size_t()
-        rc = lib.pw_prover_prove(self._h, d_trace_ptr, log_height, C.byref(words), C.byref(n))
-        abi.check(rc, "pw_prover_prove")
+        fn = lib.pw_prover_prove_consuming if consume else lib.pw_prover_prove
+        rc = fn(self._h, d_trace_ptr, log_height, C.byref(words), C.byref(n))
+        abi.check(rc, "pw_prover_prove_consuming" if consume else "pw_prover_prove")
         a = np.ctypeslib.as_array(words, shape=(n.value,))
         return a.copy() if copy else a
 
@@ -433,6 +442,10 @@ class Prover:
         lib.pw_prover_stream_log_blocks.restype = C.c_int
         lib.pw_prover_stream_log_blocks.argtypes = [C.c_void_p, C.c_uint32]
         return int(lib.pw_prover_stream_log_blocks(self._h, log_height))
+
+    def stream_log_blocks_consuming(self, log_height: int) -> int:
+        """the same for prove(..., consume=True): the trace's coefficients need no buffer of their own"""
+        return int(lib.pw_prover_stream_log_blocks_consuming(self._h, log_height))
 
     def specialise(self) -> bool:
         """pw_prover_specialise: compile the run-time specialised kernels now. True if the prover has them."""
@@ -470,3 +483,12 @@ class Prover:
             self.close()
         except Exception:
             pass
+
+
+def trace_from_coefficients(d_ptr: int, width: int, log_height: int) -> None:
+    """pw_trace_from_coefficients, in place: what a streamed consuming proof left in the caller's trace buffer -> the trace."""
+    import torch
+
+    scratch = torch.empty(1 << 13, dtype=torch.int32, device="cuda")
+    abi.check(lib.pw_trace_from_coefficients(d_ptr, width, log_height, scratch.data_ptr()), "pw_trace_from_coefficients")
+    torch.cuda.synchronize()  # (the scratch goes out of scope)

@@ -244,3 +244,81 @@ def test_streamed_airs_of_a_segment_share_a_bus_seed_and_balance(gpu, monkeypatc
     descs = [(w, lh, *c, it) for (_, w, c, it, lh) in airs]
     rc, total = prover.verify_airs(descs, proofs[2], num_queries=7, shared_bus_seed=True, check_balance=True)
     assert rc == 0 and (total == 0).all()
+
+
+# ---- the trace handed over (pw_prover_prove_consuming, VERDICT r4 #2b) -------------------------------------------------------------
+def _prove_consuming(torch, prover, monkeypatch, flat, W, log_h, bc, spans, it, nq, pow_bits, log_blocks, jit):
+    """One consuming proof on a fresh copy of the trace; returns (words, what is left in the buffer, the buffer restored, state)."""
+    monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", str(log_blocks))
+    monkeypatch.setenv("POWDR_JIT", "1" if jit else "0")
+    pr = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits, interactions=it)
+    assert pr.stream_log_blocks_consuming(log_h) == min(log_blocks, max(log_h - 1, 0))
+    streamed = pr.stream_log_blocks_consuming(log_h) > 0  # (a resident proof leaves the trace alone)
+    d_t = to_dev(torch, flat)
+    got = pr.prove(d_t.data_ptr(), log_h, consume=True)
+    torch.cuda.synchronize()
+    left = d_t.clone()
+    if streamed:
+        prover.trace_from_coefficients(d_t.data_ptr(), W, log_h)
+    again = pr.prove(d_t.data_ptr(), log_h, consume=True)  # buffer reuse, on the restored trace
+    assert (got == again).all()
+    # a plain proof on the same prover afterwards (its tcoef buffer comes back): same words
+    if streamed:
+        prover.trace_from_coefficients(d_t.data_ptr(), W, log_h)
+    plain = pr.prove(d_t.data_ptr(), log_h)
+    assert (got == plain).all()
+    state = pr.specialised()["state"]
+    pr.close()
+    return got, left, d_t, state
+
+
+@pytest.mark.parametrize("shape,calls,nq,pow_bits", [("T0", 7, 4, 0), ("T1", 100, 6, 0), ("T1", 1000, 8, 3), ("T1", 5000, 10, 0)])
+@pytest.mark.parametrize("logup", [False, True])
+def test_consuming_proof_words_equal_the_oracle(gpu, monkeypatch, shape, calls, nq, pow_bits, logup):
+    """The caller hands its trace over: streamed, the trace's coefficient arrays end up IN the caller's buffer (no tcoef), with LogUp
+    via the permutation buffer while the permutation columns are computed from the trace's values. Same words as the oracle for 2, 4
+    and 8 sub-cosets, interpreter and specialised kernels; what is left in the buffer is the H-scaled bit-reversed coefficient arrays,
+    and pw_trace_from_coefficients turns it back into the trace exactly. Resident (0 sub-cosets): the trace is left alone."""
+    torch, abi, prover = gpu
+    flat, W, log_h, bc, spans, it = _synthetic(shape, calls, seed=21)
+    want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=nq, pow_bits=pow_bits) if logup else \
+        sm.prove(flat, W, log_h, bc, spans, num_queries=nq, pow_bits=pow_bits)
+    H = 1 << log_h
+    d_ref = to_dev(torch, flat)
+    d_c = torch.empty(W * H, dtype=torch.int32, device="cuda")
+    d_l = torch.empty(W * 2 * H, dtype=torch.int32, device="cuda")
+    abi.check(prover.lib.pw_lde_batch(d_ref.data_ptr(), W, log_h, d_c.data_ptr(), d_l.data_ptr()), "pw_lde_batch")
+    torch.cuda.synchronize()
+    for log_blocks in (0, 1, 2, 3):
+        for jit in (False, True):
+            got, left, restored, state = _prove_consuming(torch, prover, monkeypatch, flat, W, log_h, bc, spans, it if logup else None, nq, pow_bits,
+                                                          log_blocks, jit)
+            assert len(got) == len(want) and (got == want).all(), \
+                f"blocks 2^{log_blocks} jit={jit}: first differing word {int(np.argmax(got != want))} of {len(want)}"
+            streamed = min(log_blocks, max(log_h - 1, 0)) > 0
+            assert torch.equal(left, d_c if streamed else d_ref)
+            assert torch.equal(restored, d_ref)
+
+
+@pytest.mark.parametrize("shape,log_h,log_blocks,jit", [("C3", 12, 1, True), ("C3", 12, 2, False), ("C2", 14, 1, True)])
+def test_baseline_shapes_consuming_with_logup(gpu, monkeypatch, shape, log_h, log_blocks, jit):
+    """configs[2]'s mode of round 5 — the C3 shape with its 2 314 interactions, trace handed over, TWO sub-cosets, specialised
+    kernels with permutation panels — at 2^12 rows against sm.prove_logup; both verifiers accept."""
+    torch, abi, prover = gpu
+    flat, W, lh, bc, spans, it = _synthetic(shape, (1 << log_h) - 5, seed=0)
+    want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=6, pow_bits=4)
+    got, left, restored, state = _prove_consuming(torch, prover, monkeypatch, flat, W, log_h, bc, spans, it, 6, 4, log_blocks, jit)
+    assert (state == 1) if jit else (state in (0, -1))
+    assert len(got) == len(want) and (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
+    assert torch.equal(restored, to_dev(torch, flat))
+    assert prover.verify_logup(got, W, log_h, bc, spans, it, num_queries=6, pow_bits=4)[0] == 0
+    assert sm.verify_logup(got, W, log_h, bc, spans, *it, num_queries=6, pow_bits=4) == 0
+
+
+def test_consuming_tall_trace(gpu, monkeypatch):
+    """2^16 rows (strided stage groups in the restore transform and the sub-coset transforms), 2 sub-cosets, LogUp."""
+    torch, abi, prover = gpu
+    flat, W, log_h, bc, spans, it = _synthetic("T1", 40000, seed=3)
+    want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=12, pow_bits=0)
+    got, left, restored, _ = _prove_consuming(torch, prover, monkeypatch, flat, W, log_h, bc, spans, it, 12, 0, 1, True)
+    assert (got == want).all() and torch.equal(restored, to_dev(torch, flat))
