@@ -178,6 +178,8 @@ def compact_line(full: dict) -> dict:
         out["gauges"] = {k: v for k, v in full["gauges"].items() if k != "note"}
     if full.get("comm"):
         out["comm"] = _pick(full["comm"], "backend", "launch", "ranks")
+    if full.get("jit_cache"):
+        out["jit_cache"] = dict(units_compiled=sum(full["jit_cache"]["units_compiled"]), units_from_disk=sum(full["jit_cache"]["units_from_disk"]))
     out["hbm_copy_GBps_measured"] = full.get("hbm_copy_GBps_measured")
     out["full_record"] = full.get("full_record")
     out = _clean(out, sig=6, strlen=119)
@@ -422,6 +424,24 @@ def comm_facts(world):
                 note=None if backend == "nccl" else "POWDR_DIST_BACKEND test hook: every rank on GPU 0, collectives over gloo - not a multi-GPU measurement")
 
 
+def jit_cache_by_rank(world):
+    """Translation units every rank compiled / loaded from the shared on-disk cache (pw_jit_cache_stats), gathered on all ranks: with
+    N ranks specialising the same AIRs the compile phase is serialised by the cache directory's lock, so every unit is compiled by
+    exactly one of them. Collective: every rank calls it."""
+    from powdr_amd import prover
+
+    st = prover.jit_cache_stats()
+    mine = [int(st["compiled"]), int(st["from_disk"])]
+    if world <= 1:
+        return dict(units_compiled=[mine[0]], units_from_disk=[mine[1]])
+    import torch.distributed as dist
+
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    got = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(got, torch.tensor(mine, dtype=torch.int64, device=dev))
+    return dict(units_compiled=[int(t[0]) for t in got], units_from_disk=[int(t[1]) for t in got])
+
+
 def gauges_of(stage_ms):
     """Kernel times grouped under the reference's gauge names (openvm/metrics-viewer/CLAUDE.md:55-116)."""
     g = lambda *names: sum(stage_ms.get(n, 0.0) for n in names)
@@ -437,22 +457,45 @@ def gauges_of(stage_ms):
              "stark_prove_excluding_trace_time_ms = ms_per_step - trace_gen_time_ms")
 
 
-def _segment_checks(seg, proof, rec):
-    """After the timed region: the proof against the product's host verifier, the device's mock prover on the traces it was made
-    from, and the lookup buses' balance (segment_workload.HonestSegment.balance_witness). Results into `rec`."""
+def _segment_checks(seg, segments, rec, distinct=True):
+    """After the timed region, for EVERY segment in `segments` (the ones this process proved; their inputs are staged again one at a time):
+    the proof against the product's host verifier, the device's mock prover on the traces it was made from, and the lookup buses'
+    balance (segment_workload.HonestSegment.balance_witness). Into `rec`: the worst code over the segments + the per-segment lists."""
     t0 = time.perf_counter()
-    rec["verify_rc"] = seg.verify(proof)
+    vrc, viol, roots = [], [], []
+    hdr = 5 + 4 * len(seg.airs)
+    for u in segments:
+        if distinct:
+            seg.stage_inputs(u)
+        seg.generate_traces()
+        pf = np.array(seg.prove(), copy=True)
+        vrc.append(int(seg.verify(pf)))
+        viol.append(int(seg.check_constraints()))
+        roots.append(tuple(int(x) for x in pf[hdr:hdr + 8]))
+    rec["verify_rc"] = max(vrc, key=abs) if vrc else None
+    rec["verify_rc_by_segment"] = vrc
     rec["verify_s"] = time.perf_counter() - t0
-    rec["constraint_violations"] = int(seg.check_constraints())
+    rec["constraint_violations"] = int(sum(viol))
+    rec["checked_segments"] = [int(u) for u in segments]
+    rec["distinct_commitments"] = len(set(roots))
     prev = os.environ.get("POWDR_JIT")
     try:
-        os.environ["POWDR_JIT"] = "0"  # the witness is proven once: not worth compiling 26 more sets of kernels
+        os.environ["POWDR_JIT"] = "0"  # the witness is proven once per segment: not worth compiling 26 more sets of kernels
         seg.release_provers()
-        rc, total = seg.balance_witness()
-        rec["lookup_balance"] = dict(verify_rc=rc, total_sum=[int(x) for x in total], buses=[3, 6, 7],
-                                     note="the same traces, every AIR restricted to the lookup buses (var-range 3, bitwise 6, tuple 7), one segment proof, "
-                                          "pw_verify_segment with check_balance: the APC and instruction AIRs' sends and the periphery AIRs' receives cancel. "
-                                          "Memory / execution-bridge / program buses: send side only (their receivers are external chips)")
+        brc, totals = [], []
+        for u in segments:
+            if distinct:
+                seg.stage_inputs(u)
+            seg.generate_traces()
+            rc, total = seg.balance_witness()
+            brc.append(int(rc))
+            totals.append([int(x) for x in total])
+        rec["lookup_balance"] = dict(verify_rc=max(brc, key=abs) if brc else None, verify_rc_by_segment=brc,
+                                     total_sum=[max(t[k] for t in totals) for k in range(4)] if totals else None, buses=[3, 6, 7],
+                                     note="per segment: the same traces, every AIR restricted to the lookup buses (var-range 3, bitwise 6, tuple 7), one segment "
+                                          "proof, pw_verify_segment with check_balance: the APC and instruction AIRs' sends and the periphery AIRs' receives cancel "
+                                          "(total_sum: the largest word over the segments). Memory / execution-bridge / program buses: send side only (their "
+                                          "receivers are external chips)")
     except Exception as e:
         rec["lookup_balance"] = dict(verify_rc=None, error=f"{type(e).__name__}: {e}")
     finally:
@@ -482,12 +525,15 @@ def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup,
     hdr = 5 + 4 * len(seg0.airs)
     last = {}
 
+    mine0 = set()
+
     def prove_one(segment, worker, device):
+        workers[worker].stage_inputs(segment)  # every segment has its own inputs (same AIRs, other rows), staged in the worker's buffers
         workers[worker].generate_traces()
         pf = workers[worker].prove()
         last["words"] = len(pf)
         if worker == 0:
-            last["proof"] = pf.copy()
+            mine0.add(int(segment))
         return pf[hdr:hdr + 8].copy()
 
     def run_steps(n):
@@ -512,8 +558,9 @@ def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup,
                commitment_merge={1: "RCCL all-gather (one communicator per device set, ncclCommInitAll at first use)", 2: "host (RCCL not available)"}[last["merge"]],
                note="pw_prove_segments_multi: one process, one host thread + launch stream per worker; per segment: trace generation of every AIR + one "
                     "pw-stark v1 proof (segment_workload.HonestSegment: one resident segment per worker, regenerated and proven for every unit)")
+    rec["distinct_segments"] = True
     with torch.cuda.device(devices[0]):
-        _segment_checks(seg0, last["proof"], rec)
+        _segment_checks(seg0, sorted(mine0), rec)
     for wk in workers:
         wk.close()
     return rec
@@ -525,27 +572,33 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
     AIRs: gather + derived columns + bus replay; instruction AIRs: record expansion + replay of their lookups; periphery AIRs from
     the histograms) and ONE pw-stark v1 proof (pw_prove_segment: all AIRs of a phase in one mixed-height commitment, one FRI), both
     inside the timed region — and the main commitments are all-gathered (32 B per segment). Every rank keeps ONE resident segment
-    (powdr_amd/segment_workload.py) that is regenerated and proven once per unit placed on it: the segments of a run are copies of
-    each other (a real execution's segments differ in values, not in shape). After the timed region: host verification of the last
-    proof, the device's mock prover on its traces, the lookup buses' balance. Returns the record (rank 0) or None."""
+    (powdr_amd/segment_workload.py) whose INPUTS are replaced per unit by those of the segment being proven (HonestSegment.stage_inputs:
+    a real execution's segments differ in values, not in shape). After the timed region: host verification, the device's mock prover
+    and the lookup buses' balance for every segment rank 0 proved. Returns the record (rank 0) or None."""
     from powdr_amd import segment_workload as sw, sharding
 
     seg = sw.HonestSegment(kind, max_log_height=max_log_height, seed=0, queries=queries, pow_bits=pow_bits, logup=logup)
     cells_seg = seg.cells
     hdr = 5 + 4 * len(seg.airs)  # proof words before the main commitment
-    last = dict(gen_s=0.0, prove_s=0.0, units=0)
+    last = dict(gen_s=0.0, prove_s=0.0, stage_s=0.0, units=0)
 
     def prove_one(u):
+        # segment u's OWN inputs (the dummy traces behind every APC AIR, the instruction AIRs' records), generated on the device into the
+        # resident segment's buffers: inside the timed region (one write-only pass over the sources, reported as input_staging_ms_per_segment)
+        ts = time.perf_counter()
+        seg.stage_inputs(u)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         seg.generate_traces()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         pf = seg.prove()
         t2 = time.perf_counter()
+        last["stage_s"] += t0 - ts
         last["gen_s"] += t1 - t0
         last["prove_s"] += t2 - t1
         last["units"] += 1
-        last["words"], last["proof"] = len(pf), pf
+        last["words"] = len(pf)
         return pf[hdr:hdr + 8].copy()
 
     def run_steps(n):
@@ -554,7 +607,7 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
             last["mine"], last["merged"] = mine, merged
 
     run_steps(warmup)
-    last.update(gen_s=0.0, prove_s=0.0, units=0)
+    last.update(gen_s=0.0, prove_s=0.0, stage_s=0.0, units=0)
     elapsed, timing = timed_leg(run_steps, steps, 0, barrier, abi, world)
     per_rank_ms = [t / steps * 1e3 for t in LAST_PER_RANK_S]
     assert (last["merged"] != 0).any(axis=1).all(), "a segment's commitment is missing from the merge"
@@ -566,6 +619,8 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
                airs_by_role={r: sum(1 for a in seg.airs if a["role"] == r) for r in ("apc", "instruction", "periphery")}, cells_by_role=seg.cells_by_role,
                cells_per_segment=cells_seg, value=total_cells / elapsed, unit="cells/s", ms_per_step=elapsed / steps * 1e3, steps=steps,
                trace_gen_ms_per_segment=last["gen_s"] / units * 1e3, prove_ms_per_segment=last["prove_s"] / units * 1e3,
+               input_staging_ms_per_segment=last["stage_s"] / units * 1e3, distinct_segments=True,
+               distinct_commitments_in_merge=len({tuple(int(x) for x in r) for r in last["merged"]}),
                cells_per_s_prove_only=cells_seg / (last["prove_s"] / units) if last["prove_s"] else None,
                warmup=warmup, logup=bool(logup), proof_bytes_per_segment=int(last["words"]) * 4, per_rank_ms=per_rank_ms, ranks=world,
                widths=f"{min(s[1] for s in shapes)}..{max(s[1] for s in shapes)} (sum {sum(s[1] for s in shapes)})",
@@ -574,13 +629,14 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
                prover_device_bytes=seg.device_bytes(), stage_ms_rank0=stage,
                stage_ms_note="per-kernel elapsed times; the per-AIR stages of a segment run on side streams (POWDR_SEGMENT_STREAMS, default 4) and "
                              "overlap, so the sum exceeds the wall time of the step",
-               note="per unit: trace generation of every AIR + one pw-stark v1 proof, both timed; ONE resident segment per rank regenerated for every "
-                    "unit placed on it (the run's segments are copies); value = all segments of all ranks / max-over-ranks time. AIRs: synthetic APCs with "
+               note="per unit: the segment's own inputs staged on the device (seeded by the segment's index: same AIRs, other rows — the segments of one "
+                    "execution), trace generation of every AIR + one pw-stark v1 proof, all timed; one segment's buffers resident per rank; "
+                    "value = all segments of all ranks / max-over-ranks time. AIRs: synthetic APCs with "
                     "generated traces, the 13 RV32IM instruction AIRs with the reference's real constraints / interactions on traces expanded from "
                     "records, the 3 lookup periphery AIRs from the histograms; the other 5 system AIRs of the reference's 19 (connector, program, "
                     "memory boundary, Merkle, Poseidon2: 357 of 819 columns) are external chips and are left out")
     if rank == 0:
-        _segment_checks(seg, np.array(last["proof"], copy=True), rec)
+        _segment_checks(seg, list(last["mine"]), rec)
     seg.close()
     import gc
 
@@ -855,6 +911,7 @@ def main():
         # BASELINE configs[3] / configs[4]: multi-AIR segments sharded over the GPUs of the node, strong scaling
         rec = segment_bench(args.shape, args.segments, args.segment_log_height, args.steps, args.warmup, args.logup, args.queries,
                             args.pow_bits, rank, world, abi, barrier)
+        jit_cache = jit_cache_by_rank(world)
         if rank == 0:
             whole = rec["value"] / world * ALGO_BYTES_PER_CELL / 1e9
             line = dict(metric="STARK cells/sec (trace rows x cols), multi-segment " + ("guest-pairing-shaped" if args.shape == "C4" else "reth-shaped")
@@ -870,7 +927,7 @@ def main():
                                     parallelism=f"segments over {world} ranks (strong)", proof_bytes=rec["proof_bytes_per_segment"]),
                         roofline=dict(bound="hbm", kernel="whole step", achieved=whole, peak=HBM_PEAK_GBS, unit="GB/s", frac=whole / HBM_PEAK_GBS,
                                       traffic=None, algo_bytes_per_cell=ALGO_BYTES_PER_CELL, note="per GPU, 48 B per cell (proof stages only use 40 of them)"),
-                        cpu_baseline=None, multi_segment=rec)
+                        cpu_baseline=None, multi_segment=rec, jit_cache=jit_cache)
             emit(line)
         if world > 1:
             import torch.distributed as dist
@@ -1243,6 +1300,7 @@ def main():
             c3 = dict(value=None, error=f"{type(e).__name__}: {e}")
             torch.cuda.empty_cache()
 
+    jit_cache = jit_cache_by_rank(world)
     if rank == 0:
         per_kernel = {k: (c, ms) for k, (c, ms) in timing.items()}
         dom = max(per_kernel, key=lambda k: per_kernel[k][1]) if per_kernel else None
@@ -1376,7 +1434,7 @@ def main():
                         caveat="proof system pw-stark v0 is this repository's own (oracle/stark_oracle.cpp); its Poseidon2 round constants are a "
                                "documented placeholder stream: proofs are byte-exact against the oracle, not interoperable with the reference prover"),
             roofline=roof, roofline_by_kernel=by_kernel, logup=logup_leg, constraints_only=constraints_only_leg, multi_segment=segment_leg, c3=c3, build=build_info(), tracegen_callmajor=callmajor_leg, tracegen_column_structured=colstruct_leg, tracegen_from_records=records_leg, cpu_baseline=cpu, stage_ms=stage_ms, gauges=gauges,
-            hbm_copy_GBps_measured=copy_gbs,
+            hbm_copy_GBps_measured=copy_gbs, jit_cache=jit_cache,
         )
         emit(line)
     if world > 1:

@@ -3,6 +3,8 @@
 #include "../common.hpp"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/file.h>
 #include <spawn.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -244,9 +246,35 @@ std::string disk_cache_dir() {
     // code objects are LOADED from here: only a directory that belongs to the caller and that nobody else can write to is trusted
     // (a predictable path under a world-writable parent could otherwise be prepared by another local user)
     struct stat sb;
-    if (lstat(dir.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != geteuid() || (sb.st_mode & (S_IWGRP | S_IWOTH))) return "";
+    const char* why = nullptr;
+    if (lstat(dir.c_str(), &sb) != 0) why = "cannot be examined";
+    else if (S_ISLNK(sb.st_mode)) why = "is a symbolic link";
+    else if (!S_ISDIR(sb.st_mode)) why = "is not a directory";
+    else if (sb.st_uid != geteuid()) why = "belongs to another user";
+    else if (sb.st_mode & (S_IWGRP | S_IWOTH)) why = "is writable by group or others (chmod go-w)";
+    if (why) {
+        // said once: every process that gets here recompiles its kernels (seconds per AIR) instead of loading them
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true)) fprintf(stderr, "powdr jit: the code-object cache %s %s: not used, kernels are recompiled\n", dir.c_str(), why);
+        return "";
+    }
     return dir;
 }
+
+// One compiler at a time per cache directory, ACROSS processes (eight ranks of one node specialise the same AIRs against one cache:
+// the first one compiles, the others wait here and then find the code objects on disk). flock on <dir>/.lock; released by close().
+struct DirLock {
+    int fd = -1;
+    explicit DirLock(const std::string& dir) {
+        if (dir.empty()) return;
+        if (const char* e = getenv("POWDR_JIT_CACHE_LOCK")) if (atoi(e) == 0) return;
+        fd = open((dir + "/.lock").c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
+        if (fd >= 0 && flock(fd, LOCK_EX) != 0) { close(fd); fd = -1; }
+    }
+    ~DirLock() { if (fd >= 0) close(fd); }
+    DirLock(const DirLock&) = delete;
+    DirLock& operator=(const DirLock&) = delete;
+};
 
 std::string disk_entry_path(const std::string& dir, const std::string& source) {
     char name[64];
@@ -337,6 +365,22 @@ std::vector<ProgramPtr> compile_all(const std::vector<std::string>& sources, std
         for (auto& e : from_disk) publish(e.first, std::move(e.second));
     }
     if (!todo.empty()) {
+        // the compile phase of this batch under the cache directory's lock; what another process compiled while this one waited is loaded
+        DirLock lock(cache_dir);
+        if (lock.fd >= 0) {
+            std::vector<size_t> still;
+            std::vector<std::pair<size_t, std::vector<char>>> late;
+            for (size_t i : todo) {
+                std::vector<char> c;
+                if (disk_load(cache_dir, sources[i], c)) late.emplace_back(i, std::move(c));
+                else still.push_back(i);
+            }
+            todo.swap(still);
+            g_units_from_disk += late.size();
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (auto& e : late) publish(e.first, std::move(e.second));
+        }
+      if (!todo.empty()) {
         unsigned n_procs = std::thread::hardware_concurrency();
         if (n_procs > 32) n_procs = 32;
         if (const char* e = getenv("POWDR_JIT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_procs = (unsigned)v; }
@@ -358,6 +402,7 @@ std::vector<ProgramPtr> compile_all(const std::vector<std::string>& sources, std
         for (size_t k = 0; k < todo.size(); ++k) publish(todo[k], std::move(code[k]));
         if (g_cache.size() > 4096)  // expired slots of AIRs long gone
             for (auto it = g_cache.begin(); it != g_cache.end();) it = it->second.expired() ? g_cache.erase(it) : std::next(it);
+      }
     }
     return out;
 }

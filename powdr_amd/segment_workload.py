@@ -77,6 +77,46 @@ def build_apc_workload(shape, log_h: int, exact_heights: bool, seed: int, calls_
                 calls=calls, log_h=log_h, H=H, W=apc.width, cons=(cons_bc, cons_spans), src_bytes=src_bytes)
 
 
+def _synth_lib():
+    """libpowdr_synth.so (powdr_amd/synth_csrc/synth_fill.hip): the benches' input generator, a library of its own."""
+    global _SYNTH
+    if _SYNTH is None:
+        from . import build as b
+
+        if not b.SYNTH_LIB.exists():
+            raise RuntimeError(f"{b.SYNTH_LIB} is missing: run `python -m powdr_amd.build`")
+        _SYNTH = C.CDLL(str(b.SYNTH_LIB))
+        _SYNTH.powdr_synth_fill_sources.restype = C.c_int
+        _SYNTH.powdr_synth_fill_sources.argtypes = [C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+    return _SYNTH
+
+
+_SYNTH = None
+
+
+def source_bounds(wl) -> dict:
+    """Per source matrix of an APC workload: the device table bounds[col * b + row] of the cells that feed bounded APC columns
+    (0 = any field element) — what powdr_synth_fill_sources needs to refill the matrix from a seed."""
+    s = wl["synth"]
+    tabs = {n: np.zeros(w * b, np.uint32) for n, (t, w, h, b) in wl["tensors"].items()}
+    for pid, (name, row, col) in s.source_of.items():
+        kind, bound = s.kinds[pid]
+        if bound < P:
+            t, w, h, b = wl["tensors"][name]
+            cur = tabs[name][col * b + row]
+            tabs[name][col * b + row] = bound if cur == 0 else min(int(cur), bound)
+    return {n: torch.from_numpy(a.view(np.int32)).cuda() for n, a in tabs.items()}
+
+
+def refill_sources(wl, bounds: dict, seed: int) -> None:
+    """The original chips' dummy traces of this APC, regenerated on the device from `seed` (one write-only launch per matrix, on the
+    library's launch stream): uniform field elements, cells that feed bounded columns drawn below their bound."""
+    lib, st = _synth_lib(), abi.lib.powdr_gpu_get_stream()
+    for k, (n, (t, w, h, b)) in enumerate(wl["tensors"].items()):
+        abi.check(lib.powdr_synth_fill_sources(t.data_ptr(), w, h, b, bounds[n].data_ptr(), (seed * 1000003 + k * 7919 + 1) & ((1 << 64) - 1), st),
+                  "powdr_synth_fill_sources")
+
+
 def apc_air_shape(name: str, width: int, log_h: int, config_id: int) -> synth.Shape:
     """A synthetic APC of `width` columns at the keccak APC's densities (187 constraints / 1 734 interactions per 2 022 columns) with
     DENSE gather sources (about 1.3 source cells per APC cell instead of keccak's 13.6: ten such AIRs must fit beside the prover) and
@@ -120,6 +160,40 @@ def plausible_records(table: oc.InstructionTable, num_calls: int, seed: int):
         if e.kind in (oc.LOAD_STORE, oc.LOAD_SIGN_EXTEND, oc.JALR):
             rec[e.rec_off] = torch.randint(0, 1 << 22, (num_calls,), dtype=torch.int32, device="cuda", generator=g) << 2  # rs1: < 2^24, 4-aligned
     return rec.reshape(-1)
+
+
+class RecordStager:
+    """plausible_records without the per-instruction launches (a dozen launches for the whole block): the index tensors are built
+    once, fill() draws the records of one segment into an existing buffer on the library's launch stream."""
+
+    def __init__(self, table: oc.InstructionTable, num_calls: int):
+        self.words, self.calls = table.words_per_call, num_calls
+        rows, delta, ptr_rows = [], [], []
+        for e in table.entries:
+            n_prev = oc.N_PREV_TS[e.kind]
+            first = e.rec_off + oc.RECORD_WORDS[e.kind] - n_prev
+            rows += list(range(first, first + n_prev))
+            delta += [e.ts_delta] * n_prev
+            if e.kind in (oc.LOAD_STORE, oc.LOAD_SIGN_EXTEND, oc.JALR):
+                ptr_rows.append(e.rec_off)
+        dev = lambda a, dt: torch.tensor(a, dtype=dt, device="cuda")
+        self.rows, self.delta, self.ptr_rows = dev(rows, torch.int64), dev(delta, torch.int32), dev(ptr_rows, torch.int64)
+
+    def fill(self, rec_flat: torch.Tensor, seed: int) -> None:
+        s = abi.lib.powdr_gpu_get_stream()
+        import contextlib
+
+        with (torch.cuda.stream(torch.cuda.ExternalStream(int(s))) if s else contextlib.nullcontext()):
+            g = torch.Generator(device="cuda").manual_seed(seed)
+            rec = rec_flat.view(self.words, self.calls)
+            rec.random_(-(1 << 31), (1 << 31) - 1, generator=g)
+            base = torch.randint(1 << 10, 1 << 26, (self.calls,), dtype=torch.int32, device="cuda", generator=g)
+            rec[0] = base
+            if len(self.rows):
+                gap = torch.randint(1, 1 << 20, (len(self.rows), self.calls), dtype=torch.int32, device="cuda", generator=g)
+                rec[self.rows] = torch.clamp(base[None, :] + self.delta[:, None] - gap, min=0)
+            if len(self.ptr_rows):  # rs1 of loads / stores / jumps: < 2^24, 4-aligned
+                rec[self.ptr_rows] = torch.randint(0, 1 << 22, (len(self.ptr_rows), self.calls), dtype=torch.int32, device="cuda", generator=g) << 2
 
 
 def _offset_operands(ibc: np.ndarray, ispans: np.ndarray, height: int) -> np.ndarray:
@@ -213,6 +287,22 @@ class HonestSegment:
         self.cells_by_role = {r: sum(a["width"] << a["log_h"] for a in self.airs if a["role"] == r) for r in ("apc", "instruction", "periphery")}
         self.seg = [(a["prover"], a["trace"].data_ptr(), a["log_h"]) for a in self.airs]
         self.source_bytes = sum(wl["src_bytes"] for wl in self.apcs) + self.records.numel() * 4
+        self._bounds, self._stager, self.data_seed = None, None, None
+
+    # ---- the inputs of ANOTHER segment of the same execution (same chips, other rows) ---------------------------------------
+    def stage_inputs(self, data_seed: int):
+        """Replace this segment's inputs — the original chips' dummy traces behind every APC AIR and the call records of the
+        instruction AIRs — by those of segment `data_seed`, generated on the device in the buffers the resident segment already has
+        (the reference cuts ONE execution into segments: /root/reference/openvm-riscv/src/lib.rs:585-592 — the same AIRs, different
+        rows; nothing about the AIRs, their programs or the provers changes). Runs on the library's launch stream, in order with the
+        trace generation that follows."""
+        if self._bounds is None:
+            self._bounds = [source_bounds(wl) for wl in self.apcs]
+            self._stager = RecordStager(self.table, self.calls)
+        for k, wl in enumerate(self.apcs):
+            refill_sources(wl, self._bounds[k], data_seed * 4099 + k)
+        self._stager.fill(self.records, data_seed * 31 + 5)
+        self.data_seed = data_seed
 
     # ---- the timed pieces -----------------------------------------------------------------------------------------------
     def generate_traces(self):

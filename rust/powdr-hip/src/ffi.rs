@@ -284,6 +284,11 @@ extern "C" {
     pub fn pw_prover_destroy(p: *mut PwProver);
     pub fn pw_prover_prove(p: *mut PwProver, d_trace: *const u32, log_height: u32, proof_words: *mut *const u32,
                            n_words: *mut usize) -> c_int;
+    /// The trace is handed over (the engine owns `common_main`): a streamed proof leaves the coefficient arrays in its place.
+    pub fn pw_prover_prove_consuming(p: *mut PwProver, d_trace: *mut u32, log_height: u32, proof_words: *mut *const u32,
+                                     n_words: *mut usize) -> c_int;
+    pub fn pw_prover_stream_log_blocks_consuming(p: *const PwProver, log_height: u32) -> c_int;
+    pub fn pw_trace_from_coefficients(d_coeffs: *mut u32, width: u32, log_height: u32, d_scratch: *mut u32) -> c_int;
     pub fn pw_prover_check_constraints(p: *mut PwProver, d_trace: *const u32, log_height: u32, n_violations: *mut u64,
                                        first_row: *mut u64, first_constraint: *mut u32) -> c_int;
     pub fn pw_verify(cfg: *const PwStarkConfig, width: u32, log_height: u32, cons_bytecode: *const u32, bytecode_len: usize,

@@ -103,6 +103,10 @@ def test_default_line_has_the_contract_fields():
     assert ms["value"] > 0 and ms["proof_bytes_per_segment"] > 0 and ms["segments_on_rank0"] == 8
     # an honest workload: traces generated inside the timed region, the proof verifies, the constraints hold, the lookup buses balance
     assert ms["verify_rc"] == 0 and ms["constraint_violations"] == 0 and ms["lookup_balance"]["verify_rc"] == 0
+    # ... for EVERY one of the 8 segments, which differ in their inputs: eight different commitments in the merge
+    assert ms["distinct_segments"] is True and ms["distinct_commitments_in_merge"] == 8 and ms["distinct_commitments"] == 8
+    assert ms["checked_segments"] == list(range(8)) and ms["verify_rc_by_segment"] == [0] * 8 and ms["lookup_balance"]["verify_rc_by_segment"] == [0] * 8
+    assert ms["input_staging_ms_per_segment"] > 0
     assert ms["trace_gen_ms_per_segment"] > 0 and ms["prove_ms_per_segment"] > 0
     # the dominant kernel's HBM bytes and VALU instructions are measured in the run itself (two rocprofv3 --pmc passes)
     if r["kernel"] == "leaf_hash_kernel":
@@ -189,3 +193,36 @@ def test_plain_command_with_gpus_2_produces_a_two_rank_line():
     # asked for more GPUs than the box has, without the hook: refused, not relabelled
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "64", "--log-height", "12"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 2 and "only" in out.stderr
+
+
+def test_eight_ranks_on_one_gpu_with_a_cold_kernel_cache(tmp_path):
+    """`python bench.py --gpus 8 ...` as typed — eight ranks (all on GPU 0 over gloo, the one-GPU test hook), every
+    prover specialised (POWDR_JIT=1) against ONE cold on-disk cache: the line says n_gpus 8 / 8 ranks / 8 per-rank times, the eight
+    segments of the strong-scaling leg land one per rank with eight different commitments, and every translation unit was compiled by
+    exactly one rank (the others loaded it). Not a multi-GPU measurement — RCCL has still not seen two devices."""
+    import os
+
+    env = dict(os.environ, POWDR_DIST_BACKEND="gloo", POWDR_JIT="1", POWDR_JIT_CACHE_DIR=str(tmp_path / "jit"), POWDR_JIT_THREADS="4")
+    d = run_bench("--gpus", "8", "--no-cpu-baseline", "--no-c3-leg", "--segment-log-height", "10", env=env,
+                  base=("--log-height", "12", "--steps", "2", "--warmup", "1"), timeout=1500)
+    c = d["_compact"]
+    assert c["n_gpus"] == 8 and c["rccl_ranks"] == 8 and len(c["per_rank_ms"]) == 8 and c["comm"]["backend"] == "gloo"
+    assert d["comm"]["launch"] == "self" and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * d["config"]["rows"] * d["config"]["cols"] / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    ms = d["multi_segment"]
+    assert ms["ranks"] == 8 and ms["n_segments"] == 8 and ms["segments_on_rank0"] == 1 and len(ms["per_rank_ms"]) == 8
+    assert ms["distinct_commitments_in_merge"] == 8 and ms["verify_rc"] == 0 and ms["lookup_balance"]["verify_rc"] == 0
+    jc = d["jit_cache"]
+    assert len(jc["units_compiled"]) == 8 and sum(jc["units_compiled"]) > 0
+    n_entries = len(list((tmp_path / "jit").glob("*.pwjc")))
+    assert sum(jc["units_compiled"]) == n_entries, (jc, n_entries)  # one compile per distinct unit over the eight ranks
+    assert sum(jc["units_from_disk"]) >= 7 * n_entries  # every other rank loaded what it did not compile
+    assert c["jit_cache"]["units_compiled"] == n_entries
+
+
+def test_inproc_eight_workers_on_one_device():
+    """pw_prove_segments_multi with EIGHT worker threads on one device (the in-process form of an 8-GPU node): 8 segments, one each."""
+    d = run_bench("--shape", "C4", "--segments", "8", "--segment-log-height", "10", "--gpus", "8", "--inproc", "--no-cpu-baseline")
+    ms = d["multi_segment"]
+    assert d["n_gpus"] == 8 and ms["workers"] == 8 and ms["devices"] == [0] * 8 and sum(ms["segments_per_worker"]) == 8
+    assert ms["verify_rc"] == 0 and ms["constraint_violations"] == 0 and ms["distinct_segments"] is True

@@ -101,6 +101,44 @@ def test_code_objects_are_kept_on_disk_across_provers(tmp_path, monkeypatch):
     assert r5 == r1 and s5["compiled"] - s4["compiled"] == r1["kernels"] and s5["from_disk"] == s4["from_disk"]
 
 
+def test_ranks_that_share_a_cold_cache_compile_every_unit_once(tmp_path):
+    """N ranks of one node specialise the same AIRs against ONE on-disk cache. The compile phase runs
+    under the cache directory's lock (flock), so the first process compiles and the others load: over 4 concurrent processes with a
+    cold cache every translation unit is compiled exactly once, and a symlinked cache directory is refused with a diagnostic."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parents[1]
+    code = ("import json, sys; sys.path.insert(0, %r)\n"
+            "from tests.test_jit import hand_made_air, _tables\n"
+            "from powdr_amd import prover\n"
+            "out = []\n"
+            "for shape in ('hand', 'T1'):\n"
+            "    W, (bc, spans), it = hand_made_air() if shape == 'hand' else _tables(shape)\n"
+            "    r = prover.jit_compile_check(W, bc, spans, it)\n"
+            "    out.append(r)\n"
+            "print(json.dumps(dict(results=out, stats=prover.jit_cache_stats())))\n") % str(root)
+    env = dict(os.environ, POWDR_JIT_CACHE_DIR=str(tmp_path / "shared"), POWDR_JIT_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=root) for _ in range(4)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [e[-800:] for _, e in outs]
+    recs = [json.loads(o.strip().splitlines()[-1]) for o, _ in outs]
+    units = sum(r["kernels"] for r in recs[0]["results"])
+    assert all(r["rc"] == 0 for rec in recs for r in rec["results"]) and all(rec["results"] == recs[0]["results"] for rec in recs)
+    assert sum(rec["stats"]["compiled"] for rec in recs) == units, [rec["stats"] for rec in recs]
+    assert sum(rec["stats"]["from_disk"] for rec in recs) == 3 * units
+    assert len(list((tmp_path / "shared").glob("*.pwjc"))) == units and not list((tmp_path / "shared").glob("*.tmp*"))
+    # a cache directory reached through a symbolic link is not trusted — and says so (ADVICE r4)
+    (tmp_path / "link").symlink_to(tmp_path / "shared")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, POWDR_JIT_CACHE_DIR=str(tmp_path / "link")), cwd=root,
+                         timeout=600)
+    assert out.returncode == 0 and "is a symbolic link" in out.stderr and out.stderr.count("powdr jit:") == 1
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["stats"]["compiled"] == units and rec["stats"]["from_disk"] == 0
+
+
 def test_jit_is_off_with_POWDR_JIT_0(monkeypatch):
     from powdr_amd import prover
 

@@ -73,3 +73,39 @@ def test_a_second_generation_gives_the_same_proof(gpu):
     p2 = seg.prove(copy=True)
     assert (p1 == p2).all() and seg.verify(p2) == 0
     seg.close()
+
+
+def test_staged_inputs_give_other_segments_of_the_same_shape(gpu):
+    """HonestSegment.stage_inputs(u): the inputs of segment u — dummy traces behind the APC AIRs (libpowdr_synth.so, one
+    write-only launch per matrix), the instruction AIRs' records — replace the resident ones. Same AIRs, other rows: the traces and the
+    commitment change, every constraint still holds, the proof verifies and equals the oracle's on the traces read back, the lookup
+    buses balance (every bounded cell was drawn below its bound), and the same index gives the same segment again."""
+    torch, sw = gpu
+    seg = sw.HonestSegment("C4", max_log_height=10, seed=1, queries=5, pow_bits=3, logup=True, max_apc_airs=3)
+    hdr = 5 + 4 * len(seg.airs)
+    seen, traces = {}, {}
+    for u in (0, 1, 5, 1):
+        seg.stage_inputs(u)
+        seg.generate_traces()
+        torch.cuda.synchronize()
+        assert seg.check_constraints() == 0
+        proof = seg.prove(copy=True)
+        assert seg.verify(proof) == 0
+        root = tuple(int(x) for x in proof[hdr:hdr + 8])
+        snap = [a["trace"].clone() for a in seg.airs]
+        if u in seen:
+            assert seen[u] == root and all(torch.equal(x, y) for x, y in zip(traces[u], snap))
+            continue
+        seen[u], traces[u] = root, snap
+        if u == 5:
+            airs = _host_airs(seg)
+            want = sm.prove_segment(airs, num_queries=5, pow_bits=3, logup=True)
+            assert len(proof) == len(want) and (proof == want).all()
+            rc, total = seg.balance_witness()
+            assert rc == 0 and (np.asarray(total) == 0).all()
+    assert len(set(seen.values())) == 3
+    # APC and instruction traces differ between segments (periphery tables differ through their multiplicities)
+    for i, a in enumerate(seg.airs):
+        if a["role"] != "periphery":
+            assert not torch.equal(traces[0][i], traces[1][i]), a["name"]
+    seg.close()
