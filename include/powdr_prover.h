@@ -79,6 +79,7 @@ int pw_prover_prove(PwProver* p, const uint32_t* d_trace, uint32_t log_height, c
  * configs[2] (3 731 x 2^22 + 4 632 permutation columns) that is 62.6 GB, the difference between walking the extended
  * domain as 4 sub-cosets and as 2 (half the coefficient re-reads of every pass). Afterwards d_trace holds, per column,
  * H * (the coefficients) in bit-reversed order; pw_trace_from_coefficients turns that back into the trace (exact).
+ * d_trace must be 16-byte aligned (hipErrorInvalidValue otherwise; pw_prover_prove takes any 4-byte aligned trace).
  * pw_prover_stream_log_blocks_consuming: the mode such a proof would run in with the memory free now. */
 int pw_prover_prove_consuming(PwProver* p, uint32_t* d_trace, uint32_t log_height, const uint32_t** proof_words,
                               size_t* n_words);

@@ -534,6 +534,8 @@ namespace {
 // of the trace end up in d_trace itself (no tcoef buffer: 62.6 GB at configs[2], which is what lets it run on 2 sub-cosets instead of 4).
 int prove_impl(PwProver* p, const uint32_t* d_trace, uint32_t log_h, const uint32_t** proof_words, size_t* n_words, bool consume) {
     if (!p || !d_trace || log_h < 1 || log_h > 26) return -1;
+    // a handed-over trace becomes a coefficient array that is read 2 / 4 words at a time (fold loads, the DEEP combination)
+    if (consume && ((uintptr_t)d_trace & 15)) return (int)hipErrorInvalidValue;
     (void)hipGetLastError();
     const uint32_t W = p->width, nc = p->n_constraints;
     const size_t H = (size_t)1 << log_h, N = 2 * H;
@@ -553,14 +555,25 @@ int prove_impl(PwProver* p, const uint32_t* d_trace, uint32_t log_h, const uint3
     // ---- buffers --------------------------------------------------------------------------
     // digest arena: trace tree | quotient tree | (perm tree) | FRI trees
     // (a consuming proof commits in its own way: a pw_prover_trace_root before it is not reused)
-    const bool have_commitment = !consume && p->committed_trace == d_trace && p->committed_log_h == log_h;
+    bool have_commitment = !consume && p->committed_trace == d_trace && p->committed_log_h == log_h;
     p->committed_trace = nullptr;  // one-shot
     // resident LDE, or streamed over 2^sb sub-cosets of the extended domain ("streamed proofs" above)
-    const int sb = have_commitment ? p->committed_b : stream_log_blocks(p, log_h, consume);
+    int sb = have_commitment ? p->committed_b : stream_log_blocks(p, log_h, consume);
     if (sb < 0) return (int)hipErrorOutOfMemory;
-    const bool eat = consume && sb > 0;  // the trace is overwritten by its coefficient arrays
     CommitLayout L;
-    TRY(ensure_prove_buffers(p, log_h, sb, L, eat));
+    int rc_buf = ensure_prove_buffers(p, log_h, sb, L, consume && sb > 0);
+    if (rc_buf == (int)hipErrorOutOfMemory && have_commitment && sb == 0) {
+        // pw_prove_airs commits every AIR first: several of them may each have chosen "resident" against the same free memory
+        // (ADVICE r4). The commitment is dropped and made again in the streamed mode that fits NOW — same root, same words.
+        (void)hipGetLastError();
+        p->lde.release();
+        have_commitment = false;
+        sb = stream_log_blocks(p, log_h, false);
+        if (sb <= 0) return (int)hipErrorOutOfMemory;
+        rc_buf = ensure_prove_buffers(p, log_h, sb, L, false);
+    }
+    if (rc_buf) return rc_buf;
+    const bool eat = consume && sb > 0;  // the trace is overwritten by its coefficient arrays
     const size_t tree_words = L.tree_words, n_trees = L.n_trees;
     // streamed: the trace's coefficient arrays — in tcoef, or (eat) in the caller's buffer, from the moment nothing reads the trace any more
     uint32_t* d_tcoef = eat ? const_cast<uint32_t*>(d_trace) : p->tcoef.as<uint32_t>();
@@ -806,7 +819,7 @@ int prove_impl(PwProver* p, const uint32_t* d_trace, uint32_t log_h, const uint3
         // the second opening point) columns; the eight quotient columns join from their resident LDE
         TRY(streamed::deep_from_coefficients(stream_ctx(p, L, log_h), lg, d_tcoef, d_perm, d_qlde, logN, d_gpow, opened_sums, opened_sum, opened_sum2, zeta,
                                              gzeta, d_v));
-    } else if (log_h >= kDeepComboMinLogHeight && !getenv("POWDR_DEEP_DIRECT")) {
+    } else if (log_h >= kDeepComboMinLogHeight && !getenv("POWDR_DEEP_DIRECT") && !((uintptr_t)d_trace & 7)) {  // (the combination reads 8-byte pairs)
         // resident: the same combination on the evaluations over <g_n> (the caller's trace, the permutation matrix), extended like any column
         uint32_t* d_gev = p->gbuf.as<uint32_t>();
         uint32_t* d_glde = d_gev + 8 * H;

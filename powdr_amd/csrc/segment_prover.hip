@@ -520,7 +520,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             if (sbv[a])
                 TRY(streamed::deep_from_coefficients(sctx(a), lg, p->tcoef.as<uint32_t>(), p->perm.as<uint32_t>(), p->qlde.as<uint32_t>(), s.logN,
                                                      d_gpow + s.koff, [] {}, sum1, sum2, zeta, gzeta[a], out));
-            else if (s.log_h >= kDeepComboMinLogHeight && !getenv("POWDR_DEEP_DIRECT")) {
+            else if (s.log_h >= kDeepComboMinLogHeight && !getenv("POWDR_DEEP_DIRECT") && !((uintptr_t)airs[a].d_trace & 7)) {
                 // resident and tall: the numerator is combined on the evaluations over <g_n> — the caller's trace, the permutation
                 // matrix: half the bytes their LDE holds — and extended as 4 (+ 4) columns, like the one-AIR prover does
                 uint32_t* d_gev = p->gbuf.as<uint32_t>();

@@ -132,6 +132,9 @@ int ext_lincomb(const uint32_t* ma, uint32_t wa, const uint32_t* mb, uint32_t wb
                 uint32_t* out) {
     ScopedKernelTimer t("ext_lincomb_kernel");
     if (len & 1) return (int)hipErrorInvalidValue;  // (traces have at least two rows)
+    // the kernel reads two words per load: the matrices (and with an even column length every column of them) must be 8-byte aligned —
+    // the resident provers fall back to deep_quotient* for a caller's trace that is not, the streamed ones refuse it
+    if ((((uintptr_t)ma) | ((uintptr_t)mb) | ((uintptr_t)out)) & 7) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(ext_lincomb_kernel, dim3(div_up(len / 2, kBlock)), dim3(kBlock), 0, stream(), ma, wa, mb, wb, len, d_gpow, second, out);
     return (int)hipGetLastError();
 }

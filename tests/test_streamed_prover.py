@@ -322,3 +322,26 @@ def test_consuming_tall_trace(gpu, monkeypatch):
     want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=12, pow_bits=0)
     got, left, restored, _ = _prove_consuming(torch, prover, monkeypatch, flat, W, log_h, bc, spans, it, 12, 0, 1, True)
     assert (got == want).all() and torch.equal(restored, to_dev(torch, flat))
+
+
+def test_a_trace_at_an_odd_word_offset(gpu, monkeypatch):
+    """from 2^16 rows on the resident DEEP numerator is combined with 8-byte loads of the caller's trace; a trace that is
+    only 4-byte aligned (a view into a larger tensor) takes the accumulating kernel instead — same words. The consuming call wants
+    16 bytes and says so."""
+    torch, abi, prover = gpu
+    flat, W, log_h, bc, spans, it = _synthetic("T1", 40000, seed=3)
+    assert log_h == 16
+    monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", "0")
+    d_t = to_dev(torch, flat)
+    big = torch.empty(d_t.numel() + 8, dtype=torch.int32, device="cuda")
+    assert big.data_ptr() % 16 == 0
+    odd = big[1:1 + d_t.numel()]
+    odd.copy_(d_t)
+    for inter in (None, it):
+        pr = prover.Prover(W, bc, spans, num_queries=7, pow_bits=0, interactions=inter)
+        a = pr.prove(d_t.data_ptr(), log_h)
+        b = pr.prove(odd.data_ptr(), log_h)
+        assert (a == b).all()
+        with pytest.raises(Exception):
+            pr.prove(odd.data_ptr(), log_h, consume=True)
+        pr.close()
