@@ -4,10 +4,11 @@
 //! word-major call records `powdr_apc_generate_witness_from_records` consumes (include/powdr_gpu.h; INTEGRATION.md §3b lists word
 //! by word what goes where). With it `PowdrChipHip::generate_proving_ctx` needs neither dummy chips nor dummy traces.
 //!
-//! Covered: the five chips a keccak block uses — BaseAlu, Shift, LoadStore, BranchEqual, JalLui (`POWDR_ORIG_*` 0..4) — plus
-//! LessThan, which shares BaseAlu's adapter. The remaining seven chips follow the same three adapter shapes (ALU adapter:
-//! Multiplication, MulH, DivRem; load/store adapter: LoadSignExtend; branch adapter: BranchLessThan; rd-write adapter: Auipc;
-//! jalr adapter: Jalr) and are left as `Unsupported` until someone compiles this against openvm-rv32im-circuit.
+//! Covered: all thirteen RV32IM instruction chips of the reference's snapshot (`POWDR_ORIG_*` 0..12, the chip list of
+//! openvm-riscv/tests/openvm_constraints.txt): BaseAlu, Shift, LessThan (ALU adapter), Multiplication, MulH, DivRem (mult adapter:
+//! the same three accesses), LoadStore, LoadSignExtend (load/store adapter), BranchEqual, BranchLessThan (branch adapter), JalLui
+//! (conditional rd-write adapter), Auipc (rd-write adapter), Jalr (jalr adapter). `tests/test_rust_adapter_sync.py` checks the word
+//! counts of every `RecordView` impl and the kind numbers against what the library and the oracle consume.
 //!
 //! The record structs themselves are EXTERNAL (openvm-rv32im-circuit / openvm-circuit at the tag of /root/reference/Cargo.toml:
 //! 51-86); the field names below are the ones of that crate's `*AdapterRecord` / `*CoreRecord` types as of its "new execution"
@@ -17,9 +18,13 @@ use crate::ffi;
 
 use openvm_circuit::arch::{DenseRecordArena, RecordSeeker};
 use openvm_rv32im_circuit::adapters::{
-    Rv32BaseAluAdapterRecord, Rv32BranchAdapterRecord, Rv32CondRdWriteAdapterRecord, Rv32LoadStoreAdapterRecord,
+    Rv32BaseAluAdapterRecord, Rv32BranchAdapterRecord, Rv32CondRdWriteAdapterRecord, Rv32JalrAdapterRecord, Rv32LoadStoreAdapterRecord,
+    Rv32MultAdapterRecord, Rv32RdWriteAdapterRecord,
 };
-use openvm_rv32im_circuit::{BaseAluCoreRecord, BranchEqualCoreRecord, LessThanCoreRecord, LoadStoreCoreRecord, Rv32JalLuiCoreRecord, ShiftCoreRecord};
+use openvm_rv32im_circuit::{
+    BaseAluCoreRecord, BranchEqualCoreRecord, BranchLessThanCoreRecord, DivRemCoreRecord, LessThanCoreRecord, LoadSignExtendCoreRecord,
+    LoadStoreCoreRecord, MulHCoreRecord, MultiplicationCoreRecord, Rv32AuipcCoreRecord, Rv32JalLuiCoreRecord, Rv32JalrCoreRecord, ShiftCoreRecord,
+};
 use powdr_openvm::powdr_extension::executor::OriginalArenas;
 
 /// chip kinds of include/powdr_gpu.h (`POWDR_ORIG_*`)
@@ -29,11 +34,18 @@ pub const LOAD_STORE: u32 = 2;
 pub const BRANCH_EQ: u32 = 3;
 pub const JAL_LUI: u32 = 4;
 pub const LESS_THAN: u32 = 5;
+pub const BRANCH_LT: u32 = 6;
+pub const JALR: u32 = 7;
+pub const LOAD_SIGN_EXTEND: u32 = 8;
+pub const DIV_REM: u32 = 9;
+pub const MUL_H: u32 = 10;
+pub const MUL: u32 = 11;
+pub const AUIPC: u32 = 12;
 
 #[derive(Debug)]
 pub enum BridgeError {
-    /// the block uses a chip this bridge has no record accessor for yet (kind = POWDR_ORIG_*)
-    Unsupported(u32),
+    /// a chip kind outside POWDR_ORIG_* (0..12): the instruction table is malformed
+    UnknownKind(u32),
     /// an AIR's arena holds fewer records than `rows of that AIR per call x calls`
     ShortArena { air: String, have: usize, want: usize },
 }
@@ -135,13 +147,87 @@ impl RecordView for (&Rv32CondRdWriteAdapterRecord, &Rv32JalLuiCoreRecord) {
     }
 }
 
+/// Mult adapter (Multiplication, MulH, DivRem): the ALU adapter's three accesses — `b` (rs1), `c` (rs2), `writes_aux.prev_data`
+macro_rules! mult_view {
+    ($core:ty) => {
+        impl RecordView for (&Rv32MultAdapterRecord, &$core) {
+            fn words(&self) -> RecordWords {
+                let (a, c) = *self;
+                RecordWords {
+                    data: [word(c.b), word(c.c), word(a.writes_aux.prev_data)],
+                    n_data: 3,
+                    prev_ts: [a.reads_aux[0].prev_timestamp, a.reads_aux[1].prev_timestamp, a.writes_aux.prev_timestamp],
+                    n_prev: 3,
+                    from_timestamp: a.from_timestamp,
+                }
+            }
+        }
+    };
+}
+mult_view!(MultiplicationCoreRecord<4, 8>);
+mult_view!(MulHCoreRecord<4, 8>);
+mult_view!(DivRemCoreRecord<4>);
+
+impl RecordView for (&Rv32LoadStoreAdapterRecord, &LoadSignExtendCoreRecord<4>) {
+    /// LOADB / LOADH: `rs1_data`, the ALIGNED word that is read, `prev_data` (rd before); rs1_aux, read_data_aux, write_base_aux
+    fn words(&self) -> RecordWords {
+        let (a, c) = *self;
+        RecordWords {
+            data: [a.rs1_val, word(c.read_data), word(c.prev_data)],
+            n_data: 3,
+            prev_ts: [a.rs1_aux_record.prev_timestamp, a.read_data_aux.prev_timestamp, a.write_prev_timestamp],
+            n_prev: 3,
+            from_timestamp: a.from_timestamp,
+        }
+    }
+}
+impl RecordView for (&Rv32BranchAdapterRecord, &BranchLessThanCoreRecord<4, 8>) {
+    /// `a` (rs1), `b` (rs2); reads_aux[0], reads_aux[1]
+    fn words(&self) -> RecordWords {
+        let (a, c) = *self;
+        RecordWords {
+            data: [word(c.a), word(c.b), 0],
+            n_data: 2,
+            prev_ts: [a.reads_aux[0].prev_timestamp, a.reads_aux[1].prev_timestamp, 0],
+            n_prev: 2,
+            from_timestamp: a.from_timestamp,
+        }
+    }
+}
+impl RecordView for (&Rv32JalrAdapterRecord, &Rv32JalrCoreRecord) {
+    /// `rs1_data`, `rd_aux_cols.prev_data`; rs1_aux_cols, rd_aux_cols (rd = x0: the write is disabled and its words stay unused)
+    fn words(&self) -> RecordWords {
+        let (a, c) = *self;
+        RecordWords {
+            data: [c.rs1_val, word(a.writes_aux.prev_data), 0],
+            n_data: 2,
+            prev_ts: [a.reads_aux.prev_timestamp, a.writes_aux.prev_timestamp, 0],
+            n_prev: 2,
+            from_timestamp: a.from_timestamp,
+        }
+    }
+}
+impl RecordView for (&Rv32RdWriteAdapterRecord, &Rv32AuipcCoreRecord) {
+    /// `rd_aux_cols.prev_data`; rd_aux_cols
+    fn words(&self) -> RecordWords {
+        let (a, _c) = *self;
+        RecordWords {
+            data: [word(a.rd_aux_record.prev_data), 0, 0],
+            n_data: 1,
+            prev_ts: [a.rd_aux_record.prev_timestamp, 0, 0],
+            n_prev: 1,
+            from_timestamp: a.from_timestamp,
+        }
+    }
+}
+
 /// (data words, previous timestamps) of a chip kind = `RECORD_WORDS` / `N_PREV_TS` of powdr_amd/original_chips.py
 fn shape_of(kind: u32) -> Result<(usize, usize), BridgeError> {
     match kind {
-        BASE_ALU | SHIFT | LOAD_STORE | LESS_THAN => Ok((3, 3)),
-        BRANCH_EQ => Ok((2, 2)),
-        JAL_LUI => Ok((1, 1)),
-        k => Err(BridgeError::Unsupported(k)),
+        BASE_ALU | SHIFT | LOAD_STORE | LESS_THAN | LOAD_SIGN_EXTEND | DIV_REM | MUL_H | MUL => Ok((3, 3)),
+        BRANCH_EQ | BRANCH_LT | JALR => Ok((2, 2)),
+        JAL_LUI | AUIPC => Ok((1, 1)),
+        k => Err(BridgeError::UnknownKind(k)),
     }
 }
 
@@ -206,7 +292,14 @@ pub fn records_from_arenas(
             LOAD_STORE => walk!(Rv32LoadStoreAdapterRecord, LoadStoreCoreRecord<4>),
             BRANCH_EQ => walk!(Rv32BranchAdapterRecord, BranchEqualCoreRecord<4>),
             JAL_LUI => walk!(Rv32CondRdWriteAdapterRecord, Rv32JalLuiCoreRecord),
-            k => return Err(BridgeError::Unsupported(k)),
+            BRANCH_LT => walk!(Rv32BranchAdapterRecord, BranchLessThanCoreRecord<4, 8>),
+            JALR => walk!(Rv32JalrAdapterRecord, Rv32JalrCoreRecord),
+            LOAD_SIGN_EXTEND => walk!(Rv32LoadStoreAdapterRecord, LoadSignExtendCoreRecord<4>),
+            DIV_REM => walk!(Rv32MultAdapterRecord, DivRemCoreRecord<4>),
+            MUL_H => walk!(Rv32MultAdapterRecord, MulHCoreRecord<4, 8>),
+            MUL => walk!(Rv32MultAdapterRecord, MultiplicationCoreRecord<4, 8>),
+            AUIPC => walk!(Rv32RdWriteAdapterRecord, Rv32AuipcCoreRecord),
+            k => return Err(BridgeError::UnknownKind(k)),
         }
     }
     // (a block whose FIRST instruction keeps no cell has nobody to read the call's first timestamp from: set_call_timestamps below)

@@ -123,18 +123,57 @@ def test_every_isa_member_the_crate_uses_exists(reference_dir):
 
 
 def test_record_bridge_matches_the_record_layout_tables():
-    """records_from_arena.rs restates RECORD_WORDS / N_PREV_TS (powdr_amd/original_chips.py = include/powdr_gpu.h) for the chips it
-    covers, and its kind constants are the POWDR_ORIG_* numbers."""
+    """records_from_arena.rs (all thirteen chips, no `Unsupported` arm) against the three other statements of the record
+    layout: include/powdr_gpu.h (POWDR_ORIG_* numbers), powdr_amd/original_chips.py (RECORD_WORDS / N_PREV_TS, what the library
+    consumes) and oracle/original_chips.py (what the oracle consumes). Per chip kind: the kind constant, the (data words, previous
+    timestamps) of `shape_of`, a `walk!` arm with an (adapter, core) record pair, and a `RecordView` impl for exactly that pair whose
+    `n_data` / `n_prev` and filled array slots equal the tables'."""
+    from oracle import original_chips as ooc
     from powdr_amd import original_chips as oc
 
     text = _rust_sources()["records_from_arena.rs"]
-    for name, kind in (("BASE_ALU", oc.BASE_ALU), ("SHIFT", oc.SHIFT), ("LOAD_STORE", oc.LOAD_STORE), ("BRANCH_EQ", oc.BRANCH_EQ),
-                       ("JAL_LUI", oc.JAL_LUI), ("LESS_THAN", oc.LESS_THAN)):
-        assert re.search(rf"pub const {name}: u32 = {kind};", text), name
-    shapes = {k: (oc.RECORD_WORDS[k] - oc.N_PREV_TS[k], oc.N_PREV_TS[k]) for k in range(oc.N_KINDS)}
-    assert shapes[oc.BASE_ALU] == shapes[oc.SHIFT] == shapes[oc.LOAD_STORE] == shapes[oc.LESS_THAN] == (3, 3)
-    assert shapes[oc.BRANCH_EQ] == (2, 2) and shapes[oc.JAL_LUI] == (1, 1)
-    assert "BASE_ALU | SHIFT | LOAD_STORE | LESS_THAN => Ok((3, 3))" in text and "BRANCH_EQ => Ok((2, 2))" in text and "JAL_LUI => Ok((1, 1))" in text
+    code = re.sub(r"//[^\n]*", "", text)
+    assert "Unsupported" not in code
+    hdr = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "powdr_gpu.h").read_text(), flags=re.S)
+    hdr_kinds = {m.group(1): int(m.group(2)) for m in re.finditer(r"POWDR_ORIG_(\w+) = (\d+)", hdr)}
+    assert hdr_kinds.pop("KIND_COUNT") == 13 == oc.N_KINDS and len(hdr_kinds) == 13
+    rust_kinds = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const (\w+): u32 = (\d+);", code)}
+    assert rust_kinds == hdr_kinds
+    assert list(ooc.RECORD_WORDS) == list(oc.RECORD_WORDS) and [ooc.N_PREV_TS[k] for k in range(13)] == list(oc.N_PREV_TS)
+    # shape_of
+    shape_fn = code[code.index("fn shape_of"):code.index("pub fn records_from_arenas")]
+    shape = {}
+    for arm in re.finditer(r"((?:\w+\s*\|\s*)*\w+)\s*=>\s*Ok\(\((\d+), (\d+)\)\)", shape_fn):
+        for name in re.split(r"\s*\|\s*", arm.group(1)):
+            shape[rust_kinds[name]] = (int(arm.group(2)), int(arm.group(3)))
+    want = {k: (oc.RECORD_WORDS[k] - oc.N_PREV_TS[k], oc.N_PREV_TS[k]) for k in range(13)}
+    assert shape == want
+    # walk! arms: kind -> (adapter, core)
+    walk = {rust_kinds[m.group(1)]: (m.group(2), re.sub(r"\s", "", m.group(3))) for m in re.finditer(r"(\w+) => walk!\((\w+), ([\w<>, ]+)\)", code)}
+    assert sorted(walk) == list(range(13))
+    # RecordView impls (the mult adapter's three come from one macro)
+    impls = {}
+    for m in re.finditer(r"impl RecordView for \(&(\w+), &([\w<>, $:]+)\) \{(.*?)\n\s*\}\n\s*\}", code, flags=re.S):
+        impls[(m.group(1), re.sub(r"\s", "", m.group(2)))] = m.group(3)
+    for core in re.findall(r"mult_view!\(([\w<>, ]+)\);", code):
+        impls[("Rv32MultAdapterRecord", re.sub(r"\s", "", core))] = impls[("Rv32MultAdapterRecord", "$core")]
+    for k in range(13):
+        body = impls[walk[k]]
+        n_data, n_prev = int(re.search(r"n_data: (\d)", body).group(1)), int(re.search(r"n_prev: (\d)", body).group(1))
+        assert (n_data, n_prev) == want[k], (oc.KIND_NAMES[k], walk[k])
+        data = [x.strip() for x in re.search(r"data: \[(.*?)\],\s*n_data", body, flags=re.S).group(1).split(",")]
+        prev = [x.strip() for x in re.search(r"prev_ts: \[(.*?)\],\s*n_prev", body, flags=re.S).group(1).split(",")]
+        # top-level commas only (word(c.prev_data.map(|x| x as u8)) has none): three slots, the unused ones literally 0
+        assert len(data) == 3 and len(prev) == 3, (oc.KIND_NAMES[k], data, prev)
+        assert [d != "0" for d in data] == [i < n_data for i in range(3)] and [t != "0" for t in prev] == [i < n_prev for i in range(3)]
+        assert all("prev_timestamp" in t for t in prev[:n_prev]) and "from_timestamp" in body
+    # the adapter each chip uses: the shapes INTEGRATION.md §3b tabulates
+    by_adapter = {}
+    for k, (ad, _) in walk.items():
+        by_adapter.setdefault(ad, set()).add(oc.KIND_NAMES[k])
+    assert by_adapter == {"Rv32BaseAluAdapterRecord": {"BaseAlu", "Shift", "LessThan"}, "Rv32MultAdapterRecord": {"Multiplication", "MulH", "DivRem"},
+                          "Rv32LoadStoreAdapterRecord": {"LoadStore", "LoadSignExtend"}, "Rv32BranchAdapterRecord": {"BranchEqual", "BranchLessThan"},
+                          "Rv32CondRdWriteAdapterRecord": {"JalLui"}, "Rv32RdWriteAdapterRecord": {"Auipc"}, "Rv32JalrAdapterRecord": {"Jalr"}}
     first = [lo for lo, hi, k in sorted(oc.OPCODE_RANGES, key=lambda t: t[2])]
     chip = _rust_sources()["chip.rs"]
     assert "[" + ", ".join(str(x) for x in first) + "]" in chip  # FIRST_OPCODE of air_name_of_kind
