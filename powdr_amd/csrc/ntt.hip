@@ -196,11 +196,15 @@ __device__ __forceinline__ uint32_t fold_load(const uint32_t* __restrict__ src, 
 // 2H-sized vector is src[g >> 1] * scale_br[g >> 1].
 // `tw_base` enters as the twiddle base of this round's slot 0 and leaves as the one of the next round's slot 0.
 // MODE: 0 = plain loads, 1 = EXPAND, 2 = FOLD (fold_load above).
-template <bool DIF, int LOGR, int EPT, int MODE, bool TWT = false>
-__device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, const GroupParams& gp, int round,
-                                          const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+// NC (two-column experiment): a thread runs its slot for NC columns — column cc in tile0 + cc * tile_cs, src0 + cc * src_cs,
+// dst0 + cc * dst_cs — with ONE set of slot indices and twiddles (the table loads and the index arithmetic are shared).
+template <bool DIF, int LOGR, int EPT, int MODE, bool TWT = false, int NC = 1>
+__device__ __forceinline__ void run_round(uint32_t* tile0, const IndexMap& im, const GroupParams& gp, int round,
+                                          const uint32_t* __restrict__ src0, uint32_t* __restrict__ dst0,
                                           const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid,
-                                          uint32_t& tw_base, bool io_first = true, bool io_last = true) {
+                                          uint32_t& tw_base, bool io_first = true, bool io_last = true, size_t src_cs = 0, size_t dst_cs = 0,
+                                          uint32_t tile_cs = 0) {
+    static_assert(NC == 1 || MODE == 0, "several columns per thread: plain loads only");
     constexpr bool EXPAND = MODE == 1, FOLD = MODE == 2;
     const int rb = gp.rb[round];
     // io_first / io_last = false: the group's first round reads / its last round writes the LDS tile instead of HBM
@@ -219,7 +223,6 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
     };
 #pragma unroll 1
     for (int m = 0; m < SLOTS; ++m) {
-        uint32_t x[R];
         const uint32_t sigma = (uint32_t)tid + 256u * m;
         const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
         const uint32_t p0 = lds_phys(l0);
@@ -234,6 +237,12 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
             if (m + 1 < SLOTS) tw_base = load_twiddle_base<DIF>(im, gp, round, m + 1, tid, tw);
             else if (!last_round) tw_base = load_twiddle_base<DIF>(im, gp, round + 1, 0, tid, tw);
         }
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        uint32_t x[R];
+        uint32_t* tile = tile0 + (size_t)cc * tile_cs;
+        const uint32_t* src = src0 + (size_t)cc * src_cs;
+        uint32_t* dst = dst0 + (size_t)cc * dst_cs;
         // ---- load ----
         if (first) {
             if (FOLD) {
@@ -324,6 +333,7 @@ __device__ __forceinline__ void run_round(uint32_t* tile, const IndexMap& im, co
 #pragma unroll
             for (int rho = 0; rho < R; ++rho) tile[p0 + lds_off(rho)] = x[rho];
         }
+      }
     }
 }
 
@@ -369,16 +379,17 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
 }
 
 // all rounds of one stage group on the workgroup's tile(s). TWT: `tw` is the group's twiddle TABLE (FusedTwiddles).
-template <bool DIF, int EPT, bool TWT = false>
+template <bool DIF, int EPT, bool TWT = false, int NC = 1>
 __device__ __forceinline__ void run_group(uint32_t* tile, const IndexMap& im, const GroupParams& gp, const uint32_t* __restrict__ src,
-                                          uint32_t* __restrict__ dst, const uint32_t* __restrict__ tw, int tid, bool io_first, bool io_last) {
+                                          uint32_t* __restrict__ dst, const uint32_t* __restrict__ tw, int tid, bool io_first, bool io_last,
+                                          size_t src_cs = 0, size_t dst_cs = 0, uint32_t tile_cs = 0) {
     uint32_t tw_base = TWT ? 0u : load_twiddle_base<DIF>(im, gp, 0, 0, tid, tw);
     for (int r = 0; r < gp.n_rounds; ++r) {
         switch (gp.logr[r]) {
-            case 1: run_round<DIF, 1, EPT, 0, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
-            case 2: run_round<DIF, 2, EPT, 0, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
-            case 3: run_round<DIF, 3, EPT, 0, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
-            default: run_round<DIF, 4, EPT, 0, TWT>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last); break;
+            case 1: run_round<DIF, 1, EPT, 0, TWT, NC>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last, src_cs, dst_cs, tile_cs); break;
+            case 2: run_round<DIF, 2, EPT, 0, TWT, NC>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last, src_cs, dst_cs, tile_cs); break;
+            case 3: run_round<DIF, 3, EPT, 0, TWT, NC>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last, src_cs, dst_cs, tile_cs); break;
+            default: run_round<DIF, 4, EPT, 0, TWT, NC>(tile, im, gp, r, src, dst, tw, nullptr, tid, tw_base, io_first, io_last, src_cs, dst_cs, tile_cs); break;
         }
         if (r + 1 < gp.n_rounds) __syncthreads();
     }
@@ -390,37 +401,42 @@ __device__ __forceinline__ void run_group(uint32_t* tile, const IndexMap& im, co
 // rounds, expands through LDS and runs the DIT rounds on the 2^(ka+1) results: the H-sized coefficient array is neither
 // written nor re-read (8 of the 44 bytes the unfused schedule moves per trace cell). For H <= 2^12 the whole LDE of a
 // column is this one launch.
-__global__ __launch_bounds__(kBlock) void lde_fused_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t in_stride,
-                                                           size_t out_stride, GroupParams ga, GroupParams gd,
-                                                           const uint32_t* __restrict__ tw_inv, const uint32_t* __restrict__ tw_fwd,
-                                                           const uint32_t* __restrict__ scale_br) {
+template <int NC>
+__device__ __forceinline__ void lde_fused_body(uint32_t* tile, const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t in_stride,
+                                               size_t out_stride, const GroupParams& ga, const GroupParams& gd, const uint32_t* __restrict__ tw_inv,
+                                               const uint32_t* __restrict__ tw_fwd, const uint32_t* __restrict__ scale_br) {
     constexpr int LOGA = 12, LOGD = 13;
-    __shared__ uint32_t tile[(1 << LOGD) + ((1 << LOGD) >> 5)];
+    constexpr uint32_t kTileWords = (1u << LOGD) + ((1u << LOGD) >> 5);
     const int tid = threadIdx.x;
-    const uint32_t* src = in + (size_t)blockIdx.y * in_stride;
-    uint32_t* dst = out + (size_t)blockIdx.y * out_stride;
+    const uint32_t* src = in + (size_t)blockIdx.y * NC * in_stride;
+    uint32_t* dst = out + (size_t)blockIdx.y * NC * out_stride;
     IndexMap ia;
     ia.B = ga.B; ia.c = ga.c; ia.lowbits = ga.lowbits; ia.k = ga.k;
     ia.cmask = (1u << ga.c) - 1u;
     ia.tile0 = (size_t)blockIdx.x << (LOGA - ga.B);
     ia.n_tiles = (size_t)ga.n_tiles;
-    run_group<true, (1 << LOGA) / kBlock, true>(tile, ia, ga, src, nullptr, tw_inv, tid, true, false);
+    run_group<true, (1 << LOGA) / kBlock, true, NC>(tile, ia, ga, src, nullptr, tw_inv, tid, true, false, in_stride, 0, kTileWords);
     __syncthreads();
     // scale and duplicate: element l of the coefficient tile becomes elements 2l, 2l + 1 of the forward tile
-    uint32_t v[(1 << LOGA) / kBlock];
+    uint32_t v[NC][(1 << LOGA) / kBlock];
 #pragma unroll
     for (int m = 0; m < (1 << LOGA) / kBlock; ++m) {
         const uint32_t l = (uint32_t)tid + 256u * m;
         bool valid;
         const size_t q = ia.global(l, valid);
-        v[m] = valid ? bb::mul(tile[lds_phys(l)], scale_br[q]) : 0u;
+        const uint32_t sc = valid ? scale_br[q] : 0u;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) v[cc][m] = bb::mul(tile[cc * kTileWords + lds_phys(l)], sc);
     }
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < (1 << LOGA) / kBlock; ++m) {
         const uint32_t l = (uint32_t)tid + 256u * m;
-        tile[lds_phys(2 * l)] = v[m];
-        tile[lds_phys(2 * l + 1)] = v[m];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            tile[cc * kTileWords + lds_phys(2 * l)] = v[cc][m];
+            tile[cc * kTileWords + lds_phys(2 * l + 1)] = v[cc][m];
+        }
     }
     __syncthreads();
     IndexMap id;
@@ -428,7 +444,25 @@ __global__ __launch_bounds__(kBlock) void lde_fused_kernel(const uint32_t* __res
     id.cmask = (1u << gd.c) - 1u;
     id.tile0 = (size_t)blockIdx.x << (LOGD - gd.B);
     id.n_tiles = (size_t)gd.n_tiles;
-    run_group<false, (1 << LOGD) / kBlock, true>(tile, id, gd, nullptr, dst, tw_fwd, tid, false, true);
+    run_group<false, (1 << LOGD) / kBlock, true, NC>(tile, id, gd, nullptr, dst, tw_fwd, tid, false, true, 0, out_stride, kTileWords);
+}
+
+__global__ __launch_bounds__(kBlock) void lde_fused_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t in_stride,
+                                                           size_t out_stride, GroupParams ga, GroupParams gd,
+                                                           const uint32_t* __restrict__ tw_inv, const uint32_t* __restrict__ tw_fwd,
+                                                           const uint32_t* __restrict__ scale_br) {
+    __shared__ uint32_t tile[(1 << 13) + ((1 << 13) >> 5)];
+    lde_fused_body<1>(tile, in, out, in_stride, out_stride, ga, gd, tw_inv, tw_fwd, scale_br);
+}
+
+// Two columns per workgroup (POWDR_NTT_TWO_COL=1; VERDICT r4 #5, measured in profiles/r05_ntt_two_column.txt): both columns' tiles in
+// LDS (67.6 KB, dynamic: two workgroups per CU instead of four), one set of twiddle-table loads and slot indices for the pair.
+__global__ __launch_bounds__(kBlock) void lde_fused2_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t in_stride,
+                                                            size_t out_stride, GroupParams ga, GroupParams gd,
+                                                            const uint32_t* __restrict__ tw_inv, const uint32_t* __restrict__ tw_fwd,
+                                                            const uint32_t* __restrict__ scale_br) {
+    extern __shared__ uint32_t tile2[];
+    lde_fused_body<2>(tile2, in, out, in_stride, out_stride, ga, gd, tw_inv, tw_fwd, scale_br);
 }
 
 struct Tables {
@@ -777,7 +811,23 @@ int lde_fused(const uint32_t* in, uint32_t* tmp, uint32_t* out, size_t in_stride
         const size_t tiles = (size_t)1 << (n - ka);
         const size_t per_wg = (size_t)1 << (12 - ka);
         const unsigned wgs = (unsigned)((tiles + per_wg - 1) / per_wg);
-        for (uint32_t c0 = 0; c0 < cols; c0 += 65535u) {
+        uint32_t done = 0;
+        static const bool two_col = [] { const char* e = getenv("POWDR_NTT_TWO_COL"); return e && atoi(e) != 0; }();
+        if (two_col && cols >= 2) {
+            constexpr size_t kLds2 = 2 * ((1u << 13) + ((1u << 13) >> 5)) * sizeof(uint32_t);
+            static const hipError_t attr = hipFuncSetAttribute((const void*)lde_fused2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds2);
+            if (attr == hipSuccess) {
+                const uint32_t pairs = cols / 2;
+                for (uint32_t p0 = 0; p0 < pairs; p0 += 65535u) {
+                    const uint32_t pc = pairs - p0 < 65535u ? pairs - p0 : 65535u;
+                    ScopedKernelTimer t("lde_fused_kernel");
+                    hipLaunchKernelGGL(lde_fused2_kernel, dim3(wgs, pc), dim3(kBlock), kLds2, stream(), src + (size_t)(2 * p0) * src_stride,
+                                       out + (size_t)(2 * p0) * out_stride, src_stride, out_stride, ga, gd, ft->d, ft->d + ft->dit_base, tn->shift_br);
+                }
+                done = 2 * pairs;
+            } else (void)hipGetLastError();
+        }
+        for (uint32_t c0 = done; c0 < cols; c0 += 65535u) {
             const uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;
             ScopedKernelTimer t("lde_fused_kernel");
             hipLaunchKernelGGL(lde_fused_kernel, dim3(wgs, cc), dim3(kBlock), 0, stream(), src + (size_t)c0 * src_stride,
