@@ -359,11 +359,44 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     // outputs of its slot: 64 lanes x 16 instructions walking 64 cache lines side by side, which L1 does not hold for a CU's worth of waves.)
     constexpr bool kStageFold = MODE == 2;
     if (kStageFold) {
+        if (gp.B == LOGT && gp.c == 0 && gp.lowbits == 0 && gp.fold <= 1) {
+            // The whole-tile case of a tall transform (one tile per workgroup, element l of the tile = element tile * 2^LOGT + l of the
+            // transform's input): every lane issues ALL its loads — 16 bytes each — before the first product, instead of four 4-byte
+            // loads at a time (round 5: the group ran at 56 % of the issue rate with 30 % of the HBM rate, waiting for its own loads).
+            const size_t g0 = (size_t)blockIdx.x << LOGT;
+            constexpr int kVec = (1 << LOGT) / (4 * kBlock);  // uint4 loads per lane and coefficient word of an output
+            if (gp.fold == 0) {
+                const uint4* pv = reinterpret_cast<const uint4*>(src + g0);
+                uint4 d[kVec];
+#pragma unroll
+                for (int m = 0; m < kVec; ++m) d[m] = pv[(uint32_t)tid + kBlock * m];
+                const uint32_t k0 = gp.foldk[0];
+#pragma unroll
+                for (int m = 0; m < kVec; ++m) {
+                    const uint32_t l = 4u * ((uint32_t)tid + kBlock * m);
+                    tile[lds_phys(l)] = bb::mul(d[m].x, k0); tile[lds_phys(l + 1)] = bb::mul(d[m].y, k0);
+                    tile[lds_phys(l + 2)] = bb::mul(d[m].z, k0); tile[lds_phys(l + 3)] = bb::mul(d[m].w, k0);
+                }
+            } else {  // two coefficient words per output: a uint4 holds two outputs
+                const uint4* pv = reinterpret_cast<const uint4*>(src + 2 * g0);
+                uint4 d[2 * kVec];
+#pragma unroll
+                for (int m = 0; m < 2 * kVec; ++m) d[m] = pv[(uint32_t)tid + kBlock * m];
+                const uint32_t k0 = gp.foldk[0], k1 = gp.foldk[1];
+#pragma unroll
+                for (int m = 0; m < 2 * kVec; ++m) {
+                    const uint32_t l = 2u * ((uint32_t)tid + kBlock * m);
+                    tile[lds_phys(l)] = bb::mul2(d[m].x, k0, d[m].y, k1);
+                    tile[lds_phys(l + 1)] = bb::mul2(d[m].z, k0, d[m].w, k1);
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (uint32_t l = (uint32_t)tid; l < (1u << LOGT); l += kBlock) {
-            bool valid;
-            const size_t g = im.global(l, valid);
-            tile[lds_phys(l)] = valid ? fold_load(src, gp.foldk, g, gp.fold) : 0u;
+            for (uint32_t l = (uint32_t)tid; l < (1u << LOGT); l += kBlock) {
+                bool valid;
+                const size_t g = im.global(l, valid);
+                tile[lds_phys(l)] = valid ? fold_load(src, gp.foldk, g, gp.fold) : 0u;
+            }
         }
         __syncthreads();
     }
