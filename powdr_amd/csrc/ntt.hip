@@ -78,6 +78,12 @@ struct GroupParams {
     int coset;
     uint32_t foldk[16];
     uint32_t cst[4];
+    // SELECT (the query phase of a streamed proof, subcoset_query_rows): the group's outputs are not stored — of every tile only the
+    // n_sel positions sel_pos[q] are used: position * sel_xpow[q * n_tiles + tile] is added to sel_acc[column * n_sel + q] (64-bit sums).
+    int n_sel;
+    const uint32_t* sel_pos;
+    const uint32_t* sel_xpow;
+    unsigned long long* sel_acc;
 };
 
 __device__ __forceinline__ uint32_t lds_phys(uint32_t l) { return l + (l >> 5); }
@@ -358,6 +364,7 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     // reads 2^fold * 256 CONTIGUOUS bytes per instruction. (Loaded slot by slot like the other modes, a lane would read the 16 neighbouring
     // outputs of its slot: 64 lanes x 16 instructions walking 64 cache lines side by side, which L1 does not hold for a CU's worth of waves.)
     constexpr bool kStageFold = MODE == 2;
+    const bool select = MODE == 2 && gp.n_sel > 0;
     if (kStageFold) {
         if (gp.B == LOGT && gp.c == 0 && gp.lowbits == 0 && gp.fold <= 1) {
             // The whole-tile case of a tall transform (one tile per workgroup, element l of the tile = element tile * 2^LOGT + l of the
@@ -402,12 +409,21 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     }
     for (int r = 0; r < gp.n_rounds; ++r) {
         switch (gp.logr[r]) {
-            case 1: run_round<DIF, 1, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold); break;
-            case 2: run_round<DIF, 2, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold); break;
-            case 3: run_round<DIF, 3, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold); break;
-            default: run_round<DIF, 4, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold); break;
+            case 1: run_round<DIF, 1, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
+            case 2: run_round<DIF, 2, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
+            case 3: run_round<DIF, 3, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
+            default: run_round<DIF, 4, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
         }
         if (r + 1 < gp.n_rounds) __syncthreads();  // the next round reads what this round wrote
+    }
+    if (select) {
+        // the tile stays in LDS (the forward network's [0, 2p) representatives): this tile's term of every selected output
+        __syncthreads();
+        const size_t t = blockIdx.x;  // (one tile per workgroup: the host only selects then)
+        for (int q = tid; q < gp.n_sel; q += kBlock) {
+            const uint32_t v = bb::reduce_2p(tile[lds_phys(gp.sel_pos[q])]);
+            atomicAdd(gp.sel_acc + (size_t)blockIdx.y * gp.n_sel + q, (unsigned long long)bb::mul(v, gp.sel_xpow[(size_t)q * gp.n_tiles + t]));
+        }
     }
 }
 
@@ -668,6 +684,11 @@ struct CosetSpec {
     uint32_t foldk[16];
     uint32_t C[32];       // C[s] = c^(2^(n-1-s)), s < n
     uint32_t* d_scratch;  // room for a group's derived twiddle table (< 2^13 words)
+    // SELECT (GroupParams): only with max_groups = 1 and one tile per workgroup
+    int n_sel = 0;
+    const uint32_t* sel_pos = nullptr;
+    const uint32_t* sel_xpow = nullptr;
+    unsigned long long* sel_acc = nullptr;
 };
 
 template <bool DIF>
@@ -695,6 +716,7 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
             g.coset = 1;
             g.fold = mode == 2 ? cs->fold_log : 0;
             for (int k = 0; k < 16; ++k) g.foldk[k] = cs->foldk[k];
+            if (mode == 2 && cs->n_sel > 0) { g.n_sel = cs->n_sel; g.sel_pos = cs->sel_pos; g.sel_xpow = cs->sel_xpow; g.sel_acc = cs->sel_acc; }
             for (int r = 0; r < g.n_rounds; ++r) g.cst[r] = cs->C[g.s0 + g.rb[r] + g.logr[r] - 1 - g.c];
             if (gt) {
                 CosetTableArgs a{};
@@ -952,7 +974,72 @@ __global__ __launch_bounds__(256) void subcoset_rows_kernel(const uint32_t* __re
     }
     out[(size_t)(slot ? slot[blockIdx.y] : blockIdx.y) * cols + c] = acc;
 }
+// xpow[q * n_tiles + t] = x_q^(bitrev_k2(t)), x_q = c0 wm^(idx[q]): the factor tile t's element contributes to output idx[q] with
+__global__ __launch_bounds__(256) void select_xpow_kernel(const uint32_t* __restrict__ idx, uint32_t n_idx, int k2, uint32_t c0, uint32_t wm,
+                                                         uint32_t* __restrict__ xpow, uint32_t* __restrict__ pos, uint32_t pos_mask) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n_tiles = (size_t)1 << k2;
+    if (gid >= (size_t)n_idx * n_tiles) return;
+    const uint32_t q = (uint32_t)(gid >> k2), t = (uint32_t)(gid & (n_tiles - 1));
+    const uint32_t i = idx[q];
+    const uint32_t x = bb::mul(c0, bb::pow_u32(wm, i));
+    const uint32_t u = k2 ? (__brev(t) >> (32 - k2)) : 0u;
+    xpow[gid] = bb::pow_u32(x, u);
+    if (t == 0) pos[q] = i & pos_mask;
+}
+
+// rows_out[slot(q) * cols + c] = acc[c * n + q] mod p, as a Montgomery word in [0, p)
+__global__ __launch_bounds__(256) void select_finish_kernel(const unsigned long long* __restrict__ acc, uint32_t n, uint32_t cols,
+                                                           const uint32_t* __restrict__ slot, uint32_t* __restrict__ out) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= cols) return;
+    const uint32_t q = blockIdx.y;
+    out[(size_t)(slot ? slot[q] : q) * cols + c] = (uint32_t)(acc[(size_t)c * n + q] % bb::P);
+}
 }  // namespace
+
+// The rows d_local_idx[q] (q < n_idx) of sub-coset r's LDE WITHOUT storing the partial transform: the first stage group with SELECT
+// (the tile stays in LDS, every selected output gets this tile's term through a 64-bit atomic sum) — the query phase of a streamed
+// proof reads the coefficients once and writes a few megabytes. Tall transforms only (one 2^12-tile per workgroup and at least one
+// strided stage left); returns 1 when the shape does not qualify and nothing was done (the caller then takes
+// subcoset_lde_first_group + subcoset_rows). d_work: 2^13 + n_idx * (2^k2 + 1) words + cols * n_idx 64-bit sums.
+int subcoset_query_rows(const uint32_t* coeffs, size_t in_stride, uint32_t cols, int n, int b, uint32_t r, const uint32_t* d_local_idx,
+                        uint32_t n_idx, const uint32_t* d_slot, uint32_t* rows_out, uint32_t* d_work, size_t work_words) {
+    const int nm = n + 1 - b;
+    if (!n_idx || !cols) return 0;
+    if (cols > 65535u) return 1;  // (one launch: blockIdx.y is the column)
+    if (getenv("POWDR_QUERY_SELECT") && atoi(getenv("POWDR_QUERY_SELECT")) == 0) return 1;
+    CosetSpec cs;
+    if (!subcoset_spec(n, b, r, d_work, cs)) return (int)hipErrorInvalidValue;
+    int logt = 12;
+    auto groups = plan_groups(false, nm, 0, logt);
+    if (groups.size() < 2 || logt != 12 || groups[0].B != 12 || groups[0].c != 0 || groups[0].lowbits != 0 || cs.fold_log > 1) return 1;
+    const int k1 = groups[0].k, k2 = nm - k1;
+    const size_t n_tiles = (size_t)1 << k2;
+    uint32_t* d_pos = d_work + (1u << 13);
+    uint32_t* d_xpow = d_pos + ((n_idx + 1u) & ~1u);
+    unsigned long long* d_acc = reinterpret_cast<unsigned long long*>(d_xpow + (((size_t)n_idx * n_tiles + 1) & ~(size_t)1));
+    const size_t need = (size_t)(reinterpret_cast<uint32_t*>(d_acc + (size_t)cols * n_idx) - d_work);
+    if (need > work_words || ((uintptr_t)d_work & 7)) return 1;
+    const Tables* tm = tables(nm);
+    if (!tm) return (int)hipErrorOutOfMemory;
+    const uint32_t c0 = bb::mul(bb::to_monty(field::kCosetShift), bb::pow_u32(field::root_of_unity(n + 1), r));
+    {
+        ScopedKernelTimer t("subcoset_rows_kernel");
+        hipLaunchKernelGGL(select_xpow_kernel, dim3((unsigned)div_up((size_t)n_idx * n_tiles, 256)), dim3(256), 0, stream(), d_local_idx, n_idx, k2, c0,
+                           field::root_of_unity(nm), d_xpow, d_pos, (1u << k1) - 1u);
+    }
+    PW_HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)cols * n_idx * sizeof(unsigned long long), stream()));
+    cs.n_sel = (int)n_idx; cs.sel_pos = d_pos; cs.sel_xpow = d_xpow; cs.sel_acc = d_acc;
+    int done = 0;
+    // (`out` of the group is never written in SELECT mode: the coefficient array stands in for it)
+    run_groups<false>(coeffs, const_cast<uint32_t*>(coeffs), in_stride, in_stride, cols, nm, 0, tm->tw_fwd, nullptr, "ntt_group_kernel<dit>", &cs, 1, &done);
+    {
+        ScopedKernelTimer t("subcoset_rows_kernel");
+        hipLaunchKernelGGL(select_finish_kernel, dim3(div_up(cols, 256), n_idx), dim3(256), 0, stream(), d_acc, n_idx, cols, d_slot, rows_out);
+    }
+    return (int)hipGetLastError();
+}
 
 int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, uint32_t r,
                  uint32_t* d_scratch) {

@@ -41,6 +41,10 @@ int subcoset_lde(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t
 int values_from_coefficients(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, uint32_t* d_scratch);
 int subcoset_lde_first_group(const uint32_t* coeffs, uint32_t* out, size_t in_stride, size_t out_stride, uint32_t cols, int n, int b, uint32_t r,
                              uint32_t* d_scratch, int* stages_done);
+// The same rows in ONE pass that stores no partial transform (tall transforms; ntt.hip subcoset_query_rows): 0 = done, 1 = the shape
+// does not qualify (use the two calls above), else an error. d_work: 8-byte aligned scratch of work_words words.
+int subcoset_query_rows(const uint32_t* coeffs, size_t in_stride, uint32_t cols, int n, int b, uint32_t r, const uint32_t* d_local_idx,
+                        uint32_t n_idx, const uint32_t* d_slot, uint32_t* rows_out, uint32_t* d_work, size_t work_words);
 int subcoset_rows(const uint32_t* part, size_t stride, uint32_t cols, int n, int b, uint32_t r, int stages_done, const uint32_t* d_local_idx,
                   uint32_t n_idx, const uint32_t* d_slot, uint32_t* rows_out);  // row q goes to slot d_slot[q] (null: q)
 

@@ -112,6 +112,10 @@ inline int query_rows(const Ctx& c, const uint32_t* coef, uint32_t cols, const u
     for (uint32_t r = 0; r < nb; ++r) {
         const uint32_t k0 = first[r], cnt = first[r + 1] - first[r];
         if (!cnt) continue;
+        // tall sub-cosets: one pass that keeps the tiles in LDS and sums the queried rows' terms (p->lde is only scratch then)
+        const int sel = subcoset_query_rows(coef, c.H, cols, (int)c.log_h, c.b, r, d_loc + k0, cnt, d_slot + k0, d_rows, d_blk, c.p->lde.bytes / 4);
+        if (sel == 0) continue;
+        if (sel != 1) return sel;
         int done = 0;
         PW_STRY(subcoset_lde_first_group(coef, d_blk, c.H, c.m, cols, (int)c.log_h, c.b, r, fs, &done));
         PW_STRY(subcoset_rows(d_blk, c.m, cols, (int)c.log_h, c.b, r, done, d_loc + k0, cnt, d_slot + k0, d_rows));
