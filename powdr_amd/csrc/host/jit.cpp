@@ -380,29 +380,29 @@ std::vector<ProgramPtr> compile_all(const std::vector<std::string>& sources, std
             std::lock_guard<std::mutex> lk(g_cache_mu);
             for (auto& e : late) publish(e.first, std::move(e.second));
         }
-      if (!todo.empty()) {
-        unsigned n_procs = std::thread::hardware_concurrency();
-        if (n_procs > 32) n_procs = 32;
-        if (const char* e = getenv("POWDR_JIT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_procs = (unsigned)v; }
-        if (n_procs < 1) n_procs = 1;
-        if (n_procs > todo.size()) n_procs = (unsigned)todo.size();
-        std::vector<std::vector<char>> code(todo.size());
-        bool compiled = false;
-        const std::string helper = n_procs > 1 ? helper_path() : std::string();
-        std::string e;
-        if (!helper.empty() && compile_with_helpers(helper, sources, todo, n_procs, code, compiled, &e)) {
-            if (!compiled) { if (err) *err = e; return {}; }
-        } else {
-            for (size_t k = 0; k < todo.size(); ++k)
-                if (!compile_code(sources[todo[k]], code[k], &e)) { if (err) *err = e; return {}; }
+        if (!todo.empty()) {
+            unsigned n_procs = std::thread::hardware_concurrency();
+            if (n_procs > 32) n_procs = 32;
+            if (const char* e = getenv("POWDR_JIT_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 256) n_procs = (unsigned)v; }
+            if (n_procs < 1) n_procs = 1;
+            if (n_procs > todo.size()) n_procs = (unsigned)todo.size();
+            std::vector<std::vector<char>> code(todo.size());
+            bool compiled = false;
+            const std::string helper = n_procs > 1 ? helper_path() : std::string();
+            std::string e;
+            if (!helper.empty() && compile_with_helpers(helper, sources, todo, n_procs, code, compiled, &e)) {
+                if (!compiled) { if (err) *err = e; return {}; }
+            } else {
+                for (size_t k = 0; k < todo.size(); ++k)
+                    if (!compile_code(sources[todo[k]], code[k], &e)) { if (err) *err = e; return {}; }
+            }
+            g_units_compiled += todo.size();
+            for (size_t k = 0; k < todo.size(); ++k) disk_store(cache_dir, sources[todo[k]], code[k]);
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            for (size_t k = 0; k < todo.size(); ++k) publish(todo[k], std::move(code[k]));
+            if (g_cache.size() > 4096)  // expired slots of AIRs long gone
+                for (auto it = g_cache.begin(); it != g_cache.end();) it = it->second.expired() ? g_cache.erase(it) : std::next(it);
         }
-        g_units_compiled += todo.size();
-        for (size_t k = 0; k < todo.size(); ++k) disk_store(cache_dir, sources[todo[k]], code[k]);
-        std::lock_guard<std::mutex> lk(g_cache_mu);
-        for (size_t k = 0; k < todo.size(); ++k) publish(todo[k], std::move(code[k]));
-        if (g_cache.size() > 4096)  // expired slots of AIRs long gone
-            for (auto it = g_cache.begin(); it != g_cache.end();) it = it->second.expired() ? g_cache.erase(it) : std::next(it);
-      }
     }
     return out;
 }
