@@ -74,6 +74,7 @@ struct GroupParams {
     // wave-uniform constants foldk[] — and a COSET transform: the twiddles of stage s carry the constant c^(2^(n-1-s)). Tile-invariant
     // groups read them from a table derived for the sub-coset; the others multiply a round's top twiddle base by cst[round] (the lower
     // stages' constants follow from the squaring chain).
+    int logt;     // log2 of the LDS tile the group's kernel is instantiated for (0: the plan's common size)
     int fold;
     int coset;
     uint32_t foldk[16];
@@ -227,7 +228,9 @@ __device__ __forceinline__ void run_round(uint32_t* tile0, const IndexMap& im, c
     auto lds_off = [rb](int rho) -> uint32_t {
         return ((uint32_t)rho << rb) + (rb >= 5 ? ((uint32_t)rho << (rb - 5)) : ((uint32_t)rho >> (5 - rb)));
     };
-#pragma unroll 1
+    // (2^14-element tiles — two workgroups per CU — keep two slots' loads in flight per lane)
+    constexpr int kSlotUnroll = EPT >= 64 ? 2 : 1;
+#pragma unroll kSlotUnroll
     for (int m = 0; m < SLOTS; ++m) {
         const uint32_t sigma = (uint32_t)tid + 256u * m;
         const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
@@ -590,16 +593,9 @@ std::vector<GroupParams> plan_groups(bool dif, int n, int first, int& logt_out, 
         n_groups = total > 0 ? passes(logt) : 0;
     }
     logt_out = logt;
-    int s = first;
-    int groups_left = n_groups;
-    while (s < end) {
-        int rem = end - s, k = rem < logt ? rem : logt;
-        if (balance && groups_left > 0) { const int target = (rem + groups_left - 1) / groups_left; if (k > target) k = target; }
-        --groups_left;
-        int c = 0;
-        for (; k >= 1; --k) { int lb = dif ? n - s - k : s; c = lb < kStridedC ? lb : kStridedC; if (k + c <= logt) break; }
+    auto make_group = [&](int s, int k, int c, int lt) {
         GroupParams g{};
-        g.n = n; g.s0 = s; g.k = k; g.c = c; g.lowbits = dif ? n - s - k : s; g.B = k + c;
+        g.n = n; g.s0 = s; g.k = k; g.c = c; g.lowbits = dif ? n - s - k : s; g.B = k + c; g.logt = lt;
         g.n_tiles = 1ull << (n - g.B);
         // rounds: ceil(k/4) windows of nearly equal width
         int nr = (k + 3) / 4;
@@ -613,8 +609,30 @@ std::vector<GroupParams> plan_groups(bool dif, int n, int first, int& logt_out, 
             int bot = c;
             for (int r = 0; r < nr; ++r) { g.rb[r] = bot; g.logr[r] = widths[r]; bot += widths[r]; }
         }
-        out.push_back(g);
+        return g;
+    };
+    int s = first;
+    int groups_left = n_groups;
+    while (s < end) {
+        int rem = end - s, k = rem < logt ? rem : logt;
+        if (balance && groups_left > 0) { const int target = (rem + groups_left - 1) / groups_left; if (k > target) k = target; }
+        --groups_left;
+        int c = 0;
+        for (; k >= 1; --k) { int lb = dif ? n - s - k : s; c = lb < kStridedC ? lb : kStridedC; if (k + c <= logt) break; }
+        out.push_back(make_group(s, k, c, logt));
         s += k;
+    }
+    // A tall transform whose greedy plan is three passes over HBM (2^22 points: 12 contiguous + 7 + 3 stages forward, 7 + 7 + 8 inverse)
+    // as TWO: the 12 contiguous stages on a 2^12 tile and ALL strided stages (at most 10) as one group on a 2^14-element tile with
+    // 64-byte segments (c = 4) — the strided groups run at the box's copy rate, so a pass less is the only way to make them faster
+    // (round 5; POWDR_NTT_TILE14=0 keeps the three-pass plan).
+    static const int tile14 = [] { const char* e = getenv("POWDR_NTT_TILE14"); return e ? atoi(e) : 0; }();
+    if (tile14 && !balance && out.size() == 3 && end == n && (dif || first == 0) && total - 12 >= 1 && total - 12 <= 10) {
+        const int ks = total - 12;
+        out.clear();
+        if (dif) { out.push_back(make_group(first, ks, 4, 14)); out.push_back(make_group(first + ks, 12, 0, 12)); }
+        else     { out.push_back(make_group(first, 12, 0, 12)); out.push_back(make_group(first + 12, ks, 4, 14)); }
+        logt_out = 12;
     }
     return out;
 }
@@ -706,8 +724,9 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
     int mode = cs ? 2 : expand_scale_br != nullptr ? 1 : 0;
     if (!groups.empty() && complete) groups.back().canonical_out = 1;
     for (auto& g : groups) {
+        const int glt = g.logt ? g.logt : logt;
         const size_t tiles = (size_t)1 << (n - g.B);
-        const size_t per_wg = (size_t)1 << (logt - g.B);
+        const size_t per_wg = (size_t)1 << (glt - g.B);
         const unsigned wgs = (unsigned)((tiles + per_wg - 1) / per_wg);
         const GroupTwiddles* gt = group_twiddles(g, DIF);  // tile-invariant groups read their twiddles from a table
         if (gt) for (int r = 0; r < 4; ++r) g.twt_off[r] = gt->off[r];
@@ -740,7 +759,8 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
             dim3 grid(wgs, cc), block(kBlock);
 #define PW_LAUNCH_NTT(LT, MD) do { if (gt) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, MD, true>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, table, expand_scale_br); \
                                    else hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, MD, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br); } while (0)
-            if (logt == 13) { if (mode == 2) PW_LAUNCH_NTT(13, 2); else if (mode == 1) PW_LAUNCH_NTT(13, 1); else PW_LAUNCH_NTT(13, 0); }
+            if (glt == 14) hipLaunchKernelGGL((ntt_group_kernel<DIF, 14, 0, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br);  // (a strided group: never the first of a coset / expanding transform)
+            else if (glt == 13) { if (mode == 2) PW_LAUNCH_NTT(13, 2); else if (mode == 1) PW_LAUNCH_NTT(13, 1); else PW_LAUNCH_NTT(13, 0); }
             else            { if (mode == 2) PW_LAUNCH_NTT(12, 2); else if (mode == 1) PW_LAUNCH_NTT(12, 1); else PW_LAUNCH_NTT(12, 0); }
 #undef PW_LAUNCH_NTT
         }
@@ -774,7 +794,7 @@ void launch_groups(std::vector<GroupParams>& groups, int logt, const uint32_t* i
     size_t src_stride = in_stride;
     for (auto& g : groups) {
         const size_t tiles = (size_t)1 << (n - g.B);
-        const size_t per_wg = (size_t)1 << (logt - g.B);
+        const size_t per_wg = (size_t)1 << (logt - g.B);  // (balanced plans: every group on the plan's tile size)
         const unsigned wgs = (unsigned)((tiles + per_wg - 1) / per_wg);
         for (uint32_t c0 = 0; c0 < cols; c0 += 65535u) {
             const uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;
@@ -1013,7 +1033,7 @@ int subcoset_query_rows(const uint32_t* coeffs, size_t in_stride, uint32_t cols,
     if (!subcoset_spec(n, b, r, d_work, cs)) return (int)hipErrorInvalidValue;
     int logt = 12;
     auto groups = plan_groups(false, nm, 0, logt);
-    if (groups.size() < 2 || logt != 12 || groups[0].B != 12 || groups[0].c != 0 || groups[0].lowbits != 0 || cs.fold_log > 1) return 1;
+    if (groups.size() < 2 || (groups[0].logt ? groups[0].logt : logt) != 12 || groups[0].B != 12 || groups[0].c != 0 || groups[0].lowbits != 0 || cs.fold_log > 1) return 1;
     const int k1 = groups[0].k, k2 = nm - k1;
     const size_t n_tiles = (size_t)1 << k2;
     uint32_t* d_pos = d_work + (1u << 13);
