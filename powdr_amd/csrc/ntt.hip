@@ -228,9 +228,7 @@ __device__ __forceinline__ void run_round(uint32_t* tile0, const IndexMap& im, c
     auto lds_off = [rb](int rho) -> uint32_t {
         return ((uint32_t)rho << rb) + (rb >= 5 ? ((uint32_t)rho << (rb - 5)) : ((uint32_t)rho >> (5 - rb)));
     };
-    // (2^14-element tiles — two workgroups per CU — keep two slots' loads in flight per lane)
-    constexpr int kSlotUnroll = EPT >= 64 ? 2 : 1;
-#pragma unroll kSlotUnroll
+#pragma unroll 1
     for (int m = 0; m < SLOTS; ++m) {
         const uint32_t sigma = (uint32_t)tid + 256u * m;
         const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
