@@ -13,8 +13,12 @@ rm -rf $R/gpurun_out/r05_prof_stats $R/gpurun_out/r05_prof_c3 /tmp/c3_fetch /tmp
 ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r05_prof_stats -- python $R/bench.py --steps 10 --warmup 3 $LEGS --full-out $R/gpurun_out/r05_bench_c2_under_rocprofv3_full.json ) > $R/gpurun_out/r05_bench_c2_under_rocprofv3.json 2> $R/gpurun_out/r05_prof_stats.err
 ( timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r05_prof_c3 -- python $R/tools/run_c3_logup.py 2 --no-constraints-only --no-segment ) > $R/gpurun_out/r05_c3_logup_under_rocprofv3.txt 2> $R/gpurun_out/r05_prof_c3.err
 cp $R/gpurun_out/c3_logup.json $R/gpurun_out/r05_c3_logup_profiled.json
+# (PMC passes: POWDR_QUERY_SELECT=0 — on the round's last build the FETCH_SIZE pass did not come back within its 600 s with the query phase's
+#  64-bit atomic sums under counter collection; the two-kernel query path profiles like round 4's. The kernel-trace passes above are unaffected.)
+export POWDR_QUERY_SELECT=0
 ( timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/c3_fetch -- python $R/tools/run_c3_logup.py 1 --no-constraints-only --no-segment ) > /dev/null 2> $R/gpurun_out/r05_pmc_c3_fetch.err
 ( timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/c3_write -- python $R/tools/run_c3_logup.py 1 --no-constraints-only --no-segment ) > /dev/null 2> $R/gpurun_out/r05_pmc_c3_write.err
+unset POWDR_QUERY_SELECT
 cd $R
 python tools/pmc_traffic_json.py /tmp/c3_fetch /tmp/c3_write 2 "C3 3731 cols x 2^22 rows with LogUp, trace handed over, streamed over 2 sub-cosets (bytes per PROOF: 1 warm-up + 1 timed proof under the counters; trace generation and the two restoring transforms run once each)" > gpurun_out/r05_pmc_traffic_c3_logup.json 2> gpurun_out/r05_pmc_traffic_c3.err
 for f in $(find gpurun_out/r05_prof_stats -name "*kernel_stats.csv" | head -1); do cp $f gpurun_out/r05_kernel_stats_c2.csv; done
