@@ -15,7 +15,8 @@ N>1: one process per GPU, every rank proves its own independent segments (weak s
 data-path collective); the only RCCL traffic is the final all-gather of the per-segment trace
 commitments (32 B per segment), inside the timed region.
 
-Output: ONE JSON line on rank 0 (see the repository contract).
+Output: ONE JSON line on rank 0 (see the repository contract) — the COMPACT record (compact_line: under 6 000 bytes, strict JSON, every
+string under 120 characters); the full record of the run (kernel tables, notes, every sub-benchmark) goes to bench_full.json (--full-out).
 """
 from __future__ import annotations
 
