@@ -120,11 +120,11 @@ struct IndexMap {
 // The twiddle base of slot m of a round: w^(g << shift) for the slot's low global index bits g and the round's
 // smallest shift (the one of window bit logr-1). A table lookup with global-memory latency on the critical path
 // of the slot's butterflies, so callers fetch it one slot (or one round) ahead.
-template <bool DIF>
+template <bool DIF, int NT = kBlock>
 __device__ __forceinline__ uint32_t load_twiddle_base(const IndexMap& im, const GroupParams& gp, int round, int m, int tid,
                                                       const uint32_t* __restrict__ tw) {
     const int rb = gp.rb[round], logr = gp.logr[round];
-    const uint32_t sigma = (uint32_t)tid + 256u * m;
+    const uint32_t sigma = (uint32_t)tid + (uint32_t)NT * m;
     const uint32_t l0 = ((sigma >> rb) << (rb + logr)) | (sigma & ((1u << rb) - 1u));
     const size_t g = im.glow(l0, rb);
     const int sh_top = DIF ? gp.s0 + gp.k - 1 - (rb + (logr - 1) - gp.c)       // stage number s_q
@@ -205,7 +205,7 @@ __device__ __forceinline__ uint32_t fold_load(const uint32_t* __restrict__ src, 
 // MODE: 0 = plain loads, 1 = EXPAND, 2 = FOLD (fold_load above).
 // NC (two-column experiment): a thread runs its slot for NC columns — column cc in tile0 + cc * tile_cs, src0 + cc * src_cs,
 // dst0 + cc * dst_cs — with ONE set of slot indices and twiddles (the table loads and the index arithmetic are shared).
-template <bool DIF, int LOGR, int EPT, int MODE, bool TWT = false, int NC = 1>
+template <bool DIF, int LOGR, int EPT, int MODE, bool TWT = false, int NC = 1, int NT = kBlock>
 __device__ __forceinline__ void run_round(uint32_t* tile0, const IndexMap& im, const GroupParams& gp, int round,
                                           const uint32_t* __restrict__ src0, uint32_t* __restrict__ dst0,
                                           const uint32_t* __restrict__ tw, const uint32_t* __restrict__ scale_br, int tid,
@@ -230,7 +230,7 @@ __device__ __forceinline__ void run_round(uint32_t* tile0, const IndexMap& im, c
     };
 #pragma unroll 1
     for (int m = 0; m < SLOTS; ++m) {
-        const uint32_t sigma = (uint32_t)tid + 256u * m;
+        const uint32_t sigma = (uint32_t)tid + (uint32_t)NT * m;
         const uint32_t l0 = ((sigma >> rb) << (rb + LOGR)) | (sigma & ((1u << rb) - 1u));
         const uint32_t p0 = lds_phys(l0);
         // fetch the next slot's (or the next round's first) twiddle base while this slot computes
@@ -241,8 +241,8 @@ __device__ __forceinline__ void run_round(uint32_t* tile0, const IndexMap& im, c
 #pragma unroll
             for (int j = 0; j < R - 1; ++j) tt[j] = tab[(uint32_t)j << rb];
         } else {
-            if (m + 1 < SLOTS) tw_base = load_twiddle_base<DIF>(im, gp, round, m + 1, tid, tw);
-            else if (!last_round) tw_base = load_twiddle_base<DIF>(im, gp, round + 1, 0, tid, tw);
+            if (m + 1 < SLOTS) tw_base = load_twiddle_base<DIF, NT>(im, gp, round, m + 1, tid, tw);
+            else if (!last_round) tw_base = load_twiddle_base<DIF, NT>(im, gp, round + 1, 0, tid, tw);
         }
 #pragma unroll
       for (int cc = 0; cc < NC; ++cc) {
@@ -345,12 +345,14 @@ __device__ __forceinline__ void run_round(uint32_t* tile0, const IndexMap& im, c
 }
 
 // TWT: `tw` is the group's twiddle TABLE (tile-invariant groups, see group_twiddles) instead of the transform's root table
-template <bool DIF, int LOGT, int MODE, bool TWT = false>
-__global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                           size_t in_stride, size_t out_stride, GroupParams gp,
-                                                           const uint32_t* __restrict__ tw,
-                                                           const uint32_t* __restrict__ scale_br) {
-    constexpr int EPT = (1 << LOGT) / kBlock;
+// NT: threads per workgroup (256; 1 024 for the 2^14-element tiles of the two-pass plan: the same 16 elements per lane, 8 waves per SIMD)
+template <bool DIF, int LOGT, int MODE, bool TWT = false, int NT = kBlock>
+__global__ __launch_bounds__(NT) void ntt_group_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                       size_t in_stride, size_t out_stride, GroupParams gp,
+                                                       const uint32_t* __restrict__ tw,
+                                                       const uint32_t* __restrict__ scale_br) {
+    static_assert(NT == kBlock || MODE == 0, "wide workgroups: plain strided groups only");
+    constexpr int EPT = (1 << LOGT) / NT;
     __shared__ uint32_t tile[(1 << LOGT) + ((1 << LOGT) >> 5)];
     const int tid = threadIdx.x;
     IndexMap im;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     im.n_tiles = (size_t)gp.n_tiles;
     const uint32_t* src = in + (size_t)blockIdx.y * in_stride;
     uint32_t* dst = out + (size_t)blockIdx.y * out_stride;
-    uint32_t tw_base = TWT ? 0u : load_twiddle_base<DIF>(im, gp, 0, 0, tid, tw);
+    uint32_t tw_base = TWT ? 0u : load_twiddle_base<DIF, NT>(im, gp, 0, 0, tid, tw);
     // FOLD (sub-coset evaluation): the folded inputs of the workgroup's tile(s) are staged through LDS first — lane = output, so a wave
     // reads 2^fold * 256 CONTIGUOUS bytes per instruction. (Loaded slot by slot like the other modes, a lane would read the 16 neighbouring
     // outputs of its slot: 64 lanes x 16 instructions walking 64 cache lines side by side, which L1 does not hold for a CU's worth of waves.)
@@ -410,10 +412,10 @@ __global__ __launch_bounds__(kBlock) void ntt_group_kernel(const uint32_t* __res
     }
     for (int r = 0; r < gp.n_rounds; ++r) {
         switch (gp.logr[r]) {
-            case 1: run_round<DIF, 1, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
-            case 2: run_round<DIF, 2, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
-            case 3: run_round<DIF, 3, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
-            default: run_round<DIF, 4, EPT, MODE, TWT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
+            case 1: run_round<DIF, 1, EPT, MODE, TWT, 1, NT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
+            case 2: run_round<DIF, 2, EPT, MODE, TWT, 1, NT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
+            case 3: run_round<DIF, 3, EPT, MODE, TWT, 1, NT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
+            default: run_round<DIF, 4, EPT, MODE, TWT, 1, NT>(tile, im, gp, r, src, dst, tw, scale_br, tid, tw_base, !kStageFold, !select); break;
         }
         if (r + 1 < gp.n_rounds) __syncthreads();  // the next round reads what this round wrote
     }
@@ -757,7 +759,7 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
             dim3 grid(wgs, cc), block(kBlock);
 #define PW_LAUNCH_NTT(LT, MD) do { if (gt) hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, MD, true>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, table, expand_scale_br); \
                                    else hipLaunchKernelGGL((ntt_group_kernel<DIF, LT, MD, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br); } while (0)
-            if (glt == 14) hipLaunchKernelGGL((ntt_group_kernel<DIF, 14, 0, false>), grid, block, 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br);  // (a strided group: never the first of a coset / expanding transform)
+            if (glt == 14) hipLaunchKernelGGL((ntt_group_kernel<DIF, 14, 0, false, 1024>), grid, dim3(1024), 0, stream(), s_, d_, src_stride, out_stride, g, tw, expand_scale_br);  // (a strided group: never the first of a coset / expanding transform)
             else if (glt == 13) { if (mode == 2) PW_LAUNCH_NTT(13, 2); else if (mode == 1) PW_LAUNCH_NTT(13, 1); else PW_LAUNCH_NTT(13, 0); }
             else            { if (mode == 2) PW_LAUNCH_NTT(12, 2); else if (mode == 1) PW_LAUNCH_NTT(12, 1); else PW_LAUNCH_NTT(12, 0); }
 #undef PW_LAUNCH_NTT
