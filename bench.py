@@ -193,6 +193,17 @@ def compact_line(full: dict) -> dict:
             out["stage_ms"] = dict(top)
             continue
         out.pop(victim, None)
+    if len(json.dumps(out, allow_nan=False, separators=(", ", ": "))) > LINE_LIMIT:
+        # still too long after every optional block went: the contract's fields and the pointer to the full record, nothing else
+        print("bench.py: compact record above the line limit; printing the contract fields only", file=sys.stderr)
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "full_record")
+        out = {k: out.get(k) for k in keep if k in out}
+        for victim in ("cpu_baseline", "roofline", "config"):
+            if len(json.dumps(out, allow_nan=False, separators=(", ", ": "))) <= LINE_LIMIT:
+                break
+            v = out.get(victim)
+            out[victim] = {k: x for k, x in v.items() if not isinstance(x, (dict, list, str)) or k in ("bound", "unit", "kind", "workload")} if isinstance(v, dict) else None
     return out
 
 
@@ -212,7 +223,8 @@ def emit(line: dict):
         except OSError as e:
             print(f"bench.py: could not write {full_path}: {e}", file=sys.stderr)
     text = json.dumps(compact_line(line), allow_nan=False)
-    assert len(text) <= LINE_LIMIT, len(text)
+    if len(text) > LINE_LIMIT:  # (compact_line degrades to the contract's fields; a line is printed whatever happens)
+        print(f"bench.py: line of {len(text)} bytes is above the {LINE_LIMIT}-byte limit", file=sys.stderr)
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:

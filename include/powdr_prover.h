@@ -86,7 +86,7 @@ int pw_prover_prove_consuming(PwProver* p, uint32_t* d_trace, uint32_t log_heigh
 int pw_prover_stream_log_blocks_consuming(const PwProver* p, uint32_t log_height);
 /* In place: width columns of 2^log_height H-scaled bit-reversed coefficients (what a streamed pw_prover_prove_consuming
  * leaves) -> the values on the trace domain, natural row order, canonical Montgomery words. d_scratch: 2^13 words. */
-int pw_trace_from_coefficients(uint32_t* d_coeffs, uint32_t width, uint32_t log_height, uint32_t* d_scratch);
+int pw_trace_from_coefficients(uint32_t* d_coeffs, uint32_t width, uint32_t log_height, uint32_t* d_scratch); /* d_coeffs 16-byte aligned */
 
 /* "Mock prover": evaluate every constraint on every row of the trace on the device and report violations —
  * the counterpart of the reference's `debug_proving_ctx` used by its `prove_mock` tests
@@ -284,6 +284,7 @@ int pw_lde_fused(const uint32_t* d_trace, uint32_t width, uint32_t log_height, u
 /* One sub-coset of the LDE from coefficient arrays (the stage the streamed mode is built on): d_coeffs as pw_lde_batch leaves them
  * (width x H, bit-reversed, H-scaled); d_out (width x 2H / 2^log_blocks) receives the rows r + 2^log_blocks * i of the LDE, i.e. the
  * evaluations on (31 g_(n+1)^r) <g_(n+1)^(2^log_blocks)>; d_scale: H words of scratch. 1 <= log_blocks <= min(log_height, 5). */
+/* d_coeffs must be 16-byte aligned (hipErrorInvalidValue otherwise). */
 int pw_lde_subcoset(const uint32_t* d_coeffs, uint32_t width, uint32_t log_height, uint32_t log_blocks, uint32_t r, uint32_t* d_scale,
                     uint32_t* d_out);
 

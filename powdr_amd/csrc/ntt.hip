@@ -30,6 +30,7 @@
 #include "common.hpp"
 #include "prover_internal.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -890,8 +891,17 @@ int lde_fused(const uint32_t* in, uint32_t* tmp, uint32_t* out, size_t in_stride
         static const bool two_col = [] { const char* e = getenv("POWDR_NTT_TWO_COL"); return e && atoi(e) != 0; }();
         if (two_col && cols >= 2) {
             constexpr size_t kLds2 = 2 * ((1u << 13) + ((1u << 13) >> 5)) * sizeof(uint32_t);
-            static const hipError_t attr = hipFuncSetAttribute((const void*)lde_fused2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds2);
-            if (attr == hipSuccess) {
+            // the attribute belongs to the current device's code object: set it once per device (worker threads of pw_prove_segments_multi)
+            static std::atomic<uint64_t> attr_ok{0}, attr_tried{0};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const uint64_t bit = 1ull << (dev & 63);
+            if (!(attr_tried.load() & bit)) {
+                if (hipFuncSetAttribute((const void*)lde_fused2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds2) == hipSuccess) attr_ok |= bit;
+                else (void)hipGetLastError();
+                attr_tried |= bit;
+            }
+            if (attr_ok.load() & bit) {
                 const uint32_t pairs = cols / 2;
                 for (uint32_t p0 = 0; p0 < pairs; p0 += 65535u) {
                     const uint32_t pc = pairs - p0 < 65535u ? pairs - p0 : 65535u;
@@ -900,7 +910,7 @@ int lde_fused(const uint32_t* in, uint32_t* tmp, uint32_t* out, size_t in_stride
                                        out + (size_t)(2 * p0) * out_stride, src_stride, out_stride, ga, gd, ft->d, ft->d + ft->dit_base, tn->shift_br);
                 }
                 done = 2 * pairs;
-            } else (void)hipGetLastError();
+            }
         }
         for (uint32_t c0 = done; c0 < cols; c0 += 65535u) {
             const uint32_t cc = cols - c0 < 65535u ? cols - c0 : 65535u;

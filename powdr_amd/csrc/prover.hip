@@ -360,11 +360,12 @@ int stream_log_blocks(const PwProver* p, uint32_t log_h, bool consume = false) {
 }
 
 int apply_commit_buffers(PwProver* p, const BufferPlan& B) {
+    // release before growing: stream_log_blocks counted a held tcoef as available (a consuming proof after a plain streamed one)
+    if (!B.tcoef) p->tcoef.release();
     TRY(p->coef.ensure(B.coef));
     TRY(p->lde.ensure(B.lde));
     TRY(p->digests.ensure(B.digests));
     if (B.tcoef) TRY(p->tcoef.ensure(B.tcoef));
-    else p->tcoef.release();  // (a consuming proof after a plain one: the room is needed)
     if (B.fscale) TRY(p->fscale.ensure(B.fscale));
     return 0;
 }
@@ -989,6 +990,7 @@ extern "C" int pw_prover_stream_log_blocks_consuming(const PwProver* p, uint32_t
 extern "C" int pw_trace_from_coefficients(uint32_t* d_coeffs, uint32_t width, uint32_t log_h, uint32_t* d_scratch8k) {
     (void)hipGetLastError();
     if (!d_coeffs || !d_scratch8k || !width || log_h < 1 || log_h > 26) return -1;
+    if ((uintptr_t)d_coeffs & 15) return (int)hipErrorInvalidValue;  // the first stage group stages whole tiles with 16-byte loads
     TRY(values_from_coefficients(d_coeffs, d_coeffs, (size_t)1 << log_h, (size_t)1 << log_h, width, (int)log_h, d_scratch8k));
     return (int)hipGetLastError();
 }
@@ -1037,6 +1039,7 @@ extern "C" int pw_lde_subcoset(const uint32_t* d_coeffs, uint32_t width, uint32_
                                uint32_t* d_out) {
     (void)hipGetLastError();
     if (!d_coeffs || !d_scale || !d_out || !width || log_blocks < 1 || log_blocks > log_h || log_h > 26 || (r >> log_blocks)) return -1;
+    if ((uintptr_t)d_coeffs & 15) return (int)hipErrorInvalidValue;  // (16-byte staged loads, as above)
     const size_t H = (size_t)1 << log_h, m = (2 * H) >> log_blocks;
     TRY(subcoset_lde(d_coeffs, d_out, H, m, width, (int)log_h, (int)log_blocks, r, d_scale));
     return (int)hipGetLastError();

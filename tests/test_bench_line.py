@@ -85,3 +85,20 @@ def test_segment_shape_and_launch_check_lines(bench):
     assert len(json.dumps(d).encode()) < 2000
     lc = bench.compact_line(dict(launch_check=True, n_gpus=3, ranks=[0, 1, 2], launch="self"))
     assert lc == dict(launch_check=True, n_gpus=3, ranks=[0, 1, 2], launch="self")
+
+
+def test_a_record_that_cannot_be_shrunk_still_prints_a_line(bench, canned, tmp_path, capsys, monkeypatch):
+    """a record that stays above the limit after every optional block went must not turn a 200 s run into an
+    AssertionError without a line (simulated with a limit below what the fixed blocks need)."""
+    monkeypatch.setattr(bench, "LINE_LIMIT", 1400)
+    full = copy.deepcopy(canned)
+    d = bench.compact_line(full)
+    assert len(json.dumps(d, allow_nan=False).encode()) <= 1400
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
+        assert k in d
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
+    assert "c3" not in d and "multi_segment" not in d
+    monkeypatch.setattr(bench, "FULL_OUT", str(tmp_path / "full.json"))
+    bench.emit(full)
+    out = capsys.readouterr()
+    assert len([l for l in out.out.splitlines() if l.strip()]) == 1 and "contract fields only" in out.err

@@ -267,6 +267,11 @@ def _prove_consuming(torch, prover, monkeypatch, flat, W, log_h, bc, spans, it, 
         prover.trace_from_coefficients(d_t.data_ptr(), W, log_h)
     plain = pr.prove(d_t.data_ptr(), log_h)
     assert (got == plain).all()
+    # ... and a consuming proof after the plain streamed one (tcoef is released BEFORE the other buffers grow)
+    third = pr.prove(d_t.data_ptr(), log_h, consume=True)
+    assert (got == third).all()
+    if streamed:
+        prover.trace_from_coefficients(d_t.data_ptr(), W, log_h)
     state = pr.specialised()["state"]
     pr.close()
     return got, left, d_t, state
@@ -345,3 +350,12 @@ def test_a_trace_at_an_odd_word_offset(gpu, monkeypatch):
         with pytest.raises(Exception):
             pr.prove(odd.data_ptr(), log_h, consume=True)
         pr.close()
+    # the public transforms that stage whole tiles with 16-byte loads refuse a 4-byte-aligned view as well
+    H = 1 << log_h
+    scale = torch.empty(H, dtype=torch.int32, device="cuda")
+    out = torch.empty(W * H, dtype=torch.int32, device="cuda")
+    assert prover.lib.pw_lde_subcoset(odd.data_ptr(), W, log_h, 1, 0, scale.data_ptr(), out.data_ptr()) == 1  # hipErrorInvalidValue
+    assert prover.lib.pw_lde_subcoset(d_t.data_ptr(), W, log_h, 1, 0, scale.data_ptr(), out.data_ptr()) == 0
+    scratch = torch.empty(8192, dtype=torch.int32, device="cuda")
+    assert prover.lib.pw_trace_from_coefficients(odd.data_ptr(), W, log_h, scratch.data_ptr()) == 1
+    torch.cuda.synchronize()
