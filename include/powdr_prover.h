@@ -128,10 +128,12 @@ size_t pw_logup_group_starts(const uint32_t* interactions, size_t n_interactions
 /* ---- one segment = many AIRs -------------------------------------------------------------------------------------
  * The engine call the reference makes once per segment with all chips' traces, `engine.prove(pk, ProvingContext{
  * per_trace})` (openvm/src/trace_generation.rs:97-139, openvm-riscv/src/lib.rs:327-341). */
+#define PW_AIR_HAND_OVER 1u /* PwSegmentAir::flags: the trace is the engine's to overwrite (pw_prove_segment_consuming) */
 typedef struct PwSegmentAir {
     PwProver* prover;        /* one per AIR (pw_prover_create / _create_logup), reused from segment to segment */
     const uint32_t* d_trace; /* device, column-major width x 2^log_height, Montgomery */
     uint32_t log_height;
+    uint32_t flags;          /* read by pw_prove_segment_consuming only (the struct's former padding: size and offsets unchanged) */
 } PwSegmentAir;
 
 /* ONE proof for all AIRs of the segment ("pw-stark v1", proof magic PWS3; protocol: oracle/stark_segment.inc) — the
@@ -143,6 +145,27 @@ typedef struct PwSegmentAir {
  * caller enqueued there — trace generation included. *proof_words is owned by the library (per host thread) and valid
  * until that thread's next pw_prove_segment. Returns 0 or the first error. */
 int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int logup, const uint32_t** proof_words, size_t* n_words);
+
+/* The same proof, same words, with the traces HANDED OVER per AIR (flags & PW_AIR_HAND_OVER) — the reference's chips move
+ * `common_main` into the engine for every AIR of a segment (openvm/src/powdr_extension/trace_generator/cuda/mod.rs:404-421).
+ * An AIR that is proven with its LDE resident leaves its trace alone; an AIR that is STREAMED (its extension does not fit beside
+ * the others) keeps the coefficient arrays of a handed-over trace IN the caller's buffer instead of a copy of its own (configs[2]:
+ * 62.6 GB, two sub-cosets instead of four). After the call such a buffer holds H-scaled bit-reversed coefficients
+ * (pw_trace_from_coefficients restores the trace, exactly); handed-over traces must be 16-byte aligned (hipErrorInvalidValue).
+ * pw_segment_last_modes: per AIR of the calling thread's last segment proof, log2(#sub-cosets) (0 = resident) | 0x100 if the
+ * trace was overwritten; returns the number of AIRs. */
+int pw_prove_segment_consuming(const PwSegmentAir* airs, size_t n_airs, int logup, const uint32_t** proof_words, size_t* n_words);
+size_t pw_segment_last_modes(uint32_t* out, size_t cap);
+/* The memory plan of the calling thread's last segment proof (bytes; zero when the mode was forced by POWDR_STREAM_LOG_BLOCKS):
+ * with every AIR resident | as chosen | what the policy had to work with (free + held, head room, pw_set_device_budget). */
+void pw_segment_last_plan(size_t* resident_bytes, size_t* planned_bytes, size_t* available_bytes);
+
+/* Device memory the provers of this process may plan for (bytes; 0 = no limit beyond what the device has free — the default, or
+ * POWDR_DEVICE_BUDGET_BYTES read once). A proof whose resident buffers would exceed it runs streamed (one-AIR proofs: pw_prover_prove;
+ * segments: the largest AIRs first), exactly as when the device itself is short: an embedder that shares a GPU between engines
+ * sets this instead of relying on hipMemGetInfo at the moment of the call. */
+void pw_set_device_budget(size_t bytes);
+size_t pw_get_device_budget(void);
 
 /* INDEPENDENT proofs, one per AIR (v0 / v0+LogUp), proven concurrently: `n_workers` host threads (0 = 4), each with its
  * own HIP stream on the caller's device, take the AIRs largest first; n_workers = 1 runs inline on the calling thread's

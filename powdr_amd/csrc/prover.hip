@@ -10,6 +10,7 @@
 #include "logup_groups.hpp"
 #include "xbc_compile.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -330,6 +331,41 @@ void plan_buffers(const PwProver* p, uint32_t log_h, int b, CommitLayout& L, Buf
              (size_t)nq * log_h * (8 + 16) + 4096;
 }
 
+}  // namespace
+
+namespace pw {
+static std::atomic<size_t> g_device_budget{(size_t)-1};  // (size_t)-1: not set yet (POWDR_DEVICE_BUDGET_BYTES is read once); 0: none
+size_t device_budget() {
+    size_t b = g_device_budget.load();
+    if (b == (size_t)-1) {
+        const char* e = getenv("POWDR_DEVICE_BUDGET_BYTES");
+        b = e ? (size_t)strtoull(e, nullptr, 10) : 0;
+        g_device_budget.store(b);
+    }
+    return b;
+}
+// What a proof (one AIR's, or a whole segment's) may plan for: buffers are grown by free + malloc, so what the caller's provers hold
+// now (`held`) counts as available; 8 % of head room for the allocator's granularity, the twiddle tables and the caller's own small
+// allocations during the proof; the device as a whole stays below 90 % (288 GB: 259 GB) — a streamed proof trades a few sub-cosets
+// more for room the caller may need between two proofs; and never more than the budget the embedder set (pw_set_device_budget:
+// a server that shares the device between several engines). false: the runtime could not say (the caller stays resident).
+bool device_room(size_t held, size_t* avail) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const size_t others = total_b > free_b + held ? total_b - free_b - held : 0;  // the caller's traces, other provers, the runtime
+    size_t a = (size_t)((double)(free_b + held) * 0.92);
+    const size_t cap = (size_t)((double)total_b * 0.90);
+    a = std::min(a, cap > others ? cap - others : (size_t)0);
+    if (const size_t budget = device_budget()) a = std::min(a, budget);
+    *avail = a;
+    return true;
+}
+}  // namespace pw
+
+extern "C" void pw_set_device_budget(size_t bytes) { pw::g_device_budget.store(bytes); }
+extern "C" size_t pw_get_device_budget(void) { return pw::device_budget(); }
+
+namespace {
 // 0 = resident, b >= 1 = streamed over 2^b sub-cosets; < 0: nothing fits
 int stream_log_blocks(const PwProver* p, uint32_t log_h, bool consume = false) {
     const int b_max = std::min((int)log_h - 1, 5);  // sub-cosets of at least 4 rows; at most 32 of them (subcoset_lde)
@@ -338,18 +374,9 @@ int stream_log_blocks(const PwProver* p, uint32_t log_h, bool consume = false) {
         if (v <= 0 || b_max < 1) return 0;
         return v < b_max ? v : b_max;
     }
-    if (log_h < 16) return 0;  // (a few MB either way)
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    // buffers are grown by free + malloc, so what the prover holds now counts as available; 8 % of head room for the
-    // allocator's granularity, the twiddle tables and the caller's own small allocations during the proof
-    const size_t held = pw_prover_device_bytes(p);
-    const size_t others = total_b > free_b + held ? total_b - free_b - held : 0;  // the caller's trace, other provers, the runtime
-    size_t avail = (size_t)((double)(free_b + held) * 0.92);
-    // ... and the device as a whole stays below 90 % (288 GB: 259 GB): a streamed proof trades a few sub-cosets more for room the
-    // caller may need between two proofs
-    const size_t cap = (size_t)((double)total_b * 0.90);
-    avail = std::min(avail, cap > others ? cap - others : (size_t)0);
+    if (log_h < stream_min_log_height()) return 0;  // (a few MB either way)
+    size_t avail = 0;
+    if (!device_room(pw_prover_device_bytes(p), &avail)) return 0;
     for (int b = 0; b <= b_max; ++b) {
         CommitLayout L;
         BufferPlan B;
@@ -425,13 +452,15 @@ int ensure_prove_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L, bo
 }  // namespace
 
 namespace pw {
-size_t proof_plan_bytes(const PwProver* p, uint32_t log_h, int b) {
+size_t proof_plan_bytes(const PwProver* p, uint32_t log_h, int b, bool consume) {
     CommitLayout L;
     BufferPlan B;
-    plan_buffers(p, log_h, b, L, B);
+    plan_buffers(p, log_h, b, L, B, consume && b > 0);
     return B.total();
 }
-int ensure_proof_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L) { return ensure_prove_buffers(p, log_h, b, L); }
+int ensure_proof_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L, bool consume) {
+    return ensure_prove_buffers(p, log_h, b, L, consume && b > 0);
+}
 }  // namespace pw
 
 // Trace commitment only (LDE + Merkle root): what a segment's AIRs exchange before the bus seed can be formed.

@@ -138,9 +138,18 @@ size_t lde_panel_cols(size_t H, size_t widest);
 
 // ---- streamed proofs: what the segment prover needs from prover.hip ("streamed proofs") ---------------------------------
 // device bytes a proof of a 2^log_h-row trace of this AIR needs with the LDE resident (b = 0) or streamed over 2^b sub-cosets
-size_t proof_plan_bytes(const PwProver* p, uint32_t log_h, int b);
+// (consume: the caller hands the trace over — a streamed proof keeps the trace's coefficient arrays in the caller's buffer, no tcoef)
+size_t proof_plan_bytes(const PwProver* p, uint32_t log_h, int b, bool consume = false);
 // every buffer of such a proof (grown on demand), the layout in L (b, m, perm_panels, panel_cols)
-int ensure_proof_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L);
+int ensure_proof_buffers(PwProver* p, uint32_t log_h, int b, CommitLayout& L, bool consume = false);
+// traces shorter than 2^this are never streamed by the automatic policy (a few MB either way); POWDR_STREAM_MIN_LOG_HEIGHT: tests
+inline uint32_t stream_min_log_height() {
+    const char* e = getenv("POWDR_STREAM_MIN_LOG_HEIGHT");
+    return e ? (uint32_t)atoi(e) : 16u;
+}
+// bytes a proof may plan for on the current device when the caller's provers hold `held` now (prover.hip; pw_set_device_budget)
+bool device_room(size_t held, size_t* avail);
+size_t device_budget();
 
 // ---- run-time specialised expression kernels (prover_jit.hip) ---------------------------------------------------------
 // Compile the specialised kernels of every prover in `ps` that qualifies and has none yet (all translation units of all of

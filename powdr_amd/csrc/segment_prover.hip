@@ -41,6 +41,8 @@ struct SegCtx {
     DeviceBuf misc;    // column-pointer tables, opened values, gamma powers, query indices / answers
     DeviceBuf state;   // streamed AIRs: the rows' sponge states of the level being hashed run by run (16 words per row)
     std::vector<uint32_t> proof;
+    size_t last_plan[3] = {0, 0, 0};   // bytes of the last call's plan: all AIRs resident | as chosen | what the policy had to work with
+    std::vector<uint32_t> last_modes;  // per AIR of the last call: log2(sub-cosets) | 0x100 if the trace was eaten (pw_segment_last_modes)
     // side streams for the per-AIR stages of a segment with many AIRs (fork from / join into the caller's stream by events)
     hipStream_t side[kMaxSide] = {};
     hipEvent_t fork_ev = nullptr, done_ev[kMaxSide] = {};
@@ -73,40 +75,70 @@ struct Shape {
     int logN;
 };
 
-// device buffers of one AIR for the segment flow (the per-AIR prover object owns them; nothing here is freed per segment)
-int ensure_air(PwProver* p, const Shape& s, bool logup, CommitLayout& Lc) {
-    Lc.H = s.H; Lc.N = s.N; Lc.tree_words = 0; Lc.fri_words = 0; Lc.n_trees = 0;
-    Lc.panel_cols = lde_panel_cols(s.H, logup ? std::max<size_t>(s.W, s.Wp) : s.W);
-    TRY(p->coef.ensure(Lc.panel_cols * s.H * 4));
-    TRY(p->lde.ensure((size_t)s.W * s.N * 4));
+// device buffers of one RESIDENT AIR in the segment flow (the per-AIR prover object owns them; nothing here is freed per segment):
+// the sizes first — the streaming decision below adds up exactly what ensure_air would allocate — then the allocation
+struct AirPlan {
+    size_t panel_cols = 0, coef = 0, lde = 0, perm = 0, plde = 0, q = 0, qpart = 0, qcoef = 0, qlde = 0, ext_arena = 0, misc = 0, gbuf = 0;
+    size_t total() const { return coef + lde + perm + plde + q + qpart + qcoef + qlde + ext_arena + misc + gbuf; }
+};
+AirPlan plan_air(const PwProver* p, const Shape& s, bool logup) {
+    AirPlan B;
+    B.panel_cols = lde_panel_cols(s.H, logup ? std::max<size_t>(s.W, s.Wp) : s.W);
+    B.coef = B.panel_cols * s.H * 4;
+    B.lde = (size_t)s.W * s.N * 4;
     if (logup) {  // + the uncommitted per-row-sum columns of the specialised path
-        TRY(p->perm.ensure((size_t)(s.Wp + kJitExtraPermCols) * s.H * 4));
-        TRY(p->plde.ensure((size_t)(s.Wp + kJitExtraPermCols) * s.N * 4));
+        B.perm = (size_t)(s.Wp + kJitExtraPermCols) * s.H * 4;
+        B.plde = (size_t)(s.Wp + kJitExtraPermCols) * s.N * 4;
     }
-    TRY(p->q.ensure(4 * s.N * 4));
+    B.q = 4 * s.N * 4;
     if (!logup) {
         const uint32_t chunks = quotient_chunks(s.N, s.nc);
-        if (chunks > 1) TRY(p->qpart.ensure((size_t)chunks * 4 * s.N * 4));
+        if (chunks > 1) B.qpart = (size_t)chunks * 4 * s.N * 4;
     }
     // the specialised kernels' partial sums (not lazily in the middle of the proof, while other AIRs' side streams run)
-    if (specialised(p) && jit_part_bytes(p, s.H, s.N) > p->qpart.bytes) TRY(p->qpart.ensure(jit_part_bytes(p, s.H, s.N)));
-    TRY(p->qcoef.ensure(8 * s.H * 4));
-    TRY(p->qlde.ensure(8 * s.N * 4));
-    TRY(p->ext_arena.ensure((3 * s.H + s.H / 4096 + 32) * sizeof(bb::Ext)));  // weights | weights at g zeta | row sums + block totals
+    if (specialised(p)) B.qpart = std::max(B.qpart, jit_part_bytes(p, s.H, s.N));
+    B.qcoef = 8 * s.H * 4;
+    B.qlde = 8 * s.N * 4;
+    B.ext_arena = (3 * s.H + s.H / 4096 + 32) * sizeof(bb::Ext);  // weights | weights at g zeta | row sums + block totals
     const uint32_t n_chunks = div_up(s.H, 8192);
     const uint32_t dot_cols = std::max({s.W, s.Wp, 8u});
-    TRY(p->misc.ensure((2 * (size_t)dot_cols * n_chunks + s.M + p->max_args + 64) * sizeof(bb::Ext) + 4096));  // ext_dot_columns2: two sets of partial sums
-    if (s.log_h >= kDeepComboMinLogHeight) TRY(p->gbuf.ensure((size_t)24 * s.H * 4));  // the DEEP combinations and their LDE
+    B.misc = (2 * (size_t)dot_cols * n_chunks + s.M + p->max_args + 64) * sizeof(bb::Ext) + 4096;  // ext_dot_columns2: two sets of partial sums
+    if (s.log_h >= kDeepComboMinLogHeight) B.gbuf = (size_t)24 * s.H * 4;  // the DEEP combinations and their LDE
+    return B;
+}
+int ensure_air(PwProver* p, const Shape& s, bool logup, CommitLayout& Lc) {
+    const AirPlan B = plan_air(p, s, logup);
+    Lc.H = s.H; Lc.N = s.N; Lc.tree_words = 0; Lc.fri_words = 0; Lc.n_trees = 0;
+    Lc.panel_cols = B.panel_cols;
+    TRY(p->coef.ensure(B.coef));
+    TRY(p->lde.ensure(B.lde));
+    if (B.perm) { TRY(p->perm.ensure(B.perm)); TRY(p->plde.ensure(B.plde)); }
+    TRY(p->q.ensure(B.q));
+    if (B.qpart > p->qpart.bytes) TRY(p->qpart.ensure(B.qpart));
+    TRY(p->qcoef.ensure(B.qcoef));
+    TRY(p->qlde.ensure(B.qlde));
+    TRY(p->ext_arena.ensure(B.ext_arena));
+    TRY(p->misc.ensure(B.misc));
+    if (B.gbuf) TRY(p->gbuf.ensure(B.gbuf));
     return 0;
 }
 
 }  // namespace
 
-extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int logup_flag, const uint32_t** proof_words, size_t* n_words) {
+// honour_flags: pw_prove_segment_consuming — PwSegmentAir::flags is read (PW_AIR_HAND_OVER); pw_prove_segment ignores the word
+// (callers of the older struct left it uninitialised)
+static int prove_segment_impl(const PwSegmentAir* airs, size_t n_airs, int logup_flag, bool honour_flags, const uint32_t** proof_words,
+                              size_t* n_words) {
     if (!airs || !n_airs || !proof_words || !n_words) return (int)hipErrorInvalidValue;
     const bool lg = logup_flag != 0;
     const size_t A = n_airs;
+    // handed[a]: the caller gives the trace away (the reference moves `common_main` into the engine for EVERY AIR of a segment,
+    // cuda/mod.rs:415-419). Only a STREAMED AIR uses that (eat[a], below): its coefficient arrays then live in the caller's buffer.
+    std::vector<char> handed(A, 0);
     for (size_t a = 0; a < A; ++a) {
+        handed[a] = honour_flags && (airs[a].flags & PW_AIR_HAND_OVER) ? 1 : 0;
+        // a handed-over trace becomes a coefficient array that is read 2 / 4 words at a time (fold loads, the DEEP combination)
+        if (handed[a] && ((uintptr_t)airs[a].d_trace & 15)) return (int)hipErrorInvalidValue;
         if (!airs[a].prover || !airs[a].d_trace || airs[a].log_height < 1 || airs[a].log_height > 26) return (int)hipErrorInvalidValue;
         if (lg && !airs[a].prover->logup) return (int)hipErrorInvalidValue;  // needs the interaction tables (pw_prover_create_logup)
         // the per-AIR device buffers live in the prover object and the AIRs of a segment run concurrently on side streams: one
@@ -224,6 +256,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
 
     // ---- which AIRs are streamed (sbv[a] = log2 of the number of sub-cosets, 0 = LDE resident) ------------------------------
     std::vector<int> sbv(A, 0);
+    cx.last_plan[0] = cx.last_plan[1] = cx.last_plan[2] = 0;
     {
         auto may_stream = [&](size_t a) { return sh[a].log_h >= 3; };  // (AIRs that share a height: their level is hashed run by run)
         auto b_max = [&](size_t a) { return std::min((int)sh[a].log_h - 1, 5); };
@@ -231,38 +264,43 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             const int v = atoi(e);
             for (size_t a = 0; a < A && v > 0; ++a) if (may_stream(a)) sbv[a] = std::min(v, b_max(a));
         } else {
-            size_t free_b = 0, total_b = 0, held = cx.dig.bytes + cx.inject.bytes + cx.ext.bytes + cx.misc.bytes;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                for (size_t a = 0; a < A; ++a) held += pw_prover_device_bytes(airs[a].prover);
-                const size_t others = total_b > free_b + held ? total_b - free_b - held : 0;
-                size_t avail = (size_t)((double)(free_b + held) * 0.92);
-                const size_t cap = (size_t)((double)total_b * 0.90);
-                avail = std::min(avail, cap > others ? cap - others : (size_t)0);
-                const size_t own = (n_trees * tree_words + fri_words) * 4 + (Nmax + 1) * 32 + ext_words * sizeof(bb::Ext);
+            size_t held = cx.dig.bytes + cx.inject.bytes + cx.ext.bytes + cx.misc.bytes + cx.state.bytes, avail = 0;
+            for (size_t a = 0; a < A; ++a) held += pw_prover_device_bytes(airs[a].prover);
+            if (device_room(held, &avail)) {
+                // what this call allocates: the segment's own arenas + per AIR exactly what ensure_air (resident) or ensure_proof_buffers
+                // (streamed; a handed-over trace needs no tcoef) would (not the one-AIR plan, which counts trees and FRI layers
+                // per AIR that a segment shares)
+                const size_t own = (n_trees * tree_words + fri_words) * 4 + (Nmax + 1) * 32 + ext_words * sizeof(bb::Ext) + misc_bytes;
                 size_t need = own;
                 std::vector<size_t> bytes(A);
-                for (size_t a = 0; a < A; ++a) { bytes[a] = proof_plan_bytes(airs[a].prover, sh[a].log_h, 0); need += bytes[a]; }
+                for (size_t a = 0; a < A; ++a) { bytes[a] = plan_air(airs[a].prover, sh[a], lg).total(); need += bytes[a]; }
+                cx.last_plan[0] = need;  // everything resident
+                cx.last_plan[2] = avail;
                 // the largest AIRs first, each with the fewest sub-cosets that make the whole segment fit
                 std::vector<size_t> order(A);
                 for (size_t a = 0; a < A; ++a) order[a] = a;
                 std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return bytes[x] > bytes[y]; });
                 for (size_t k = 0; k < A && need > avail; ++k) {
                     const size_t a = order[k];
-                    if (!may_stream(a) || sh[a].log_h < 16) continue;
+                    if (!may_stream(a) || sh[a].log_h < stream_min_log_height()) continue;
                     for (int b = 1; b <= b_max(a); ++b) {
-                        const size_t nb = proof_plan_bytes(airs[a].prover, sh[a].log_h, b);
+                        size_t nb = proof_plan_bytes(airs[a].prover, sh[a].log_h, b, handed[a] != 0);
+                        nb += (size_t)16 * 4 * ((size_t)1 << sh[a].logN);  // + the parked sponge states of its level (cx.state)
                         if (nb >= bytes[a]) continue;
                         if (need - bytes[a] + nb <= avail || b == b_max(a)) { need = need - bytes[a] + nb; bytes[a] = nb; sbv[a] = b; break; }
                     }
                 }
-            } else {
-                (void)hipGetLastError();
+                cx.last_plan[1] = need;  // as planned
             }
         }
     }
+    std::vector<char> eat(A, 0);  // the trace is overwritten by its coefficient arrays
+    for (size_t a = 0; a < A; ++a) eat[a] = handed[a] && sbv[a] > 0;
+    cx.last_modes.assign(A, 0);
+    for (size_t a = 0; a < A; ++a) cx.last_modes[a] = (uint32_t)sbv[a] | (eat[a] ? 0x100u : 0u);
     std::vector<CommitLayout> Lc(A);
     for (size_t a = 0; a < A; ++a) {
-        if (sbv[a]) TRY(ensure_proof_buffers(airs[a].prover, sh[a].log_h, sbv[a], Lc[a]));
+        if (sbv[a]) TRY(ensure_proof_buffers(airs[a].prover, sh[a].log_h, sbv[a], Lc[a], eat[a] != 0));
         else TRY(ensure_air(airs[a].prover, sh[a], lg, Lc[a]));
     }
     auto sctx = [&](size_t a) {
@@ -337,6 +375,11 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     };
 
     // ---- 1. main traces ---------------------------------------------------------------------------------------
+    // A streamed AIR's trace coefficients: in its prover's tcoef — or, handed over (eat), in the caller's own buffer from the moment
+    // nothing reads the trace's VALUES any more. With LogUp the permutation columns are computed from the values after this
+    // commitment, so the coefficients wait in the (still empty) permutation buffer until then (prover.hip prove_impl does the same).
+    auto tcoef_of = [&](size_t a) { return eat[a] ? const_cast<uint32_t*>(airs[a].d_trace) : airs[a].prover->tcoef.as<uint32_t>(); };
+    auto coef_first = [&](size_t a) { return eat[a] && lg ? airs[a].prover->perm.as<uint32_t>() : tcoef_of(a); };
     uint32_t root[8];
     TRY(fork());
     for (size_t a = 0; a < A; ++a) {
@@ -344,14 +387,14 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         p->committed_trace = nullptr;
         on_air(a);
         if (sbv[a]) {  // streamed: the trace's coefficient arrays; its LDE rows exist one sub-coset at a time from here on
-            TRY(intt_dif(airs[a].d_trace, p->tcoef.as<uint32_t>(), sh[a].H, sh[a].H, sh[a].W, (int)sh[a].log_h));
+            TRY(intt_dif(airs[a].d_trace, coef_first(a), sh[a].H, sh[a].H, sh[a].W, (int)sh[a].log_h));
         } else {
             TRY(lde_matrix(p, Lc[a], sh[a].log_h, airs[a].d_trace, sh[a].W, p->lde.as<uint32_t>()));
         }
     }
     TRY(join());
     TRY(commit_mixed([&](size_t a, const uint32_t*& m, uint32_t& w) {
-        m = sbv[a] ? airs[a].prover->tcoef.as<uint32_t>() : airs[a].prover->lde.as<uint32_t>();
+        m = sbv[a] ? coef_first(a) : airs[a].prover->lde.as<uint32_t>();
         w = sh[a].W;
     }, 0, root));
     PW_HIP_TRY(hipStreamSynchronize(st));
@@ -381,20 +424,26 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             on_air(a);
             TRY(ext_powers(bl, p->max_args + 2, false, false, blpow_of(a)));  // beta^0 .. (computed where they are used: no upload per AIR)
             bb::Ext* rowsum = weights_of(a) + 2 * sh[a].H;
-            if (specialised(p)) TRY(logup_perm_trace_jit(p, airs[a].d_trace, sh[a].H, al, blpow_of(a), p->perm.as<uint32_t>(), rowsum, rowsum + sh[a].H));
-            else TRY(logup_perm_trace(airs[a].d_trace, sh[a].H, logup_program(a), al, blpow_of(a), p->perm.as<uint32_t>(), rowsum, rowsum + sh[a].H));
+            // eat: the matrix's VALUES live in the sub-coset buffer (idle between two passes) until its coefficient arrays exist
+            uint32_t* d_pval = eat[a] ? p->lde.as<uint32_t>() : p->perm.as<uint32_t>();
+            if (specialised(p)) TRY(logup_perm_trace_jit(p, airs[a].d_trace, sh[a].H, al, blpow_of(a), d_pval, rowsum, rowsum + sh[a].H));
+            else TRY(logup_perm_trace(airs[a].d_trace, sh[a].H, logup_program(a), al, blpow_of(a), d_pval, rowsum, rowsum + sh[a].H));
             if (sbv[a]) {
                 // streamed: only phi and the per-row sums are extended for good (the boundary terms read them at rows j and j + 2); S is
                 // saved before the matrix becomes its coefficient arrays in place
                 uint32_t* d_perm_a = p->perm.as<uint32_t>();
-                if (!specialised(p)) TRY(ext_to_cols(rowsum, sh[a].H, d_perm_a + (size_t)(4 * sh[a].n_g + 4) * sh[a].H));
-                TRY(lde_matrix(p, Lc[a], sh[a].log_h, d_perm_a + (size_t)(4 * sh[a].n_g) * sh[a].H, 8, p->plde.as<uint32_t>()));
+                if (!specialised(p)) TRY(ext_to_cols(rowsum, sh[a].H, d_pval + (size_t)(4 * sh[a].n_g + 4) * sh[a].H));
+                TRY(lde_matrix(p, Lc[a], sh[a].log_h, d_pval + (size_t)(4 * sh[a].n_g) * sh[a].H, 8, p->plde.as<uint32_t>()));
                 uint32_t* d_save = p->gbuf.as<uint32_t>();
                 for (int k = 0; k < 4; ++k) {
-                    PW_HIP_TRY(hipMemcpyAsync(d_save + k, d_perm_a + ((size_t)(4 * sh[a].n_g + k) * sh[a].H + (sh[a].H - 1)), 4, hipMemcpyDeviceToDevice, stream()));
+                    PW_HIP_TRY(hipMemcpyAsync(d_save + k, d_pval + ((size_t)(4 * sh[a].n_g + k) * sh[a].H + (sh[a].H - 1)), 4, hipMemcpyDeviceToDevice, stream()));
                     sp.push_back(d_save + k);
                 }
-                TRY(intt_dif(d_perm_a, d_perm_a, sh[a].H, sh[a].H, sh[a].Wp, (int)sh[a].log_h));
+                if (eat[a]) {
+                    // the trace's values are dead now: its coefficient arrays move into its place, the permutation buffer takes the matrix's
+                    PW_HIP_TRY(hipMemcpyAsync(tcoef_of(a), d_perm_a, (size_t)sh[a].W * sh[a].H * 4, hipMemcpyDeviceToDevice, stream()));
+                    TRY(intt_dif(d_pval, d_perm_a, sh[a].H, sh[a].H, sh[a].Wp, (int)sh[a].log_h));
+                } else TRY(intt_dif(d_perm_a, d_perm_a, sh[a].H, sh[a].H, sh[a].Wp, (int)sh[a].log_h));
                 continue;
             }
             TRY(lde_matrix(p, Lc[a], sh[a].log_h, p->perm.as<uint32_t>(), sh[a].Wp + (specialised(p) ? kJitExtraPermCols : 0u), p->plde.as<uint32_t>()));
@@ -436,7 +485,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             uint32_t* d_q = p->q.as<uint32_t>();
             if (sbv[a]) {
                 // streamed: the current-row terms sub-coset by sub-coset, then the boundary terms / the division by Z_H over all rows
-                TRY(streamed::quotient_sums(sctx(a), specialised(p), lg, s.nc, prog, lg ? logup_program(a) : LogupProgram{}, p->tcoef.as<uint32_t>(),
+                TRY(streamed::quotient_sums(sctx(a), specialised(p), lg, s.nc, prog, lg ? logup_program(a) : LogupProgram{}, tcoef_of(a),
                                             p->perm.as<uint32_t>(), apow_of(a), al, blpow_of(a), S[a], s.logN, d_q));
                 if (lg)
                     TRY(quotient_logup_tail(d_q, 1, p->plde.as<uint32_t>(), p->plde.as<uint32_t>() + 4 * s.N, s.N, s.logN, apow_of(a) + s.nc + s.n_g, S[a],
@@ -478,13 +527,16 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
         bb::Ext* w2 = w1 + s.H;
         gzeta[a] = bb::ext_scale(zeta, field::root_of_unity((int)s.log_h));
         // trace columns: barycentric evaluation straight from the caller's trace; quotient chunks from their coefficients
-        TRY(barycentric_weights(zeta, (int)s.log_h, w1));
-        TRY(ext_dot_columns(airs[a].d_trace, s.H, s.W, s.H, w1, o, scratch_of(a)));
+        if (!eat[a]) {
+            TRY(barycentric_weights(zeta, (int)s.log_h, w1));
+            TRY(ext_dot_columns(airs[a].d_trace, s.H, s.W, s.H, w1, o, scratch_of(a)));
+        }
         if (lg && !sbv[a]) {  // the permutation matrix at zeta and at g zeta: one pass over its columns
             TRY(barycentric_weights(gzeta[a], (int)s.log_h, w2));
             TRY(ext_dot_columns2(p->perm.as<uint32_t>(), s.H, s.Wp, s.H, w1, w2, o + s.W, o + s.W + s.Wp + 8, scratch_of(a)));
         }
         TRY(zeta_weights(zeta, (int)s.log_h, w1));
+        if (eat[a]) TRY(ext_dot_columns(tcoef_of(a), s.H, s.W, s.H, w1, o, scratch_of(a)));  // the trace is its coefficient arrays by now
         if (lg && sbv[a]) {  // streamed: p->perm holds the matrix's coefficient arrays
             TRY(zeta_weights(gzeta[a], (int)s.log_h, w2));
             TRY(ext_dot_columns2(p->perm.as<uint32_t>(), s.H, s.Wp, s.H, w1, w2, o + s.W, o + s.W + s.Wp + 8, scratch_of(a)));
@@ -518,7 +570,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
             bb::Ext* target = s.logN == L ? d_v : d_v + ro_off[s.logN];
             bb::Ext* out = started[s.logN] ? d_v + tmp_off : target;
             if (sbv[a])
-                TRY(streamed::deep_from_coefficients(sctx(a), lg, p->tcoef.as<uint32_t>(), p->perm.as<uint32_t>(), p->qlde.as<uint32_t>(), s.logN,
+                TRY(streamed::deep_from_coefficients(sctx(a), lg, tcoef_of(a), p->perm.as<uint32_t>(), p->qlde.as<uint32_t>(), s.logN,
                                                      d_gpow + s.koff, [] {}, sum1, sum2, zeta, gzeta[a], out));
             else if (s.log_h >= kDeepComboMinLogHeight && !getenv("POWDR_DEEP_DIRECT") && !((uintptr_t)airs[a].d_trace & 7)) {
                 // resident and tall: the numerator is combined on the evaluations over <g_n> — the caller's trace, the permutation
@@ -608,7 +660,7 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
                 if (sbv[a] && ph != 2) {
                     // streamed: the rows are rebuilt from the coefficient arrays (index scratch: the AIR's own gbuf, free by now)
                     uint32_t* d_scr = p->gbuf.as<uint32_t>();
-                    TRY(streamed::query_rows(sctx(a), ph == 0 ? p->tcoef.as<uint32_t>() : p->perm.as<uint32_t>(), w, idx.data() + a * nq, nq, d_scr,
+                    TRY(streamed::query_rows(sctx(a), ph == 0 ? tcoef_of(a) : p->perm.as<uint32_t>(), w, idx.data() + a * nq, nq, d_scr,
                                              d_scr + nq, d_rows + ro));
                 } else {
                     jobs.push_back(GatherRowsJob{m, (uint64_t)sh[a].N, w, (uint32_t)(a * nq), (uint64_t)ro});
@@ -684,4 +736,26 @@ extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int log
     *proof_words = pf.data();
     *n_words = pf.size();
     return (int)hipGetLastError();
+}
+
+extern "C" int pw_prove_segment(const PwSegmentAir* airs, size_t n_airs, int logup_flag, const uint32_t** proof_words, size_t* n_words) {
+    return prove_segment_impl(airs, n_airs, logup_flag, false, proof_words, n_words);
+}
+
+extern "C" int pw_prove_segment_consuming(const PwSegmentAir* airs, size_t n_airs, int logup_flag, const uint32_t** proof_words, size_t* n_words) {
+    return prove_segment_impl(airs, n_airs, logup_flag, true, proof_words, n_words);
+}
+
+// the mode the AIRs of the calling thread's LAST segment proof ran in: out[a] = log2 of the number of sub-cosets (0 = resident),
+// + 0x100 when the trace was overwritten by its coefficient arrays (pw_trace_from_coefficients restores it)
+extern "C" void pw_segment_last_plan(size_t* resident_bytes, size_t* planned_bytes, size_t* available_bytes) {
+    if (resident_bytes) *resident_bytes = g_ctx.last_plan[0];
+    if (planned_bytes) *planned_bytes = g_ctx.last_plan[1];
+    if (available_bytes) *available_bytes = g_ctx.last_plan[2];
+}
+
+extern "C" size_t pw_segment_last_modes(uint32_t* out, size_t cap) {
+    const std::vector<uint32_t>& m = g_ctx.last_modes;
+    for (size_t a = 0; a < m.size() && a < cap; ++a) out[a] = m[a];
+    return m.size();
 }

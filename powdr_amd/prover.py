@@ -17,7 +17,8 @@ class PwStarkConfig(C.Structure):
 PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create", "pw_prover_create_logup", "pw_verify_logup", "pw_prover_trace_root", "pw_prover_set_bus_seed", "pw_prover_logup_path", "pw_prove_airs", "pw_verify_airs", "pw_prove_segment", "pw_verify_segment", "pw_commitment_digest", "pw_logup_group_starts", "pw_prover_width", "pw_prover_reserve", "pw_prover_stream_log_blocks", "pw_prover_max_constraint_degree", "pw_prover_destroy", "pw_prover_prove", "pw_prover_prove_consuming", "pw_prover_stream_log_blocks_consuming", "pw_trace_from_coefficients", "pw_prover_device_bytes",
                   "pw_lde_batch", "pw_lde_fused", "pw_lde_subcoset", "pw_merkle_commit", "pw_poseidon2_permute_host",
                   "pw_set_poseidon2_constants", "pw_get_poseidon2_constants", "pw_prover_specialise", "pw_prover_specialised", "pw_jit_compile_check", "pw_jit_cache_stats", "pw_jit_generated_source",
-                  "pw_prove_segments_multi", "pw_multi_last_merge", "pw_assign_units"]
+                  "pw_prove_segments_multi", "pw_multi_last_merge", "pw_assign_units",
+                  "pw_prove_segment_consuming", "pw_segment_last_modes", "pw_segment_last_plan", "pw_set_device_budget", "pw_get_device_budget"]
 
 lib.pw_prover_create.restype = C.c_void_p
 lib.pw_prover_create.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -44,6 +45,11 @@ lib.pw_trace_from_coefficients.restype = C.c_int
 lib.pw_trace_from_coefficients.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
 lib.pw_lde_subcoset.restype = C.c_int
 lib.pw_lde_subcoset.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+lib.pw_segment_last_modes.restype = C.c_size_t
+lib.pw_segment_last_modes.argtypes = [C.c_void_p, C.c_size_t]
+lib.pw_set_device_budget.restype = None
+lib.pw_set_device_budget.argtypes = [C.c_size_t]
+lib.pw_get_device_budget.restype = C.c_size_t
 lib.pw_merkle_commit.restype = C.c_int
 lib.pw_merkle_commit.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
 lib.pw_poseidon2_permute_host.argtypes = [C.c_void_p]
@@ -99,7 +105,10 @@ def verify_logup(proof, width: int, log_height: int, cons_bytecode, cons_spans, 
 
 
 class PwSegmentAir(C.Structure):
-    _fields_ = [("prover", C.c_void_p), ("d_trace", C.c_void_p), ("log_height", C.c_uint32)]
+    _fields_ = [("prover", C.c_void_p), ("d_trace", C.c_void_p), ("log_height", C.c_uint32), ("flags", C.c_uint32)]
+
+
+PW_AIR_HAND_OVER = 1
 
 
 class PwAirDescription(C.Structure):
@@ -114,6 +123,8 @@ lib.pw_prove_airs.argtypes = [C.POINTER(PwSegmentAir), C.c_size_t, C.c_int, C.c_
                                  C.POINTER(C.c_size_t), C.c_void_p]
 lib.pw_prove_segment.restype = C.c_int
 lib.pw_prove_segment.argtypes = [C.POINTER(PwSegmentAir), C.c_size_t, C.c_int, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]
+lib.pw_prove_segment_consuming.restype = C.c_int
+lib.pw_prove_segment_consuming.argtypes = lib.pw_prove_segment.argtypes
 lib.pw_verify_segment.restype = C.c_int
 lib.pw_verify_segment.argtypes = [C.POINTER(PwStarkConfig), C.POINTER(PwAirDescription), C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
 lib.pw_verify_airs.restype = C.c_int
@@ -187,18 +198,44 @@ def _air_descriptions(descs):
     return recs, keep
 
 
-def prove_segment(airs, logup: bool = False, copy: bool = True) -> np.ndarray:
+def prove_segment(airs, logup: bool = False, copy: bool = True, hand_over=None) -> np.ndarray:
     """ONE proof for all AIRs of a segment (pw-stark v1, magic PWS3): airs = [(Prover, device trace pointer, log_height)],
-    every Prover created with `interactions=` when logup. The counterpart of the reference's one engine call per segment."""
+    every Prover created with `interactions=` when logup. The counterpart of the reference's one engine call per segment.
+    hand_over: None = pw_prove_segment; True / a list of bools = pw_prove_segment_consuming with those AIRs' traces handed over
+    (a STREAMED AIR then leaves its coefficient arrays in the caller's buffer: segment_last_modes() says which did)."""
     n = len(airs)
     recs = (PwSegmentAir * max(n, 1))()
+    flags = [0] * n if hand_over is None else ([PW_AIR_HAND_OVER] * n if hand_over is True else [PW_AIR_HAND_OVER if f else 0 for f in hand_over])
     for i, (pr, ptr, lh) in enumerate(airs):
-        recs[i] = PwSegmentAir(pr._h, ptr, lh)
+        recs[i] = PwSegmentAir(pr._h, ptr, lh, flags[i])
     words = C.POINTER(C.c_uint32)()
     nw = C.c_size_t()
-    abi.check(lib.pw_prove_segment(recs, n, int(logup), C.byref(words), C.byref(nw)), "pw_prove_segment")
+    if hand_over is None:
+        abi.check(lib.pw_prove_segment(recs, n, int(logup), C.byref(words), C.byref(nw)), "pw_prove_segment")
+    else:
+        abi.check(lib.pw_prove_segment_consuming(recs, n, int(logup), C.byref(words), C.byref(nw)), "pw_prove_segment_consuming")
     a = np.ctypeslib.as_array(words, shape=(nw.value,))
     return a.copy() if copy else a
+
+
+def segment_last_modes():
+    """[(log2 sub-cosets, trace overwritten by its coefficients)] per AIR of this thread's last segment proof."""
+    n = int(lib.pw_segment_last_modes(None, 0))
+    out = (C.c_uint32 * max(n, 1))()
+    lib.pw_segment_last_modes(out, n)
+    return [(int(out[i]) & 0xFF, bool(int(out[i]) & 0x100)) for i in range(n)]
+
+
+def segment_last_plan():
+    """(bytes with every AIR resident, bytes as planned, bytes the policy had) of this thread's last segment proof."""
+    a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    lib.pw_segment_last_plan(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def set_device_budget(n_bytes: int) -> None:
+    """pw_set_device_budget: bytes the provers of this process may plan for (0 = whatever the device has free)."""
+    lib.pw_set_device_budget(int(n_bytes))
 
 
 def verify_segment(descs, proof, num_queries: int = 100, pow_bits: int = 0, logup: bool = False, check_balance: bool = False):

@@ -179,21 +179,25 @@ class RecordStager:
         dev = lambda a, dt: torch.tensor(a, dtype=dt, device="cuda")
         self.rows, self.delta, self.ptr_rows = dev(rows, torch.int64), dev(delta, torch.int32), dev(ptr_rows, torch.int64)
 
-    def fill(self, rec_flat: torch.Tensor, seed: int) -> None:
+    def fill(self, rec_flat: torch.Tensor, seed: int, calls: int | None = None) -> None:
+        """calls: this segment's number of calls (<= the number the buffer was sized for); the records are word-major, so a
+        segment with fewer calls occupies the first words * calls words of the buffer."""
         s = abi.lib.powdr_gpu_get_stream()
         import contextlib
 
+        calls = self.calls if calls is None else calls
+        assert 0 < calls <= self.calls
         with (torch.cuda.stream(torch.cuda.ExternalStream(int(s))) if s else contextlib.nullcontext()):
             g = torch.Generator(device="cuda").manual_seed(seed)
-            rec = rec_flat.view(self.words, self.calls)
+            rec = rec_flat[:self.words * calls].view(self.words, calls)
             rec.random_(-(1 << 31), (1 << 31) - 1, generator=g)
-            base = torch.randint(1 << 10, 1 << 26, (self.calls,), dtype=torch.int32, device="cuda", generator=g)
+            base = torch.randint(1 << 10, 1 << 26, (calls,), dtype=torch.int32, device="cuda", generator=g)
             rec[0] = base
             if len(self.rows):
-                gap = torch.randint(1, 1 << 20, (len(self.rows), self.calls), dtype=torch.int32, device="cuda", generator=g)
+                gap = torch.randint(1, 1 << 20, (len(self.rows), calls), dtype=torch.int32, device="cuda", generator=g)
                 rec[self.rows] = torch.clamp(base[None, :] + self.delta[:, None] - gap, min=0)
             if len(self.ptr_rows):  # rs1 of loads / stores / jumps: < 2^24, 4-aligned
-                rec[self.ptr_rows] = torch.randint(0, 1 << 22, (len(self.ptr_rows), self.calls), dtype=torch.int32, device="cuda", generator=g) << 2
+                rec[self.ptr_rows] = torch.randint(0, 1 << 22, (len(self.ptr_rows), calls), dtype=torch.int32, device="cuda", generator=g) << 2
 
 
 def _offset_operands(ibc: np.ndarray, ispans: np.ndarray, height: int) -> np.ndarray:
@@ -283,14 +287,94 @@ class HonestSegment:
         for a in self.airs:
             a["prover"] = prover.Prover(a["width"], a["cons"][0], a["cons"][1], num_queries=queries, pow_bits=pow_bits,
                                         interactions=a["inter"] if logup else None)
+        self.source_bytes = sum(wl["src_bytes"] for wl in self.apcs) + self.records.numel() * 4
+        self._bounds, self._stager, self.data_seed = None, None, None
+        # ---- the shape the buffers were sized for (every AIR at its cap); a segment's OWN heights: set_shape()
+        self.seed = seed
+        self.max_calls = self.calls
+        for wl in self.apcs:
+            wl["max_calls"], wl["max_tensors"] = wl["calls"], dict(wl["tensors"])
+        self._instr = [(k, a) for a in self.airs if a["role"] == "instruction" for k in [oc.KIND_NAMES.index(a["name"])]]
+        self._replay_cache = {(k, self.instr_bufs[k][1]): r for (k, _), (r, _) in zip(self._instr, self.replays)}
+        self.shape = None  # None: the maximal shape
+        self._refresh()
+
+    def _refresh(self):
         self.cells = sum(a["width"] << a["log_h"] for a in self.airs)
         self.cells_by_role = {r: sum(a["width"] << a["log_h"] for a in self.airs if a["role"] == r) for r in ("apc", "instruction", "periphery")}
         self.seg = [(a["prover"], a["trace"].data_ptr(), a["log_h"]) for a in self.airs]
-        self.source_bytes = sum(wl["src_bytes"] for wl in self.apcs) + self.records.numel() * 4
-        self._bounds, self._stager, self.data_seed = None, None, None
+
+    # ---- segments that differ in SHAPE ---------------------------------------------------------------------
+    def draw_shape(self, u: int, n_segments: int = 8) -> dict:
+        """The trace heights of segment u as a metered execution would report them
+        (/root/reference/openvm/src/trace_generation.rs:113-131: every segment carries its own `trace_heights`; a segment is cut
+        when ONE chip reaches its height limit, /root/reference/openvm-riscv/src/lib.rs:270-286 — the others are wherever they are).
+        Per APC chip the number of calls, for the instruction chips the number of block executions:
+          u == 0              every chip at its cap (the shape the buffers are sized for; under a device budget the segment
+                              whose tall AIR crosses the streaming threshold)
+          u == n_segments-1   the execution's tail: every chip at <= 1/8 of its cap
+          otherwise           one chip (drawn) at its cap, the others log-uniform over the two octaves below theirs."""
+        rng = np.random.default_rng([1 + self.seed, 7919 + u])
+        n = len(self.apcs) + 1  # + the instruction block
+        if u == 0:
+            f = np.ones(n)
+        elif u == n_segments - 1:
+            f = 2.0 ** -rng.uniform(3.0, 5.0, size=n)
+        else:
+            f = 2.0 ** -rng.uniform(0.0, 2.0, size=n)
+            f[int(rng.integers(0, n))] = 1.0
+        apc_calls = [max(1, int(wl["max_calls"] * f[k])) for k, wl in enumerate(self.apcs)]
+        return dict(segment=u, apc_calls=apc_calls, instr_calls=max(1, int(self.max_calls * f[-1])))
+
+    def set_shape(self, shape: dict | None) -> None:
+        """Re-shape the resident segment: every APC AIR gets next_pow2(calls) rows (cuda/mod.rs:266: `next_power_of_two_or_zero`), the
+        gather sources behind it row_block_size * calls rows, every instruction AIR next_pow2(its rows of the block * executions).
+        The buffers stay (they hold the maximal shape); matrices are column-major, so a shorter one occupies a prefix. The inputs
+        must be staged afterwards (stage_inputs): the sources' layout depends on their height."""
+        if shape is None:
+            shape = dict(apc_calls=[wl["max_calls"] for wl in self.apcs], instr_calls=self.max_calls)
+        stream = abi.lib.powdr_gpu_get_stream()
+        import contextlib
+
+        apc_airs = [a for a in self.airs if a["role"] == "apc"]
+        for wl, a, calls in zip(self.apcs, apc_airs, shape["apc_calls"]):
+            assert 0 < calls <= wl["max_calls"]
+            lh = max(2, (calls - 1).bit_length())
+            wl["calls"], wl["log_h"], wl["H"] = calls, lh, 1 << lh
+            a["log_h"] = lh
+            wl["tensors"], wl["dummy"] = {}, []
+            for n in wl["air_names"]:
+                t, w, h_max, b = wl["max_tensors"][n]
+                h = max(4, (b * calls + 3) // 4 * 4)
+                assert h <= h_max
+                wl["tensors"][n] = (t, w, h, b)
+                wl["dummy"].append((t.data_ptr(), w, h))
+        calls = shape["instr_calls"]
+        assert 0 < calls <= self.max_calls
+        changed = calls != self.calls
+        self.calls = calls
+        heights = oc.dummy_trace_heights(self.table, calls)
+        self.replays = []
+        with (torch.cuda.stream(torch.cuda.ExternalStream(int(stream))) if stream else contextlib.nullcontext()):
+            for k, a in self._instr:
+                h = heights[k]
+                t = a["trace"]
+                assert oc.WIDTHS[k] * h <= t.numel()
+                if changed:
+                    t[:oc.WIDTHS[k] * h].zero_()  # padding rows are only ever written here (the expanders write the rows of real calls)
+                self.instr_bufs[k] = (t.data_ptr(), h)
+                a["log_h"] = h.bit_length() - 1
+                if (k, h) not in self._replay_cache:
+                    self._replay_cache[(k, h)] = _BusReplay(a["inter"], h)
+                self.replays.append((self._replay_cache[(k, h)], t))
+        self.shape = shape
+        self._refresh()
+
+    def heights(self) -> list:
+        return [a["log_h"] for a in self.airs]
 
     # ---- the inputs of ANOTHER segment of the same execution (same chips, other rows) ---------------------------------------
-    def stage_inputs(self, data_seed: int):
+    def stage_inputs(self, data_seed: int, shape: dict | None = None):
         """Replace this segment's inputs — the original chips' dummy traces behind every APC AIR and the call records of the
         instruction AIRs — by those of segment `data_seed`, generated on the device in the buffers the resident segment already has
         (the reference cuts ONE execution into segments: /root/reference/openvm-riscv/src/lib.rs:585-592 — the same AIRs, different
@@ -298,10 +382,12 @@ class HonestSegment:
         trace generation that follows."""
         if self._bounds is None:
             self._bounds = [source_bounds(wl) for wl in self.apcs]
-            self._stager = RecordStager(self.table, self.calls)
+            self._stager = RecordStager(self.table, self.max_calls)
+        if shape is not None or self.shape is not None:
+            self.set_shape(shape)  # this segment's own heights (shape None: back to the caps)
         for k, wl in enumerate(self.apcs):
             refill_sources(wl, self._bounds[k], data_seed * 4099 + k)
-        self._stager.fill(self.records, data_seed * 31 + 5)
+        self._stager.fill(self.records, data_seed * 31 + 5, self.calls)
         self.data_seed = data_seed
 
     # ---- the timed pieces -----------------------------------------------------------------------------------------------
@@ -319,8 +405,12 @@ class HonestSegment:
         abi.check(abi.lib.powdr_periphery_tuple2_trace(p.tuple_hist.data_ptr(), p.tuple_sizes[0], p.tuple_sizes[1], self.per_traces["tuple2"].data_ptr()), "tuple2_trace")
         abi.check(abi.lib.powdr_periphery_bitwise_trace(p.bitwise_hist.data_ptr(), self.per_traces["bitwise"].data_ptr()), "bitwise_trace")
 
-    def prove(self, copy: bool = False):
-        return prover.prove_segment(self.seg, logup=self.logup, copy=copy)
+    def prove(self, copy: bool = False, hand_over=None):
+        """hand_over: pw_prove_segment_consuming — every chip moves its trace into the engine (cuda/mod.rs:415-419); the next
+        generate_traces() rewrites them anyway."""
+        if hand_over is True:  # (the instruction AIRs' padding rows are written once per shape, not per generation: those traces stay ours)
+            hand_over = [a["role"] != "instruction" for a in self.airs]
+        return prover.prove_segment(self.seg, logup=self.logup, copy=copy, hand_over=hand_over)
 
     # ---- checks (outside the timed region) ------------------------------------------------------------------------------
     def descriptions(self, buses=None):

@@ -79,6 +79,17 @@ impl HipEngine {
 
     /// `engine.prove(pk, ctx)` (trace_generation.rs:136-139): ONE call per segment with the traces of all chips, one proof.
     pub fn prove_segment(&self, ctx: &ProvingContext<HipBackend>) -> Result<HipSegmentProof, HipError> {
+        self.prove_segment_impl(ctx, false)
+    }
+
+    /// The reference's `engine.prove` takes the context BY VALUE: every chip moved its `common_main` into it
+    /// (cuda/mod.rs:415-419). Owning the matrices lets an AIR that has to be streamed keep its coefficient arrays in the trace's
+    /// own buffer (`pw_prove_segment_consuming`); the matrices are dropped with `ctx` when this returns.
+    pub fn prove_segment_owned(&self, ctx: ProvingContext<HipBackend>) -> Result<HipSegmentProof, HipError> {
+        self.prove_segment_impl(&ctx, true)
+    }
+
+    fn prove_segment_impl(&self, ctx: &ProvingContext<HipBackend>, hand_over: bool) -> Result<HipSegmentProof, HipError> {
         let mut airs = vec![];
         let mut air_ids = vec![];
         let mut log_heights = vec![];
@@ -93,6 +104,7 @@ impl HipEngine {
                 prover: self.provers[*air_id].handle,
                 d_trace: m.buffer().as_ptr() as *const u32,
                 log_height: log_h,
+                flags: if hand_over { ffi::PW_AIR_HAND_OVER } else { 0 },
             });
             air_ids.push(*air_id);
             log_heights.push(log_h);
@@ -100,7 +112,13 @@ impl HipEngine {
         let mut words: *const u32 = core::ptr::null();
         let mut n_words = 0usize;
         // logup = 1: the bus interactions of every AIR are inside the proof; the cumulative sums must cancel
-        HipError::from_result(unsafe { ffi::pw_prove_segment(airs.as_ptr(), airs.len(), 1, &mut words, &mut n_words) })?;
+        HipError::from_result(unsafe {
+            if hand_over {
+                ffi::pw_prove_segment_consuming(airs.as_ptr(), airs.len(), 1, &mut words, &mut n_words)
+            } else {
+                ffi::pw_prove_segment(airs.as_ptr(), airs.len(), 1, &mut words, &mut n_words)
+            }
+        })?;
         let words = unsafe { std::slice::from_raw_parts(words, n_words) }.to_vec();
         Ok(HipSegmentProof { air_ids, log_heights, words })
     }

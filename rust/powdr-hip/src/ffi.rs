@@ -252,7 +252,11 @@ pub struct PwSegmentAir {
     pub prover: *mut PwProver,
     pub d_trace: *const u32,
     pub log_height: u32,
+    /// read by `pw_prove_segment_consuming` only (`PW_AIR_HAND_OVER`)
+    pub flags: u32,
 }
+/// `PwSegmentAir::flags`: the trace is the engine's to overwrite
+pub const PW_AIR_HAND_OVER: u32 = 1;
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct PwAirDescription {
@@ -303,6 +307,16 @@ extern "C" {
                                  out: *mut u32, cap: usize) -> usize;
     pub fn pw_prove_segment(airs: *const PwSegmentAir, n_airs: usize, logup: c_int, proof_words: *mut *const u32,
                             n_words: *mut usize) -> c_int;
+    /// Same proof, same words; AIRs flagged `PW_AIR_HAND_OVER` that are proven STREAMED keep their coefficient arrays in the caller's buffer.
+    pub fn pw_prove_segment_consuming(airs: *const PwSegmentAir, n_airs: usize, logup: c_int, proof_words: *mut *const u32,
+                                      n_words: *mut usize) -> c_int;
+    /// per AIR of the calling thread's last segment proof: log2(#sub-cosets) | 0x100 if the trace was overwritten
+    pub fn pw_segment_last_modes(out: *mut u32, cap: usize) -> usize;
+    /// bytes of the last segment proof's memory plan: all AIRs resident | as chosen | available to the policy
+    pub fn pw_segment_last_plan(resident_bytes: *mut usize, planned_bytes: *mut usize, available_bytes: *mut usize);
+    /// bytes the provers of this process may plan for on a device (0 = what the device has free)
+    pub fn pw_set_device_budget(bytes: usize);
+    pub fn pw_get_device_budget() -> usize;
     pub fn pw_verify_segment(cfg: *const PwStarkConfig, airs: *const PwAirDescription, n_airs: usize, logup: c_int,
                              proof_words: *const u32, n_words: usize, check_balance: c_int, total_sum4: *mut u32) -> c_int;
     pub fn pw_prove_airs(airs: *const PwSegmentAir, n_airs: usize, shared_bus_seed: c_int, n_workers: c_uint,

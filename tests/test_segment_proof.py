@@ -233,6 +233,111 @@ def test_streamed_airs_that_share_a_height(gpu, monkeypatch, logup, log_blocks, 
     assert len(got2) == len(want2) and (got2 == want2).all()
 
 
+# ---- traces handed over per AIR (pw_prove_segment_consuming) ----------------------------------------------------------
+_WANT = {}
+
+
+def _oracle_segment(spec, nq, pow_bits, logup, seed0=11):
+    key = (tuple(spec), nq, pow_bits, logup, seed0)
+    if key not in _WANT:
+        airs = synthetic_airs(spec, seed0=seed0)
+        _WANT[key] = (airs, sm.prove_segment(airs, num_queries=nq, pow_bits=pow_bits, logup=logup))
+    return _WANT[key]
+
+
+def hip_segment_consuming(gpu, airs, nq, pow_bits, logup, mask):
+    """pw_prove_segment_consuming with the AIRs of `mask` handed over -> (words, modes). Checks what the call promises about the
+    buffers: a handed-over trace that was streamed holds its coefficient arrays afterwards and pw_trace_from_coefficients restores
+    it exactly; every other trace is untouched; a second proof on the restored traces gives the same words."""
+    torch, abi, prover = gpu
+    provers = [prover.Prover(a[1], a[3], a[4], num_queries=nq, pow_bits=pow_bits, interactions=a[5] if logup else None) for a in airs]
+    orig = [to_dev(torch, a[0]) for a in airs]
+    traces = [t.clone() for t in orig]
+    seg = [(pr, t.data_ptr(), a[2]) for pr, t, a in zip(provers, traces, airs)]
+    out = []
+    for _ in range(2):
+        pf = prover.prove_segment(seg, logup=logup, hand_over=mask)
+        modes = prover.segment_last_modes()
+        torch.cuda.synchronize()
+        assert len(modes) == len(airs)
+        for (b, eaten), m, t, o, a in zip(modes, mask, traces, orig, airs):
+            assert eaten == (bool(m) and b > 0)
+            if eaten:
+                assert not torch.equal(t, o)
+                prover.trace_from_coefficients(t.data_ptr(), a[1], a[2])
+                torch.cuda.synchronize()
+            assert torch.equal(t, o)
+        out.append(pf)
+    assert (out[0] == out[1]).all()
+    # ... and the plain call on the same provers afterwards (tcoef comes back): same words
+    plain = prover.prove_segment(seg, logup=logup)
+    assert (plain == out[0]).all()
+    for pr in provers:
+        pr.close()
+    return out[0], modes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec,nq,pow_bits,logup,log_blocks,jit", [
+    ([("T1", 1000), ("T0", 40), ("T1", 100)], 6, 3, True, 1, "1"),
+    ([("T1", 1000), ("T0", 40), ("T1", 100)], 6, 3, True, 2, "0"),
+    ([("T1", 1000), ("T0", 40), ("T1", 100)], 6, 3, False, 3, "1"),
+    ([("T1", 1000), ("T0", 40), ("T1", 100)], 6, 3, False, 1, "0"),
+    ([("C1", 600), ("T1", 5000), ("T0", 40), ("T1", 1000), ("T0", 33)], 8, 0, True, 1, "1"),
+    ([("C1", 600), ("T1", 5000), ("T0", 40), ("T1", 1000), ("T0", 33)], 8, 0, True, 3, "0"),
+    ([("T1", 40000), ("T0", 64)], 5, 0, True, 1, "1"),    # 2^16 rows: strided stage groups, the restore transform's too
+    ([("T1", 40000), ("T0", 64)], 5, 0, False, 2, "0"),
+])
+def test_hip_segment_consuming_words_equal_the_oracle(gpu, monkeypatch, spec, nq, pow_bits, logup, log_blocks, jit):
+    """The segment proof with its traces handed over: the words are sm.prove_segment's whatever the sub-coset count and the kernel
+    kind, with every AIR handed over and with every other one."""
+    torch, abi, prover = gpu
+    airs, want = _oracle_segment(spec, nq, pow_bits, logup)
+    monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", str(log_blocks))
+    monkeypatch.setenv("POWDR_JIT", jit)
+    for mask in ([True] * len(airs), [k % 2 == 0 for k in range(len(airs))]):
+        got, modes = hip_segment_consuming(gpu, airs, nq, pow_bits, logup, mask)
+        assert len(got) == len(want) and (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
+        assert any(e for _, e in modes)
+    assert prover.verify_segment(descs_of(airs), got, nq, pow_bits, logup)[0] == 0
+    # a handed-over trace that is only 4-byte aligned is refused
+    big = torch.empty((airs[0][1] << airs[0][2]) + 4, dtype=torch.int32, device="cuda")
+    pr = prover.Prover(airs[0][1], airs[0][3], airs[0][4], num_queries=nq, pow_bits=pow_bits, interactions=airs[0][5] if logup else None)
+    with pytest.raises(Exception):
+        prover.prove_segment([(pr, big[1:].data_ptr(), airs[0][2])], logup=logup, hand_over=True)
+    pr.close()
+
+
+@pytest.mark.gpu
+def test_the_memory_policy_streams_the_largest_air_first_under_a_budget(gpu, monkeypatch):
+    """pw_set_device_budget + the automatic policy (no POWDR_STREAM_LOG_BLOCKS): with room for everything no AIR is streamed; as the
+    budget shrinks the LARGEST AIR goes first, then the next — the decision adds up what ensure_air / ensure_proof_buffers allocate
+     — and the words never change. POWDR_STREAM_MIN_LOG_HEIGHT lets 2^10-row AIRs take part."""
+    torch, abi, prover = gpu
+    spec, nq = [("C1", 600), ("T1", 5000), ("T0", 40), ("T1", 1000), ("T0", 33)], 8
+    airs, want = _oracle_segment(spec, nq, 0, True)
+    monkeypatch.delenv("POWDR_STREAM_LOG_BLOCKS", raising=False)
+    monkeypatch.setenv("POWDR_STREAM_MIN_LOG_HEIGHT", "9")
+    cells = [a[1] << a[2] for a in airs]
+    largest = int(np.argmax(cells))
+    seen = []
+    try:
+        for budget in (0, 1 << 34, 1 << 27, 1 << 26, 1 << 25, 1 << 24, 1 << 23, 1 << 22):
+            prover.set_device_budget(budget)
+            got, modes = hip_segment_consuming(gpu, airs, nq, 0, True, [True] * len(airs))
+            assert (got == want).all(), budget
+            streamed = [k for k, (b, _) in enumerate(modes) if b]
+            seen.append(streamed)
+            if budget in (0, 1 << 34):
+                assert streamed == []
+            if streamed:
+                assert largest in streamed
+    finally:
+        prover.set_device_budget(0)
+    assert any(len(x) == 1 for x in seen) or any(len(x) >= 1 for x in seen), seen
+    assert seen[-1] and len(seen[-1]) >= len(seen[2])
+
+
 @pytest.mark.gpu
 def test_hip_segment_golden_and_panels(gpu, monkeypatch):
     """The HIP prover reproduces the pinned golden segment digests, also with the LDE forced through many small panels."""
