@@ -47,8 +47,10 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--pow-bits", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log-height", type=int, default=16,
-                    help="rows (log2) of the CPU-baseline sample of the same AIR (2^16 rows of C2 = 132 M cells: ~25 s on the box's host cores)")
+    ap.add_argument("--cpu-log-height", type=int, default=18,
+                    help="rows (log2) of the CPU-baseline sample of the same AIR, minus one with the LogUp phase: 2^17 rows of C2 = 265 M cells, "
+                         "~70 s on the box's host cores (round 5's 2^15-row sample under-stated the oracle ~2x: 256 OpenMP threads on 66 M cells; "
+                         "cpu_baseline.full_size quotes the 2^20-row figure)")
     ap.add_argument("--no-logup-leg", "--no-second-leg", dest="no_logup_leg", action="store_true",
                     help="skip the second timed leg of the default run (the same step with the OTHER proof kind: `constraints_only`, or `logup` "
                          "under --constraints-only)")
@@ -67,6 +69,14 @@ def parse_args():
     ap.add_argument("--no-segment-leg", action="store_true",
                     help="skip the multi_segment leg of the default run (C4: 10 APC AIRs + 19 system AIRs per segment, strong scaling)")
     ap.add_argument("--segment-steps", type=int, default=2, help="timed steps of the multi_segment leg (after one warm-up)")
+    ap.add_argument("--segment-shapes", choices=("own", "equal"), default="own",
+                    help="own: every segment has its OWN trace heights (HonestSegment.draw_shape: segment 0 at the caps, the last one a short tail, "
+                         "the others one chip at its cap and the rest log-uniform over two octaves), like the reference's metered segments "
+                         "(trace_generation.rs:113-131); equal: round 5's segments (same heights, other rows)")
+    ap.add_argument("--segment-budget-frac", type=float, default=0.8,
+                    help="the segment legs run under pw_set_device_budget(frac x the resident memory plan of the capped segment): the segment "
+                         "whose AIRs are all at their caps crosses the streaming threshold (its largest AIRs are proven from coefficient arrays, "
+                         "traces handed over), the others stay resident; 0 = no budget")
     ap.add_argument("--no-c3-leg", action="store_true", help="skip the C3-scale leg of the default run (3 731 cols x 2^22 rows, reported as `c3`)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="host threads / HIP streams proving independent segments concurrently on each GPU "
@@ -155,6 +165,8 @@ def compact_line(full: dict) -> dict:
         cc["sample"] = c.get("sample_short") or cc.get("sample")
         if c.get("tuned"):
             cc["tuned"] = _pick(c["tuned"], "value", "upper_bound_commit_stages_only")
+        if c.get("full_size"):
+            cc["full_size"] = _pick(c["full_size"], "value", "value_prover_only", "cores", "log_height", "source")
         out["cpu_baseline"] = cc
     else:
         out["cpu_baseline"] = None
@@ -166,7 +178,10 @@ def compact_line(full: dict) -> dict:
         out["c3"] = _pick(c3, "value", "prove_ms", "trace_gen_ms", "verify_rc", "logup", "cells", "committed_columns", "stream_log_blocks", "trace_handed_over", "skipped", "error")
     ms = full.get("multi_segment")
     if ms:
-        m = _pick(ms, "value", "ms_per_step", "verify_rc", "n_segments", "distinct_segments", "constraint_violations", "error")
+        m = _pick(ms, "value", "ms_per_step", "verify_rc", "n_segments", "distinct_segments", "constraint_violations", "segment_shapes", "cells_by_segment",
+                  "device_budget_bytes", "error")
+        if isinstance(ms.get("streamed_airs_by_segment"), dict):
+            m["segments_with_streamed_airs"] = sorted(int(u) for u, v in ms["streamed_airs_by_segment"].items() if v)
         if isinstance(ms.get("lookup_balance"), dict):
             m["lookup_balance_rc"] = ms["lookup_balance"].get("verify_rc")
         out["multi_segment"] = m
@@ -344,13 +359,39 @@ def cpu_baseline(shape_name, log_h, queries, pow_bits, seed, logup=False):
         tuned = cpu_baseline_tuned(len(idx), (4 * len(sm.group_starts(*it)) if logup else 0) + 8, log_h, cells, t1 - t0, t2 - t1, cores)
     except Exception as e:  # the tuned figure is an extra
         tuned = dict(value=None, error=f"{type(e).__name__}: {e}")
-    return dict(value=cells / (t2 - t0), unit="cells/s", cores=cores, kind="port", tuned=tuned,
+    full_size = cpu_baseline_full_size(shape_name, len(idx), logup, log_h, t1 - t0)
+    return dict(value=cells / (t2 - t0), unit="cells/s", cores=cores, kind="port", tuned=tuned, full_size=full_size,
                 sample=f"{shape_name} AIR W={len(idx)} at 2^{log_h} rows ({cells} cells): oracle trace generation "
                        f"(single thread, like the reference's row loop) {t1 - t0:.2f}s + oracle prover{' with the LogUp phase' if logup else ''} "
                        f"(OpenMP, {cores} threads) {t2 - t1:.2f}s",
                 sample_short=f"{shape_name} W={len(idx)} at 2^{log_h} rows ({cells / 1e6:.1f} M cells): oracle tracegen 1 thread {t1 - t0:.1f} s + oracle "
                              f"prover{' +LogUp' if logup else ''} OpenMP x{cores} {t2 - t1:.1f} s",
                 trace_gen_s=t1 - t0, prove_s=t2 - t1)
+
+
+def cpu_baseline_full_size(shape_name, width, logup, sample_log_h, sample_trace_gen_s):
+    """The same oracle at the FULL size of the GPU workload, from the committed profile of the run that byte-compared the two proofs
+    (tools/full_size_parity.py: the oracle prover on all host cores of a GPU box of this pool, 2^20 rows) — too long for every bench run
+    (~8 minutes), so it is quoted, with its file; trace generation (the reference's sequential row loop, cpu/mod.rs:161-225: exactly
+    linear in the rows) is this run's own single-thread sample scaled to the full height. The live `value` above is a SAMPLE of the
+    same code; VERDICT r5 #3: it has to land within 25 % of this figure."""
+    name = {("C2", True): "r03_full_size_parity_c2_logup.json", ("C2", False): "r02_full_size_parity_c2.json"}.get((shape_name, bool(logup)))
+    f = ROOT / "profiles" / name if name else None
+    if f is None or not f.exists():
+        return None
+    try:
+        d = json.loads(f.read_text())
+        if d.get("cols") != width or not d.get("proofs_identical"):
+            return None
+        rows = 1 << d["log_height"]
+        tg = sample_trace_gen_s * rows / (1 << sample_log_h)
+        cells = width * rows
+        return dict(value=cells / (tg + d["oracle_prove_s"]), value_prover_only=cells / d["oracle_prove_s"], unit="cells/s", cores=d.get("host_cores"),
+                    log_height=d["log_height"], prove_s=d["oracle_prove_s"], trace_gen_s_scaled_from_sample=tg, source=f"profiles/{name}",
+                    note="oracle prover at the GPU workload's full size (committed profile, proof words identical to the HIP prover's) + this run's "
+                         "single-thread trace generation scaled linearly to that height")
+    except Exception as e:  # a quoted figure must never cost the line
+        return dict(value=None, error=f"{type(e).__name__}: {e}")
 
 
 def cpu_baseline_tuned(width, extra_cols, log_h, cells, oracle_tracegen_s, oracle_prove_s, cores):
@@ -470,16 +511,17 @@ def gauges_of(stage_ms):
              "stark_prove_excluding_trace_time_ms = ms_per_step - trace_gen_time_ms")
 
 
-def _segment_checks(seg, segments, rec, distinct=True):
+def _segment_checks(seg, segments, rec, distinct=True, shapes=None):
     """After the timed region, for EVERY segment in `segments` (the ones this process proved; their inputs are staged again one at a time):
     the proof against the product's host verifier, the device's mock prover on the traces it was made from, and the lookup buses'
     balance (segment_workload.HonestSegment.balance_witness). Into `rec`: the worst code over the segments + the per-segment lists."""
     t0 = time.perf_counter()
     vrc, viol, roots = [], [], []
     hdr = 5 + 4 * len(seg.airs)
+    stage = (lambda u: seg.stage_inputs(u, shapes[u])) if shapes is not None else seg.stage_inputs
     for u in segments:
         if distinct:
-            seg.stage_inputs(u)
+            stage(u)
         seg.generate_traces()
         pf = np.array(seg.prove(), copy=True)
         vrc.append(int(seg.verify(pf)))
@@ -498,7 +540,7 @@ def _segment_checks(seg, segments, rec, distinct=True):
         brc, totals = [], []
         for u in segments:
             if distinct:
-                seg.stage_inputs(u)
+                stage(u)
             seg.generate_traces()
             rc, total = seg.balance_witness()
             brc.append(int(rc))
@@ -518,6 +560,38 @@ def _segment_checks(seg, segments, rec, distinct=True):
             os.environ["POWDR_JIT"] = prev
 
 
+SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC = "own", 0.8  # (--segment-shapes / --segment-budget-frac; set in main)
+
+
+def _segment_plan(seg, n_segments):
+    """(shapes, cells, log-heights) per segment: the segments' own trace heights (--segment-shapes own) or the caps for all."""
+    shapes = [seg.draw_shape(u, n_segments) if SEGMENT_SHAPES == "own" else None for u in range(n_segments)]
+    return shapes, [int(seg.shape_cells(sh)) for sh in shapes], [seg.shape_heights(sh) for sh in shapes]
+
+
+def _segment_budget(seg, shapes, prover):
+    """The capped segment (every AIR at its cap) proven once, outside any timed region, to read its resident memory plan; the budget
+    the leg then runs under is SEGMENT_BUDGET_FRAC of it (an embedder sharing the device would set such a budget). Returns the record."""
+    if not SEGMENT_BUDGET_FRAC or SEGMENT_SHAPES != "own":
+        return dict(device_budget_bytes=None)
+    seg.stage_inputs(0, None)
+    seg.generate_traces()
+    seg.prove()
+    resident = prover.segment_last_plan()[0]
+    budget = int(SEGMENT_BUDGET_FRAC * resident)
+    prover.set_device_budget(budget)
+    return dict(device_budget_bytes=budget, resident_plan_bytes_capped_segment=int(resident), budget_frac=SEGMENT_BUDGET_FRAC)
+
+
+def _shape_record(seg, shapes, cells, heights):
+    names = [a["name"] for a in seg.airs]
+    return dict(segment_shapes=SEGMENT_SHAPES, air_names=names, heights_by_segment=heights, cells_by_segment=cells,
+                calls_by_segment=[None if sh is None else dict(apc=sh["apc_calls"], instruction_block=sh["instr_calls"]) for sh in shapes],
+                shape_note="per segment its own trace heights, like a metered execution's (trace_generation.rs:113-131): segment 0 every chip at its cap, "
+                           "the last one the execution's tail (<= 1/8), the others one chip at its cap and the rest log-uniform over two octaves; "
+                           "log2 heights in air_names order" if SEGMENT_SHAPES == "own" else "every segment at the caps (round 5's legs)")
+
+
 def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup, queries, pow_bits, n_workers, abi):
     """The same strong-scaling workload as segment_bench, driven from ONE process through the C ABI's multi-device entry
     pw_prove_segments_multi: one host thread per worker (worker w on GPU w mod #GPUs) with its own launch stream and its own
@@ -534,16 +608,21 @@ def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup,
     for d in set(devices):
         torch.cuda.synchronize(d)
     seg0 = workers[0]
-    cells_seg = seg0.cells
+    shapes, cells, heights = _segment_plan(seg0, n_segments)
     hdr = 5 + 4 * len(seg0.airs)
     last = {}
+    with torch.cuda.device(devices[0]):
+        budget = _segment_budget(seg0, shapes, prover)
 
     mine0 = set()
+    streamed = {}
 
     def prove_one(segment, worker, device):
-        workers[worker].stage_inputs(segment)  # every segment has its own inputs (same AIRs, other rows), staged in the worker's buffers
+        # every segment has its own inputs AND its own trace heights, staged in the worker's buffers; the traces are handed over
+        workers[worker].stage_inputs(segment, shapes[segment])
         workers[worker].generate_traces()
-        pf = workers[worker].prove()
+        pf = workers[worker].prove(hand_over=True)
+        streamed[int(segment)] = [f"{a['name']}:{1 << b} sub-cosets" for a, (b, _) in zip(workers[worker].airs, prover.segment_last_modes()) if b]
         last["words"] = len(pf)
         if worker == 0:
             mine0.add(int(segment))
@@ -551,7 +630,7 @@ def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup,
 
     def run_steps(n):
         for _ in range(n):
-            last["merged"], last["owner"], last["merge"] = prover.prove_segments_multi(devices, [cells_seg] * n_segments, prove_one)
+            last["merged"], last["owner"], last["merge"] = prover.prove_segments_multi(devices, cells, prove_one)
 
     def barrier():
         for d in set(devices):
@@ -565,15 +644,19 @@ def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup,
     elapsed = time.perf_counter() - t0
     assert (last["merged"] != 0).any(axis=1).all(), "a segment's commitment is missing from the merge"
     rec = dict(shape=kind, scaling="strong", n_segments=n_segments, workers=n_workers, devices=devices, airs_per_segment=len(seg0.airs),
-               cells_per_segment=cells_seg, value=cells_seg * n_segments * steps / elapsed, unit="cells/s", ms_per_step=elapsed / steps * 1e3,
+               cells_per_segment=max(cells), cells_per_step=sum(cells), value=sum(cells) * steps / elapsed, unit="cells/s", ms_per_step=elapsed / steps * 1e3,
                steps=steps, warmup=warmup, logup=bool(logup), proof_bytes_per_segment=int(last["words"]) * 4,
                segments_per_worker=[int((last["owner"] == w).sum()) for w in range(n_workers)],
+               cells_per_worker=[int(sum(c for c, o in zip(cells, last["owner"]) if o == w)) for w in range(n_workers)],
+               streamed_airs_by_segment=[streamed.get(u, []) for u in range(n_segments)], traces_handed_over=True, **budget,
+               **_shape_record(seg0, shapes, cells, heights),
                commitment_merge={1: "RCCL all-gather (one communicator per device set, ncclCommInitAll at first use)", 2: "host (RCCL not available)"}[last["merge"]],
                note="pw_prove_segments_multi: one process, one host thread + launch stream per worker; per segment: trace generation of every AIR + one "
                     "pw-stark v1 proof (segment_workload.HonestSegment: one resident segment per worker, regenerated and proven for every unit)")
     rec["distinct_segments"] = True
+    prover.set_device_budget(0)
     with torch.cuda.device(devices[0]):
-        _segment_checks(seg0, sorted(mine0), rec)
+        _segment_checks(seg0, sorted(mine0), rec, shapes=shapes)
     for wk in workers:
         wk.close()
     return rec
@@ -590,23 +673,29 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
     and the lookup buses' balance for every segment rank 0 proved. Returns the record (rank 0) or None."""
     from powdr_amd import segment_workload as sw, sharding
 
+    from powdr_amd import prover
+
     seg = sw.HonestSegment(kind, max_log_height=max_log_height, seed=0, queries=queries, pow_bits=pow_bits, logup=logup)
-    cells_seg = seg.cells
+    shapes, cells, heights = _segment_plan(seg, n_segments)
     hdr = 5 + 4 * len(seg.airs)  # proof words before the main commitment
     last = dict(gen_s=0.0, prove_s=0.0, stage_s=0.0, units=0)
+    budget = _segment_budget(seg, shapes, prover)
+    streamed, unit_ms = {}, {}
 
     def prove_one(u):
         # segment u's OWN inputs (the dummy traces behind every APC AIR, the instruction AIRs' records), generated on the device into the
         # resident segment's buffers: inside the timed region (one write-only pass over the sources, reported as input_staging_ms_per_segment)
         ts = time.perf_counter()
-        seg.stage_inputs(u)
+        seg.stage_inputs(u, shapes[u])  # ... at the segment's OWN trace heights (re-planning, buffer reuse and kernel-cache hits inside the timed region)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         seg.generate_traces()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        pf = seg.prove()
+        pf = seg.prove(hand_over=True)  # every chip moves its trace into the engine (cuda/mod.rs:415-419)
         t2 = time.perf_counter()
+        streamed[int(u)] = [f"{a['name']}:{1 << b} sub-cosets" for a, (b, _) in zip(seg.airs, prover.segment_last_modes()) if b]
+        unit_ms[int(u)] = dict(stage=(t0 - ts) * 1e3, trace_gen=(t1 - t0) * 1e3, prove=(t2 - t1) * 1e3)
         last["stage_s"] += t0 - ts
         last["gen_s"] += t1 - t0
         last["prove_s"] += t2 - t1
@@ -616,7 +705,7 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
 
     def run_steps(n):
         for _ in range(n):
-            mine, merged = sharding.prove_segments_sharded([cells_seg] * n_segments, prove_one, rank, world)
+            mine, merged = sharding.prove_segments_sharded(cells, prove_one, rank, world)
             last["mine"], last["merged"] = mine, merged
 
     run_steps(warmup)
@@ -624,21 +713,27 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
     elapsed, timing = timed_leg(run_steps, steps, 0, barrier, abi, world)
     per_rank_ms = [t / steps * 1e3 for t in LAST_PER_RANK_S]
     assert (last["merged"] != 0).any(axis=1).all(), "a segment's commitment is missing from the merge"
-    total_cells = cells_seg * n_segments * steps
+    total_cells = sum(cells) * steps
     stage = {k: ms / steps for k, (c, ms) in timing.items()}
     units = max(1, last["units"])
-    shapes = [(a["name"], a["width"], a["log_h"], len(a["cons"][1]), len(a["inter"][0])) for a in seg.airs]
-    rec = dict(shape=kind, scaling="strong", n_segments=n_segments, segments_on_rank0=len(last["mine"]), airs_per_segment=len(shapes),
-               airs_by_role={r: sum(1 for a in seg.airs if a["role"] == r) for r in ("apc", "instruction", "periphery")}, cells_by_role=seg.cells_by_role,
-               cells_per_segment=cells_seg, value=total_cells / elapsed, unit="cells/s", ms_per_step=elapsed / steps * 1e3, steps=steps,
+    cells_mine = sum(cells[u] for u in last["mine"]) or 1
+    cap_heights = seg.shape_heights(None)
+    air_shapes = [(a["name"], a["width"], lh, len(a["cons"][1]), len(a["inter"][0])) for a, lh in zip(seg.airs, cap_heights)]
+    placement = sharding.assign_units(list(cells), world)
+    rec = dict(shape=kind, scaling="strong", n_segments=n_segments, segments_on_rank0=len(last["mine"]), airs_per_segment=len(air_shapes),
+               airs_by_role={r: sum(1 for a in seg.airs if a["role"] == r) for r in ("apc", "instruction", "periphery")},
+               cells_per_segment=int(seg.shape_cells(None)), cells_per_step=sum(cells), value=total_cells / elapsed, unit="cells/s", ms_per_step=elapsed / steps * 1e3, steps=steps,
+               placement=[[int(u) for u in p_] for p_ in placement], cells_per_rank=[int(sum(cells[u] for u in p_)) for p_ in placement],
+               streamed_airs_by_segment={str(u): v for u, v in sorted(streamed.items())}, ms_by_segment_rank0={str(u): v for u, v in sorted(unit_ms.items())},
+               traces_handed_over=True, **budget, **_shape_record(seg, shapes, cells, heights),
                trace_gen_ms_per_segment=last["gen_s"] / units * 1e3, prove_ms_per_segment=last["prove_s"] / units * 1e3,
                input_staging_ms_per_segment=last["stage_s"] / units * 1e3, distinct_segments=True,
                distinct_commitments_in_merge=len({tuple(int(x) for x in r) for r in last["merged"]}),
-               cells_per_s_prove_only=cells_seg / (last["prove_s"] / units) if last["prove_s"] else None,
+               cells_per_s_prove_only=cells_mine * steps / last["prove_s"] if last["prove_s"] else None,
                warmup=warmup, logup=bool(logup), proof_bytes_per_segment=int(last["words"]) * 4, per_rank_ms=per_rank_ms, ranks=world,
-               widths=f"{min(s[1] for s in shapes)}..{max(s[1] for s in shapes)} (sum {sum(s[1] for s in shapes)})",
-               log_heights=f"{min(s[2] for s in shapes)}..{max(s[2] for s in shapes)}",
-               constraints=sum(s[3] for s in shapes), interactions=sum(s[4] for s in shapes), source_bytes=seg.source_bytes,
+               widths=f"{min(s[1] for s in air_shapes)}..{max(s[1] for s in air_shapes)} (sum {sum(s[1] for s in air_shapes)})",
+               log_heights=f"{min(min(h) for h in heights)}..{max(max(h) for h in heights)}",
+               constraints=sum(s[3] for s in air_shapes), interactions=sum(s[4] for s in air_shapes), source_bytes=seg.source_bytes,
                prover_device_bytes=seg.device_bytes(), stage_ms_rank0=stage,
                stage_ms_note="per-kernel elapsed times; the per-AIR stages of a segment run on side streams (POWDR_SEGMENT_STREAMS, default 4) and "
                              "overlap, so the sum exceeds the wall time of the step",
@@ -648,8 +743,9 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
                     "generated traces, the 13 RV32IM instruction AIRs with the reference's real constraints / interactions on traces expanded from "
                     "records, the 3 lookup periphery AIRs from the histograms; the other 5 system AIRs of the reference's 19 (connector, program, "
                     "memory boundary, Merkle, Poseidon2: 357 of 819 columns) are external chips and are left out")
+    prover.set_device_budget(0)
     if rank == 0:
-        _segment_checks(seg, list(last["mine"]), rec)
+        _segment_checks(seg, list(last["mine"]), rec, shapes=shapes)
     seg.close()
     import gc
 
@@ -884,7 +980,9 @@ def load_profile_json(name):
 
 
 def main():
+    global SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC
     args = parse_args()
+    SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC = args.segment_shapes, args.segment_budget_frac
     self_launch(args)  # --gpus N > 1 without a launcher: re-run as N ranks (does not return)
     if args.launch_check:
         launch_check()
@@ -913,7 +1011,7 @@ def main():
             higher_is_better=True, scaling="strong", vs_baseline=None, dtype="u32 (BabyBear, Montgomery)", data="synthetic",
             metric_short=f"STARK cells/sec (trace rows x cols), multi-segment {args.shape}" + (" [with the bus argument]" if args.logup else " [constraints-only]"),
             config=dict(workload_short=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs, one proof per segment, {rec['workers']} in-process workers",
-                        workload=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs ({rec['cells_per_segment']} cells each), one proof "
+                        workload=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs (up to {rec['cells_per_segment']} cells, {rec['cells_per_step']} in all), one proof "
                                  f"per segment, {rec['workers']} in-process workers on devices {rec['devices']} (pw_prove_segments_multi)",
                         parallelism=f"segments over {rec['workers']} host threads in one process (strong)", proof_bytes=rec["proof_bytes_per_segment"]),
             roofline=dict(bound="hbm", kernel="whole step", achieved=whole, peak=HBM_PEAK_GBS, unit="GB/s", frac=whole / HBM_PEAK_GBS, traffic=None,
@@ -934,7 +1032,7 @@ def main():
                         rccl_ranks=comm_facts(world)["ranks"], comm=comm_facts(world), per_rank_ms=rec.get("per_rank_ms"),
                         metric_short=f"STARK cells/sec (trace rows x cols), multi-segment {args.shape}" + (" [with the bus argument]" if args.logup else " [constraints-only]"),
                         config=dict(workload_short=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs, one proof per segment, sharded over {world} GPU(s) by cells",
-                                    workload=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs ({rec['cells_per_segment']} cells each, "
+                                    workload=f"{args.shape}: {args.segments} segments x {rec['airs_per_segment']} AIRs (up to {rec['cells_per_segment']} cells, {rec['cells_per_step']} in all, "
                                              f"heights 2^{rec['log_heights']}, widths {rec['widths']}), one proof per segment, segments sharded over "
                                              f"{world} GPU(s) by cells, main commitments all-gathered",
                                     parallelism=f"segments over {world} ranks (strong)", proof_bytes=rec["proof_bytes_per_segment"]),

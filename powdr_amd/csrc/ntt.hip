@@ -81,11 +81,14 @@ struct GroupParams {
     uint32_t foldk[16];
     uint32_t cst[4];
     // SELECT (the query phase of a streamed proof, subcoset_query_rows): the group's outputs are not stored — of every tile only the
-    // n_sel positions sel_pos[q] are used: position * sel_xpow[q * n_tiles + tile] is added to sel_acc[column * n_sel + q] (64-bit sums).
+    // n_sel positions sel_pos[q] are used: the term position * sel_xpow[q * n_tiles + tile] of output q goes to
+    // sel_part[(column * n_tiles + tile) * n_sel + q] (one plain store per term; select_reduce_kernel sums a column's tiles) — or, with
+    // sel_part == nullptr (POWDR_QUERY_SELECT=2, round 5's form), is added to sel_acc[column * n_sel + q] by a 64-bit atomic.
     int n_sel;
     const uint32_t* sel_pos;
     const uint32_t* sel_xpow;
     unsigned long long* sel_acc;
+    uint32_t* sel_part;
 };
 
 __device__ __forceinline__ uint32_t lds_phys(uint32_t l) { return l + (l >> 5); }
@@ -424,9 +427,12 @@ __global__ __launch_bounds__(NT) void ntt_group_kernel(const uint32_t* __restric
         // the tile stays in LDS (the forward network's [0, 2p) representatives): this tile's term of every selected output
         __syncthreads();
         const size_t t = blockIdx.x;  // (one tile per workgroup: the host only selects then)
+        uint32_t* part = gp.sel_part ? gp.sel_part + ((size_t)blockIdx.y * gp.n_tiles + t) * (size_t)gp.n_sel : nullptr;
         for (int q = tid; q < gp.n_sel; q += kBlock) {
             const uint32_t v = bb::reduce_2p(tile[lds_phys(gp.sel_pos[q])]);
-            atomicAdd(gp.sel_acc + (size_t)blockIdx.y * gp.n_sel + q, (unsigned long long)bb::mul(v, gp.sel_xpow[(size_t)q * gp.n_tiles + t]));
+            const uint32_t term = bb::mul(v, gp.sel_xpow[(size_t)q * gp.n_tiles + t]);
+            if (part) part[q] = term;  // n_sel consecutive words per workgroup
+            else atomicAdd(gp.sel_acc + (size_t)blockIdx.y * gp.n_sel + q, (unsigned long long)term);
         }
     }
 }
@@ -708,6 +714,7 @@ struct CosetSpec {
     const uint32_t* sel_pos = nullptr;
     const uint32_t* sel_xpow = nullptr;
     unsigned long long* sel_acc = nullptr;
+    uint32_t* sel_part = nullptr;
 };
 
 template <bool DIF>
@@ -736,7 +743,7 @@ void run_groups(const uint32_t* in, uint32_t* out, size_t in_stride, size_t out_
             g.coset = 1;
             g.fold = mode == 2 ? cs->fold_log : 0;
             for (int k = 0; k < 16; ++k) g.foldk[k] = cs->foldk[k];
-            if (mode == 2 && cs->n_sel > 0) { g.n_sel = cs->n_sel; g.sel_pos = cs->sel_pos; g.sel_xpow = cs->sel_xpow; g.sel_acc = cs->sel_acc; }
+            if (mode == 2 && cs->n_sel > 0) { g.n_sel = cs->n_sel; g.sel_pos = cs->sel_pos; g.sel_xpow = cs->sel_xpow; g.sel_acc = cs->sel_acc; g.sel_part = cs->sel_part; }
             for (int r = 0; r < g.n_rounds; ++r) g.cst[r] = cs->C[g.s0 + g.rb[r] + g.logr[r] - 1 - g.c];
             if (gt) {
                 CosetTableArgs a{};
@@ -1026,6 +1033,18 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const unsigned long 
     const uint32_t q = blockIdx.y;
     out[(size_t)(slot ? slot[q] : q) * cols + c] = (uint32_t)(acc[(size_t)c * n + q] % bb::P);
 }
+// rows_out[slot(q) * cols + c] = sum_t part[(c * n_tiles + t) * n + q] mod p: lane = output q (a tile's n terms are consecutive words),
+// the tiles of the column one after the other. 2^k2 <= 2^14 terms below p: the sum fits 64 bits with room to spare.
+__global__ __launch_bounds__(128) void select_reduce_kernel(const uint32_t* __restrict__ part, uint32_t n, uint32_t cols, size_t n_tiles,
+                                                           const uint32_t* __restrict__ slot, uint32_t* __restrict__ out) {
+    const uint32_t q = blockIdx.x * 128u + threadIdx.x, c = blockIdx.y;
+    if (q >= n) return;
+    const uint32_t* col = part + (size_t)c * n_tiles * n + q;
+    unsigned long long acc = 0;
+#pragma unroll 8
+    for (size_t t = 0; t < n_tiles; ++t) acc += col[t * n];
+    out[(size_t)(slot ? slot[q] : q) * cols + c] = (uint32_t)(acc % bb::P);
+}
 }  // namespace
 
 // The rows d_local_idx[q] (q < n_idx) of sub-coset r's LDE WITHOUT storing the partial transform: the first stage group with SELECT
@@ -1038,7 +1057,12 @@ int subcoset_query_rows(const uint32_t* coeffs, size_t in_stride, uint32_t cols,
     const int nm = n + 1 - b;
     if (!n_idx || !cols) return 0;
     if (cols > 65535u) return 1;  // (one launch: blockIdx.y is the column)
-    if (getenv("POWDR_QUERY_SELECT") && atoi(getenv("POWDR_QUERY_SELECT")) == 0) return 1;
+    // POWDR_QUERY_SELECT: 0 = never (the stored partial transform + subcoset_rows), 2 = round 5's 64-bit atomic sums, default (1) =
+    // every workgroup STORES its n_idx terms and select_reduce_kernel adds a column's tiles: the same words, no atomics — tiles x cols x
+    // n_idx of them per pass (4.3e8 at configs[2]), all tiles of a column on the same n_idx addresses — and a kernel that profiles
+    // under rocprofv3 --pmc (the atomic form's FETCH_SIZE pass did not return: DESIGN §3.8 round 6, tools/repro_select_atomics.py)
+    const int sel_mode = getenv("POWDR_QUERY_SELECT") ? atoi(getenv("POWDR_QUERY_SELECT")) : 1;
+    if (sel_mode == 0) return 1;
     CosetSpec cs;
     if (!subcoset_spec(n, b, r, d_work, cs)) return (int)hipErrorInvalidValue;
     int logt = 12;
@@ -1049,7 +1073,10 @@ int subcoset_query_rows(const uint32_t* coeffs, size_t in_stride, uint32_t cols,
     uint32_t* d_pos = d_work + (1u << 13);
     uint32_t* d_xpow = d_pos + ((n_idx + 1u) & ~1u);
     unsigned long long* d_acc = reinterpret_cast<unsigned long long*>(d_xpow + (((size_t)n_idx * n_tiles + 1) & ~(size_t)1));
-    const size_t need = (size_t)(reinterpret_cast<uint32_t*>(d_acc + (size_t)cols * n_idx) - d_work);
+    uint32_t* d_part = reinterpret_cast<uint32_t*>(d_acc + (size_t)cols * n_idx);
+    bool partial = sel_mode != 2;
+    size_t need = (size_t)(d_part - d_work) + (partial ? (size_t)cols * n_tiles * n_idx : 0);
+    if (partial && need > work_words) { partial = false; need = (size_t)(d_part - d_work); }  // (no room for the terms: the atomic sums)
     if (need > work_words || ((uintptr_t)d_work & 7)) return 1;
     const Tables* tm = tables(nm);
     if (!tm) return (int)hipErrorOutOfMemory;
@@ -1059,14 +1086,15 @@ int subcoset_query_rows(const uint32_t* coeffs, size_t in_stride, uint32_t cols,
         hipLaunchKernelGGL(select_xpow_kernel, dim3((unsigned)div_up((size_t)n_idx * n_tiles, 256)), dim3(256), 0, stream(), d_local_idx, n_idx, k2, c0,
                            field::root_of_unity(nm), d_xpow, d_pos, (1u << k1) - 1u);
     }
-    PW_HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)cols * n_idx * sizeof(unsigned long long), stream()));
-    cs.n_sel = (int)n_idx; cs.sel_pos = d_pos; cs.sel_xpow = d_xpow; cs.sel_acc = d_acc;
+    if (!partial) PW_HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)cols * n_idx * sizeof(unsigned long long), stream()));
+    cs.n_sel = (int)n_idx; cs.sel_pos = d_pos; cs.sel_xpow = d_xpow; cs.sel_acc = d_acc; cs.sel_part = partial ? d_part : nullptr;
     int done = 0;
     // (`out` of the group is never written in SELECT mode: the coefficient array stands in for it)
     run_groups<false>(coeffs, const_cast<uint32_t*>(coeffs), in_stride, in_stride, cols, nm, 0, tm->tw_fwd, nullptr, "ntt_group_kernel<dit>", &cs, 1, &done);
     {
         ScopedKernelTimer t("subcoset_rows_kernel");
-        hipLaunchKernelGGL(select_finish_kernel, dim3(div_up(cols, 256), n_idx), dim3(256), 0, stream(), d_acc, n_idx, cols, d_slot, rows_out);
+        if (partial) hipLaunchKernelGGL(select_reduce_kernel, dim3(div_up(n_idx, 128), cols), dim3(128), 0, stream(), d_part, n_idx, cols, n_tiles, d_slot, rows_out);
+        else hipLaunchKernelGGL(select_finish_kernel, dim3(div_up(cols, 256), n_idx), dim3(256), 0, stream(), d_acc, n_idx, cols, d_slot, rows_out);
     }
     return (int)hipGetLastError();
 }

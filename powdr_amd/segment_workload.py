@@ -323,7 +323,8 @@ class HonestSegment:
         else:
             f = 2.0 ** -rng.uniform(0.0, 2.0, size=n)
             f[int(rng.integers(0, n))] = 1.0
-        apc_calls = [max(1, int(wl["max_calls"] * f[k])) for k, wl in enumerate(self.apcs)]
+        # (at least 3 calls: the library sizes an APC trace as next_pow2(calls) rows and the provers want >= 4 rows, the shapes' minimum)
+        apc_calls = [max(min(3, wl["max_calls"]), int(wl["max_calls"] * f[k])) for k, wl in enumerate(self.apcs)]
         return dict(segment=u, apc_calls=apc_calls, instr_calls=max(1, int(self.max_calls * f[-1])))
 
     def set_shape(self, shape: dict | None) -> None:
@@ -338,7 +339,7 @@ class HonestSegment:
 
         apc_airs = [a for a in self.airs if a["role"] == "apc"]
         for wl, a, calls in zip(self.apcs, apc_airs, shape["apc_calls"]):
-            assert 0 < calls <= wl["max_calls"]
+            assert 0 < calls <= wl["max_calls"] and (calls >= 3 or calls == wl["max_calls"])
             lh = max(2, (calls - 1).bit_length())
             wl["calls"], wl["log_h"], wl["H"] = calls, lh, 1 << lh
             a["log_h"] = lh
@@ -372,6 +373,26 @@ class HonestSegment:
 
     def heights(self) -> list:
         return [a["log_h"] for a in self.airs]
+
+    def shape_heights(self, shape: dict | None) -> list:
+        """log2 heights of every AIR (in self.airs order) a segment of this shape has — without re-shaping anything"""
+        if shape is None:
+            shape = dict(apc_calls=[wl["max_calls"] for wl in self.apcs], instr_calls=self.max_calls)
+        apc = iter(shape["apc_calls"])
+        ih = oc.dummy_trace_heights(self.table, shape["instr_calls"])
+        out = []
+        for a in self.airs:
+            if a["role"] == "apc":
+                out.append(max(2, (next(apc) - 1).bit_length()))
+            elif a["role"] == "instruction":
+                out.append(ih[oc.KIND_NAMES.index(a["name"])].bit_length() - 1)
+            else:
+                out.append(a["log_h"])
+        return out
+
+    def shape_cells(self, shape: dict | None) -> int:
+        """main-trace cells (rows x columns over all AIRs) of a segment of this shape: what the placement balances"""
+        return sum(a["width"] << lh for a, lh in zip(self.airs, self.shape_heights(shape)))
 
     # ---- the inputs of ANOTHER segment of the same execution (same chips, other rows) ---------------------------------------
     def stage_inputs(self, data_seed: int, shape: dict | None = None):

@@ -109,3 +109,99 @@ def test_staged_inputs_give_other_segments_of_the_same_shape(gpu):
         if a["role"] != "periphery":
             assert not torch.equal(traces[0][i], traces[1][i]), a["name"]
     seg.close()
+
+
+def test_segments_with_their_own_trace_heights(gpu, monkeypatch):
+    """the reference's segments each carry their own `trace_heights` (openvm/src/trace_generation.rs:113-131). One
+    resident HonestSegment is re-shaped per unit (draw_shape: every chip at its cap / one chip at its cap and the others log-uniform
+    over two octaves / the execution's tail at <= 1/8), its inputs staged for that shape, traces generated, ONE segment proof — for
+    three differently-shaped segments: every constraint holds, both verifiers accept, the words equal sm.prove_segment's on the traces
+    read back, the lookup buses balance; going back to an earlier shape gives that segment's proof again (plan caches keyed by
+    height, buffers that only grow, padding rows rewritten)."""
+    torch, sw = gpu
+    from powdr_amd import prover
+
+    seg = sw.HonestSegment("C4", max_log_height=10, seed=3, queries=5, pow_bits=3, logup=True, max_apc_airs=3)
+    n_segments = 6
+    shapes = {u: seg.draw_shape(u, n_segments) for u in range(n_segments)}
+    caps = [wl["max_calls"] for wl in seg.apcs]
+    assert shapes[0]["apc_calls"] == caps and shapes[0]["instr_calls"] == seg.max_calls
+    assert all(c <= cap // 8 for c, cap in zip(shapes[n_segments - 1]["apc_calls"], caps)) and shapes[n_segments - 1]["instr_calls"] <= max(1, seg.max_calls // 8)
+    for u in range(1, n_segments - 1):
+        f = [c / cap for c, cap in zip(shapes[u]["apc_calls"], caps)] + [shapes[u]["instr_calls"] / seg.max_calls]
+        assert max(f) == 1.0 and min(f) >= 0.24
+    roots, heights, proofs = {}, {}, {}
+    for u in (0, 2, n_segments - 1, 3, 0, 2):
+        seg.stage_inputs(u, shapes[u])
+        seg.generate_traces()
+        torch.cuda.synchronize()
+        assert seg.check_constraints() == 0, u
+        proof = seg.prove(copy=True)
+        assert seg.verify(proof) == 0, u
+        hdr = 5 + 4 * len(seg.airs)
+        root = tuple(int(x) for x in proof[hdr:hdr + 8])
+        if u in roots:
+            assert roots[u] == root and heights[u] == seg.heights() and (proofs[u] == proof).all()
+            continue
+        roots[u], heights[u], proofs[u] = root, seg.heights(), proof
+        airs = _host_airs_shaped(seg)
+        want = sm.prove_segment(airs, num_queries=5, pow_bits=3, logup=True)
+        assert len(proof) == len(want) and (proof == want).all(), f"segment {u}: first differing word {int(np.argmax(proof != want))} of {len(want)}"
+        assert sm.verify_segment(proof, airs, 5, 3, True)[0] == 0
+        rc, total = seg.balance_witness()
+        assert rc == 0 and (np.asarray(total) == 0).all(), u
+        # the same segment with its traces handed over (pw_prove_segment_consuming; nothing is streamed at this size): same words
+        assert (seg.prove(copy=True, hand_over=True) == proof).all()
+    assert len(set(roots.values())) == 4 and len({tuple(h) for h in heights.values()}) == 4
+    # the tail is short: every APC and instruction AIR at most 1/8 of the capped segment's rows
+    for h0, ht, a in zip(heights[0], heights[n_segments - 1], seg.airs):
+        if a["role"] == "apc":
+            assert ht <= h0 - 3
+        elif a["role"] == "instruction":  # (four block executions at this cap: the tail has one)
+            assert ht < h0 or h0 <= 2
+    seg.close()
+
+
+def _host_airs_shaped(seg):
+    """like _host_airs, for a re-shaped segment: a trace is the prefix of its buffer"""
+    airs = []
+    for a in seg.airs:
+        n = a["width"] << a["log_h"]
+        flat = om.from_monty(a["trace"][:n].cpu().numpy().view(np.uint32))
+        airs.append((flat, a["width"], a["log_h"], a["cons"][0], a["cons"][1], a["inter"]))
+    return airs
+
+
+def test_a_budget_makes_the_capped_segment_stream_and_the_words_stay(gpu, monkeypatch):
+    """The bench's `multi_segment` leg under a device budget of 0.8 x the capped segment's resident plan: segment 0 (every chip at its
+    cap) streams its largest AIR with the trace handed over, the shorter segments stay resident — decisions made per segment, inside
+    the run — and every proof equals the one made without a budget."""
+    torch, sw = gpu
+    from powdr_amd import prover
+
+    monkeypatch.setenv("POWDR_STREAM_MIN_LOG_HEIGHT", "9")
+    seg = sw.HonestSegment("C4", max_log_height=11, seed=4, queries=4, pow_bits=0, logup=True, max_apc_airs=3)
+    shapes = {u: seg.draw_shape(u, 4) for u in range(4)}
+    plain = {}
+    for u in range(4):
+        seg.stage_inputs(u, shapes[u])
+        seg.generate_traces()
+        plain[u] = seg.prove(copy=True)
+        if u == 0:
+            resident = prover.segment_last_plan()[0]
+            assert resident > 0 and all(b == 0 for b, _ in prover.segment_last_modes())
+    try:
+        prover.set_device_budget(int(0.8 * resident))
+        streamed_in = {}
+        for u in (3, 0, 1, 0, 2):
+            seg.stage_inputs(u, shapes[u])
+            seg.generate_traces()
+            got = seg.prove(copy=True, hand_over=True)
+            assert (got == plain[u]).all(), u
+            modes = prover.segment_last_modes()
+            streamed_in[u] = [a["name"] for a, (b, eaten) in zip(seg.airs, modes) if b]
+            assert all(eaten == (b > 0 and a["role"] != "instruction") for a, (b, eaten) in zip(seg.airs, modes))
+        assert streamed_in[0] and streamed_in[0][0] == "apc0" and streamed_in[3] == []
+    finally:
+        prover.set_device_budget(0)
+    seg.close()

@@ -134,8 +134,12 @@ def test_tall_trace_query_rows_from_the_partial_transform(gpu, monkeypatch, log_
     assert log_h == 16
     want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=12, pow_bits=0)
     d_t = to_dev(torch, flat)
-    got, _ = _prove(prover, monkeypatch, d_t, W, log_h, bc, spans, it, 12, 0, log_blocks, jit)
-    assert len(got) == len(want) and (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
+    # the three forms of the query pass (ntt.hip subcoset_query_rows): the tiles' terms stored and reduced (default), round 5's 64-bit
+    # atomic sums, the stored partial transform + subcoset_rows — the same words
+    for select in ("1", "2", "0"):
+        monkeypatch.setenv("POWDR_QUERY_SELECT", select)
+        got, _ = _prove(prover, monkeypatch, d_t, W, log_h, bc, spans, it, 12, 0, log_blocks, jit)
+        assert len(got) == len(want) and (got == want).all(), f"select {select}: first differing word {int(np.argmax(got != want))} of {len(want)}"
 
 
 def test_streamed_equals_resident_at_2_to_18_rows(gpu, monkeypatch):

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Is the rocprofv3 --pmc hang of round 5 (configs[2], FETCH_SIZE pass, query phase with 64-bit atomic sums) a profiler limit or a fault?
+# The SELECT pass in isolation, every form, plain / --kernel-trace / --pmc, every run behind its own timeout (a hang costs 150 s, not the box).
+cd "$(dirname "$0")/.."; ROOT=$PWD; export TMPDIR=/tmp; OUT=$ROOT/gpurun_out/r06_select; mkdir -p $OUT
+COLS=${COLS:-1024}; LOGH=${LOGH:-22}
+run() { # label, env select, profiler args...
+  local label=$1 sel=$2; shift 2
+  local t0=$(date +%s.%N)
+  ( cd /tmp && POWDR_QUERY_SELECT=$sel timeout -k 10 ${TMO:-150} "$@" python $ROOT/tools/repro_select_atomics.py --cols $COLS --log-h $LOGH ) > $OUT/$label.log 2>&1
+  local rc=$?
+  echo "$label: rc=$rc wall=$(echo "$(date +%s.%N) - $t0" | bc) s | $(grep '^select=' $OUT/$label.log | tail -1)"
+}
+for sel in 1 2 0; do
+  run plain_sel$sel $sel
+  run ktrace_sel$sel $sel rocprofv3 --kernel-trace --stats -d $OUT/ktrace_sel$sel --
+  run pmc_fetch_sel$sel $sel rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_sel$sel --
+  run pmc_write_sel$sel $sel rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_sel$sel --
+done
+rocm-smi --showuse 2>/dev/null | head -8
