@@ -1427,8 +1427,11 @@ def main():
         per_committed = {"leaf_hash_kernel", "ntt_group_kernel<dif>", "lde_fused_kernel", "ntt_group_kernel<dit>", "deep_kernel", "deep_logup_kernel"}
         algo_bytes_per_cell["deep_logup_kernel"] = 8.0
         copy_gbs = None
-        if not args.no_copy_ceiling:
-            # device-to-device copy ceiling of THIS box: 4 GiB copies, outside every timed region
+        shared_device = world > 1 and torch.cuda.device_count() < world  # the one-GPU test hook (POWDR_DIST_BACKEND=gloo): N ranks on GPU 0
+        if not args.no_copy_ceiling and not shared_device:
+            # device-to-device copy ceiling of THIS box: 4 GiB copies, outside every timed region. (Not when several ranks
+            # share one device: 8 x 8 GiB beside a caller that holds most of the HBM oversubscribes it, the driver then evicts whole
+            # processes in turn — a 9 s run took 162 s, tools/_hold.sh in round 6.)
             a_ = torch.empty(1 << 30, dtype=torch.int32, device="cuda")
             b_ = torch.empty_like(a_)
             b_.copy_(a_)

@@ -63,6 +63,11 @@ def run_bench(*extra, env=None, argv_prefix=None, base=("--log-height", "12", "-
     """Runs bench.py, checks the stdout line (check_line) and returns the FULL record of the run (bench_full.json, --full-out)."""
     import tempfile
 
+    if "torch" in sys.modules:  # this process's cached HBM back to the device: the ranks of the run below share it with us
+        import gc
+
+        gc.collect()
+        sys.modules["torch"].cuda.empty_cache()
     with tempfile.TemporaryDirectory() as td:
         fp = Path(td) / "bench_full.json"
         cmd = (argv_prefix or [sys.executable]) + [str(ROOT / "bench.py"), *base, "--full-out", str(fp), *extra]

@@ -18,8 +18,9 @@ sys.path.insert(0, str(ROOT))
 
 pytestmark = pytest.mark.gpu
 
-# profiles/r05_full_size_parity_c3_logup.json (queries 100, pow_bits 16): three modes, one digest
-R05_SHA256 = "2303258f0ce9b02aee51e008a0a71cadecedfcd47922bc90f2847761953ba2ef"
+# queries 100, pow_bits 16, sources seeded below. (profiles/r05_full_size_parity_c3_logup.json holds round 5's digest of the same AIR on
+# sources drawn from the process's unseeded generator: same length, not comparable.)
+PINNED_SHA256 = "e175ef35834f068e96f19af67057e8c98af8398c987e15c1b2ce0a6a292ce086"
 R05_WORDS = 1155836
 
 
@@ -41,6 +42,8 @@ def test_configs2_full_size_two_modes_one_proof_both_verifiers(monkeypatch):
 
     nq, pow_bits, log_h = 100, 16, 22
     monkeypatch.delenv("POWDR_STREAM_LOG_BLOCKS", raising=False)
+    torch.manual_seed(20260930)  # the gather sources are drawn from torch's global generator: pinned here, whatever ran before in this process
+    torch.cuda.manual_seed_all(20260930)
     wl = bench.build_workload("C3p", log_h, False, seed=0)
     W = wl["W"]
     wl["apc"].generate_witness_gpu(wl["instr_air"], wl["dummy"], wl["calls"], wl["out"].data_ptr(), wl["per"])
@@ -63,9 +66,11 @@ def test_configs2_full_size_two_modes_one_proof_both_verifiers(monkeypatch):
     b = pr.prove(wl["out"].data_ptr(), log_h).copy()
     pr.close()
     assert len(a) == len(b) == R05_WORDS and (a == b).all()
-    assert hashlib.sha256(a.tobytes()).hexdigest() == R05_SHA256
     assert prover.verify_logup(a, W, log_h, bc, spans, it, nq, pow_bits)[0] == 0
     assert sm.verify_logup(a, W, log_h, bc, spans, *it, num_queries=nq, pow_bits=pow_bits) == 0
+    digest = hashlib.sha256(a.tobytes()).hexdigest()
+    print("configs[2] full-size proof sha256", digest)
+    assert digest == PINNED_SHA256, digest
     # one flipped word is rejected by both
     bad = a.copy()
     bad[len(bad) // 2] ^= 1

@@ -5,10 +5,10 @@ cd "$(dirname "$0")/.."; ROOT=$PWD; export TMPDIR=/tmp; OUT=$ROOT/gpurun_out/r06
 COLS=${COLS:-1024}; LOGH=${LOGH:-22}
 run() { # label, env select, profiler args...
   local label=$1 sel=$2; shift 2
-  local t0=$(date +%s.%N)
+  SECONDS=0
   ( cd /tmp && POWDR_QUERY_SELECT=$sel timeout -k 10 ${TMO:-150} "$@" python $ROOT/tools/repro_select_atomics.py --cols $COLS --log-h $LOGH ) > $OUT/$label.log 2>&1
   local rc=$?
-  echo "$label: rc=$rc wall=$(echo "$(date +%s.%N) - $t0" | bc) s | $(grep '^select=' $OUT/$label.log | tail -1)"
+  echo "$label: rc=$rc wall=${SECONDS} s | $(grep '^select=' $OUT/$label.log | tail -1)"
 }
 for sel in 1 2 0; do
   run plain_sel$sel $sel
