@@ -879,17 +879,34 @@ def c3_leg(queries, pow_bits, steps=2, constraints_only_too=True, segment_too=Tr
                      (5, 16, *empty, per_.bitwise_interactions(p_.bitwise_bus))]
             provers = [prover.Prover(w, bc, sp, num_queries=queries, pow_bits=pow_bits, interactions=ia) for (w, lh, bc, sp, ia) in descs]
             seg = [(pr_, t.data_ptr(), d[1]) for pr_, t, d in zip(provers, traces, descs)]
-            prover.prove_segment(seg, logup=True, copy=False)  # warm-up: buffers, kernels
+            # pw_prove_segment_consuming (round 6): the APC chip moves its trace into the engine like the reference's (cuda/mod.rs:415-419) — the
+            # streamed AIR keeps its coefficient arrays in the trace's own buffer (two sub-cosets instead of four); restored outside the timed region
+            hand = [True, False, False, False]
+
+            def restore():
+                modes = prover.segment_last_modes()
+                if modes and modes[0][1]:
+                    prover.trace_from_coefficients(wl["out"].data_ptr(), W, log_h)
+                return modes
+
+            prover.prove_segment(seg, logup=True, copy=False, hand_over=hand)  # warm-up: buffers, kernels
+            torch.cuda.synchronize()
+            restore()
             torch.cuda.synchronize()
             t3 = time.perf_counter()
-            pf = prover.prove_segment(seg, logup=True, copy=True)
+            pf = prover.prove_segment(seg, logup=True, copy=True, hand_over=hand)
             t_seg = time.perf_counter() - t3
+            modes = restore()
+            plan = prover.segment_last_plan()
             seg_cells = sum(d[0] << d[1] for d in descs)
             rec["segment"] = dict(airs=len(descs), cells=seg_cells, prove_ms=t_seg * 1e3, cells_per_s_prove_only=seg_cells / t_seg,
                                   verify_rc=int(prover.verify_segment(descs, pf, queries, pow_bits, True)[0]), proof_bytes=int(len(pf) * 4),
-                                  apc_air_stream_log_blocks=provers[0].stream_log_blocks(log_h), prover_device_bytes=sum(x.device_bytes() for x in provers),
-                                  note="ONE pw-stark v1 proof for {the C3 APC AIR with all its interactions, var-range, tuple and bitwise periphery AIRs from "
-                                       "the histograms trace generation filled}; the APC AIR is streamed inside the segment proof (the only AIR of its height)")
+                                  apc_air_stream_log_blocks=int(modes[0][0]), trace_handed_over=bool(modes[0][1]),
+                                  plan_bytes=dict(all_resident=plan[0], as_planned=plan[1], available=plan[2]),
+                                  prover_device_bytes=sum(x.device_bytes() for x in provers),
+                                  note="ONE pw-stark v1 proof (pw_prove_segment_consuming) for {the C3 APC AIR with all its interactions, var-range, tuple and "
+                                       "bitwise periphery AIRs from the histograms trace generation filled}; the APC AIR is streamed inside the segment proof "
+                                       "with its trace handed over: its coefficient arrays stay in the caller's buffer")
             for x in provers:
                 x.close()
             del traces, seg

@@ -5,7 +5,8 @@ plain streamed proof (4 sub-cosets): the same words, the words of round 5's proo
 product's host verifier AND the oracle's verifier (a second implementation, canonical u64 arithmetic) accept them.
 The oracle's PROVER cannot make this proof for a byte comparison (~2 h, ~900 GB of host memory): its byte parity with the HIP prover
 is pinned at this shape with 2^12 rows (tests/test_streamed_prover.py) and at the full C2 size (profiles/r03_full_size_parity_c2_logup.json).
-Needs ~230 GB of free HBM: skipped with the reason on a smaller or shared device."""
+Needs ~230 GB of free HBM: skipped with the reason on a smaller or shared device. (The file's name puts it FIRST in the suite: later
+on, the pytest process itself holds tens of gigabytes in library caches and torch's allocator.)"""
 import hashlib
 import sys
 from pathlib import Path
@@ -29,6 +30,10 @@ def test_configs2_full_size_two_modes_one_proof_both_verifiers(monkeypatch):
 
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
     free = torch.cuda.mem_get_info()[0]
     if free < 230e9:
         pytest.skip(f"needs ~230 GB of free HBM for 3 731 x 2^22 with the bus argument; {free / 1e9:.0f} GB free")

@@ -10,10 +10,18 @@ run() { # label, env select, profiler args...
   local rc=$?
   echo "$label: rc=$rc wall=${SECONDS} s | $(grep '^select=' $OUT/$label.log | tail -1)"
 }
-for sel in 1 2 0; do
-  run plain_sel$sel $sel
-  run ktrace_sel$sel $sel rocprofv3 --kernel-trace --stats -d $OUT/ktrace_sel$sel --
-  run pmc_fetch_sel$sel $sel rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_sel$sel --
-  run pmc_write_sel$sel $sel rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_sel$sel --
-done
+if [ "${STAGE:-small}" = small ]; then
+run plain_sel1 1
+run plain_sel2 2
+run plain_sel0 0
+run ktrace_sel2 2 rocprofv3 --kernel-trace --stats -d $OUT/ktrace_sel2 --
+run pmc_fetch_sel2 2 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_sel2 --
+run pmc_fetch_sel1 1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_sel1 --
+run pmc_write_sel1 1 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_sel1 --
+else  # STAGE=wide COLS=4632: the width of configs[2]'s permutation matrix, where round 5's FETCH_SIZE pass did not return
+run wide_plain_sel2 2
+run wide_plain_sel1 1
+run wide_pmc_fetch_sel1 1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/wide_pmc_fetch_sel1 --
+run wide_pmc_fetch_sel2 2 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/wide_pmc_fetch_sel2 --
+fi
 rocm-smi --showuse 2>/dev/null | head -8
