@@ -206,6 +206,9 @@ def test_c2_shape_proof_bytes_match_oracle(gpu, monkeypatch, logup):
     pr.close()
 
 
+_C1_TRACE = {}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("logup", [False, True])
 def test_c1_full_size_proof_bytes_match_oracle(gpu, logup):
@@ -215,9 +218,11 @@ def test_c1_full_size_proof_bytes_match_oracle(gpu, logup):
     torch, abi, prover = gpu
     from tests.test_oracle_apc import run_oracle_gpu_convention
 
-    s = synth.generate("C1", seed=1)
-    calls = (1 << 16) - 3
-    apc, idx, trace, _, _ = run_oracle_gpu_convention(s, calls, seed=1)
+    if "c1" not in _C1_TRACE:  # the oracle's single-threaded row loop over 2^16 rows: once for both proof kinds
+        s = synth.generate("C1", seed=1)
+        calls = (1 << 16) - 3
+        _C1_TRACE["c1"] = run_oracle_gpu_convention(s, calls, seed=1)[:3]
+    apc, idx, trace = _C1_TRACE["c1"]
     W, H = trace.shape
     assert (W, H) == (1204, 1 << 16)
     bc, spans = sm.compile_constraints(apc, idx)

@@ -245,3 +245,21 @@ def test_prove_segments_multi_on_one_gpu(n_workers):
     for ps in per_worker + [seq]:
         for p in ps:
             p.close()
+
+
+def test_placement_of_segments_with_their_own_shapes():
+    """The cell counts of the bench's eight C4 segments with their OWN trace heights (profiles/r06_c4_budget_sweep.txt: the capped
+    segment, six with one chip at its cap, the short tail) placed on 1 / 2 / 4 / 8 ranks: unequal segment counts, loads within the
+    largest segment of each other; on 8 ranks the step is the capped segment (what strong scaling over unequal segments costs)."""
+    cells = [3267841024, 2474124800, 2476166144, 2145864704, 2578982400, 2605196800, 2542282240, 299164864]
+    for world in (1, 2, 4, 8):
+        parts = sharding.assign_units(cells, world)
+        loads = [sum(cells[u] for u in p) for p in parts]
+        assert sorted(u for p in parts for u in p) == list(range(8))
+        assert max(loads) - min(loads) <= max(cells)
+        if world == 2:
+            assert max(loads) / (sum(cells) / 2) < 1.07  # (the best split of these eight is 1.05)
+        if world == 4:
+            assert sorted(len(p) for p in parts) == [2, 2, 2, 2] and max(loads) / (sum(cells) / 4) < 1.10
+        if world == 8:
+            assert max(loads) == cells[0]  # 8 ranks: 18.39 G cells in the time of 3.27 G -> at most 5.6x of one rank's rate

@@ -58,6 +58,21 @@ def test_subcoset_lde_is_the_rows_of_the_lde(gpu, log_h, W, log_blocks):
         assert (got == want[:, r::B]).all(), f"sub-coset {r} of {B}"
 
 
+_MEMO = {}
+
+
+def _baseline_case(shape, log_h):
+    """(_synthetic(shape, 2^log_h - 5, seed 0), sm.prove_logup of it with 6 queries / 4 grinding bits): the oracle's side of the BASELINE-shape
+    tests, computed once per (shape, height) — the streamed and the consuming tests prove the same trace."""
+    key = (shape, log_h)
+    if key not in _MEMO:
+        case = _synthetic(shape, (1 << log_h) - 5, seed=0)
+        flat, W, lh, bc, spans, it = case
+        assert lh == log_h
+        _MEMO[key] = (case, sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=6, pow_bits=4))
+    return _MEMO[key]
+
+
 def _synthetic(shape, calls, seed):
     from tests.test_oracle_apc import run_oracle_gpu_convention
 
@@ -114,9 +129,7 @@ def test_baseline_shapes_streamed_with_logup(gpu, monkeypatch, shape, log_h, log
     """the C3 shape (3 731 columns, 3 114 constraints, 2 314 interactions) at 2^12 rows and the C2 shape at 2^14
     through the streamed path with the LogUp phase: words == sm.prove_logup, both verifiers accept."""
     torch, abi, prover = gpu
-    flat, W, lh, bc, spans, it = _synthetic(shape, (1 << log_h) - 5, seed=0)
-    assert lh == log_h
-    want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=6, pow_bits=4)
+    (flat, W, lh, bc, spans, it), want = _baseline_case(shape, log_h)
     d_t = to_dev(torch, flat)
     got, state = _prove(prover, monkeypatch, d_t, W, log_h, bc, spans, it, 6, 4, log_blocks, jit)
     assert (state == 1) if jit else (state in (0, -1))
@@ -314,8 +327,7 @@ def test_baseline_shapes_consuming_with_logup(gpu, monkeypatch, shape, log_h, lo
     """configs[2]'s mode of round 5 — the C3 shape with its 2 314 interactions, trace handed over, TWO sub-cosets, specialised
     kernels with permutation panels — at 2^12 rows against sm.prove_logup; both verifiers accept."""
     torch, abi, prover = gpu
-    flat, W, lh, bc, spans, it = _synthetic(shape, (1 << log_h) - 5, seed=0)
-    want = sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=6, pow_bits=4)
+    (flat, W, lh, bc, spans, it), want = _baseline_case(shape, log_h)
     got, left, restored, state = _prove_consuming(torch, prover, monkeypatch, flat, W, log_h, bc, spans, it, 6, 4, log_blocks, jit)
     assert (state == 1) if jit else (state in (0, -1))
     assert len(got) == len(want) and (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
