@@ -106,6 +106,15 @@ def parse_args():
     return args
 
 
+_T0 = time.perf_counter()
+
+
+def phase(name):
+    """POWDR_BENCH_TRACE=1: wall-clock marks on stderr (where a run's seconds outside the timed regions go)."""
+    if os.environ.get("POWDR_BENCH_TRACE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - _T0:7.2f}s] {name}", file=sys.stderr, flush=True)
+
+
 LINE_LIMIT = 6000  # bytes; BENCH_r04.json.parsed was null on a 23 KB line (VERDICT r4 #1)
 FULL_OUT = None    # --full-out / POWDR_BENCH_FULL; default <repo>/bench_full.json
 
@@ -1007,8 +1016,11 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != max(1, args.gpus) and not args.inproc:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {os.environ.get('WORLD_SIZE', '1')} rank(s)", file=sys.stderr)
         sys.exit(2)
+    phase("main: arguments parsed")
     rank, local, world = setup_distributed(args.gpus)
+    phase("process group up")
     from powdr_amd import abi, prover, synth
+    phase("library loaded")
 
     def barrier():
         if world > 1:
@@ -1073,6 +1085,7 @@ def main():
         torch.cuda.empty_cache()
         args.exact_source_heights = True
         wl = build_workload(args.shape, log_h, True, seed=rank, calls_fraction=args.calls_fraction)
+    phase("workload built")
     all_inter = wl["apc"].compile_bus(1)  # (interactions, spans, bytecode) with column operands
     lg_perm_cols = 4 * len(prover.logup_group_starts(all_inter))  # 4 * (groups + 1)
     inter = all_inter if args.logup else None
@@ -1133,7 +1146,9 @@ def main():
         [t.start() for t in th]
         [t.join() for t in th]
 
+    phase("headline: warm-up + timed steps start")
     elapsed, timing = timed_leg(run_steps, args.steps, max(args.warmup, len(workers) if args.warmup else 0), barrier, abi, world)
+    phase("headline: done")
     per_rank_ms = [t / args.steps * 1e3 for t in LAST_PER_RANK_S]
     cells_per_step = wl["W"] * wl["H"]
     total_cells = cells_per_step * args.steps * world
@@ -1285,6 +1300,7 @@ def main():
     # ---- trace generation FROM RECORDS (producer half): the original chips expand their records inside the
     # gather (powdr_apc_tracegen_records) — no dummy traces. Checked at full size against the reference flow on the same records:
     # powdr_original_airs_expand into the (now overwritten) source buffers, then the timed step's own gather. Not part of `value`.
+    phase("second leg + call-major done")
     records_leg = None
     if not args.no_callmajor_leg and args.pipeline == 1 and args.shape == "C2":
         try:
@@ -1407,6 +1423,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             seg_log = min(args.segment_log_height, log_h)
+            phase("records leg done; multi_segment starts")
             segment_leg = segment_bench("C4", args.segments, seg_log, args.segment_steps, 1, args.logup, args.queries, args.pow_bits, rank, world,
                                         abi, barrier)
         except Exception as e:  # must never take the headline down
@@ -1428,6 +1445,7 @@ def main():
             c3 = dict(value=None, error=f"{type(e).__name__}: {e}")
             torch.cuda.empty_cache()
 
+    phase("multi_segment done")
     jit_cache = jit_cache_by_rank(world)
     if rank == 0:
         per_kernel = {k: (c, ms) for k, (c, ms) in timing.items()}

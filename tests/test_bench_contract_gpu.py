@@ -228,8 +228,10 @@ def test_eight_ranks_on_one_gpu_with_a_cold_kernel_cache(tmp_path):
     import os
 
     env = dict(os.environ, POWDR_DIST_BACKEND="gloo", POWDR_JIT="1", POWDR_JIT_CACHE_DIR=str(tmp_path / "jit"))
-    d = run_bench("--gpus", "8", "--no-cpu-baseline", "--no-c3-leg", "--no-logup-leg", "--no-callmajor-leg", "--segment-log-height", "10", env=env,
-                  base=("--log-height", "12", "--steps", "2", "--warmup", "1"), timeout=1500)
+    # (headline shape T1: on a box whose hiprtc / comgr caches are cold too, the C2 headline's 350 translation units alone take ~115 s
+    # of the ranks' first step — profiles/r06_eight_ranks_phases.txt; the segment leg's 291 units keep the cold-cache claim honest)
+    d = run_bench("--gpus", "8", "--shape", "T1", "--no-cpu-baseline", "--no-c3-leg", "--no-logup-leg", "--no-callmajor-leg", "--segment-log-height", "10",
+                  env=env, base=("--log-height", "12", "--steps", "2", "--warmup", "1"), timeout=1500)
     c = d["_compact"]
     assert c["n_gpus"] == 8 and c["rccl_ranks"] == 8 and len(c["per_rank_ms"]) == 8 and c["comm"]["backend"] == "gloo"
     assert d["comm"]["launch"] == "self" and d["scaling"] == "weak"
