@@ -108,13 +108,24 @@ def compile_constraints(apc: om.Apc, idx: dict):
     return np.array(bc, np.uint32), np.array(spans, np.uint32).reshape(-1, 2)
 
 
+def _proof_cap(num_queries, shapes) -> int:
+    """An upper bound of a proof's words for `shapes` = [(width, permutation columns, log_h)]: the output buffer is sized ONCE — a buffer
+    that turns out too small makes or_prove* return the size it needs and the wrapper prove again, which doubled the CPU time of every
+    proof above 2^18 words (the bench's `cpu_baseline` with 100 queries, round 6) without changing a word of it."""
+    log_n = max(lh for _, _, lh in shapes) + 1
+    opened = sum(w + 2 * wp + 8 for w, wp, _ in shapes)
+    rows = sum(w + wp + 8 for w, wp, _ in shapes)
+    per_query = 1 + rows + 3 * 8 * log_n + log_n * (4 + 8 * log_n)
+    return 4096 + 16 * len(shapes) + 4 * opened + 12 * log_n + num_queries * per_query
+
+
 def prove(trace_cm, width, log_h, cons_bc, cons_spans, num_queries=8, pow_bits=0) -> np.ndarray:
     lib = _lib()
     t = np.ascontiguousarray(trace_cm, dtype=np.uint32)
     bc = np.ascontiguousarray(cons_bc, dtype=np.uint32)
     sp = np.ascontiguousarray(cons_spans, dtype=np.uint32)
     args = (C.c_uint32(num_queries), C.c_uint32(pow_bits), _p(t), C.c_uint32(width), C.c_uint32(log_h), _p(bc), _p(sp), C.c_size_t(len(sp)))
-    cap = 1 << 16
+    cap = max(1 << 16, _proof_cap(num_queries, [(width, 0, log_h)]))
     while True:
         buf = np.zeros(cap, np.uint32)
         n = lib.or_prove(*args, _p(buf), C.c_size_t(cap))
@@ -163,7 +174,7 @@ def prove_logup(trace_cm, width, log_h, cons_bc, cons_spans, inter, ispans, ibc,
     t, bc, sp, it, isp, ib = arrs
     args = (C.c_uint32(num_queries), C.c_uint32(pow_bits), _p(t), C.c_uint32(width), C.c_uint32(log_h), _p(bc), _p(sp),
             C.c_size_t(len(sp.reshape(-1, 2))), _p(it), C.c_size_t(len(it.reshape(-1, 3))), _p(isp), _p(ib), seed_p)
-    cap = 1 << 18
+    cap = max(1 << 18, _proof_cap(num_queries, [(width, 4 * (len(it.reshape(-1, 3)) + 1), log_h)]))
     while True:
         buf = np.zeros(cap, np.uint32)
         n = lib.or_prove_logup(*args, _p(buf), C.c_size_t(cap))
@@ -226,7 +237,8 @@ def prove_segment(airs, num_queries=8, pow_bits=0, logup=False) -> np.ndarray:
     lib = _lib()
     lib.or_prove_segment.restype = C.c_size_t
     recs, keep = _seg_airs(airs)
-    cap = 1 << 18
+    cap = max(1 << 18, _proof_cap(num_queries, [(w, 4 * ((0 if it is None else len(np.asarray(it[0]).reshape(-1, 3))) + 1) if logup else 0, lh)
+                                                  for (_, w, lh, _, _, it) in airs]))
     while True:
         buf = np.zeros(cap, np.uint32)
         n = lib.or_prove_segment(C.c_uint32(num_queries), C.c_uint32(pow_bits), C.c_int(int(logup)), recs, C.c_size_t(len(airs)), _p(buf), C.c_size_t(cap))

@@ -210,7 +210,7 @@ _C1_TRACE = {}
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("logup", [False, True])
+@pytest.mark.parametrize("logup", [pytest.param(False, marks=pytest.mark.slow), True])
 def test_c1_full_size_proof_bytes_match_oracle(gpu, logup):
     """BASELINE configs[0] (sha256-shaped single segment, 2^16 rows, 1 204 columns, 377 constraints, 954 interactions)
     at its FULL size: oracle trace generation -> oracle proof == HIP proof (tools/run_c1_oracle.py records the

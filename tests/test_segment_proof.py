@@ -173,6 +173,17 @@ def test_hip_segment_proof_bytes_match_oracle(gpu, spec, nq, pow_bits, logup):
     assert sm.verify_segment(got, airs, nq, pow_bits, logup)[0] == 0
 
 
+_WANT = {}
+
+
+def _oracle_segment(spec, nq, pow_bits, logup, seed0=11):
+    key = (tuple(spec), nq, pow_bits, logup, seed0)
+    if key not in _WANT:
+        airs = synthetic_airs(spec, seed0=seed0)
+        _WANT[key] = (airs, sm.prove_segment(airs, num_queries=nq, pow_bits=pow_bits, logup=logup))
+    return _WANT[key]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("spec,nq,pow_bits", [
     ([("T1", 1000), ("T0", 40), ("T1", 100)], 6, 3),                                # three heights, each AIR alone at its own: all streamed
@@ -188,8 +199,7 @@ def test_hip_segment_proof_with_streamed_airs(gpu, monkeypatch, spec, nq, pow_bi
     torch, abi, prover = gpu
     if len(spec) == 2 and (log_blocks == 1 or (not logup and log_blocks != 2)):
         pytest.skip("the tall case runs once per kernel kind")
-    airs = synthetic_airs(spec, seed0=11)
-    want = sm.prove_segment(airs, num_queries=nq, pow_bits=pow_bits, logup=logup)
+    airs, want = _oracle_segment(spec, nq, pow_bits, logup)  # (once per spec and proof kind: the sub-coset counts prove the same segment)
     monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", str(log_blocks))
     monkeypatch.setenv("POWDR_JIT", jit)
     got = hip_segment(gpu, airs, nq, pow_bits, logup)
@@ -234,17 +244,6 @@ def test_streamed_airs_that_share_a_height(gpu, monkeypatch, logup, log_blocks, 
 
 
 # ---- traces handed over per AIR (pw_prove_segment_consuming) ----------------------------------------------------------
-_WANT = {}
-
-
-def _oracle_segment(spec, nq, pow_bits, logup, seed0=11):
-    key = (tuple(spec), nq, pow_bits, logup, seed0)
-    if key not in _WANT:
-        airs = synthetic_airs(spec, seed0=seed0)
-        _WANT[key] = (airs, sm.prove_segment(airs, num_queries=nq, pow_bits=pow_bits, logup=logup))
-    return _WANT[key]
-
-
 def hip_segment_consuming(gpu, airs, nq, pow_bits, logup, mask):
     """pw_prove_segment_consuming with the AIRs of `mask` handed over -> (words, modes). Checks what the call promises about the
     buffers: a handed-over trace that was streamed holds its coefficient arrays afterwards and pw_trace_from_coefficients restores
