@@ -73,10 +73,11 @@ def parse_args():
                     help="own: every segment has its OWN trace heights (HonestSegment.draw_shape: segment 0 at the caps, the last one a short tail, "
                          "the others one chip at its cap and the rest log-uniform over two octaves), like the reference's metered segments "
                          "(trace_generation.rs:113-131); equal: round 5's segments (same heights, other rows)")
-    ap.add_argument("--segment-budget-frac", type=float, default=0.8,
+    ap.add_argument("--segment-budget-frac", type=float, default=0.95,
                     help="the segment legs run under pw_set_device_budget(frac x the resident memory plan of the capped segment): the segment "
                          "whose AIRs are all at their caps crosses the streaming threshold (its largest AIRs are proven from coefficient arrays, "
-                         "traces handed over), the others stay resident; 0 = no budget")
+                         "traces handed over), the others stay resident; 0 = no budget. profiles/r06_c4_budget_sweep.txt: 6.76 G cells/s without a "
+                         "budget, 6.63 at 0.95 (one AIR of the capped segment on two sub-cosets), 6.36 at 0.8 (four AIRs of it, one of two more segments)")
     ap.add_argument("--no-c3-leg", action="store_true", help="skip the C3-scale leg of the default run (3 731 cols x 2^22 rows, reported as `c3`)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="host threads / HIP streams proving independent segments concurrently on each GPU "
@@ -569,7 +570,7 @@ def _segment_checks(seg, segments, rec, distinct=True, shapes=None):
             os.environ["POWDR_JIT"] = prev
 
 
-SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC = "own", 0.8  # (--segment-shapes / --segment-budget-frac; set in main)
+SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC = "own", 0.95  # (--segment-shapes / --segment-budget-frac; set in main)
 
 
 def _segment_plan(seg, n_segments):

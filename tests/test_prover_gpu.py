@@ -175,7 +175,7 @@ def _prove_both_and_compare(torch, prover, flat, W, log_h, bc, spans, it, nq, po
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("logup", [False, True])
+@pytest.mark.parametrize("logup", [pytest.param(False, marks=pytest.mark.slow), True])
 def test_c2_shape_proof_bytes_match_oracle(gpu, monkeypatch, logup):
     """BASELINE configs[1]'s AIR itself — 2 022 columns, 187 constraints, 1 734 bus interactions (867 LogUp groups,
     3 472 permutation columns) — at 2^14 rows, the largest height the CPU oracle proves in seconds: the trace comes
