@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--no-segment-leg", action="store_true",
                     help="skip the multi_segment leg of the default run (C4: 10 APC AIRs + 19 system AIRs per segment, strong scaling)")
     ap.add_argument("--segment-steps", type=int, default=2, help="timed steps of the multi_segment leg (after one warm-up)")
+    ap.add_argument("--segment-jit-by-height", action="store_true",
+                    help="segment legs: leave the run-time specialisation to the library's per-proof rule (traces of >= 2^18 rows, POWDR_JIT*) instead "
+                         "of compiling every AIR's kernels once at set-up (pw_provers_specialise)")
     ap.add_argument("--segment-shapes", choices=("own", "equal"), default="own",
                     help="own: every segment has its OWN trace heights (HonestSegment.draw_shape: segment 0 at the caps, the last one a short tail, "
                          "the others one chip at its cap and the rest log-uniform over two octaves), like the reference's metered segments "
@@ -185,7 +188,10 @@ def compact_line(full: dict) -> dict:
             out[key] = _pick(full[key], "value", "ms_per_step", "error")
     c3 = full.get("c3")
     if c3:
-        out["c3"] = _pick(c3, "value", "prove_ms", "trace_gen_ms", "verify_rc", "logup", "cells", "committed_columns", "stream_log_blocks", "trace_handed_over", "skipped", "error")
+        out["c3"] = _pick(c3, "value", "prove_ms", "trace_gen_ms", "verify_rc", "logup", "cells", "committed_columns", "stream_log_blocks", "trace_handed_over",
+                          "specialise_s", "skipped", "error")
+        if isinstance(c3.get("segment"), dict):
+            out["c3"]["segment"] = _pick(c3["segment"], "prove_ms", "verify_rc", "apc_air_stream_log_blocks", "trace_handed_over", "error")
     ms = full.get("multi_segment")
     if ms:
         m = _pick(ms, "value", "ms_per_step", "verify_rc", "n_segments", "distinct_segments", "constraint_violations", "segment_shapes", "cells_by_segment",
@@ -570,6 +576,7 @@ def _segment_checks(seg, segments, rec, distinct=True, shapes=None):
             os.environ["POWDR_JIT"] = prev
 
 
+SPECIALISE_ALL = True  # the segment legs compile every AIR's specialised kernels at set-up (--segment-jit-by-height: only tall traces')
 SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC = "own", 0.95  # (--segment-shapes / --segment-budget-frac; set in main)
 
 
@@ -614,7 +621,8 @@ def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup,
     workers = []
     for w in range(n_workers):
         with torch.cuda.device(devices[w]):
-            workers.append(sw.HonestSegment(kind, max_log_height=max_log_height, seed=0, queries=queries, pow_bits=pow_bits, logup=logup))
+            workers.append(sw.HonestSegment(kind, max_log_height=max_log_height, seed=0, queries=queries, pow_bits=pow_bits, logup=logup,
+                                            specialise_all=SPECIALISE_ALL and max_log_height >= 16))
     for d in set(devices):
         torch.cuda.synchronize(d)
     seg0 = workers[0]
@@ -685,7 +693,10 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
 
     from powdr_amd import prover
 
-    seg = sw.HonestSegment(kind, max_log_height=max_log_height, seed=0, queries=queries, pow_bits=pow_bits, logup=logup)
+    t_spec = time.perf_counter()
+    seg = sw.HonestSegment(kind, max_log_height=max_log_height, seed=0, queries=queries, pow_bits=pow_bits, logup=logup,
+                           specialise_all=SPECIALISE_ALL and max_log_height >= 16)  # (capped test heights: the library's per-proof rule)
+    t_spec = time.perf_counter() - t_spec
     shapes, cells, heights = _segment_plan(seg, n_segments)
     hdr = 5 + 4 * len(seg.airs)  # proof words before the main commitment
     last = dict(gen_s=0.0, prove_s=0.0, stage_s=0.0, units=0)
@@ -736,6 +747,7 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
                placement=[[int(u) for u in p_] for p_ in placement], cells_per_rank=[int(sum(cells[u] for u in p_)) for p_ in placement],
                streamed_airs_by_segment={str(u): v for u, v in sorted(streamed.items())}, ms_by_segment_rank0={str(u): v for u, v in sorted(unit_ms.items())},
                traces_handed_over=True, **budget, **_shape_record(seg, shapes, cells, heights),
+               airs_specialised_at_setup=seg.specialised, setup_s_including_specialisation=t_spec,
                trace_gen_ms_per_segment=last["gen_s"] / units * 1e3, prove_ms_per_segment=last["prove_s"] / units * 1e3,
                input_staging_ms_per_segment=last["stage_s"] / units * 1e3, distinct_segments=True,
                distinct_commitments_in_merge=len({tuple(int(x) for x in r) for r in last["merged"]}),
@@ -1007,9 +1019,10 @@ def load_profile_json(name):
 
 
 def main():
-    global SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC
+    global SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC, SPECIALISE_ALL
     args = parse_args()
     SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC = args.segment_shapes, args.segment_budget_frac
+    SPECIALISE_ALL = not args.segment_jit_by_height and os.environ.get("POWDR_JIT", "") != "0"
     self_launch(args)  # --gpus N > 1 without a launcher: re-run as N ranks (does not return)
     if args.launch_check:
         launch_check()

@@ -220,6 +220,17 @@ extern "C" int pw_prover_specialise(PwProver* p) {
     return p->jit.state == 1 ? 0 : 1;
 }
 
+// Every prover of `ps` that has no specialised kernels yet, compiled in ONE concurrent batch (all translation units of all AIRs next to
+// each other on the compiler's helper processes) whatever the trace heights: what an embedder does once per AIR set — the reference fixes
+// an APC's AIR at key generation and proves it in every segment. Returns how many of the n provers run specialised kernels afterwards.
+extern "C" size_t pw_provers_specialise(PwProver* const* ps, size_t n) {
+    if (!ps || !n) return 0;
+    (void)pw::specialise_provers(ps, n, nullptr, true);
+    size_t ok = 0;
+    for (size_t i = 0; i < n; ++i) ok += ps[i] && ps[i]->jit.state == 1;
+    return ok;
+}
+
 extern "C" int pw_prover_specialised(const PwProver* p, size_t* n_kernels, size_t* code_bytes, size_t* n_chunks) {
     if (!p) return -1;
     size_t k = 0, b = 0, c = 0;

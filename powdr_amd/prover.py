@@ -18,7 +18,7 @@ PROVER_SYMBOLS = ["pw_prover_check_constraints", "pw_verify", "pw_prover_create"
                   "pw_lde_batch", "pw_lde_fused", "pw_lde_subcoset", "pw_merkle_commit", "pw_poseidon2_permute_host",
                   "pw_set_poseidon2_constants", "pw_get_poseidon2_constants", "pw_prover_specialise", "pw_prover_specialised", "pw_jit_compile_check", "pw_jit_cache_stats", "pw_jit_generated_source",
                   "pw_prove_segments_multi", "pw_multi_last_merge", "pw_assign_units",
-                  "pw_prove_segment_consuming", "pw_segment_last_modes", "pw_segment_last_plan", "pw_set_device_budget", "pw_get_device_budget"]
+                  "pw_prove_segment_consuming", "pw_segment_last_modes", "pw_segment_last_plan", "pw_set_device_budget", "pw_get_device_budget", "pw_provers_specialise"]
 
 lib.pw_prover_create.restype = C.c_void_p
 lib.pw_prover_create.argtypes = [C.POINTER(PwStarkConfig), C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -231,6 +231,16 @@ def segment_last_plan():
     a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
     lib.pw_segment_last_plan(C.byref(a), C.byref(b), C.byref(c))
     return a.value, b.value, c.value
+
+
+def specialise_all(provers) -> int:
+    """pw_provers_specialise: the run-time specialised kernels of all `provers` (Prover objects) in one concurrent compile batch,
+    whatever their traces' heights. Returns how many run specialised kernels afterwards."""
+    n = len(provers)
+    arr = (C.c_void_p * max(n, 1))(*[p._h for p in provers])
+    lib.pw_provers_specialise.restype = C.c_size_t
+    lib.pw_provers_specialise.argtypes = [C.c_void_p, C.c_size_t]
+    return int(lib.pw_provers_specialise(arr, n))
 
 
 def set_device_budget(n_bytes: int) -> None:

@@ -242,7 +242,7 @@ class HonestSegment:
     kind "C5": reth-shaped — the APC AIRs of synth.segment_shape("C5") (log-uniform heights and widths) + the same system AIRs."""
 
     def __init__(self, kind: str, max_log_height: int = 20, seed: int = 0, queries: int = 100, pow_bits: int = 16, logup: bool = True,
-                 max_apc_airs: int | None = None):
+                 max_apc_airs: int | None = None, specialise_all: bool = False):
         self.kind, self.logup, self.queries, self.pow_bits = kind, logup, queries, pow_bits
         shrink = 20 - max_log_height
         self.per = tg.Periphery.fresh()
@@ -287,6 +287,10 @@ class HonestSegment:
         for a in self.airs:
             a["prover"] = prover.Prover(a["width"], a["cons"][0], a["cons"][1], num_queries=queries, pow_bits=pow_bits,
                                         interactions=a["inter"] if logup else None)
+        # the AIR set of an execution is fixed at key generation and proven in every segment: its specialised kernels are compiled once,
+        # for EVERY AIR (pw_provers_specialise), not only for those whose first trace happens to be tall (the library's own rule when it
+        # meets a prover for the first time inside a proof)
+        self.specialised = prover.specialise_all([a["prover"] for a in self.airs]) if specialise_all else None
         self.source_bytes = sum(wl["src_bytes"] for wl in self.apcs) + self.records.numel() * 4
         self._bounds, self._stager, self.data_seed = None, None, None
         # ---- the shape the buffers were sized for (every AIR at its cap); a segment's OWN heights: set_shape()

@@ -311,6 +311,8 @@ extern "C" {
     pub fn pw_prove_segment_consuming(airs: *const PwSegmentAir, n_airs: usize, logup: c_int, proof_words: *mut *const u32,
                                       n_words: *mut usize) -> c_int;
     /// per AIR of the calling thread's last segment proof: log2(#sub-cosets) | 0x100 if the trace was overwritten
+    /// the specialised kernels of n provers in one concurrent compile batch, whatever the heights; returns how many are specialised
+    pub fn pw_provers_specialise(provers: *const *mut PwProver, n: usize) -> usize;
     pub fn pw_segment_last_modes(out: *mut u32, cap: usize) -> usize;
     /// bytes of the last segment proof's memory plan: all AIRs resident | as chosen | available to the policy
     pub fn pw_segment_last_plan(resident_bytes: *mut usize, planned_bytes: *mut usize, available_bytes: *mut usize);

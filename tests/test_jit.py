@@ -269,6 +269,21 @@ def test_default_policy_specialises_tall_traces_only(gpu, monkeypatch):
     pr2 = prover.Prover(W, bc, spans, num_queries=3)
     assert pr2.specialise() and pr2.specialised()["state"] == 1
     pr2.close()
+    # pw_provers_specialise: a set of AIRs compiled in one batch at set-up, whatever their heights (round 6: the segment legs do this; a
+    # short trace under the interpreter pays the AIR's whole program per lane) — the short proofs then run specialised kernels, same words
+    W1, (bc1, sp1), it1 = _tables("T1")
+    ps = [prover.Prover(W, bc, spans, num_queries=3, interactions=it), prover.Prover(W1, bc1, sp1, num_queries=3, interactions=it1),
+          prover.Prover(W, bc, spans, num_queries=3)]
+    assert all(p_.specialised()["state"] == 0 for p_ in ps)
+    assert prover.specialise_all(ps) == 3 and all(p_.specialised()["state"] == 1 for p_ in ps)
+    abi.call_stats(reset=True)
+    got = ps[0].prove(small.data_ptr(), 10)
+    assert abi.call_stats()["jit_launches"] > 0 and abi.call_stats()["interpreter_launches"] == 0
+    flat = om.from_monty(small.cpu().numpy().view(np.uint32))
+    assert (got == sm.prove_logup(flat, W, 10, bc, spans, *it, num_queries=3, pow_bits=0)).all()
+    assert prover.specialise_all(ps) == 3  # (nothing left to do)
+    for p_ in ps:
+        p_.close()
 
 
 # ---- the generated code executed on the HOST ----------------------------------------------------------------------------------
