@@ -69,9 +69,10 @@ def parse_args():
     ap.add_argument("--no-segment-leg", action="store_true",
                     help="skip the multi_segment leg of the default run (C4: 10 APC AIRs + 19 system AIRs per segment, strong scaling)")
     ap.add_argument("--segment-steps", type=int, default=2, help="timed steps of the multi_segment leg (after one warm-up)")
-    ap.add_argument("--segment-jit-by-height", action="store_true",
-                    help="segment legs: leave the run-time specialisation to the library's per-proof rule (traces of >= 2^18 rows, POWDR_JIT*) instead "
-                         "of compiling every AIR's kernels once at set-up (pw_provers_specialise)")
+    ap.add_argument("--segment-jit-all", action="store_true",
+                    help="segment legs: compile EVERY AIR's specialised kernels once at set-up (pw_provers_specialise) instead of leaving it to the "
+                         "library's per-proof rule (traces of >= 2^18 rows). Measured in round 6: C5 5.17 -> 5.41 G cells/s (the tail segment 170 -> "
+                         "139 ms) for 145 s of cold compilation of its 61 AIRs; C4 6.67 -> 6.71 for 23 s: off by default")
     ap.add_argument("--segment-shapes", choices=("own", "equal"), default="own",
                     help="own: every segment has its OWN trace heights (HonestSegment.draw_shape: segment 0 at the caps, the last one a short tail, "
                          "the others one chip at its cap and the rest log-uniform over two octaves), like the reference's metered segments "
@@ -576,7 +577,7 @@ def _segment_checks(seg, segments, rec, distinct=True, shapes=None):
             os.environ["POWDR_JIT"] = prev
 
 
-SPECIALISE_ALL = True  # the segment legs compile every AIR's specialised kernels at set-up (--segment-jit-by-height: only tall traces')
+SPECIALISE_ALL = False  # --segment-jit-all: the segment legs compile every AIR's specialised kernels at set-up
 SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC = "own", 0.95  # (--segment-shapes / --segment-budget-frac; set in main)
 
 
@@ -622,7 +623,7 @@ def segment_bench_inproc(kind, n_segments, max_log_height, steps, warmup, logup,
     for w in range(n_workers):
         with torch.cuda.device(devices[w]):
             workers.append(sw.HonestSegment(kind, max_log_height=max_log_height, seed=0, queries=queries, pow_bits=pow_bits, logup=logup,
-                                            specialise_all=SPECIALISE_ALL and max_log_height >= 16))
+                                            specialise_all=SPECIALISE_ALL))
     for d in set(devices):
         torch.cuda.synchronize(d)
     seg0 = workers[0]
@@ -695,7 +696,7 @@ def segment_bench(kind, n_segments, max_log_height, steps, warmup, logup, querie
 
     t_spec = time.perf_counter()
     seg = sw.HonestSegment(kind, max_log_height=max_log_height, seed=0, queries=queries, pow_bits=pow_bits, logup=logup,
-                           specialise_all=SPECIALISE_ALL and max_log_height >= 16)  # (capped test heights: the library's per-proof rule)
+                           specialise_all=SPECIALISE_ALL)
     t_spec = time.perf_counter() - t_spec
     shapes, cells, heights = _segment_plan(seg, n_segments)
     hdr = 5 + 4 * len(seg.airs)  # proof words before the main commitment
@@ -1022,7 +1023,7 @@ def main():
     global SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC, SPECIALISE_ALL
     args = parse_args()
     SEGMENT_SHAPES, SEGMENT_BUDGET_FRAC = args.segment_shapes, args.segment_budget_frac
-    SPECIALISE_ALL = not args.segment_jit_by_height and os.environ.get("POWDR_JIT", "") != "0"
+    SPECIALISE_ALL = bool(args.segment_jit_all)
     self_launch(args)  # --gpus N > 1 without a launcher: re-run as N ranks (does not return)
     if args.launch_check:
         launch_check()
