@@ -184,23 +184,37 @@ def test_c2_shape_proof_bytes_match_oracle(gpu, monkeypatch, logup):
     /root/reference/openvm-riscv/src/lib.rs:1377-1458."""
     torch, abi, prover = gpu
     from tests.test_oracle_apc import run_oracle_gpu_convention
+    from tests._oracle_cases import baseline_case as _baseline_case
 
-    s = synth.generate("C2", seed=0)
-    calls = (1 << 14) - 5  # a few zero-padding rows
-    apc, idx, trace, _, _ = run_oracle_gpu_convention(s, calls, seed=0)
-    W, H = trace.shape
-    assert (W, H) == (2022, 1 << 14)
-    bc, spans = sm.compile_constraints(apc, idx)
-    assert len(spans) == 187
-    it = sm.compile_interactions(apc, idx) if logup else None
     if logup:
+        # the trace (2^14 - 5 calls: a few zero-padding rows) and the oracle's proof of it, made once per suite run: the streamed and the
+        # consuming tests of tests/test_streamed_prover.py prove the same trace against the same words
+        (flat, W, log_h, bc, spans, it), want = _baseline_case("C2", 14)
+        nq, pow_bits = 6, 4
+        assert (W, log_h) == (2022, 14) and len(np.asarray(spans).reshape(-1, 2)) == 187
         assert len(it[0]) == 1734 and len(prover.logup_group_starts(it)) - 1 == 867
-    flat = np.ascontiguousarray(trace).reshape(-1)
-    got = _prove_both_and_compare(torch, prover, flat, W, 14, bc, spans, it, nq=8, pow_bits=8)
+        pr = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits, interactions=it)
+        d_t = to_dev(torch, flat)
+        got = pr.prove(d_t.data_ptr(), 14)
+        pr.close()
+        assert len(got) == len(want) and (got == want).all(), f"first differing word {int(np.argmax(got != want))} of {len(want)}"
+        assert prover.verify_logup(got, W, 14, bc, spans, it, num_queries=nq, pow_bits=pow_bits)[0] == 0
+        assert sm.verify_logup(got, W, 14, bc, spans, *it, num_queries=nq, pow_bits=pow_bits) == 0
+    else:
+        s = synth.generate("C2", seed=0)
+        calls = (1 << 14) - 5
+        apc, idx, trace, _, _ = run_oracle_gpu_convention(s, calls, seed=0)
+        W, H = trace.shape
+        assert (W, H) == (2022, 1 << 14)
+        bc, spans = sm.compile_constraints(apc, idx)
+        assert len(spans) == 187
+        it, nq, pow_bits = None, 8, 8
+        flat = np.ascontiguousarray(trace).reshape(-1)
+        got = _prove_both_and_compare(torch, prover, flat, W, 14, bc, spans, it, nq=nq, pow_bits=pow_bits)
     # the opened values reach the host through host-mapped memory, the permutation matrix's in four slices that the host absorbs
     # while the next is computed; the plain path (one copy after the last kernel) gives the same words
     monkeypatch.setenv("POWDR_OPENINGS_OVERLAP", "0")
-    pr = prover.Prover(W, bc, spans, num_queries=8, pow_bits=8, interactions=it)
+    pr = prover.Prover(W, bc, spans, num_queries=nq, pow_bits=pow_bits, interactions=it)
     d_t = to_dev(torch, flat)
     assert (pr.prove(d_t.data_ptr(), 14) == got).all()
     pr.close()

@@ -58,30 +58,16 @@ def test_subcoset_lde_is_the_rows_of_the_lde(gpu, log_h, W, log_blocks):
         assert (got == want[:, r::B]).all(), f"sub-coset {r} of {B}"
 
 
-_MEMO = {}
-
-
 def _baseline_case(shape, log_h):
-    """(_synthetic(shape, 2^log_h - 5, seed 0), sm.prove_logup of it with 6 queries / 4 grinding bits): the oracle's side of the BASELINE-shape
-    tests, computed once per (shape, height) — the streamed and the consuming tests prove the same trace."""
-    key = (shape, log_h)
-    if key not in _MEMO:
-        case = _synthetic(shape, (1 << log_h) - 5, seed=0)
-        flat, W, lh, bc, spans, it = case
-        assert lh == log_h
-        _MEMO[key] = (case, sm.prove_logup(flat, W, log_h, bc, spans, *it, num_queries=6, pow_bits=4))
-    return _MEMO[key]
+    from tests._oracle_cases import baseline_case
+
+    return baseline_case(shape, log_h)
 
 
 def _synthetic(shape, calls, seed):
-    from tests.test_oracle_apc import run_oracle_gpu_convention
+    from tests._oracle_cases import synthetic
 
-    s = synth.generate(shape, seed=seed)
-    apc, idx, trace, _, _ = run_oracle_gpu_convention(s, calls, seed=seed)
-    W, H = trace.shape
-    bc, spans = sm.compile_constraints(apc, idx)
-    it = sm.compile_interactions(apc, idx)
-    return np.ascontiguousarray(trace).reshape(-1), W, H.bit_length() - 1, bc, spans, it
+    return synthetic(shape, calls, seed)
 
 
 def _prove(prover, monkeypatch, d_t, W, log_h, bc, spans, it, nq, pow_bits, log_blocks, jit):
