@@ -45,17 +45,21 @@ int synth_pcg64_bounded_u32(SynthPcg64* s, uint32_t bound_excl, uint32_t* out, s
     uint32_t has = s->has_uint32, held = s->uinteger;
     const uint32_t rng = bound_excl - 1u;
     const uint32_t threshold = (uint32_t)((0xFFFFFFFFu - rng) % bound_excl);
-    const size_t kBlock = (size_t)1 << 24; /* outputs per block: 146 MB of raw values at most */
-    uint64_t* raw = NULL;
-    size_t raw_cap = 0, done = 0;
+    /* outputs per block: 2^21 -> 9 MB of raw values, written by the team and read back by one thread out of the caches; the buffer is
+     * kept between calls (a fresh 146 MB block per call spent its time in page faults, 256 threads queueing on the mm lock) */
+    const size_t kBlock = (size_t)1 << 21;
+    static __thread uint64_t* raw = NULL;
+    static __thread size_t raw_cap = 0;
+    size_t done = 0;
     while (done < n) {
         const size_t want = n - done < kBlock ? n - done : kBlock;
         /* raw 64-bit outputs for `want` results: 2 halves each, rejection rate threshold / 2^32 (< 1/2), plus slack; a block that runs
          * out of raw values simply ends early and the next one continues from the state reached */
         const double rej = (double)threshold / 4294967296.0;
         size_t m = (size_t)((double)want * (1.0 + 1.05 * rej / (1.0 - rej)) / 2.0) + 4096;
-        if (m > raw_cap) { free(raw); raw = (uint64_t*)malloc(m * sizeof(uint64_t)); raw_cap = m; if (!raw) return 2; }
-#pragma omp parallel
+        if (m > raw_cap) { free(raw); raw = (uint64_t*)malloc(m * sizeof(uint64_t)); raw_cap = raw ? m : 0; if (!raw) return 2; }
+        uint64_t* const rawp = raw; /* (`raw` is per thread: the team writes through the calling thread's pointer) */
+#pragma omp parallel num_threads(16)
         {
 #ifdef _OPENMP
             extern int omp_get_thread_num(void);
@@ -67,7 +71,7 @@ int synth_pcg64_bounded_u32(SynthPcg64* s, uint32_t bound_excl, uint32_t* out, s
             const size_t per = (m + nt - 1) / nt, lo = t * per, hi = lo + per < m ? lo + per : m;
             if (lo < hi) {
                 u128 st = advance(state, (u128)lo, inc);
-                for (size_t i = lo; i < hi; ++i) { st = st * PCG_MULT + inc; raw[i] = output64(st); }
+                for (size_t i = lo; i < hi; ++i) { st = st * PCG_MULT + inc; rawp[i] = output64(st); }
             }
         }
         /* Lemire over the halves: the held half of an earlier 64-bit output first, then low, high, low, high ... */
@@ -76,7 +80,7 @@ int synth_pcg64_bounded_u32(SynthPcg64* s, uint32_t bound_excl, uint32_t* out, s
         while (produced < want) {
             uint32_t r;
             if (has) { r = held; has = 0; }
-            else { if (k == m) break; r = (uint32_t)raw[k]; held = (uint32_t)(raw[k] >> 32); has = 1; ++k; }
+            else { if (k == m) break; r = (uint32_t)rawp[k]; held = (uint32_t)(rawp[k] >> 32); has = 1; ++k; }
             const uint64_t mm = (uint64_t)r * bound_excl;
             /* numpy tests `leftover < bound` first to put off computing the threshold; threshold < bound, so this test alone decides
              * the same way */
@@ -86,7 +90,6 @@ int synth_pcg64_bounded_u32(SynthPcg64* s, uint32_t bound_excl, uint32_t* out, s
         state = advance(state, (u128)k, inc);
         done += produced;
     }
-    free(raw);
     s->state_hi = (uint64_t)(state >> 64); s->state_lo = (uint64_t)state;
     s->has_uint32 = has; s->uinteger = held;
     return 0;
