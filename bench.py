@@ -328,11 +328,11 @@ def setup_distributed(n):
     return rank, local, world
 
 
-def build_workload(shape_name, log_h, exact_heights, seed, calls_fraction=1.0):
+def build_workload(shape_name, log_h, exact_heights, seed, calls_fraction=1.0, data_seed=None):
     """One APC AIR's trace-generation inputs, resident in HBM (powdr_amd/segment_workload.py build_apc_workload)."""
     from powdr_amd import segment_workload as sw
 
-    return sw.build_apc_workload(shape_name, log_h, exact_heights, seed, calls_fraction)
+    return sw.build_apc_workload(shape_name, log_h, exact_heights, seed, calls_fraction, data_seed=data_seed)
 
 
 def cpu_baseline(shape_name, log_h, queries, pow_bits, seed, logup=False):
@@ -1093,13 +1093,15 @@ def main():
     shape = synth.SHAPES[args.shape]
     log_h = args.log_height or shape.log_height
     try:
-        wl = build_workload(args.shape, log_h, args.exact_source_heights, seed=rank, calls_fraction=args.calls_fraction)
+        # every rank proves the SAME AIR (the execution's APC: seed 0) on its OWN segment's values (data_seed = rank) — one set of
+        # specialised kernels for the node, compiled by rank 0 and loaded by the others
+        wl = build_workload(args.shape, log_h, args.exact_source_heights, seed=0, calls_fraction=args.calls_fraction, data_seed=rank)
     except torch.cuda.OutOfMemoryError:
         # power-of-two source heights (like the original chips' traces) need 150 GB at C2; fall back to
         # b*calls-row sources (115 GB) rather than fail — same kernels, same cells, noted in config.workload
         torch.cuda.empty_cache()
         args.exact_source_heights = True
-        wl = build_workload(args.shape, log_h, True, seed=rank, calls_fraction=args.calls_fraction)
+        wl = build_workload(args.shape, log_h, True, seed=0, calls_fraction=args.calls_fraction, data_seed=rank)
     phase("workload built")
     all_inter = wl["apc"].compile_bus(1)  # (interactions, spans, bytecode) with column operands
     lg_perm_cols = 4 * len(prover.logup_group_starts(all_inter))  # 4 * (groups + 1)

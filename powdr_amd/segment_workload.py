@@ -36,10 +36,12 @@ LOOKUP_BUSES = (synth.BUS_VAR_RANGE, synth.BUS_BITWISE, synth.BUS_TUPLE)
 
 
 def build_apc_workload(shape, log_h: int, exact_heights: bool, seed: int, calls_fraction: float = 1.0, out: torch.Tensor | None = None,
-                       per: tg.Periphery | None = None):
+                       per: tg.Periphery | None = None, data_seed: int | None = None):
     """One APC AIR's trace-generation inputs on the GPU: the APC (host mirror), the original chips' dummy traces (random, cells that
     feed bounded column kinds — bytes, range-checked limbs, flags — drawn below their bound so that every lookup is in range), the
-    output matrix and the periphery histograms. `shape`: a synth.Shape or the name of one."""
+    output matrix and the periphery histograms. `shape`: a synth.Shape or the name of one. `seed` fixes the AIR (its substitutions,
+    constraints, interactions); `data_seed` (None: the process's global generator for the uniform cells, seed + 1 for the bounded ones,
+    as before round 6) the VALUES — the ranks of a run prove the same AIR on different segments of an execution."""
     s = synth.generate(shape, seed=seed)
     apc = host.Apc(s.doc)
     H = 1 << log_h
@@ -56,11 +58,14 @@ def build_apc_workload(shape, log_h: int, exact_heights: bool, seed: int, calls_
         rows = b * calls
         h = max(4, (rows + 3) // 4 * 4 if exact_heights else synth.next_pow2_or_zero(rows))
         t = torch.empty(w * h, dtype=torch.int32, device="cuda")
-        t.random_(0, P)
+        if data_seed is None:
+            t.random_(0, P)
+        else:
+            t.random_(0, P, generator=torch.Generator(device="cuda").manual_seed(1000003 * data_seed + len(dummy)))
         tensors[n] = (t, w, h, b)
         dummy.append((t.data_ptr(), w, h))
         src_bytes += t.numel() * 4
-    g = torch.Generator(device="cuda").manual_seed(seed + 1)
+    g = torch.Generator(device="cuda").manual_seed(seed + 1 if data_seed is None else 7919 * data_seed + 1)
     for pid, (name, row, col) in s.source_of.items():
         kind, bound = s.kinds[pid]
         if bound >= P:
