@@ -242,6 +242,23 @@ class _BusReplay:
         abi.check(rc, "_apc_apply_bus")
 
 
+def draw_segment_shape(seed: int, u: int, n_segments: int, apc_max_calls, instr_max_calls: int) -> dict:
+    """HonestSegment.draw_shape as a pure function of the caps (testable without a GPU): per APC chip its number of calls, for the
+    instruction chips the number of block executions, of segment u of n_segments."""
+    rng = np.random.default_rng([1 + seed, 7919 + u])
+    n = len(apc_max_calls) + 1  # + the instruction block
+    if u == 0:
+        f = np.ones(n)
+    elif u == n_segments - 1:
+        f = 2.0 ** -rng.uniform(3.0, 5.0, size=n)
+    else:
+        f = 2.0 ** -rng.uniform(0.0, 2.0, size=n)
+        f[int(rng.integers(0, n))] = 1.0
+    # (at least 3 calls: the library sizes an APC trace as next_pow2(calls) rows and the provers want >= 4 rows, the shapes' minimum)
+    apc_calls = [max(min(3, cap), int(cap * f[k])) for k, cap in enumerate(apc_max_calls)]
+    return dict(segment=u, apc_calls=apc_calls, instr_calls=max(1, int(instr_max_calls * f[-1])))
+
+
 class HonestSegment:
     """kind "C4": 10 APC AIRs (widths synth.C4_APC_WIDTHS, 2^max_log_height rows) + 13 instruction AIRs + 3 periphery AIRs.
     kind "C5": reth-shaped — the APC AIRs of synth.segment_shape("C5") (log-uniform heights and widths) + the same system AIRs."""
@@ -323,18 +340,7 @@ class HonestSegment:
                               whose tall AIR crosses the streaming threshold)
           u == n_segments-1   the execution's tail: every chip at <= 1/8 of its cap
           otherwise           one chip (drawn) at its cap, the others log-uniform over the two octaves below theirs."""
-        rng = np.random.default_rng([1 + self.seed, 7919 + u])
-        n = len(self.apcs) + 1  # + the instruction block
-        if u == 0:
-            f = np.ones(n)
-        elif u == n_segments - 1:
-            f = 2.0 ** -rng.uniform(3.0, 5.0, size=n)
-        else:
-            f = 2.0 ** -rng.uniform(0.0, 2.0, size=n)
-            f[int(rng.integers(0, n))] = 1.0
-        # (at least 3 calls: the library sizes an APC trace as next_pow2(calls) rows and the provers want >= 4 rows, the shapes' minimum)
-        apc_calls = [max(min(3, wl["max_calls"]), int(wl["max_calls"] * f[k])) for k, wl in enumerate(self.apcs)]
-        return dict(segment=u, apc_calls=apc_calls, instr_calls=max(1, int(self.max_calls * f[-1])))
+        return draw_segment_shape(self.seed, u, n_segments, [wl["max_calls"] for wl in self.apcs], self.max_calls)
 
     def set_shape(self, shape: dict | None) -> None:
         """Re-shape the resident segment: every APC AIR gets next_pow2(calls) rows (cuda/mod.rs:266: `next_power_of_two_or_zero`), the

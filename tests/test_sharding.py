@@ -263,3 +263,22 @@ def test_placement_of_segments_with_their_own_shapes():
             assert sorted(len(p) for p in parts) == [2, 2, 2, 2] and max(loads) / (sum(cells) / 4) < 1.10
         if world == 8:
             assert max(loads) == cells[0]  # 8 ranks: 18.39 G cells in the time of 3.27 G -> at most 5.6x of one rank's rate
+
+
+def test_segment_shape_draws():
+    """HonestSegment.draw_shape's rule (powdr_amd/segment_workload.draw_segment_shape) without a GPU: segment 0 at the caps, the last one
+    a tail at <= 1/8, the others with one chip at its cap and the rest within the two octaves below theirs; deterministic per (seed, u);
+    never fewer than 3 calls for an APC chip (its trace is next_pow2(calls) rows and the provers want >= 4)."""
+    from powdr_amd.segment_workload import draw_segment_shape
+
+    caps, icap, n = [1 << 20] * 10, 1 << 10, 8
+    shapes = [draw_segment_shape(0, u, n, caps, icap) for u in range(n)]
+    assert shapes[0]["apc_calls"] == caps and shapes[0]["instr_calls"] == icap
+    assert all(c <= cap // 8 for c, cap in zip(shapes[n - 1]["apc_calls"], caps)) and shapes[n - 1]["instr_calls"] <= icap // 8
+    for u in range(1, n - 1):
+        f = [c / cap for c, cap in zip(shapes[u]["apc_calls"], caps)] + [shapes[u]["instr_calls"] / icap]
+        assert max(f) == 1.0 and min(f) >= 0.2499 and sum(x == 1.0 for x in f) == 1
+    assert shapes == [draw_segment_shape(0, u, n, caps, icap) for u in range(n)]
+    assert shapes[3] != draw_segment_shape(1, 3, n, caps, icap)
+    tiny = draw_segment_shape(0, 7, 8, [4, 4, 64], 4)
+    assert all(c >= 3 for c in tiny["apc_calls"]) and tiny["instr_calls"] >= 1
