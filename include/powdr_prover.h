@@ -217,7 +217,10 @@ int pw_verify_airs(const PwStarkConfig* cfg, const PwAirDescription* airs, size_
  * COMMITMENT MERGE: the commitments are all-gathered over RCCL (one rank per distinct device; workers may share a device) and
  * `commitments` (n_segments x 8 words, host) receives the segment-ordered list every device now holds. RCCL is loaded with
  * dlopen; without it (or POWDR_MULTI_NO_RCCL=1) the merge happens on the host — pw_multi_last_merge(): 1 = RCCL, 2 = host.
- * worker_of_segment (may be NULL) receives the placement. Returns 0, the first error of a worker, or a hipError_t. */
+ * worker_of_segment (may be NULL) receives who proved each segment in the end. The placement by cells is the PLAN (pw_assign_units):
+ * a worker whose queue runs dry steals the smallest unstarted segment of the worker with the most cells still queued — proving time is
+ * not proportional to cells (short tails, streamed AIRs) and devices differ by a few percent; POWDR_MULTI_STEAL=0 keeps the plan.
+ * Returns 0, the first error of a worker, or a hipError_t. */
 typedef int (*PwSegmentProveFn)(void* user, size_t segment, size_t worker, int device, uint32_t* commitment8);
 int pw_prove_segments_multi(const int* devices, size_t n_workers, const uint64_t* segment_cells, size_t n_segments,
                             PwSegmentProveFn prove, void* user, uint32_t* commitments, uint32_t* worker_of_segment);

@@ -108,8 +108,35 @@ extern "C" int pw_prove_segments_multi(const int* devices, size_t n_workers, con
     for (size_t w = 0; w < n_workers; ++w) if (devices[w] < 0 || devices[w] >= n_dev_present) return (int)hipErrorInvalidDevice;
     std::vector<uint32_t> owner(n_segments);
     pw_assign_units(segment_cells, n_segments, n_workers, owner.data());
-    if (worker_of_segment) memcpy(worker_of_segment, owner.data(), n_segments * 4);
     if (n_segments) memset(commitments, 0, n_segments * 8 * 4);
+    // The placement by cells is the PLAN: every worker's queue, largest segment first. A worker that runs dry STEALS — the smallest
+    // unstarted segment of the worker with the most cells still queued — because proving time is not proportional to cells (a segment's
+    // short tail proves at half the rate of a full one, a segment that has to stream an AIR takes 6-20 % longer: profiles/r06_*), and a
+    // node whose devices differ by a few percent should not wait for its slowest. POWDR_MULTI_STEAL=0: the plan is kept as it is.
+    const char* steal_env = getenv("POWDR_MULTI_STEAL");
+    const bool steal = !(steal_env && atoi(steal_env) == 0);
+    std::vector<std::vector<uint32_t>> queue(n_workers);
+    for (size_t s = 0; s < n_segments; ++s) queue[owner[s]].push_back((uint32_t)s);
+    for (auto& q : queue) std::stable_sort(q.begin(), q.end(), [&](uint32_t a, uint32_t b) { return segment_cells[a] > segment_cells[b]; });
+    std::vector<size_t> next(n_workers, 0);  // queue[w][next[w] ..] are unstarted
+    std::mutex queue_mu;
+    auto take = [&](size_t w, uint32_t* seg) -> bool {
+        std::lock_guard<std::mutex> lk(queue_mu);
+        if (next[w] < queue[w].size()) { *seg = queue[w][next[w]++]; return true; }
+        if (!steal) return false;
+        size_t victim = n_workers;
+        uint64_t most = 0;
+        for (size_t v = 0; v < n_workers; ++v) {
+            uint64_t left = 0;
+            for (size_t k = next[v]; k < queue[v].size(); ++k) left += segment_cells[queue[v][k]];
+            if (left > most) { most = left; victim = v; }
+        }
+        if (victim == n_workers) return false;
+        *seg = queue[victim].back();
+        queue[victim].pop_back();
+        owner[*seg] = (uint32_t)w;
+        return true;
+    };
     int caller_device = 0;
     (void)hipGetDevice(&caller_device);
 
@@ -123,12 +150,12 @@ extern "C" int pw_prove_segments_multi(const int* devices, size_t n_workers, con
         if (!rc) {
             const hipStream_t callers = pw::stream();  // worker 0 runs on the caller's thread: its launch stream comes back afterwards
             pw::set_stream(st);
-            for (size_t s = 0; s < n_segments && !first_error.load(); ++s) {
-                if (owner[s] != w) continue;
+            uint32_t s = 0;
+            while (!first_error.load() && take(w, &s)) {
                 uint32_t c[8] = {0};
                 rc = prove(user, s, w, devices[w], c);
                 if (rc) break;
-                records[w].push_back((uint32_t)s);
+                records[w].push_back(s);
                 records[w].insert(records[w].end(), c, c + 8);
             }
             const int rs = (int)hipStreamSynchronize(st);
@@ -146,6 +173,7 @@ extern "C" int pw_prove_segments_multi(const int* devices, size_t n_workers, con
         for (auto& t : th) t.join();
     }
     (void)hipSetDevice(caller_device);
+    if (worker_of_segment) memcpy(worker_of_segment, owner.data(), n_segments * 4);  // who proved it in the end (stolen segments included)
     if (first_error.load()) return first_error.load();
 
     // ---- the final commitment merge: all-gather over the distinct devices ------------------------------------------

@@ -490,3 +490,30 @@ def test_worker_threads_return_their_device_memory(gpu):
     assert free[-1] >= free[0] - (32 << 20), f"free HBM fell from {free[0]} to {free[-1]} over 11 more worker threads"
     for p in provers:
         p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_blocks,jit", [(1, "1"), (2, "0")])
+def test_hand_over_edge_cases(gpu, monkeypatch, log_blocks, jit):
+    """Handed-over traces where the buffer juggling of pw_prove_segment_consuming is tightest: AIRs that SHARE a height (their level is
+    absorbed run by run), widths that are no multiples of the rate, an AIR WITHOUT interactions inside a LogUp segment (its permutation
+    matrix is the four phi columns: the trace's coefficients wait in a buffer sized for the trace, not for the matrix), a one-AIR segment,
+    and a 4-row AIR that is too short to stream (handed over, left alone). Words == the oracle's; every eaten trace comes back exactly."""
+    torch, abi, prover = gpu
+    rng = np.random.default_rng(23)
+    no_inter = (np.zeros((0, 3), np.uint32), np.zeros((0, 2), np.uint32), np.zeros(0, np.uint32))
+    airs = []
+    for k, (w, lh, with_inter) in enumerate([(13, 8, True), (7, 8, False), (30, 8, True), (5, 6, False), (9, 10, True), (6, 2, True)]):
+        bc, sp, it = synth.random_air_programs(w, 3, 5, seed=300 + k)
+        airs.append((rng.integers(0, P, size=w << lh, dtype=np.uint32), w, lh, bc, sp, it if with_inter else no_inter))
+    monkeypatch.setenv("POWDR_STREAM_LOG_BLOCKS", str(log_blocks))
+    monkeypatch.setenv("POWDR_JIT", jit)
+    for logup in (True, False):
+        want = sm.prove_segment(airs, num_queries=5, pow_bits=1, logup=logup)
+        got, modes = hip_segment_consuming(gpu, airs, 5, 1, logup, [True] * len(airs))
+        assert len(got) == len(want) and (got == want).all(), f"logup={logup}: first differing word {int(np.argmax(got != want))} of {len(want)}"
+        assert modes[-1] == (0, False) and all(e for (b, e) in modes[:-1])
+    one = [airs[4]]
+    want = sm.prove_segment(one, num_queries=5, pow_bits=1, logup=True)
+    got, modes = hip_segment_consuming(gpu, one, 5, 1, True, [True])
+    assert (got == want).all() and modes == [(min(log_blocks, 5), True)]

@@ -191,8 +191,8 @@ def test_c_abi_placement_equals_python_placement():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_workers", [1, 3])
-def test_prove_segments_multi_on_one_gpu(n_workers):
+@pytest.mark.parametrize("n_workers,steal", [(1, True), (3, False), (3, True)])
+def test_prove_segments_multi_on_one_gpu(n_workers, steal, monkeypatch):
     """pw_prove_segments_multi with every worker on GPU 0 (one-GPU box): host threads with their own streams and prover
     replicas prove 7 segments of different sizes concurrently; commitments and proofs equal the ones made one after the
     other; the merge went through an RCCL communicator of size 1 (or says that RCCL is missing)."""
@@ -235,9 +235,15 @@ def test_prove_segments_multi_on_one_gpu(n_workers):
         return pf[hdr:hdr + 8]
 
     cells = [(shapes[s][0] << shapes[s][1]) + (shapes[(s + 1) % 7][0] << shapes[(s + 1) % 7][1]) for s in range(7)]
+    monkeypatch.setenv("POWDR_MULTI_STEAL", "1" if steal else "0")
     commitments, owner, merge = prover.prove_segments_multi([0] * n_workers, cells, prove_segment)
     assert merge in (1, 2)
-    assert (owner == prover.assign_units(cells, n_workers)).all() and len(set(owner.tolist())) == n_workers
+    if steal and n_workers > 1:
+        # the placement by cells is the plan; a worker that runs dry steals the smallest unstarted segment of the busiest queue: whoever
+        # proved a segment is reported as its owner, every segment is proven exactly once (the proofs below), by a worker that exists
+        assert len(proofs) == 7 and all(0 <= int(o) < n_workers for o in owner)
+    else:
+        assert (owner == prover.assign_units(cells, n_workers)).all() and len(set(owner.tolist())) == n_workers
     for s in range(7):
         assert proofs[s][0] == owner[s]
         assert (proofs[s][1] == want[s]).all()
