@@ -231,9 +231,10 @@ def test_eight_ranks_on_one_gpu_with_a_cold_kernel_cache(tmp_path):
     exactly one rank (the others loaded it). Not a multi-GPU measurement — RCCL has still not seen two devices."""
     import os
 
-    # (specialised from 2^10 rows on: the T1 headline on every rank and the APC AIRs that reach the segments' cap — not all 26 AIRs of
-    # every shape, whose ~300 translation units cost a cold box ~30 s of hiprtc)
-    env = dict(os.environ, POWDR_DIST_BACKEND="gloo", POWDR_JIT_MIN_LOG_HEIGHT="10", POWDR_JIT_CACHE_DIR=str(tmp_path / "jit"))
+    # (specialised from 2^11 rows on: the T1 headline — the SAME AIR on every rank, so rank 0 compiles its units and the seven others load
+    # them — and not the 26 AIRs of every segment shape, whose ~250 translation units cost a cold box ~30 s of hiprtc; the cross-process
+    # sharing of a cold cache is also tested without a GPU: tests/test_jit.py::test_ranks_that_share_a_cold_cache_compile_every_unit_once)
+    env = dict(os.environ, POWDR_DIST_BACKEND="gloo", POWDR_JIT_MIN_LOG_HEIGHT="11", POWDR_JIT_CACHE_DIR=str(tmp_path / "jit"))
     env.pop("POWDR_JIT", None)
     # (headline shape T1: on a box whose hiprtc / comgr caches are cold too, the C2 headline's 350 translation units alone take ~115 s
     # of the ranks' first step — profiles/r06_eight_ranks_phases.txt; the segment leg's 291 units keep the cold-cache claim honest)
