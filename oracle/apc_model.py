@@ -380,8 +380,14 @@ _HERE = Path(__file__).resolve().parent
 _LIB = None
 
 
+# POWDR_ORACLE_SAN=1: the checker itself under AddressSanitizer + UBSan (gcc), in oracle/_build_san/ (tools/asan_cpu_suite.sh oracle)
+_SAN = os.environ.get("POWDR_ORACLE_SAN", "") == "1"
+_BUILD = "_build_san" if _SAN else "_build"
+_SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"] if _SAN else []
+
+
 def build_c_oracle(force=False) -> Path:
-    out = _HERE / "_build" / "liboracle.so"
+    out = _HERE / _BUILD / "liboracle.so"
     srcs = sorted(_HERE.glob("*.c")) + [f for f in sorted(_HERE.glob("*.cpp")) if f.name != "tuned_cpu.cpp"]  # (tuned_cpu.cpp: build_tuned_cpu)
     hdrs = sorted(_HERE.glob("*.h")) + sorted(_HERE.glob("*.hpp")) + sorted(_HERE.glob("*.inc"))
     if not force and out.exists() and all(out.stat().st_mtime >= s.stat().st_mtime for s in srcs + hdrs):
@@ -391,9 +397,9 @@ def build_c_oracle(force=False) -> Path:
     for s in srcs:
         o = out.parent / (s.name + ".o")
         cc = ["gcc", "-std=c11"] if s.suffix == ".c" else ["g++", "-std=c++17"]
-        subprocess.check_call(cc + ["-O2", "-fPIC", "-fopenmp", "-c", str(s), "-o", str(o)])
+        subprocess.check_call(cc + ["-O1" if _SAN else "-O2", "-fPIC", "-fopenmp", "-c", str(s), "-o", str(o)] + _SAN_FLAGS)
         objs.append(str(o))
-    subprocess.check_call(["g++", "-shared", "-fopenmp", "-o", str(out)] + objs)
+    subprocess.check_call(["g++", "-shared", "-fopenmp", "-o", str(out)] + _SAN_FLAGS + objs)
     return out
 
 
@@ -404,10 +410,10 @@ def build_tuned_cpu(force=False):
     src = _HERE / "tuned_cpu.cpp"
     outs = {}
     for name, flags in (("avx512", ["-mavx512f", "-mavx512bw", "-mavx512dq", "-mavx512vl"]), ("scalar", [])):
-        out = _HERE / "_build" / f"libtuned_cpu_{name}.so"
+        out = _HERE / _BUILD / f"libtuned_cpu_{name}.so"
         if force or not out.exists() or out.stat().st_mtime < src.stat().st_mtime:
             out.parent.mkdir(exist_ok=True)
-            subprocess.check_call(["g++", "-std=c++17", "-O3", "-fPIC", "-fopenmp", "-shared", str(src), "-o", str(out)] + flags)
+            subprocess.check_call(["g++", "-std=c++17", "-O1" if _SAN else "-O3", "-fPIC", "-fopenmp", "-shared", str(src), "-o", str(out)] + flags + _SAN_FLAGS)
         outs[name] = out
     return outs
 

@@ -7,9 +7,11 @@ fallback path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
-_LIBPATH = Path(__file__).resolve().parent / "lib" / "libpowdr_gpu.so"
+# (POWDR_LIB_DIR: another build of the same library — the sanitizer build of tools/asan_cpu_suite.sh; a developer hook, not a fallback)
+_LIBPATH = Path(os.environ.get("POWDR_LIB_DIR") or Path(__file__).resolve().parent / "lib") / "libpowdr_gpu.so"
 
 
 class OriginalAir(C.Structure):  # cuda_abi.rs:66-73 — 24 bytes

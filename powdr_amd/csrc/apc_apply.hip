@@ -451,7 +451,7 @@ int apply_bus_impl(const PowdrFp* d_output, int num_apc_calls,
     std::vector<uint32_t> hb(bytecode_len);
     if (h_bytecode && h_interactions && (h_arg_spans || !n_arg_spans)) {
         // the caller still holds the tables on the host (powdr_apc_apply_bus_host_tables): no copy back, no synchronisation
-        memcpy(h.data(), h_interactions, n_interactions * sizeof(DevInteraction));
+        if (n_interactions) memcpy(h.data(), h_interactions, n_interactions * sizeof(DevInteraction));
         if (n_arg_spans) memcpy(hs.data(), h_arg_spans, n_arg_spans * sizeof(ExprSpan));
         if (bytecode_len) memcpy(hb.data(), h_bytecode, bytecode_len * 4);
     } else {

@@ -82,7 +82,7 @@ PW_HD int field_selftest_checks(uint64_t seed, uint32_t iterations) {
     for (uint32_t it = 0; it < iterations; ++it) {
         const uint32_t a = rp(), b = rp(), c = rp(), d = rp();
         {
-            const int32_t x = (int32_t)(rnd() % (2ull * P + P / 11)) - (int32_t)(P + P / 22);  // (-1.045 p, 1.045 p)
+            const int32_t x = (int32_t)((int64_t)(rnd() % (2ull * P + P / 11)) - (int64_t)(P + P / 22));  // (-1.045 p, 1.045 p); in 64 bits: UBSan, round 6
             uint32_t want = R_MOD_P;
             for (int k = 0; k < 7; ++k) want = mul(want, smodp(x));
             if (smodp(p2::sbox7(x)) != want) return 8;

@@ -736,16 +736,16 @@ uint32_t powdr_apc_instruction_num_subs(const PowdrApc* a, uint32_t i) { return 
 size_t powdr_apc_compile_bus(const PowdrApc* apc, size_t h, DevInteraction* inter, ExprSpan* spans, size_t* n_spans, uint32_t* bc) {
     BusTables t = compile_bus(*apc, h);
     if (n_spans) *n_spans = t.spans.size();
-    if (inter) memcpy(inter, t.inter.data(), t.inter.size() * sizeof(DevInteraction));
-    if (spans) memcpy(spans, t.spans.data(), t.spans.size() * sizeof(ExprSpan));
-    if (bc) memcpy(bc, t.bc.data(), t.bc.size() * 4);
+    if (inter && !t.inter.empty()) memcpy(inter, t.inter.data(), t.inter.size() * sizeof(DevInteraction));
+    if (spans && !t.spans.empty()) memcpy(spans, t.spans.data(), t.spans.size() * sizeof(ExprSpan));
+    if (bc && !t.bc.empty()) memcpy(bc, t.bc.data(), t.bc.size() * 4);  // (an empty vector's data() may be null: UBSan, round 6)
     return t.bc.size();
 }
 
 size_t powdr_apc_compile_derived(const PowdrApc* apc, size_t h, DerivedExprSpec* specs, uint32_t* bc) {
     DerivedTables t = compile_derived(*apc, h);
-    if (specs) memcpy(specs, t.specs.data(), t.specs.size() * sizeof(DerivedExprSpec));
-    if (bc) memcpy(bc, t.bc.data(), t.bc.size() * 4);
+    if (specs && !t.specs.empty()) memcpy(specs, t.specs.data(), t.specs.size() * sizeof(DerivedExprSpec));
+    if (bc && !t.bc.empty()) memcpy(bc, t.bc.data(), t.bc.size() * 4);
     return t.bc.size();
 }
 
@@ -758,7 +758,7 @@ size_t powdr_apc_compile_constraints(const PowdrApc* apc, ExprSpan* spans, uint3
         if (spans) spans[k] = {off, (uint32_t)out.size() - off};
         ++k;
     }
-    if (bc) memcpy(bc, out.data(), out.size() * 4);
+    if (bc && !out.empty()) memcpy(bc, out.data(), out.size() * 4);
     return out.size();
 }
 

@@ -173,7 +173,7 @@ extern "C" int pw_prove_segments_multi(const int* devices, size_t n_workers, con
         for (auto& t : th) t.join();
     }
     (void)hipSetDevice(caller_device);
-    if (worker_of_segment) memcpy(worker_of_segment, owner.data(), n_segments * 4);  // who proved it in the end (stolen segments included)
+    if (worker_of_segment && n_segments) memcpy(worker_of_segment, owner.data(), n_segments * 4);  // who proved it in the end (stolen segments included)
     if (first_error.load()) return first_error.load();
 
     // ---- the final commitment merge: all-gather over the distinct devices ------------------------------------------
