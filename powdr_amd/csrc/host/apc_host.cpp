@@ -46,10 +46,14 @@ struct JParser {
         throw std::runtime_error(std::string("JSON: ") + what + " at byte " + std::to_string((size_t)(p - begin)));
     }
     const char* begin;
+    int depth = 0;
     JParser(const char* s, size_t n) : p(s), end(s + n), begin(s) {}
     void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
     JPtr parse() {
-        // iterative-friendly recursive descent; nesting depth of the fixtures is a few hundred at most
+        // recursive descent; the nesting depth of the reference's artifacts is a few hundred at most — bounded like the CBOR reader's,
+        // so that 200 000 opening brackets are an error message and not a stack overflow (byte-level fuzz, round 6)
+        struct Depth { int& d; explicit Depth(int& x) : d(x) { ++d; } ~Depth() { --d; } } guard(depth);
+        if (depth > 4096) fail("nesting too deep");
         ws();
         if (p >= end) fail("unexpected end");
         JPtr v(new JVal());
@@ -90,7 +94,13 @@ struct JParser {
             if (c == '-') { v->neg = true; ++p; }
             if (p >= end || *p < '0' || *p > '9') fail("bad number");
             const char* num0 = p;
-            while (p < end && *p >= '0' && *p <= '9') { v->u = v->u * 10 + (uint64_t)(*p - '0'); ++p; }
+            bool wide = false;  // an integer beyond 64 bits: legal only as a float-like statistic, never as a field element or an index
+            while (p < end && *p >= '0' && *p <= '9') {
+                const uint64_t dgt = (uint64_t)(*p - '0');
+                if (v->u > (UINT64_MAX - dgt) / 10) wide = true; else v->u = v->u * 10 + dgt;
+                ++p;
+            }
+            if (wide && !(p < end && (*p == '.' || *p == 'e' || *p == 'E'))) fail("integer beyond 64 bits");
             if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) {  // a float: only statistics carry them, never field elements
                 while (p < end && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) ++p;
                 v->is_float = true;

@@ -223,3 +223,64 @@ def test_mutated_apc_documents_are_rejected_or_read_never_crash():
         h.close()
         read += 1
     assert read + rejected == 250 and rejected > 60 and read > 5
+
+
+def test_byte_level_fuzz_and_adversarial_documents():
+    """Round 6: the readers face files from another machine. Byte-level mutants of a JSON and a CBOR artifact (flips, deletions,
+    insertions, truncations) are rejected with a message or read — never a crash; and the classic attacks on a recursive-descent
+    reader are error messages: 200 000 opening brackets (the JSON reader had no depth bound: a stack overflow until this round; the
+    CBOR reader had one), length prefixes far beyond the input, an integer that does not fit 64 bits (it used to wrap silently)."""
+    import json
+    import random
+
+    from powdr_amd import synth
+
+    doc = synth.generate("T1", seed=3).doc
+    rng = random.Random(11)
+
+    def mutants(b, n):
+        for _ in range(n):
+            x = bytearray(b)
+            for _ in range(rng.randrange(1, 6)):
+                r, i = rng.random(), rng.randrange(len(x))
+                if r < 0.4:
+                    x[i] = rng.randrange(256)
+                elif r < 0.6:
+                    del x[i:i + rng.randrange(1, 20)]
+                elif r < 0.8:
+                    x[i:i] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 8)))
+                else:
+                    x = x[:i]
+                if not x:
+                    x = bytearray(b"\x00")
+            yield bytes(x)
+
+    for fmt, base in (("json", json.dumps(doc).encode()), ("cbor", cbor(doc))):
+        read = rejected = 0
+        for m in mutants(base, 300):
+            try:
+                h = host.Apc(m, fmt=fmt)
+            except (ValueError, RuntimeError, TypeError, KeyError, OverflowError, UnicodeDecodeError):
+                rejected += 1
+                host.count_apcs(m, fmt)
+                continue
+            for call in (lambda: h.compile_bus(1), h.compile_constraints, lambda: h.compile_derived(1)):
+                try:
+                    call()
+                except (ValueError, RuntimeError):
+                    pass
+            h.close()
+            read += 1
+        assert read + rejected == 300 and rejected > 200
+    for payload, fmt, what in ((b"[" * 200000, "json", "nesting too deep"), (b'{"a":' * 100000, "json", "nesting too deep"),
+                               (b"\x81" * 200000, "cbor", "nesting too deep"), (b"\xc1" * 200000, "cbor", "unexpected end"),
+                               (b"\x9b\x7f\xff\xff\xff\xff\xff\xff\xff", "cbor", "longer than the input"),
+                               (b"\x5b\x7f\xff\xff\xff\xff\xff\xff\xff\x00", "cbor", "past the end"),
+                               (b"\xbb\x00\x00\x00\x10\x00\x00\x00\x00", "cbor", "longer than the input"),
+                               (b"[" + b"9" * 100000 + b"]", "json", "beyond 64 bits"), (b'{"block": 18446744073709551617}', "json", "beyond 64 bits")):
+        with pytest.raises(ValueError, match=what):
+            host.Apc(payload, fmt=fmt)
+        assert host.count_apcs(payload, fmt) == 0
+    # 2^64 - 1 still reads as a number (no Apc in the document: a different error), a float statistic of any size is fine
+    with pytest.raises(ValueError, match="no Apc"):
+        host.Apc(b'{"x": 18446744073709551615, "y": 123456789012345678901234567890.5e3}', fmt="json")

@@ -517,3 +517,45 @@ def test_hand_over_edge_cases(gpu, monkeypatch, log_blocks, jit):
     want = sm.prove_segment(one, num_queries=5, pow_bits=1, logup=True)
     got, modes = hip_segment_consuming(gpu, one, 5, 1, True, [True])
     assert (got == want).all() and modes == [(min(log_blocks, 5), True)]
+
+
+def test_host_verifiers_reject_mutated_proofs_without_crashing():
+    """The verifiers read proofs from outside: truncated, extended and word-mutated proofs (field edges, all-ones, flipped bits, header
+    fields that claim other shapes and counts) of the three formats — pw-stark v0, v0 + LogUp, v1 — are all rejected and none crashes
+    the host library (the same loop ran under AddressSanitizer + UBSan in round 6: profiles/r06_sanitizers.txt)."""
+    import random
+
+    from powdr_amd import prover
+
+    rng = random.Random(5)
+
+    def mutate(pf):
+        x = pf.copy()
+        r = rng.random()
+        if r < 0.3:
+            return x[:rng.randrange(0, len(x))]
+        if r < 0.45:
+            return np.concatenate([x, np.array([rng.randrange(1 << 32) for _ in range(rng.randrange(1, 9))], np.uint32)])
+        for _ in range(rng.randrange(1, 4)):
+            i = rng.randrange(len(x))
+            x[i] = rng.choice([0, 1, 0x78000000, 0x78000001, 0xFFFFFFFF, rng.randrange(1 << 32), int(x[i]) ^ (1 << rng.randrange(32))])
+        return x
+
+    airs = synthetic_airs([("T0", 30), ("T1", 200), ("T0", 5)], seed0=1)
+    flat, W, lh, bc, sp, it = airs[1]
+    p0 = sm.prove(flat, W, lh, bc, sp, num_queries=5, pow_bits=3)
+    p1 = sm.prove_logup(flat, W, lh, bc, sp, *it, num_queries=5, pow_bits=3)
+    p2 = sm.prove_segment(airs, num_queries=5, pow_bits=3, logup=True)
+    checks = ((p0, lambda q: prover.verify(q, W, lh, bc, sp, 5, 3)), (p1, lambda q: prover.verify_logup(q, W, lh, bc, sp, it, 5, 3)[0]),
+              (p2, lambda q: prover.verify_segment(descs_of(airs), q, 5, 3, True)[0]))
+    for base, fn in checks:
+        assert fn(base) == 0
+        for _ in range(250):
+            m = mutate(base)
+            same = len(m) == len(base) and (m == base).all()
+            assert (fn(m) == 0) == same
+        for _ in range(60):  # header fields: claimed heights, widths, counts
+            q = base.copy()
+            q[rng.randrange(0, 12)] = rng.choice([0, 1, 26, 27, 31, 0xFFFFFFFF, 1 << 20])
+            if not (q == base).all():
+                assert fn(q) != 0
