@@ -47,6 +47,20 @@ inline int postfix_degree(const uint32_t* bc, uint32_t len) {
     return sp == 1 ? st[0] : kBadDegree;
 }
 
+// Every column operand of a (well-formed) post-fix program names a column of the trace. A program that reaches the device without this
+// check reads whatever lies behind the matrix: artifacts come from another machine (round 6).
+inline bool postfix_columns_below(const uint32_t* bc, uint32_t len, uint32_t width) {
+    for (uint32_t ip = 0; ip < len;) {
+        const uint32_t op = bc[ip++];
+        if (op == POWDR_OP_PUSH_APC || op == POWDR_OP_PUSH_CONST) {
+            if (ip >= len) return false;
+            if (op == POWDR_OP_PUSH_APC && bc[ip] >= width) return false;
+            ++ip;
+        }
+    }
+    return true;
+}
+
 // Group boundaries, n_groups + 1 entries ({0} for no interactions). An interaction joins the current group while the
 // group's constraint  q * prod d_i - sum_i m_i prod_{j != i} d_j  keeps degree <= 3 (what a blow-up-2 quotient carries):
 //   1 + sum deg d_j <= 3  and  deg m_j + sum_{k != j} deg d_k <= 3 for every member.

@@ -59,6 +59,10 @@ static PwProver* create_prover(const PwStarkConfig* cfg, uint32_t width, const u
     for (size_t k = 0; k < n_constraints; ++k) {
         const uint32_t off = spans[2 * k], len = spans[2 * k + 1];
         const int d = (size_t)off + len <= bc_len ? pw::postfix_degree(bc + off, len) : pw::kBadDegree;
+        // a span past the bytecode, an unknown opcode, an unbalanced or too deep stack, a column the trace does not have: no prover — the
+        // post-fix fallback below is for well-formed programs the xbc compiler declines, not for these (they would index past the
+        // bytecode or the trace on the device)
+        if (d == pw::kBadDegree || !pw::postfix_columns_below(bc + off, len, width)) { delete p; return nullptr; }
         if (d > p->max_degree) p->max_degree = d;
     }
     // compile the post-fix constraint programs to xbc (xbc.hpp); fall back to the post-fix interpreter if
@@ -117,6 +121,7 @@ static PwProver* create_prover_logup(const PwStarkConfig* cfg, uint32_t width, c
         for (uint32_t k = 0; k <= na && ok; ++k) {
             const uint32_t off = ispans[2 * (first + k)], len = ispans[2 * (first + k) + 1];
             if ((size_t)off + len > ibc_len) { ok = false; break; }
+            if (pw::postfix_degree(ibc + off, len) == pw::kBadDegree || !pw::postfix_columns_below(ibc + off, len, width)) { ok = false; break; }
             const uint32_t o = (uint32_t)(code.size() / 2);
             if (!cc.compile(ibc + off, len, code)) { ok = false; break; }
             pw::SmallForm f{};

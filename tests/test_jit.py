@@ -473,3 +473,41 @@ def test_generated_code_runs_on_the_host_and_means_what_it_should(tmp_path, air,
         else:
             parts = om.from_monty(out0[:total * 4]).astype(np.int64).reshape(total, 4, N).sum(axis=0) % P
             assert (parts.T == quot_want).all()
+
+
+def test_malformed_programs_get_no_prover():
+    """Round 6: a constraint or interaction program that names a column the trace does not have, runs past its bytecode, uses an unknown
+    opcode or leaves the stack unbalanced never reaches the device (pw_prover_create* return NULL; here through the host-only creation
+    path of pw_jit_generated_source: no units). Before, a malformed CONSTRAINT program fell back to the post-fix interpreter as it was."""
+    from powdr_amd import prover as _prover
+
+    prover_mod = lambda: _prover
+    W, (bc, spans), it = _tables("T1")
+    assert len(prover_mod().jit_generated_sources(W, bc, spans, it, which=0)[0]) >= 1
+
+    def first_column_operand(code):
+        ip = 0
+        while code[ip] != 0:
+            ip += 2 if code[ip] == 1 else 1
+        return ip + 1
+
+    gen = lambda b, s, i, which=0: len(prover_mod().jit_generated_sources(W, b, s, i, which=which)[0])
+    b = np.array(bc, dtype=np.uint32, copy=True)
+    b[first_column_operand(b)] = W
+    assert gen(b, spans, it) == 0
+    s2 = np.array(spans, dtype=np.uint32, copy=True).reshape(-1, 2)
+    s2[0, 1] = 10 ** 6
+    assert gen(bc, s2, it) == 0
+    b = np.array(bc, dtype=np.uint32, copy=True)
+    b[0] = 77
+    assert gen(b, spans, it) == 0
+    b = np.array(bc, dtype=np.uint32, copy=True)
+    sp = np.asarray(spans).reshape(-1, 2)
+    b[sp[0, 0] + sp[0, 1] - 1] = 1  # the last operator replaced by a PUSH_CONST without an operand inside the span
+    assert gen(b, spans, it) == 0
+    i2 = np.array(it[2], dtype=np.uint32, copy=True)
+    i2[first_column_operand(i2)] = W + 5
+    assert gen(bc, spans, (it[0], it[1], i2), which=1) == 0
+    i1 = np.array(it[1], dtype=np.uint32, copy=True).reshape(-1, 2)
+    i1[0, 0] = len(it[2]) + 3
+    assert gen(bc, spans, (it[0], i1, it[2]), which=1) == 0
