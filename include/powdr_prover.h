@@ -40,7 +40,9 @@ typedef struct {
 
 /* Constraint programs: post-fix bytecode with the trace-generation opcodes
  * (PUSH_APC=0 with a COLUMN INDEX operand, PUSH_CONST=1, ADD=2, SUB=3, MUL=4, NEG=5),
- * spans = {off, len} pairs in u32 words. Host pointers; copied. */
+ * spans = {off, len} pairs in u32 words. Host pointers; copied. Returns NULL for a malformed program — a span past the bytecode, an
+ * unknown opcode, an unbalanced or too deep stack, a column index >= width (the same for pw_prover_create_logup's interaction
+ * programs) — and when the device tables cannot be allocated. */
 PwProver* pw_prover_create(const PwStarkConfig* cfg, uint32_t width, const uint32_t* cons_bytecode,
                            size_t bytecode_len, const uint32_t* cons_spans, size_t n_constraints);
 /* The same AIR including its bus interactions (PowdrAir::eval's `push_interaction`, chip.rs:117-129), proven
